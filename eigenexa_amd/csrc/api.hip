@@ -1,0 +1,204 @@
+// api.hip -- C-ABI entry points (include/eigenexa_amd.h): life cycle, queries, memory helpers.
+// The solver entry points live in solver.hip.
+#include "eigx_context.h"
+#include "../../include/eigenexa_amd.h"
+#include <cstring>
+
+namespace eigx {
+Context g_ctx;
+}
+
+using namespace eigx;
+
+extern "C" {
+
+int eigx_init(int device) {
+  return eigx_init_multi(device, 0, 1, nullptr, 'C');
+}
+
+int eigx_get_rccl_unique_id(void* out128) {
+  return comm_get_unique_id(out128);
+}
+
+int eigx_init_multi(int device, int rank, int nranks, const void* uid, char order) {
+  if (g_ctx.initialized) {
+    // reference behaviour: a second eigen_init self-frees first (src/eigen_libs0.F:329-339)
+    fprintf(stderr, "[eigx] caution: eigx_init called twice; freeing the previous grid\n");
+    eigx_free();
+  }
+  if (nranks < 1 || rank < 0 || rank >= nranks) return EIGX_ERR_BAD_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    fprintf(stderr, "[eigx] no HIP device visible: this library has no CPU path\n");
+    return EIGX_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) return EIGX_ERR_BAD_ARG;
+  EIGX_HIP_CHECK(hipSetDevice(device));
+  g_ctx.device = device;
+  // grid rule of src/eigen_libs0.F:526-570: Px = largest divisor of P that is <= sqrt(P)
+  int Px = 1;
+  for (int x = 1; x * x <= nranks; ++x)
+    if (nranks % x == 0) Px = x;
+  Grid& g = g_ctx.grid;
+  g.Px = Px;
+  g.Py = nranks / Px;
+  g.rank = rank;
+  g.nranks = nranks;
+  if (order == 'R' || order == 'r') {  // row-major rank order (src/eigen_libs0.F:2336-2356)
+    g.px = rank / g.Py;
+    g.py = rank % g.Py;
+  } else {
+    g.px = rank % g.Px;
+    g.py = rank / g.Px;
+  }
+  EIGX_HIP_CHECK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+  EIGX_HIP_CHECK(hipStreamCreateWithFlags(&g_ctx.side_stream, hipStreamNonBlocking));
+  if (nranks > 1) {
+    int rc = comm_init(g_ctx, uid);
+    if (rc != 0) return rc;
+  }
+  g_ctx.initialized = true;
+  g_ctx.errinfo = 0;
+  return EIGX_OK;
+}
+
+int eigx_free(void) {
+  if (!g_ctx.initialized) return EIGX_OK;
+  EIGX_HIP_CHECK(hipSetDevice(g_ctx.device));
+  EIGX_HIP_CHECK(hipDeviceSynchronize());
+  if (g_ctx.grid.nranks > 1) comm_free(g_ctx);
+  g_ctx.pool.release();
+  EIGX_HIP_CHECK(hipStreamDestroy(g_ctx.stream));
+  EIGX_HIP_CHECK(hipStreamDestroy(g_ctx.side_stream));
+  g_ctx = Context();
+  return EIGX_OK;
+}
+
+int eigx_get_version(int* version, char* date32, char* vcode32) {
+  if (version) *version = 10;  // 0.10 of this library (tracks the reference's 2.13 API)
+  if (date32) { memset(date32, 0, 32); strncpy(date32, "2026-10", 31); }
+  if (vcode32) { memset(vcode32, 0, 32); strncpy(vcode32, "eigenexa_amd gfx950", 31); }
+  return EIGX_OK;
+}
+
+int eigx_get_procs(int* procs, int* x_procs, int* y_procs) {
+  if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  if (procs) *procs = g_ctx.grid.nranks;
+  if (x_procs) *x_procs = g_ctx.grid.Px;
+  if (y_procs) *y_procs = g_ctx.grid.Py;
+  return EIGX_OK;
+}
+
+int eigx_get_id(int* id, int* x_id, int* y_id) {
+  if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  if (id) *id = g_ctx.grid.rank + 1;
+  if (x_id) *x_id = g_ctx.grid.px + 1;
+  if (y_id) *y_id = g_ctx.grid.py + 1;
+  return EIGX_OK;
+}
+
+int eigx_get_errinfo(int64_t* info) {
+  if (info) *info = g_ctx.errinfo;
+  return EIGX_OK;
+}
+
+// ---- index helpers: formulas of src/eigen_libs0.F:1825 (loop_start), :1911 (loop_end),
+// :1995 (l2g), :2079 (g2l), :2163 (owner_node), :2247 (owner_index); all 1-based. --------------
+int eigx_loop_start(int istart, int nnod, int inod) { return (istart + nnod - 1 - inod) / nnod + 1; }
+int eigx_loop_end(int iend, int nnod, int inod) { return (iend + nnod - inod) / nnod; }
+int eigx_translate_l2g(int ictr, int nnod, int inod) { return (ictr - 1) * nnod + inod; }
+int eigx_translate_g2l(int ictr, int nnod, int inod) { (void)inod; return (ictr - 1) / nnod + 1; }
+int eigx_owner_node(int ictr, int nnod, int inod) { (void)inod; return (ictr - 1) % nnod + 1; }
+int eigx_owner_index(int ictr, int nnod, int inod) {
+  return ((ictr - 1) % nnod + 1 == inod) ? (ictr - 1) / nnod + 1 : -1;
+}
+
+// ---- matdims ------------------------------------------------------------------------------------
+// The reference picks nx by a cache-set heuristic (CSTAB_get_optdim, src/CSTAB.F:73-131: an odd
+// multiple of 32 nudged off A64FX cache aliasing) and ny so that z can double as D&C workspace
+// (src/eigen_libs0.F:1297-1343).  The contract that matters to callers is "allocate a(nx,ny),
+// z(nx,ny)"; we return extents >= the reference's: nx = ceil(n/Px) rounded up to an odd multiple of
+// 32 plus one more 64 step of slack, ny from the same nmz/nmw formula.
+int eigx_get_matdims(int n, int* nx, int* ny, int m_forward, int m_backward, char mode) {
+  if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  if (!nx || !ny) return EIGX_ERR_BAD_ARG;
+  (void)m_forward;
+  const Grid& g = g_ctx.grid;
+  if (n <= 0) { *nx = -1; *ny = -1; return EIGX_ERR_BAD_ARG; }
+  const int mb = m_backward > 0 ? m_backward : 128;
+  int n1 = ceil_div(n, g.Px);
+  int lnx;
+  if (mode == 'M' || mode == 'm') {
+    lnx = n1;
+  } else if (mode == 'L' || mode == 'l') {
+    lnx = ceil_div(n1, 32) * 32;
+  } else {
+    lnx = ceil_div(n1, 64) * 64 + 32;  // odd multiple of 32, >= CSTAB's choice + slack
+    if (lnx < n1 + 64) lnx += 64;
+  }
+  const int NB = mb > 64 ? mb : 64;
+  const int64_t nmz = (int64_t)ceil_div(ceil_div(n, g.Px), NB) * NB + NB + 1;
+  const int64_t nmw = (int64_t)ceil_div(ceil_div(n, g.Py), NB) * NB + NB + 1;
+  const int64_t big = nmz > lnx ? nmz : lnx;
+  int64_t lny = ceil_div64(big * nmw, lnx);
+  const int64_t n2 = ceil_div(n, g.Py);
+  if (lny < n2) lny = n2;
+  // 32-bit index guard of src/eigen_libs0.F:1349-1365
+  const int pmin = g.Px < g.Py ? g.Px : g.Py;
+  const int64_t side = ceil_div64(ceil_div(n, pmin), 64) * 64;
+  if (side * side >= ((int64_t)1 << 31) && !(getenv("EIGX_ALLOW_64BIT"))) {
+    *nx = -1; *ny = -1;
+    return EIGX_ERR_TOO_LARGE;
+  }
+  *nx = lnx;
+  *ny = (int)lny;
+  return EIGX_OK;
+}
+
+int64_t eigx_memory_internal(int n, int lda, int ldz, int m_forward, int m_backward) {
+  if (!g_ctx.initialized) return -1;
+  return solver_workspace_bytes(g_ctx, n, lda, ldz, m_forward, m_backward);
+}
+
+int eigx_get_timers(double* out16) {
+  if (!out16) return EIGX_ERR_BAD_ARG;
+  for (int i = 0; i < 16; ++i) out16[i] = g_ctx.timers[i];
+  return EIGX_OK;
+}
+
+int eigx_device_synchronize(void) {
+  if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  EIGX_HIP_CHECK(hipSetDevice(g_ctx.device));
+  EIGX_HIP_CHECK(hipDeviceSynchronize());
+  return EIGX_OK;
+}
+
+void* eigx_malloc_dev(int64_t bytes) {
+  if (!g_ctx.initialized) return nullptr;
+  void* p = nullptr;
+  if (hipMalloc(&p, (size_t)bytes) != hipSuccess) return nullptr;
+  return p;
+}
+int eigx_free_dev(void* p) {
+  if (p) EIGX_HIP_CHECK(hipFree(p));
+  return EIGX_OK;
+}
+int eigx_memcpy_h2d(void* dst, const void* src, int64_t bytes) {
+  EIGX_HIP_CHECK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+  return EIGX_OK;
+}
+int eigx_memcpy_d2h(void* dst, const void* src, int64_t bytes) {
+  EIGX_HIP_CHECK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+  return EIGX_OK;
+}
+
+int eigx_dgemm_dev(char opa, char opb, int m, int n, int k, double alpha, const double* a, int lda,
+                   const double* b, int ldb, double beta, double* c, int ldc, int tri_upper) {
+  if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  dgemm_dev(g_ctx.stream, opa, opb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, tri_upper ? 1 : 0,
+            &g_ctx.grid);
+  EIGX_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+  return EIGX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+// comm.hip -- RCCL-over-xGMI communicators for the 2-D cyclic grid.
+//
+// Replaces the MPI layer of the reference: comm_mod wrappers bcast_dbl / reduce_dbl (= allreduce) /
+// allgather_dbl / datacast_dbl (src/comm.F:726-1528) and the hand-rolled reproducible allreduces
+// (src/comm.F:2035-2580).  Communicator structure follows eigen_init_cartesian_check
+// (src/eigen_libs0.F:579-585): "X" = ranks that share my column coordinate py (size Px),
+// "Y" = ranks that share my row coordinate px (size Py), plus world.
+//
+// librccl is dlopen'ed on first multi-rank init so the single-GPU path carries no RCCL dependency.
+// RCCL reductions over a fixed communicator use a fixed ring/tree order, so every rank receives
+// bit-identical sums -- the property the reference's hand allreduce exists for (manual 5.5.1).
+#include "eigx_context.h"
+#include "eigx_comm.h"
+#include "../../include/eigenexa_amd.h"
+#include <dlfcn.h>
+#include <cstring>
+
+namespace eigx {
+
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, ncclUniqueIdBlob, int) = nullptr;
+  int (*CommSplit)(void*, int, int, void**, void*) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+} api;
+
+bool load_rccl() {
+  if (api.lib) return true;
+  api.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!api.lib) api.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!api.lib) api.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!api.lib) {
+    fprintf(stderr, "[eigx] cannot load librccl: %s\n", dlerror());
+    return false;
+  }
+#define EIGX_SYM(field, name)                                                    \
+  *(void**)(&api.field) = dlsym(api.lib, name);                                  \
+  if (!api.field) { fprintf(stderr, "[eigx] librccl lacks %s\n", name); return false; }
+  EIGX_SYM(GetUniqueId, "ncclGetUniqueId");
+  EIGX_SYM(CommInitRank, "ncclCommInitRank");
+  EIGX_SYM(CommSplit, "ncclCommSplit");
+  EIGX_SYM(CommDestroy, "ncclCommDestroy");
+  EIGX_SYM(AllReduce, "ncclAllReduce");
+  EIGX_SYM(Broadcast, "ncclBroadcast");
+  EIGX_SYM(AllGather, "ncclAllGather");
+  EIGX_SYM(GroupStart, "ncclGroupStart");
+  EIGX_SYM(GroupEnd, "ncclGroupEnd");
+  EIGX_SYM(Send, "ncclSend");
+  EIGX_SYM(Recv, "ncclRecv");
+  EIGX_SYM(GetErrorString, "ncclGetErrorString");
+#undef EIGX_SYM
+  return true;
+}
+
+#define EIGX_NCCL_CHECK(expr)                                                              \
+  do {                                                                                     \
+    int _r = (expr);                                                                       \
+    if (_r != 0) {                                                                         \
+      fprintf(stderr, "[eigx] RCCL error %d (%s) at %s:%d\n", _r,                          \
+              api.GetErrorString ? api.GetErrorString(_r) : "?", __FILE__, __LINE__);     \
+      abort();                                                                             \
+    }                                                                                      \
+  } while (0)
+
+constexpr int kNcclFloat64 = 8;  // ncclDouble
+constexpr int kNcclSum = 0, kNcclMax = 2;
+}  // namespace
+
+int comm_get_unique_id(void* out128) {
+  if (!out128) return EIGX_ERR_BAD_ARG;
+  if (!load_rccl()) return EIGX_ERR_INTERNAL;
+  EIGX_NCCL_CHECK(api.GetUniqueId(out128));
+  return EIGX_OK;
+}
+
+int comm_init(Context& ctx, const void* uid) {
+  if (!uid) return EIGX_ERR_BAD_ARG;
+  if (!load_rccl()) return EIGX_ERR_INTERNAL;
+  CommState* cs = new CommState();
+  ncclUniqueIdBlob id;
+  memcpy(id.internal, uid, 128);
+  const Grid& g = ctx.grid;
+  EIGX_NCCL_CHECK(api.CommInitRank(&cs->world, g.nranks, id, g.rank));
+  // X group: same py, ordered by px.  Y group: same px, ordered by py.
+  if (g.Px > 1) EIGX_NCCL_CHECK(api.CommSplit(cs->world, g.py, g.px, &cs->x, nullptr));
+  else EIGX_NCCL_CHECK(api.CommSplit(cs->world, g.rank, 0, &cs->x, nullptr));
+  if (g.Py > 1) EIGX_NCCL_CHECK(api.CommSplit(cs->world, g.px, g.py, &cs->y, nullptr));
+  else EIGX_NCCL_CHECK(api.CommSplit(cs->world, g.rank, 0, &cs->y, nullptr));
+  ctx.comm = cs;
+  return EIGX_OK;
+}
+
+void comm_free(Context& ctx) {
+  if (!ctx.comm) return;
+  if (ctx.comm->x) api.CommDestroy(ctx.comm->x);
+  if (ctx.comm->y) api.CommDestroy(ctx.comm->y);
+  if (ctx.comm->world) api.CommDestroy(ctx.comm->world);
+  delete ctx.comm;
+  ctx.comm = nullptr;
+}
+
+static void* pick(const Context& ctx, CommGroup grp) {
+  return grp == COMM_X ? ctx.comm->x : grp == COMM_Y ? ctx.comm->y : ctx.comm->world;
+}
+int comm_size(const Context& ctx, CommGroup grp) {
+  return grp == COMM_X ? ctx.grid.Px : grp == COMM_Y ? ctx.grid.Py : ctx.grid.nranks;
+}
+
+void comm_allreduce_sum(const Context& ctx, CommGroup grp, double* buf, size_t count, hipStream_t s) {
+  if (comm_size(ctx, grp) == 1 || count == 0) return;
+  EIGX_NCCL_CHECK(api.AllReduce(buf, buf, count, kNcclFloat64, kNcclSum, pick(ctx, grp), s));
+}
+void comm_allreduce_max(const Context& ctx, CommGroup grp, double* buf, size_t count, hipStream_t s) {
+  if (comm_size(ctx, grp) == 1 || count == 0) return;
+  EIGX_NCCL_CHECK(api.AllReduce(buf, buf, count, kNcclFloat64, kNcclMax, pick(ctx, grp), s));
+}
+void comm_bcast(const Context& ctx, CommGroup grp, double* buf, size_t count, int root, hipStream_t s) {
+  if (comm_size(ctx, grp) == 1 || count == 0) return;
+  EIGX_NCCL_CHECK(api.Broadcast(buf, buf, count, kNcclFloat64, root, pick(ctx, grp), s));
+}
+void comm_allgather(const Context& ctx, CommGroup grp, const double* send, double* recv, size_t count,
+                    hipStream_t s) {
+  if (comm_size(ctx, grp) == 1) {
+    if (send != recv && count)
+      EIGX_HIP_CHECK(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
+    return;
+  }
+  EIGX_NCCL_CHECK(api.AllGather(send, recv, count, kNcclFloat64, pick(ctx, grp), s));
+}
+
+}  // namespace eigx

@@ -1,0 +1,49 @@
+// eigx_common.h -- shared declarations for the MI355X (gfx950) EigenExa hot-path library.
+// Internal header: the public C-ABI is include/eigenexa_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <cmath>
+#include <vector>
+
+#define EIGX_HIP_CHECK(expr)                                                        \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      fprintf(stderr, "[eigx] HIP error %s at %s:%d: %s\n", hipGetErrorName(_e),    \
+              __FILE__, __LINE__, hipGetErrorString(_e));                           \
+      abort();                                                                      \
+    }                                                                               \
+  } while (0)
+
+namespace eigx {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// Process-grid position of this rank in the 2-D cyclic layout
+// (reference: src/eigen_libs0.F:526-570 grid rule, :1825-2258 index maps).
+// Global row g (0-based) lives on x-rank g % Px at local row g / Px; same for columns with Py.
+struct Grid {
+  int Px = 1, Py = 1;  // grid shape (x: rows, y: columns)
+  int px = 0, py = 0;  // my coordinates
+  int rank = 0, nranks = 1;
+};
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// number of local indices l with global index l*P+p < n
+static inline int local_count(int n, int P, int p) { return n > p ? (n - p + P - 1) / P : 0; }
+
+// ---- kernels / launchers (device pointers, column-major, all on `stream`) -------------------
+
+// C = alpha*op(A)*op(B) + beta*C ; opA/opB in {'N','T'}.
+// tri_mode: 0 = full, 1 = only tiles that intersect the upper triangle (global row <= global col)
+// of a matrix whose local element (i,j) is global (i*Px+px, j*Py+py).
+void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, double alpha,
+               const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc,
+               int tri_mode = 0, const Grid* g = nullptr);
+
+}  // namespace eigx

@@ -1,0 +1,60 @@
+// eigx_context.h -- library-global state (the reference keeps the same kind of module-global state:
+// TRD_COMM_WORLD, x_nnod, ... in src/eigen_devel.F:53-61; one live grid at a time, not re-entrant).
+#pragma once
+#include "eigx_common.h"
+#include <map>
+#include <string>
+
+namespace eigx {
+
+// Workspace cache: named device buffers that persist between solves (hipMalloc of multi-GB buffers
+// costs milliseconds; the reference allocates per call on the host where that is free).
+struct Pool {
+  struct Buf { void* p = nullptr; size_t bytes = 0; };
+  std::map<std::string, Buf> bufs;
+  void* get(const std::string& name, size_t bytes) {
+    Buf& b = bufs[name];
+    if (b.bytes < bytes) {
+      if (b.p) EIGX_HIP_CHECK(hipFree(b.p));
+      b.p = nullptr;
+      size_t want = bytes + bytes / 16 + 256;
+      EIGX_HIP_CHECK(hipMalloc(&b.p, want));
+      b.bytes = want;
+    }
+    return b.p;
+  }
+  template <typename T> T* get_t(const std::string& name, size_t count) {
+    return (T*)get(name, count * sizeof(T));
+  }
+  void release() {
+    for (auto& kv : bufs)
+      if (kv.second.p) EIGX_HIP_CHECK(hipFree(kv.second.p));
+    bufs.clear();
+  }
+};
+
+struct CommState;  // comm.hip (RCCL communicators for world / X / Y groups)
+
+struct Context {
+  bool initialized = false;
+  int device = 0;
+  Grid grid;
+  hipStream_t stream = nullptr;       // compute stream
+  hipStream_t side_stream = nullptr;  // collectives / copies overlapped with compute
+  Pool pool;
+  CommState* comm = nullptr;
+  int64_t errinfo = 0;
+  double timers[16] = {0};
+};
+
+extern Context g_ctx;
+
+// comm.hip
+int comm_get_unique_id(void* out128);
+int comm_init(Context& ctx, const void* unique_id);
+void comm_free(Context& ctx);
+
+// solver.hip
+int64_t solver_workspace_bytes(const Context& ctx, int n, int lda, int ldz, int mf, int mb);
+
+}  // namespace eigx

@@ -1,0 +1,242 @@
+// gemm_f64.hip -- fp64 GEMM on the CDNA4 matrix cores (v_mfma_f64_16x16x4_f64), gfx950 only.
+//
+// One kernel family serves the three GEMM-shaped stages of the EigenExa hot path:
+//   * trailing rank-2k update  A -= [U W][W U]^T on upper-triangle tiles
+//       (reference: eigen_common_2update, src/eigen_t1.F:250-306, two dgemm('N','T') per chunk)
+//   * WY back-transformation   W = V^T Z ('T','N'),  Z -= V (T W) ('N','N')
+//       (reference: eigen_trbakwy_block_body1/2, src/trbakwy4_body.F:504-741)
+//   * divide-and-conquer eigenvector update  Q <- Q2 * S ('N','N')
+//       (reference: PDGEMM in src/my_pdlaed1.F:310-341, DGEMM ring in src/FS_PDLAED3.F90:833-860)
+//
+// Design (MI355X-first, not a translation of the reference's chunked BLAS calls):
+//   128x128 output tile per 256-thread workgroup, 4 waves as 2x2, 64x64 per wave =
+//   4x4 MFMA 16x16 tiles (16 accumulators x 4 f64). K is consumed in slabs of 16 through a
+//   double-buffered LDS stage.  The MFMA operands are swapped (first operand = op(B) fragment,
+//   second = op(A) fragment) so that the accumulator's lane index runs along the column-major
+//   contiguous dimension of C: every epilogue load/store is 16 lanes x 8 B = one full 128-B line.
+//   LDS layouts are padded so that the ds_read_b64 fragment reads are bank-conflict free:
+//     "MC" operand (contiguous along the tile's m/n index):  [k][128+16]
+//     "KC" operand (contiguous along k):                     [m][16+1]
+#include "eigx_common.h"
+
+namespace eigx {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LD_MC = BM + 16;  // doubles; (LD_MC*2) % 64 == 32 -> lanes 16..31 land on the other bank half
+constexpr int LD_KC = BK + 1;
+constexpr int OPER_DOUBLES = (BK * LD_MC > BM * LD_KC) ? BK * LD_MC : BM * LD_KC;
+
+struct GemmArgs {
+  int M, N, K;
+  double alpha, beta;
+  const double* A;
+  int lda;
+  const double* B;
+  int ldb;
+  double* C;
+  int ldc;
+  int tri_mode;
+  int Px, px, Py, py;
+};
+
+// Load this thread's 8 elements of a 128 x 16 operand slab (rows m0.., k-range k0..) into regs.
+//   MC: element (m,k) at P[m + k*ld]     KC: element (m,k) at P[k + m*ld]
+template <bool KC>
+__device__ __forceinline__ void load_slab(double (&r)[8], const double* __restrict__ P, int ld, int m0,
+                                          int k0, int Mmax, int Kmax, int tid) {
+  if (!KC) {
+    const int m = m0 + (tid & 127);
+    const int kb = k0 + (tid >> 7);  // 0..1, then +2 per pass
+    const bool mok = m < Mmax;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int k = kb + 2 * p;
+      r[p] = (mok && k < Kmax) ? P[(size_t)m + (size_t)k * ld] : 0.0;
+    }
+  } else {
+    const int k = k0 + (tid & 15);
+    const int mb = m0 + (tid >> 4);  // 0..15, then +16 per pass
+    const bool kok = k < Kmax;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int m = mb + 16 * p;
+      r[p] = (kok && m < Mmax) ? P[(size_t)k + (size_t)m * ld] : 0.0;
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_slab(const double (&r)[8], double* __restrict__ S, int tid) {
+  if (!KC) {
+    const int m = tid & 127;
+    const int kb = tid >> 7;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) S[(kb + 2 * p) * LD_MC + m] = r[p];
+  } else {
+    const int k = tid & 15;
+    const int mb = tid >> 4;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) S[(mb + 16 * p) * LD_KC + k] = r[p];
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ double frag(const double* __restrict__ S, int m, int k) {
+  return KC ? S[m * LD_KC + k] : S[k * LD_MC + m];
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  // stage buffer b: A slab at smem + 2*b*OPER_DOUBLES, B slab right behind it
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  // XCD-aware tile order (workgroups are dealt round-robin over the 8 XCDs, so bid%8 labels the XCD):
+  //  full mode: each XCD gets a contiguous chunk of the column-major tile list (A/B slab reuse in L2);
+  //  tri mode : tile COLUMNS are dealt round-robin to XCDs, because column tn of the upper triangle
+  //             holds ~tn+1 active tiles and contiguous chunks would leave XCD 7 with 2x the mean work.
+  int bid = blockIdx.x;
+  const int tiles_m = (g.M + BM - 1) / BM;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int ntiles = tiles_m * tiles_n;
+  int tm, tn;
+  if (g.tri_mode == 1 && tiles_n % 8 == 0) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    tn = 8 * (idx / tiles_m) + xcd;
+    tm = idx % tiles_m;
+  } else {
+    if (g.tri_mode == 0 && ntiles % 8 == 0) bid = (bid & 7) * (ntiles >> 3) + (bid >> 3);
+    tm = bid % tiles_m;
+    tn = bid / tiles_m;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  if (g.tri_mode == 1) {
+    // skip tiles strictly below the diagonal: min global row > max global col
+    const long grow_min = (long)m0 * g.Px + g.px;
+    const int jmax = (n0 + BN - 1 < g.N - 1) ? n0 + BN - 1 : g.N - 1;
+    const long gcol_max = (long)jmax * g.Py + g.py;
+    if (grow_min > gcol_max) return;
+  }
+
+  const int fm = lane & 15, fk = lane >> 4;
+  // Accumulators start from (beta/alpha)*C so the C tile is fetched while the first operand slabs are
+  // in flight and the epilogue is store-only (result = alpha*acc).  acc[i][j][r] holds
+  // C(m = m0+wm*64+i*16+(lane&15), n = n0+wn*64+j*16+(lane>>4)+4r).
+  d4_t acc[4][4];
+  const bool use_c = (g.beta != 0.0) && (g.alpha != 0.0);
+  const double cscale = use_c ? g.beta / g.alpha : 0.0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wn * 64 + j * 16 + fk + 4 * r;
+      const double* cp = g.C + (size_t)n * g.ldc;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + fm;
+        acc[i][j][r] = (use_c && n < g.N && m < g.M) ? cscale * cp[m] : 0.0;
+      }
+    }
+
+  double ra[8], rb[8];
+  const int nk = (g.K + BK - 1) / BK;
+  load_slab<A_KC>(ra, g.A, g.lda, m0, 0, g.M, g.K, tid);
+  load_slab<B_KC>(rb, g.B, g.ldb, n0, 0, g.N, g.K, tid);
+  store_slab<A_KC>(ra, smem, tid);
+  store_slab<B_KC>(rb, smem + OPER_DOUBLES, tid);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      load_slab<A_KC>(ra, g.A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid);
+      load_slab<B_KC>(rb, g.B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
+    }
+    const double* as = smem + cur * 2 * OPER_DOUBLES;
+    const double* bs = as + OPER_DOUBLES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      double fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = frag<A_KC>(as, wm * 64 + i * 16 + fm, ks * 4 + fk);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = frag<B_KC>(bs, wn * 64 + j * 16 + fm, ks * 4 + fk);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          // D[x][y] = sum_k opB(k, n=x) * opA(m=y, k)  ->  lane&15 <-> m (contiguous in C)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      store_slab<A_KC>(ra, smem + (cur ^ 1) * 2 * OPER_DOUBLES, tid);
+      store_slab<B_KC>(rb, smem + (cur ^ 1) * 2 * OPER_DOUBLES + OPER_DOUBLES, tid);
+    }
+    __syncthreads();
+  }
+
+  // epilogue (store-only unless alpha == 0)
+  const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wn * 64 + j * 16 + fk + 4 * r;
+      if (n >= g.N) continue;
+      double* cp = g.C + (size_t)n * g.ldc;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + fm;
+        if (m < g.M) {
+          double v = alpha * acc[i][j][r];
+          if (alpha == 0.0 && beta != 0.0) v = beta * cp[m];
+          cp[m] = v;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, double alpha, const double* A,
+               int lda, const double* B, int ldb, double beta, double* C, int ldc, int tri_mode,
+               const Grid* grid) {
+  if (M <= 0 || N <= 0) return;
+  GemmArgs g;
+  g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.tri_mode = tri_mode;
+  g.Px = grid ? grid->Px : 1; g.px = grid ? grid->px : 0;
+  g.Py = grid ? grid->Py : 1; g.py = grid ? grid->py : 0;
+  const bool a_kc = (opA == 'T' || opA == 't');   // op(A)(m,k) = A[k + m*lda]
+  const bool b_kc = (opB == 'N' || opB == 'n');   // op(B)(k,n) = B[k + n*ldb]
+  const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
+  const size_t shmem = (size_t)4 * OPER_DOUBLES * sizeof(double);
+  dim3 grd(tiles), blk(256);
+#define EIGX_LAUNCH(AK, BK_)                                                                       \
+  do {                                                                                             \
+    static bool attr_set = false;                                                                  \
+    if (!attr_set) {                                                                               \
+      EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f64_kernel<AK, BK_>,                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+      attr_set = true;                                                                             \
+    }                                                                                              \
+    hipLaunchKernelGGL((gemm_f64_kernel<AK, BK_>), grd, blk, shmem, stream, g);                    \
+  } while (0)
+  if (a_kc && b_kc) EIGX_LAUNCH(true, true);
+  else if (a_kc && !b_kc) EIGX_LAUNCH(true, false);
+  else if (!a_kc && b_kc) EIGX_LAUNCH(false, true);
+  else EIGX_LAUNCH(false, false);
+#undef EIGX_LAUNCH
+  EIGX_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace eigx

@@ -1,0 +1,146 @@
+/* eigenexa_amd.h -- C-ABI of the MI355X-native EigenExa hot path (libeigenexa_amd.so).
+ *
+ * Plain C, plain pointers and sizes; no torch / HIP types in any signature (streams are the
+ * library's own).  Every entry point names the reference interface it replaces
+ * (paths relative to the RIKEN-RCCS/EigenExa 2.13 tree).
+ *
+ * Conventions kept from the reference:
+ *   - all matrices column-major, fp64; indices/sizes 32-bit int;
+ *   - the matrix is distributed 2-D cyclically (block size 1) over a Px x Py process grid,
+ *     global (i,j) (0-based) -> rank (i%Px, j%Py), local (i/Px, j/Py)   (src/eigen_libs0.F:1825-2258);
+ *   - only the upper triangle (global row <= global col) of `a` is read; `a` is destroyed and on
+ *     return a(1,1)=flop count, a(2,1)=elapsed seconds, a(3,1)=communication seconds or -1
+ *     (src/eigen_sx.F:285-296);
+ *   - w(1:n) ascending eigenvalues, replicated; z(ldz, *) cyclic eigenvectors;
+ *   - `mode`: only the first character is used: 'A' all eigenpairs, 'N' eigenvalues only,
+ *     'X' eigenpairs + refined eigenvalues (src/eigen_sx.F:103-118).
+ *   - errors: no status argument in the reference; here every function returns 0 on success and a
+ *     negative code on a precondition failure (the Fortran module drops it to keep the
+ *     reference's silent-return behaviour, src/eigen_sx.F:82-131).
+ *
+ * Two families of solver entry points:
+ *   eigx_sx / eigx_s          host arrays in, host arrays out     (drop-in for the Fortran API)
+ *   eigx_sx_dev / eigx_s_dev  device (HBM-resident) arrays        (what bench.py times)
+ */
+#ifndef EIGENEXA_AMD_H
+#define EIGENEXA_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EIGX_OK 0
+#define EIGX_ERR_NOT_INITIALIZED (-1)
+#define EIGX_ERR_BAD_ARG (-2)
+#define EIGX_ERR_TOO_LARGE (-3)
+#define EIGX_ERR_NO_DEVICE (-4)
+#define EIGX_ERR_NONFINITE (-5)
+#define EIGX_ERR_INTERNAL (-6)
+
+/* ---- life cycle -------------------------------------------------------------------------- */
+
+/* replaces eigen_init(comm, order)  src/eigen_libs.F:70-104 -> eigen_init0 src/eigen_libs0.F:296-376.
+ * Single-rank form: 1x1 grid on HIP device `device`. */
+int eigx_init(int device);
+
+/* Multi-rank form (one process per GPU).  `nranks` processes call this collectively; the grid is
+ * Px = largest divisor of nranks <= sqrt(nranks), Py = nranks/Px, column-major rank order
+ * (src/eigen_libs0.F:526-570).  `rccl_unique_id` is the 128-byte ncclUniqueId created by
+ * eigx_get_rccl_unique_id() on rank 0 and broadcast by the caller (MPI_Bcast in a Fortran/MPI
+ * host, torch.distributed in bench.py).  Replaces MPI_Comm_dup/MPI_Comm_split of
+ * eigen_init_comm_setup/eigen_init_cartesian_check, src/eigen_libs0.F:382-428, :579-715. */
+int eigx_init_multi(int device, int rank, int nranks, const void* rccl_unique_id, char order);
+int eigx_get_rccl_unique_id(void* out128);
+
+/* replaces eigen_free  src/eigen_libs.F:204-216 */
+int eigx_free(void);
+
+/* replaces eigen_get_version src/eigen_libs0.F:175 ; version = 100*major+minor of this library */
+int eigx_get_version(int* version, char* date32, char* vcode32);
+
+/* replaces eigen_get_procs / eigen_get_id  src/eigen_libs0.F:1575-1655 (1-based ids like the reference) */
+int eigx_get_procs(int* procs, int* x_procs, int* y_procs);
+int eigx_get_id(int* id, int* x_id, int* y_id);
+
+/* replaces eigen_get_errinfo src/eigen_libs0.F:1689-1698 */
+int eigx_get_errinfo(int64_t* info);
+
+/* replaces eigen_get_matdims(n, nx, ny, m_forward, m_backward, mode) src/eigen_libs.F:106-148,
+ * src/eigen_libs0.F:1254-1371.  Returns local array extents that are >= the reference's for the
+ * same (n, grid) so existing callers' allocations stay valid; nx = ny = -1 if too large. */
+int eigx_get_matdims(int n, int* nx, int* ny, int m_forward, int m_backward, char mode);
+
+/* replaces eigen_memory_internal src/eigen_libs0.F:1395-1549: bytes of device workspace a solve needs */
+int64_t eigx_memory_internal(int n, int lda, int ldz, int m_forward, int m_backward);
+
+/* ---- index helpers (pure functions; 1-based like the reference, src/eigen_libs0.F:1744-2356) - */
+int eigx_loop_start(int istart, int nnod, int inod);
+int eigx_loop_end(int iend, int nnod, int inod);
+int eigx_translate_l2g(int ictr, int nnod, int inod);
+int eigx_translate_g2l(int ictr, int nnod, int inod);
+int eigx_owner_node(int ictr, int nnod, int inod);
+int eigx_owner_index(int ictr, int nnod, int inod);
+
+/* ---- solvers ------------------------------------------------------------------------------ */
+
+/* replaces eigen_sx(n,nvec,a,lda,w,z,ldz,m_forward,m_backward,mode) src/eigen_sx.F:30-308
+ * (pentadiagonal route: eigen_prd -> eigen_dcx -> eigen_common_trbakwy(nb=2)). Host arrays. */
+int eigx_sx(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int m_forward,
+            int m_backward, char mode);
+
+/* replaces eigen_s(...) src/eigen_libs.F:150-202 -> eigen_FS src/eigen_FS.F:29-300 /
+ * eigen_s0 src/eigen_s.F:30-307 (tridiagonal route: eigen_trd -> dc2 -> trbakwy(nb=1)). Host arrays. */
+int eigx_s(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int m_forward,
+           int m_backward, char mode);
+
+/* Same solvers on device-resident arrays (a_dev, w_dev, z_dev are HBM pointers of this rank's GPU). */
+int eigx_sx_dev(int n, int nvec, double* a_dev, int lda, double* w_dev, double* z_dev, int ldz,
+                int m_forward, int m_backward, char mode);
+int eigx_s_dev(int n, int nvec, double* a_dev, int lda, double* w_dev, double* z_dev, int ldz,
+               int m_forward, int m_backward, char mode);
+
+/* ---- stage entry points (device arrays; used by the parity tests and the profiler) ---------- */
+
+/* replaces eigen_trd(n,a,lda,d,e,m) src/eigen_trd.F:82-113 (band=1) and
+ * eigen_prd(n,a,lda,d,e,nme,m) src/eigen_prd.F:80-115 (band=2).
+ * Out: d_dev[n]; e_dev[band*lde] with e(i,b) = band entry T(i-b,i) (1-based, zero for i<=b);
+ * reflectors stay in a_dev columns, their 1/beta recoverable from e (src/trbakwy4.F:309-335). */
+int eigx_band_reduce_dev(int n, double* a_dev, int lda, double* d_dev, double* e_dev, int lde,
+                         int m_forward, int band);
+
+/* replaces eigen_dc2 src/dc2.F (band=1) / eigen_dcx src/dcx.F:81-337 (band=2): eigen-decomposition of
+ * the symmetric band matrix (d,e); w_dev ascending, z_dev(ldz, n) eigenvectors. */
+int eigx_band_dc_dev(int n, int nvec, const double* d_dev, const double* e_dev, int lde, int band,
+                     double* w_dev, double* z_dev, int ldz);
+
+/* replaces eigen_common_trbakwy(n,nvec,a,lda,z,ldz,e,m,nb) src/trbakwy4.F:77-222 */
+int eigx_trbak_dev(int n, int nvec, const double* a_dev, int lda, double* z_dev, int ldz,
+                   const double* e_dev, int lde, int m_backward, int band);
+
+/* replaces the BLAS dgemm call sites of the path (src/eigen_t1.F:285-295, src/trbakwy4_body.F:604-608,
+ * :721-725, src/FS_PDLAED3.F90:833-860): C = alpha*op(A)*op(B)+beta*C on device arrays.
+ * tri_upper != 0 restricts the update to 128x128 tiles touching the upper triangle. */
+int eigx_dgemm_dev(char opa, char opb, int m, int n, int k, double alpha, const double* a_dev, int lda,
+                   const double* b_dev, int ldb, double beta, double* c_dev, int ldc, int tri_upper);
+
+/* timers of the last solve, seconds: [0] total [1] reduction [2] d&c [3] back-transform [4] comm
+ * (reference: TIMER_PRINT lines, src/eigen_sx.F:167-174, :300-304).  kernel-level stats for bench.py:
+ * [5] trailing-update kernel seconds (sum of launches) [6] its launch count [7] its flops
+ * [8] symv kernel seconds [9] its launch count [10] its algorithmic bytes */
+int eigx_get_timers(double* out16);
+
+/* device synchronisation helper for hosts without a HIP binding */
+int eigx_device_synchronize(void);
+
+/* device memory helpers for hosts without a HIP binding (Fortran callers, ctypes tests) */
+void* eigx_malloc_dev(int64_t bytes);
+int eigx_free_dev(void* p);
+int eigx_memcpy_h2d(void* dst_dev, const void* src_host, int64_t bytes);
+int eigx_memcpy_d2h(void* dst_host, const void* src_dev, int64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EIGENEXA_AMD_H */
