@@ -1,0 +1,621 @@
+#define _POSIX_C_SOURCE 200809L
+/* eigx_oracle.c -- CPU ORACLE for the EigenExa eigen_sx / eigen_s hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the checker, never the product: only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may build, load or call it.  libeigenexa_amd.so does not link it.
+ *
+ * It restates, in plain scalar C (column-major, 0-based internally, one thread), the algorithm of the
+ * reference's path (paths relative to RIKEN-RCCS/EigenExa 2.13):
+ *   stage 1  Householder reduction, bottom-up, to tridiagonal (band=1) or pentadiagonal (band=2):
+ *            eigen_trd  src/eigen_trd.F:349-723, reflector convention src/eigen_trd_t2.F:486-489,:574-584
+ *            eigen_prd  src/eigen_prd.F:341-578, pair reflectors src/eigen_prd_t4x.F:83-373,
+ *            two-sided update V = (AU - ...)C^T - US  src/eigen_prd_t6_3.F:399-457
+ *   stage 2  divide and conquer on the band matrix, one rank-one secular merge per singular triplet of
+ *            the coupling block: tri  src/mx_pdlaed0-3.F / src/FS_PDLAED0-3.F90 (DLAED1..4 scheme),
+ *            penta src/my_pdlaed0.F:213-266 (SVD split of the 2x2 block), :312-408 (merge loop)
+ *   stage 3  back-transformation Z <- H_n ... H_{1+band} Z, beta recovered from a(L,i)*e(i)
+ *            src/trbakwy4.F:309-335, :345-499
+ *   driver   eigen_sx src/eigen_sx.F:30-308 / eigen_s0 src/eigen_s.F:30-307 (scaling, stage order,
+ *            a(1:3,1) statistics), eigen_scaling src/eigen_scaling.F:59-154.
+ * The numerical kernels the reference takes from LAPACK (DLAED4, DSTEDC/DSYEVD leaves, DGESVD; not in
+ * the reference tree, version unpinned) are restated from their published algorithms:
+ * secular equation by the "middle way" rational interpolation with bisection safeguard (Li 1993,
+ * LAPACK working note 89), Gu-Eisenstat recomputation of z, cyclic Jacobi for the leaves.
+ *
+ * Parity pinning (see tests/test_oracle.py): the reference ships no bitwise goldens for this path
+ * (SURVEY.md 8c); its own tests are known-answer tests, and the oracle is checked against every one:
+ *   - Frank matrix analytic spectrum           benchmark/mat_set.f:117-132, :638-647, w_test.f:141-151
+ *   - residual / orthogonality thresholds      benchmark/ev_test.f:181-204
+ *   - the 2x2 C-binding smoke matrix           C/c_test.c:5-77
+ * and against LAPACK (numpy.linalg.eigh) on seeded random matrices.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <float.h>
+#include <time.h>
+
+#define A_(i, j) a[(size_t)(i) + (size_t)(j) * lda]
+#define W_(i, j) w[(size_t)(i) + (size_t)(j) * n]
+#define Z_(i, j) z[(size_t)(i) + (size_t)(j) * ldz]
+#define E_(i, b) e[(size_t)(i) + (size_t)((b)-1) * lde] /* e(i,b) = T(i-b,i), 0-based i */
+
+static double sign_of(double mag, double s) { return s >= 0.0 ? fabs(mag) : -fabs(mag); }
+
+/* ------------------------------------------------------------------------------------------------
+ * stage 1: band reduction (unblocked; the blocked/communication-avoiding forms of the reference are
+ * algebraically the same similarity transformation).
+ * in : a(lda,n), upper triangle significant.
+ * out: d[n]; e(i,b), i=0..n-1, b=1..band; reflector of column i in a(0:i-band-1, i) (u), so that
+ *      H_i = I - u u^T / beta_i,  beta_i = -a(i-band, i) * e(i,band)      (src/trbakwy4.F:309-335)
+ * ------------------------------------------------------------------------------------------------ */
+static void apply_two_sided(int len, double* w, int n, const double* u, double beta, double* p) {
+  /* W(0:len,0:len) <- H W H with H = I - u u^T/beta (full symmetric storage) */
+  if (beta == 0.0) return;
+  for (int r = 0; r < len; ++r) p[r] = 0.0;
+  for (int c = 0; c < len; ++c) {
+    const double uc = u[c];
+    if (uc == 0.0) continue;
+    const double* wc = &W_(0, c);
+    for (int r = 0; r < len; ++r) p[r] += wc[r] * uc;
+  }
+  double up = 0.0;
+  for (int r = 0; r < len; ++r) up += u[r] * p[r];
+  const double alpha = up / (2.0 * beta);
+  for (int r = 0; r < len; ++r) p[r] = (p[r] - alpha * u[r]) / beta; /* p is now v */
+  for (int c = 0; c < len; ++c) {
+    double* wc = &W_(0, c);
+    const double uc = u[c], vc = p[c];
+    for (int r = 0; r < len; ++r) wc[r] -= u[r] * vc + p[r] * uc;
+  }
+}
+
+/* make the Householder vector of x(0:len) with pivot at len-1: returns s, overwrites x by u, *beta */
+static double make_reflector(int len, double* x, double* beta) {
+  double scale = 0.0;
+  for (int r = 0; r < len; ++r) scale = fmax(scale, fabs(x[r]));
+  if (len <= 0 || scale == 0.0) { *beta = 0.0; return 0.0; }
+  double ss = 0.0;
+  for (int r = 0; r < len; ++r) { const double t = x[r] / scale; ss += t * t; }
+  const double nrm = scale * sqrt(ss);
+  const double s = -sign_of(nrm, x[len - 1]);   /* s = -sign(||x||, x_L)  src/eigen_trd_t2.F:486-489 */
+  x[len - 1] -= s;                               /* u = x - s e_L */
+  *beta = -x[len - 1] * s;                       /* beta = -u_L s = ||u||^2/2 */
+  return s;
+}
+
+int orc_band_reduce(int n, double* a, int lda, double* d, double* e, int lde, int band) {
+  if (n <= 0 || (band != 1 && band != 2) || lda < n || lde < n) return -1;
+  double* w = (double*)malloc((size_t)n * n * sizeof(double));
+  double* p = (double*)malloc((size_t)n * sizeof(double));
+  double* x1 = (double*)malloc((size_t)n * sizeof(double));
+  if (!w || !p || !x1) return -2;
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i <= j; ++i) { W_(i, j) = A_(i, j); W_(j, i) = A_(i, j); }
+  for (int b = 1; b <= band; ++b)
+    for (int i = 0; i < n; ++i) E_(i, b) = 0.0;
+  /* reflector storage: clear what we will define */
+  if (band == 1) {
+    for (int i = n - 1; i >= 1; --i) {
+      const int L = i; /* rows 0..L-1 */
+      double* u = &A_(0, i);
+      for (int r = 0; r < L; ++r) u[r] = W_(r, i);
+      double beta;
+      const double s = make_reflector(L, u, &beta);
+      E_(i, 1) = s;
+      if (beta == 0.0) { E_(i, 1) = (L > 0) ? W_(L - 1, i) : 0.0; for (int r = 0; r < L; ++r) u[r] = 0.0; }
+      apply_two_sided(L, w, n, u, beta, p);
+    }
+  } else {
+    int i = n - 1;
+    for (; i >= 2; i -= 2) {
+      const int L = i - 1; /* rows 0..L-1 ; columns i-1, i */
+      double* uA = &A_(0, i);
+      double* uB = &A_(0, i - 1);
+      for (int r = 0; r < L; ++r) { uA[r] = W_(r, i); x1[r] = W_(r, i - 1); }
+      double betaA, betaB = 0.0;
+      const double s2 = make_reflector(L, uA, &betaA);
+      if (betaA != 0.0) {
+        double dot = 0.0;
+        for (int r = 0; r < L; ++r) dot += uA[r] * x1[r];
+        dot /= betaA;
+        for (int r = 0; r < L; ++r) x1[r] -= dot * uA[r];
+        E_(i, 2) = s2;
+      } else {
+        E_(i, 2) = W_(L - 1, i);
+        for (int r = 0; r < L; ++r) uA[r] = 0.0;
+      }
+      E_(i, 1) = W_(i - 1, i);
+      E_(i - 1, 1) = x1[L - 1];
+      double s1 = 0.0;
+      for (int r = 0; r < L - 1; ++r) uB[r] = x1[r];
+      if (L - 1 >= 1) {
+        s1 = make_reflector(L - 1, uB, &betaB);
+        if (betaB == 0.0) { s1 = x1[L - 2]; for (int r = 0; r < L - 1; ++r) uB[r] = 0.0; }
+        E_(i - 1, 2) = s1;
+      }
+      uB[L - 1] = 0.0; /* a(L, i-1) := 0  (src/eigen_prd_t4x.F:333-343) */
+      apply_two_sided(L, w, n, uA, betaA, p);
+      apply_two_sided(L, w, n, uB, betaB, p); /* uB[L-1] == 0: row/col L-1 gets the one-sided part */
+      /* columns i-1,i of W above the band are now (numerically) the band entries; make them exact */
+      for (int r = 0; r < L; ++r) { W_(r, i) = W_(i, r) = 0.0; W_(r, i - 1) = W_(i - 1, r) = 0.0; }
+      W_(L - 1, i) = W_(i, L - 1) = E_(i, 2);
+      W_(L - 1, i - 1) = W_(i - 1, L - 1) = E_(i - 1, 1);
+      if (L - 2 >= 0) W_(L - 2, i - 1) = W_(i - 1, L - 2) = E_(i - 1, 2);
+    }
+    /* remaining top-left block (<= 2 columns): band entries are what is left in W */
+    for (int j = i; j >= 0; --j) {
+      if (j - 1 >= 0) E_(j, 1) = W_(j - 1, j);
+      if (j - 2 >= 0) E_(j, 2) = W_(j - 2, j);
+    }
+  }
+  for (int j = 0; j < n; ++j) d[j] = W_(j, j);
+  free(w); free(p); free(x1);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * small dense symmetric eigensolver for the D&C leaves (cyclic Jacobi; the reference calls DSYEVD /
+ * DSTEQR / DSTEDC here: src/lapack_eigen.F:31-61, src/mx_pdlaed0.F:182, src/FS_PDLAED0.F90:178)
+ * s(m,m) full symmetric in, eigenvalues ascending in ev, eigenvectors in q(ldq, m)
+ * ------------------------------------------------------------------------------------------------ */
+static void jacobi_eig(int m, double* s, double* ev, double* q, int ldq) {
+#define S_(i, j) s[(size_t)(i) + (size_t)(j) * m]
+#define Q_(i, j) q[(size_t)(i) + (size_t)(j) * ldq]
+  for (int j = 0; j < m; ++j)
+    for (int i = 0; i < m; ++i) Q_(i, j) = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int j = 0; j < m; ++j) {
+      diag += S_(j, j) * S_(j, j);
+      for (int i = 0; i < j; ++i) off += S_(i, j) * S_(i, j);
+    }
+    if (off == 0.0 || off <= 1e-34 * diag) break;
+    for (int pp = 0; pp < m - 1; ++pp)
+      for (int qq = pp + 1; qq < m; ++qq) {
+        const double apq = S_(pp, qq);
+        if (apq == 0.0) continue;
+        const double app = S_(pp, pp), aqq = S_(qq, qq);
+        if (fabs(apq) <= 1e-300) continue;
+        const double theta = (aqq - app) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < m; ++k) { /* columns */
+          const double skp = S_(k, pp), skq = S_(k, qq);
+          S_(k, pp) = c * skp - sn * skq;
+          S_(k, qq) = sn * skp + c * skq;
+        }
+        for (int k = 0; k < m; ++k) { /* rows */
+          const double spk = S_(pp, k), sqk = S_(qq, k);
+          S_(pp, k) = c * spk - sn * sqk;
+          S_(qq, k) = sn * spk + c * sqk;
+        }
+        S_(pp, qq) = S_(qq, pp) = 0.0;
+        for (int k = 0; k < m; ++k) {
+          const double qkp = Q_(k, pp), qkq = Q_(k, qq);
+          Q_(k, pp) = c * qkp - sn * qkq;
+          Q_(k, qq) = sn * qkp + c * qkq;
+        }
+      }
+  }
+  for (int j = 0; j < m; ++j) ev[j] = S_(j, j);
+  /* selection sort ascending, swapping eigenvector columns */
+  for (int j = 0; j < m - 1; ++j) {
+    int k = j;
+    for (int i = j + 1; i < m; ++i) if (ev[i] < ev[k]) k = i;
+    if (k != j) {
+      double t = ev[j]; ev[j] = ev[k]; ev[k] = t;
+      for (int r = 0; r < m; ++r) { t = Q_(r, j); Q_(r, j) = Q_(r, k); Q_(r, k) = t; }
+    }
+  }
+#undef S_
+#undef Q_
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * secular equation  f(x) = 1/rho + sum_i z_i^2/(d_i - x) = 0,  d strictly ascending, rho > 0, ||z||=1.
+ * Root j lies in (d_j, d_{j+1}) (j<K-1) or (d_{K-1}, d_{K-1}+rho).  Returns lambda_j and
+ * delta[i] = d_i - lambda_j computed without cancellation.   (role of DLAED4 at
+ * src/my_pdlaed3.F:276,490, src/FS_PDLAED3.F90:281,700,795)
+ * ------------------------------------------------------------------------------------------------ */
+static void secular_root(int K, int j, const double* d, const double* z, double rho, double* delta,
+                         double* lam) {
+  const double eps = DBL_EPSILON / 2.0; /* unit roundoff */
+  const double rhoinv = 1.0 / rho;
+  if (K == 1) { *lam = d[0] + rho * z[0] * z[0]; delta[0] = -(rho * z[0] * z[0]); return; }
+  const int last = (j == K - 1);
+  const int jl = last ? K - 2 : j;  /* the two poles the interpolation keeps exact: jl, jl+1 */
+  const int jr = jl + 1;
+  double origin, lo, hi, tau;
+  {
+    const double gap = last ? rho : d[j + 1] - d[j];
+    const double mid = last ? d[K - 1] + 0.5 * rho : 0.5 * (d[j] + d[j + 1]);
+    /* f at the midpoint without the two kept poles, then with */
+    double c = rhoinv;
+    for (int i = 0; i < K; ++i)
+      if (i != jl && i != jr) c += z[i] * z[i] / (d[i] - mid);
+    const double fmid = c + z[jl] * z[jl] / (d[jl] - mid) + z[jr] * z[jr] / (d[jr] - mid);
+    int org;
+    if (last) { org = K - 1; if (fmid <= 0.0) { lo = 0.5 * gap; hi = gap; } else { lo = 0.0; hi = 0.5 * gap; } }
+    else if (fmid > 0.0) { org = j; lo = 0.0; hi = 0.5 * gap; }
+    else { org = j + 1; lo = -0.5 * gap; hi = 0.0; }
+    origin = d[org];
+    /* initial guess: root of c + zl^2/(dl - x) + zr^2/(dr - x) in the bracket */
+    const double dl = d[jl] - origin, dr = d[jr] - origin;
+    const double zl2 = z[jl] * z[jl], zr2 = z[jr] * z[jr];
+    /* c (dl-t)(dr-t) + zl2 (dr-t) + zr2 (dl-t) = 0 */
+    const double qa = c, qb = -(c * (dl + dr) + zl2 + zr2), qc = c * dl * dr + zl2 * dr + zr2 * dl;
+    tau = 0.5 * (lo + hi);
+    double disc = qb * qb - 4.0 * qa * qc;
+    if (disc >= 0.0) {
+      const double sq = sqrt(disc);
+      const double qq = -0.5 * (qb + (qb >= 0 ? sq : -sq));
+      double r1 = (qa != 0.0) ? qq / qa : NAN, r2 = (qq != 0.0) ? qc / qq : NAN;
+      if (r1 > lo && r1 < hi) tau = r1;
+      else if (r2 > lo && r2 < hi) tau = r2;
+    }
+  }
+  for (int i = 0; i < K; ++i) delta[i] = (d[i] - origin) - tau;
+  for (int iter = 0; iter < 100; ++iter) {
+    double psi = 0.0, dpsi = 0.0, phi = 0.0, dphi = 0.0, err = 0.0;
+    for (int i = 0; i <= jl; ++i) {
+      const double t = z[i] / delta[i];
+      psi += z[i] * t; dpsi += t * t; err += psi;
+    }
+    err = fabs(err);
+    for (int i = K - 1; i > jl; --i) {
+      const double t = z[i] / delta[i];
+      phi += z[i] * t; dphi += t * t; err += fabs(phi);
+    }
+    const double wv = rhoinv + phi + psi;
+    err = 8.0 * (fabs(phi) + fabs(psi)) + err + 2.0 * rhoinv + fabs(tau) * (dpsi + dphi);
+    if (fabs(wv) <= eps * err) break;
+    if (wv < 0.0) lo = tau; else hi = tau;     /* f is increasing between poles */
+    /* middle way: psi ~ s + p/(dl - x), phi ~ r + q/(dr - x), matched in value and slope at tau */
+    const double Dl = delta[jl], Dr = delta[jr];
+    const double aa = (Dl + Dr) * wv - Dl * Dr * (dpsi + dphi);
+    const double bb = Dl * Dr * wv;
+    const double cc = wv - Dl * dpsi - Dr * dphi;
+    double eta;
+    {
+      double disc = aa * aa - 4.0 * bb * cc;
+      if (disc < 0.0) disc = 0.0;
+      const double sq = sqrt(disc);
+      if (cc == 0.0) eta = (aa != 0.0) ? bb / aa : 0.0;
+      else if (aa <= 0.0) eta = (aa - sq) / (2.0 * cc);
+      else eta = 2.0 * bb / (aa + sq);
+    }
+    /* Newton-direction sanity + bracket safeguard */
+    if (wv * eta >= 0.0) eta = -wv / (dpsi + dphi);
+    double tnew = tau + eta;
+    if (!(tnew > lo && tnew < hi)) tnew = 0.5 * (lo + hi);
+    if (tnew == tau) break;
+    eta = tnew - tau;
+    tau = tnew;
+    for (int i = 0; i < K; ++i) delta[i] = (d[i] - origin) - tau;
+  }
+  *lam = origin + tau;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * one rank-one merge:  eig( diag(d) + rho zz^T ), Q(ldq, n) <- Q * (eigenvectors); d <- sorted.
+ * d is the concatenation of two ascending lists (split at n1) or any order (n1<0 : generic sort).
+ * Deflation as in DLAED2 (src/mx_pdlaed2.F, src/FS_PDLAED2.F90:232-233 tolerance, :348-383 Givens).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct { double v; int i; } kv_t;
+static int kv_cmp(const void* x, const void* y) {
+  const double a = ((const kv_t*)x)->v, b = ((const kv_t*)y)->v;
+  return (a > b) - (a < b);
+}
+
+static void rank_one_merge(int n, double* d, double* z, double rho, double* q, int ldq, int qrows,
+                           double* flops) {
+#define Q_(i, j) q[(size_t)(i) + (size_t)(j) * ldq]
+  const double eps = DBL_EPSILON / 2.0;
+  /* normalise z */
+  double zn = 0.0;
+  for (int i = 0; i < n; ++i) zn += z[i] * z[i];
+  zn = sqrt(zn);
+  if (zn == 0.0 || rho == 0.0) goto sort_only;
+  for (int i = 0; i < n; ++i) z[i] /= zn;
+  rho *= zn * zn;
+  {
+    kv_t* ord = (kv_t*)malloc((size_t)n * sizeof(kv_t));
+    for (int i = 0; i < n; ++i) { ord[i].v = d[i]; ord[i].i = i; }
+    qsort(ord, n, sizeof(kv_t), kv_cmp);
+    double dmax = 0.0, zmax = 0.0;
+    for (int i = 0; i < n; ++i) { dmax = fmax(dmax, fabs(d[i])); zmax = fmax(zmax, fabs(z[i])); }
+    const double tol = 8.0 * eps * fmax(dmax, zmax);
+    int* nd = (int*)malloc((size_t)n * sizeof(int)); /* non-deflated original indices, ascending d */
+    int K = 0;
+    if (rho * zmax > tol) {
+      int pj = -1;
+      for (int t = 0; t < n; ++t) {
+        const int jj = ord[t].i;
+        if (rho * fabs(z[jj]) <= tol) { z[jj] = 0.0; continue; } /* deflated: keep column & d */
+        if (pj < 0) { pj = jj; continue; }
+        double s = z[pj], c = z[jj];
+        const double tau = hypot(c, s);
+        const double tt = d[jj] - d[pj];
+        c /= tau; s = -s / tau;
+        if (fabs(tt * c * s) <= tol) {
+          /* rotate columns pj, jj so that z[pj] -> 0 */
+          z[jj] = tau; z[pj] = 0.0;
+          for (int r = 0; r < qrows; ++r) {
+            const double x = Q_(r, pj), y = Q_(r, jj);
+            Q_(r, pj) = c * x + s * y;
+            Q_(r, jj) = c * y - s * x;
+          }
+          const double dp = d[pj] * c * c + d[jj] * s * s;
+          d[jj] = d[pj] * s * s + d[jj] * c * c;
+          d[pj] = dp;
+          pj = jj;
+        } else {
+          nd[K++] = pj;
+          pj = jj;
+        }
+      }
+      if (pj >= 0) nd[K++] = pj;
+    }
+    free(ord);
+    if (K > 0) {
+      double* dl = (double*)malloc((size_t)K * sizeof(double));
+      double* wz = (double*)malloc((size_t)K * sizeof(double));
+      double* lam = (double*)malloc((size_t)K * sizeof(double));
+      double* S = (double*)malloc((size_t)K * K * sizeof(double)); /* S(i,j) = d_i - lambda_j */
+      double* zh = (double*)malloc((size_t)K * sizeof(double));
+      for (int k = 0; k < K; ++k) { dl[k] = d[nd[k]]; wz[k] = z[nd[k]]; }
+      /* nd is ascending in d except for ties created by rotations: enforce strict order by sorting */
+      for (int k = 1; k < K; ++k) { /* insertion sort, nearly sorted */
+        int t = k;
+        while (t > 0 && dl[t] < dl[t - 1]) {
+          double x = dl[t]; dl[t] = dl[t - 1]; dl[t - 1] = x;
+          x = wz[t]; wz[t] = wz[t - 1]; wz[t - 1] = x;
+          int y = nd[t]; nd[t] = nd[t - 1]; nd[t - 1] = y;
+          --t;
+        }
+      }
+      /* re-normalise the kept part (deflated z were zeroed) as DLAED3 does implicitly via rho */
+      for (int j = 0; j < K; ++j) secular_root(K, j, dl, wz, rho, &S[(size_t)j * K], &lam[j]);
+      /* Gu-Eisenstat: zhat_i^2 = prod_j (lam_j - d_i) / prod_{j!=i} (d_j - d_i) */
+      for (int i = 0; i < K; ++i) {
+        double prod = -S[(size_t)i * K + i]; /* lam_i - d_i */
+        for (int j = 0; j < K; ++j) {
+          if (j == i) continue;
+          prod *= (-S[(size_t)j * K + i]) / (dl[j] - dl[i]); /* (lam_j - d_i)/(d_j - d_i) */
+        }
+        zh[i] = sign_of(sqrt(fabs(prod)), wz[i]);
+      }
+      /* eigenvectors of the rank-one update, column j: zhat_i/(d_i - lam_j), normalised */
+      for (int j = 0; j < K; ++j) {
+        double* sj = &S[(size_t)j * K];
+        double nrm = 0.0;
+        for (int i = 0; i < K; ++i) { sj[i] = zh[i] / sj[i]; nrm += sj[i] * sj[i]; }
+        nrm = 1.0 / sqrt(nrm);
+        for (int i = 0; i < K; ++i) sj[i] *= nrm;
+      }
+      /* Q(:, nd) <- Q(:, nd) * S */
+      double* row = (double*)malloc((size_t)K * sizeof(double));
+      double* out = (double*)malloc((size_t)K * sizeof(double));
+      for (int r = 0; r < qrows; ++r) {
+        for (int k = 0; k < K; ++k) row[k] = Q_(r, nd[k]);
+        for (int j = 0; j < K; ++j) {
+          const double* sj = &S[(size_t)j * K];
+          double acc = 0.0;
+          for (int k = 0; k < K; ++k) acc += row[k] * sj[k];
+          out[j] = acc;
+        }
+        for (int k = 0; k < K; ++k) Q_(r, nd[k]) = out[k];
+      }
+      if (flops) *flops += 2.0 * qrows * (double)K * K;
+      for (int k = 0; k < K; ++k) d[nd[k]] = lam[k];
+      free(row); free(out); free(dl); free(wz); free(lam); free(S); free(zh);
+    }
+    free(nd);
+  }
+sort_only:
+  /* sort eigenvalues ascending with their columns (role of MY_PDLASRT / FS_PDLASRT) */
+  {
+    kv_t* ord = (kv_t*)malloc((size_t)n * sizeof(kv_t));
+    for (int i = 0; i < n; ++i) { ord[i].v = d[i]; ord[i].i = i; }
+    qsort(ord, n, sizeof(kv_t), kv_cmp);
+    int sorted = 1;
+    for (int i = 0; i < n; ++i) if (ord[i].i != i) { sorted = 0; break; }
+    if (!sorted) {
+      double* tmp = (double*)malloc((size_t)qrows * n * sizeof(double));
+      for (int j = 0; j < n; ++j) memcpy(&tmp[(size_t)j * qrows], &Q_(0, ord[j].i), (size_t)qrows * sizeof(double));
+      for (int j = 0; j < n; ++j) { memcpy(&Q_(0, j), &tmp[(size_t)j * qrows], (size_t)qrows * sizeof(double)); d[j] = ord[j].v; }
+      free(tmp);
+    }
+    free(ord);
+  }
+#undef Q_
+}
+
+/* SVD of the band x band coupling block C (band<=2): C = sum_k sig[k] x_k y_k^T
+ * (role of DGESVD at src/my_pdlaed0.F:226,353).  c is column-major 2x2. */
+static void svd2(int band, const double* c, double* sig, double* x, double* y) {
+  if (band == 1) { sig[0] = fabs(c[0]); x[0] = (c[0] >= 0) ? 1.0 : -1.0; y[0] = 1.0; return; }
+  /* eigen-decomposition of C^T C by one Jacobi rotation */
+  const double c00 = c[0], c10 = c[1], c01 = c[2], c11 = c[3];
+  const double g00 = c00 * c00 + c10 * c10, g01 = c00 * c01 + c10 * c11, g11 = c01 * c01 + c11 * c11;
+  double cs = 1.0, sn = 0.0;
+  if (g01 != 0.0) {
+    const double theta = (g11 - g00) / (2.0 * g01);
+    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    cs = 1.0 / sqrt(t * t + 1.0); sn = t * cs;
+  }
+  /* right vectors y_0 = (cs, -sn), y_1 = (sn, cs) */
+  const double ys[2][2] = {{cs, -sn}, {sn, cs}};
+  for (int k = 0; k < 2; ++k) {
+    const double u0 = c00 * ys[k][0] + c01 * ys[k][1], u1 = c10 * ys[k][0] + c11 * ys[k][1];
+    const double s = hypot(u0, u1);
+    sig[k] = s;
+    y[2 * k] = ys[k][0]; y[2 * k + 1] = ys[k][1];
+    if (s > 0.0) { x[2 * k] = u0 / s; x[2 * k + 1] = u1 / s; } else { x[2 * k] = 0.0; x[2 * k + 1] = 0.0; }
+  }
+}
+
+#define ORC_LEAF 32
+
+/* recursive D&C on the band matrix held as dense-band arrays dd[n], ee(i,b) (0-based i, T(i-b,i)).
+ * q(ldq, n): on return the eigenvectors of this block occupy rows/cols [0,n) of the block's own
+ * diagonal position (caller passes the pointer to the block's top-left corner).               */
+static void band_dc_rec(int n, double* dd, double* e, int lde, int band, double* ev, double* q, int ldq,
+                        double* flops) {
+#define Q_(i, j) q[(size_t)(i) + (size_t)(j) * ldq]
+  if (n <= ORC_LEAF) {
+    double* s = (double*)calloc((size_t)n * n, sizeof(double));
+    for (int j = 0; j < n; ++j) {
+      s[(size_t)j + (size_t)j * n] = dd[j];
+      for (int b = 1; b <= band; ++b)
+        if (j - b >= 0) { s[(size_t)(j - b) + (size_t)j * n] = E_(j, b); s[(size_t)j + (size_t)(j - b) * n] = E_(j, b); }
+    }
+    jacobi_eig(n, s, ev, q, ldq);
+    free(s);
+    return;
+  }
+  const int n1 = n / 2, n2 = n - n1;
+  /* coupling block C: rows n1..n1+band-1 (top of block 2), cols n1-band..n1-1 (end of block 1):
+   * C(r,c) = T(n1+r, n1-band+c), nonzero iff (n1+r)-(n1-band+c) <= band  <=> r <= c */
+  double c[4] = {0, 0, 0, 0}, sig[2] = {0, 0}, x[4], y[4];
+  for (int r = 0; r < band; ++r)
+    for (int cc = r; cc < band; ++cc) {
+      const int gi = n1 + r, gj = n1 - band + cc; /* T(gj, gi), distance gi-gj */
+      c[r + band * cc] = E_(gi, gi - gj);
+    }
+  svd2(band, c, sig, x, y);
+  /* T = diag(T1 - sum sig y y^T, T2 - sum sig x x^T) + sum sig [y;x][y;x]^T   (src/my_pdlaed0.F:213-266) */
+  for (int k = 0; k < band; ++k) {
+    for (int r = 0; r < band; ++r)
+      for (int cc = 0; cc < band; ++cc) {
+        /* block 1 corner: indices n1-band+r, n1-band+cc */
+        const int i1 = n1 - band + r, j1 = n1 - band + cc;
+        const double v1 = sig[k] * y[band * k + r] * y[band * k + cc];
+        if (i1 == j1) dd[i1] -= v1; else if (i1 < j1) E_(j1, j1 - i1) -= v1;
+        const int i2 = n1 + r, j2 = n1 + cc;
+        const double v2 = sig[k] * x[band * k + r] * x[band * k + cc];
+        if (i2 == j2) dd[i2] -= v2; else if (i2 < j2) E_(j2, j2 - i2) -= v2;
+      }
+  }
+  /* zero the q block off-diagonals */
+  for (int j = 0; j < n1; ++j) for (int i = n1; i < n; ++i) Q_(i, j) = 0.0;
+  for (int j = n1; j < n; ++j) for (int i = 0; i < n1; ++i) Q_(i, j) = 0.0;
+  band_dc_rec(n1, dd, e, lde, band, ev, q, ldq, flops);
+  band_dc_rec(n2, dd + n1, e + n1, lde, band, ev + n1, &Q_(n1, n1), ldq, flops);
+  double* z = (double*)malloc((size_t)n * sizeof(double));
+  for (int k = 0; k < band; ++k) {
+    if (sig[k] == 0.0) continue;
+    /* z = Q^T [0..0, y_k, x_k, 0..0] */
+    for (int j = 0; j < n; ++j) {
+      double acc = 0.0;
+      for (int r = 0; r < band; ++r) acc += Q_(n1 - band + r, j) * y[band * k + r] + Q_(n1 + r, j) * x[band * k + r];
+      z[j] = acc;
+    }
+    rank_one_merge(n, ev, z, sig[k], q, ldq, n, flops);
+  }
+  free(z);
+#undef Q_
+}
+
+int orc_band_dc(int n, const double* d, const double* e_in, int lde, int band, double* wout, double* z,
+                int ldz, double* flops) {
+  if (n <= 0 || (band != 1 && band != 2) || ldz < n || lde < n) return -1;
+  double* dd = (double*)malloc((size_t)n * sizeof(double));
+  double* e = (double*)malloc((size_t)lde * band * sizeof(double));
+  memcpy(dd, d, (size_t)n * sizeof(double));
+  memcpy(e, e_in, (size_t)lde * band * sizeof(double));
+  /* scale to unit max-norm like MY_PDSxEDC (src/my_pdsxedc.F:277-290) */
+  double nrm = 0.0;
+  for (int i = 0; i < n; ++i) { nrm = fmax(nrm, fabs(dd[i])); for (int b = 1; b <= band; ++b) nrm = fmax(nrm, fabs(E_(i, b))); }
+  if (nrm > 0.0) { for (int i = 0; i < n; ++i) { dd[i] /= nrm; for (int b = 1; b <= band; ++b) E_(i, b) /= nrm; } }
+  double fl = 0.0;
+  band_dc_rec(n, dd, e, lde, band, wout, z, ldz, &fl);
+  if (nrm > 0.0) for (int i = 0; i < n; ++i) wout[i] *= nrm;
+  if (flops) *flops = fl;
+  free(dd); free(e);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * stage 3: back-transformation (unblocked form of src/trbakwy4.F:345-499)
+ * ------------------------------------------------------------------------------------------------ */
+int orc_trbak(int n, int nvec, const double* a, int lda, double* z, int ldz, const double* e, int lde,
+              int band) {
+  if (n <= 0 || nvec < 0 || (band != 1 && band != 2)) return -1;
+  for (int i = band; i < n; ++i) {
+    const int L = i - band + 1; /* rows 0..L-1 */
+    const double beta = -A_(L - 1, i) * E_(i, band);
+    if (beta == 0.0) continue;
+    const double* u = &A_(0, i);
+    for (int j = 0; j < nvec; ++j) {
+      double* zj = &Z_(0, j);
+      double dot = 0.0;
+      for (int r = 0; r < L; ++r) dot += u[r] * zj[r];
+      dot /= beta;
+      for (int r = 0; r < L; ++r) zj[r] -= dot * u[r];
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * drivers (src/eigen_sx.F:30-308, src/eigen_s.F:30-307).  mode 'A' (all) or 'N' (values only).
+ * On return a(0,0)=flops, a(1,0)=seconds, a(2,0)=-1 as in src/eigen_sx.F:285-296.
+ * ------------------------------------------------------------------------------------------------ */
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+static int orc_eigen(int n, int nvec, double* a, int lda, double* wout, double* z, int ldz, char mode,
+                     int band, double* times3) {
+  if (n <= 0) return -1;
+  const double t0 = now_s();
+  /* eigen_scaling (src/eigen_scaling.F:76-81, :127-147) */
+  double anrm = 0.0;
+  int bad = 0;
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i <= j; ++i) { const double v = A_(i, j); if (!(fabs(v) <= DBL_MAX)) bad = 1; anrm = fmax(anrm, fabs(v)); }
+  if (bad) { for (int i = 0; i < n; ++i) wout[i] = NAN; return 1; }
+  const double safmin = DBL_MIN, epsm = DBL_EPSILON / 2.0;
+  const double smlnum = safmin / epsm, rmin = sqrt(smlnum), rmax = fmin(sqrt(1.0 / smlnum), 1.0 / sqrt(sqrt(safmin)));
+  double sigma = 1.0;
+  if (anrm > 0.0 && anrm < rmin) sigma = rmin / anrm;
+  else if (anrm > rmax) sigma = rmax / anrm;
+  if (sigma != 1.0) for (int j = 0; j < n; ++j) for (int i = 0; i <= j; ++i) A_(i, j) *= sigma;
+
+  const int lde = n;
+  double* d = (double*)malloc((size_t)n * sizeof(double));
+  double* e = (double*)calloc((size_t)lde * 2, sizeof(double));
+  const double t1 = now_s();
+  orc_band_reduce(n, a, lda, d, e, lde, band);
+  const double t2 = now_s();
+  double fl_dc = 0.0;
+  const int want_vec = !(mode == 'N' || mode == 'n' || nvec == 0);
+  double* ztmp = z;
+  int ldzt = ldz;
+  if (!want_vec) { ztmp = (double*)malloc((size_t)n * n * sizeof(double)); ldzt = n; }
+  orc_band_dc(n, d, e, lde, band, wout, ztmp, ldzt, &fl_dc);
+  const double t3 = now_s();
+  if (want_vec) orc_trbak(n, nvec, a, lda, z, ldz, e, lde, band);
+  else free(ztmp);
+  const double t4 = now_s();
+  if (sigma != 1.0) for (int i = 0; i < n; ++i) wout[i] /= sigma;
+  const double fl = 4.0 / 3.0 * (double)n * n * n + fl_dc + (want_vec ? 2.0 * (double)nvec * n * n : 0.0);
+  A_(0, 0) = fl;
+  if (n > 1) A_(1, 0) = t4 - t0;
+  if (n > 2) A_(2, 0) = -1.0;
+  if (times3) { times3[0] = t2 - t1; times3[1] = t3 - t2; times3[2] = t4 - t3; }
+  free(d); free(e);
+  return 0;
+}
+
+int orc_eigen_sx(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, char mode, double* times3) {
+  return orc_eigen(n, nvec, a, lda, w, z, ldz, mode, 2, times3);
+}
+int orc_eigen_s(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, char mode, double* times3) {
+  return orc_eigen(n, nvec, a, lda, w, z, ldz, mode, 1, times3);
+}
