@@ -1,0 +1,764 @@
+// band_reduce.hip -- Householder reduction full -> tridiagonal (NB=1) / pentadiagonal (NB=2), gfx950.
+//
+// Replaces (reference paths relative to RIKEN-RCCS/EigenExa 2.13):
+//   eigen_trd_body   src/eigen_trd.F:349-723   + eigen_trd_au (fused SYMV)  src/eigen_trd_t2.F:161-651,:970-1400
+//   eigen_prd_body   src/eigen_prd.F:341-578   + eigen_prd_au (2-vector SYMV) src/eigen_prd_t2.F:90-214,:290-958
+//   compute_u        src/eigen_trd_t4.F:81-189, src/eigen_prd_t4x.F:83-373
+//   compute_v        src/eigen_trd_t6_3.F:85-330, src/eigen_prd_t6_3.F:76-477
+//   local_2update    src/eigen_trd_t5.F:71-137,  src/eigen_prd_t5.F:69-266
+//   panel load/store src/eigen_trd_t7.F:72-267,  src/eigen_prd_t7.F:74-250
+//   trailing update  eigen_common_2update src/eigen_t1.F:68-309  (here: the MFMA GEMM of gemm_f64.hip)
+//
+// Same mathematics as the reference (bottom-up, column i annihilated above the band, reflector
+// u = x - s e_L, s = -sign(||x||,x_L), beta = -u_L s, stored in column i of `a`; delayed rank-2k update
+// per panel of m columns), re-designed for one GPU stream instead of MPI ranks x OpenMP threads:
+//
+//   per column (NB=1) / column pair (NB=2) a chain of short kernels, all reductions two-phase and
+//   deterministic (per-workgroup partials written to HBM, re-reduced redundantly by every consumer
+//   workgroup in a fixed order -> bit-identical replicas, the property the reference's hand-written
+//   allreduce exists for), no atomics, no host synchronisation inside the reduction:
+//     K_A  finish the previous step's W = P T - U M/2 from the SYMV partials, append it to the panel,
+//          and form the next effective column(s) x = a_i - U W(i,:)^T - W U(i,:)^T  (lazy panel update),
+//          Gram partials of x
+//     K_M  (NB=2) apply the first reflector to the second column, partial norm
+//     K_B  HBM-bound fused symmetric mat-vec over the upper triangle only: one pass over A gives
+//          both  y_row += a(r,c) u(c)  and  y_col += a(r,c) u(r)  for NB vectors at once (K2/K3 of
+//          SURVEY.md 2.3); 16-byte coalesced loads down the columns, column sums reduced with a
+//          halving butterfly of wave shuffles, partial results per (row strip, column segment)
+//     K_P  panel dot products U^T u, W^T u (tall-skinny), reflector store into `a` and the panel
+//   per panel: A(0:nr,0:nr) -= [U W][W U]^T on upper-triangle tiles with the fp64 MFMA GEMM.
+#include "eigx_context.h"
+#include "../../include/eigenexa_amd.h"
+
+namespace eigx {
+
+namespace {
+
+constexpr int PD_ROWS = 512;   // rows per panel-dot chunk
+constexpr int PD_COLS = 16;    // panel columns per panel-dot workgroup
+constexpr int KA_ROWS = 32;    // rows per K_A workgroup (x 8 panel slices = 256 threads)
+constexpr int KM_ROWS = 256;   // rows per K_M workgroup
+
+// scalar slots in the small device array `sc`
+enum { SC_SA = 0, SC_BETA_A = 1, SC_SB = 2, SC_BETA_B = 3, SC_COUNT = 8 };
+
+struct RedArgs {
+  double* A; int lda; int n;
+  double* UW; int ldp; int m;     // [U | W | U], m columns each
+  double* X;                      // ldp x 3 : slot 0 = x_i, slot 1 = x_{i-1}, slot 2 = H_A x_{i-1} (K_M output)
+  double* YR; double* YC;         // SYMV partials [tile col | tile row][a][ldp]
+  double* KD;                     // panel-dot partials [chunk][kind 2*NB][m], then [chunk] uA.uB at the end
+  double* SP;                     // [wg][3] bilinear partials
+  double* GP;                     // [wg][2] Gram partials (K_A), GP2 = GP + gp2_off : [wg] (K_M)
+  double* sc;                     // scalars
+  double* d; double* e; int lde;
+  int maxseg, maxrs, maxchunk, gp2_off, kdab_off;
+};
+
+// SYMV tiling: square tiles of T = 128*RB rows/cols (RB = 1,2,4); tile (ty,tx) with tx >= ty is one
+// workgroup.  Small triangles get small tiles so that >= ~400 workgroups exist; large ones get big tiles
+// so that the number of partial sums per row (nt+1) stays ~100.
+struct SymvGeom { int L, T, nt; };
+
+__host__ __device__ inline SymvGeom symv_geom(int L) {
+  SymvGeom g;
+  g.L = L;
+  g.T = (L <= 6000) ? 128 : (L <= 14000 ? 256 : 512);
+  g.nt = (L + g.T - 1) / g.T;
+  return g;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// deterministic block sum of K values at once (256 threads, one barrier pair); results in all threads
+template <int K>
+__device__ __forceinline__ void block_sum_multi(double (&v)[K], double* red /* >= 4*K doubles LDS */) {
+#pragma unroll
+  for (int q = 0; q < K; ++q) v[q] = wave_sum(v[q]);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) red[(threadIdx.x >> 6) * K + q] = v[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < K; ++q) v[q] = (red[q] + red[K + q]) + (red[2 * K + q] + red[3 * K + q]);
+}
+
+__device__ __forceinline__ double sign_of(double mag, double s) { return s >= 0.0 ? fabs(mag) : -fabs(mag); }
+
+// =================================================================================================
+// K_A : finish previous step (if has_prev) and form the next columns (ncols = 0,1,2).
+// Workgroup = 32 rows x 8 slices: slice ks handles panel columns kk = ks (mod 8) and SYMV partials
+// t = ks (mod 8) of its row; the 8 slice sums are combined through LDS in a fixed order.
+// =================================================================================================
+struct KAArgs {
+  int has_prev;   // previous step pending: its W columns [kprev, kprev+NB) must be finished
+  int iprev;      // top column of the previous step
+  int Lprev;      // rows of the previous step's reflectors (uA), uB has Lprev-1
+  int kprev;      // panel fill before the previous step
+  int nchunk_prev;  // K_P row chunks of the previous step
+  int ncols;      // columns to form now (0 = finish only)
+  int i;          // top column of the new block (slot 0 <-> column i, slot 1 <-> column i-1)
+  int L;          // rows above the new block (Gram sums run over r < L)
+  int k;          // panel fill to use for the new columns (= kprev+NB if has_prev)
+  int rows;       // rows to cover: max(iprev+1, i+1)
+};
+
+template <int NB>
+__global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
+  __shared__ double red[32];
+  __shared__ double kd[4][256];        // reduced panel-dot vectors: [UuA, WuA, UuB, WuB][kk]  (m <= 256)
+  __shared__ double rowU[2][258], rowW[2][258];  // U(c, kk), W(c, kk) for the new block columns c
+  __shared__ double tm[8];             // T (tAA,tAB,tBB) and M (m11,m12,m21,m22)
+  __shared__ double slice[8][KA_ROWS][4];
+  const int tid = threadIdx.x;
+  const int rr = tid & (KA_ROWS - 1), ks = tid >> 5;
+  const int ldp = R.ldp, m = R.m;
+  double* Up = R.UW;
+  double* Wp = R.UW + (size_t)ldp * m;
+  const SymvGeom g = symv_geom(S.Lprev);
+
+  // ---------------------------------------------------------------- prologue: previous step scalars
+  if (S.has_prev) {
+    const int kp = S.kprev;
+    for (int idx = tid; idx < 2 * NB * kp; idx += 256) {
+      const int kind = idx / kp, kk = idx - kind * kp;
+      double v = 0.0;
+      for (int c = 0; c < S.nchunk_prev; ++c) v += R.KD[((size_t)c * 2 * NB + kind) * m + kk];
+      kd[kind][kk] = v;
+    }
+    __syncthreads();
+    // [0..2] bilinear forms of the stale matrix (SYMV workgroups, fixed order), [3..5] their panel
+    // corrections, [6] uA.uB
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    const int tot = g.nt * g.nt;
+    for (int w = tid; w < tot; w += 256) {
+      const int ty = w / g.nt, tx = w - ty * g.nt;
+      if (tx >= ty) {
+        v[0] += R.SP[(size_t)w * 3 + 0];
+        if (NB == 2) { v[1] += R.SP[(size_t)w * 3 + 1]; v[2] += R.SP[(size_t)w * 3 + 2]; }
+      }
+    }
+    for (int kk = tid; kk < kp; kk += 256) {
+      v[3] += 2.0 * kd[0][kk] * kd[1][kk];
+      if (NB == 2) {
+        v[4] += kd[0][kk] * kd[3][kk] + kd[1][kk] * kd[2][kk];
+        v[5] += 2.0 * kd[2][kk] * kd[3][kk];
+      }
+    }
+    if (NB == 2)
+      for (int c = tid; c < S.nchunk_prev; c += 256) v[6] += R.KD[R.kdab_off + c];
+    block_sum_multi<7>(v, red);
+    if (tid == 0) {
+      const double gAA = v[0] - v[3], gAB = v[1] - v[4], gBB = v[2] - v[5], uab = v[6];
+      const double bA = R.sc[SC_BETA_A], bB = (NB == 2) ? R.sc[SC_BETA_B] : 0.0;
+      const double tAA = bA != 0.0 ? 1.0 / bA : 0.0;
+      const double tBB = bB != 0.0 ? 1.0 / bB : 0.0;
+      const double tAB = -uab * tAA * tBB;
+      // GT = G T ; M = T^T GT
+      const double gt11 = gAA * tAA, gt12 = gAA * tAB + gAB * tBB;
+      const double gt21 = gAB * tAA, gt22 = gAB * tAB + gBB * tBB;
+      tm[0] = tAA; tm[1] = tAB; tm[2] = tBB;
+      tm[3] = tAA * gt11;               // m11
+      tm[4] = tAA * gt12;               // m12
+      tm[5] = tAB * gt11 + tBB * gt21;  // m21
+      tm[6] = tAB * gt12 + tBB * gt22;  // m22
+    }
+    __syncthreads();
+  }
+
+  // t-th SYMV partial of row r (tile row ty = r/T), t in [0, nt]: t <= ty -> column result of tile row t
+  // (column r of tile (t, ty)) ; t > ty -> row result of tile column t-1 (row r of tile (ty, t-1))
+  auto symv_part = [&](int r, int t, int ty, double& pA, double& pB) {
+    const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
+    pA += base[r];
+    if (NB == 2) pB += base[ldp + r];
+  };
+
+  // ---------------------------------------------------------------- rows U(c,:), W(c,:) of the new block
+  const int kold = S.has_prev ? S.kprev : S.k;  // panel slots that are final in memory
+  if (S.ncols > 0) {
+    for (int cc = 0; cc < S.ncols; ++cc) {
+      const int c = S.i - cc;
+      for (int kk = tid; kk < S.k; kk += 256) {
+        rowU[cc][kk] = Up[(size_t)kk * ldp + c];
+        rowW[cc][kk] = (kk < kold) ? Wp[(size_t)kk * ldp + c] : 0.0;
+      }
+    }
+    __syncthreads();
+    if (S.has_prev) {
+      // W(c, new slots) = row c of the previous step's W, computed redundantly by every workgroup:
+      // P(c,a) = sum of SYMV partials - panel corrections, all summed in one block reduction
+      double v[4] = {0, 0, 0, 0};
+      for (int cc = 0; cc < S.ncols; ++cc) {
+        const int c = S.i - cc;
+        const int ty = c / g.T;
+        for (int t = tid; t < g.nt + 1; t += 256) symv_part(c, t, ty, v[2 * cc], v[2 * cc + 1]);
+        for (int kk = tid; kk < S.kprev; kk += 256) {
+          const double u = rowU[cc][kk], w = rowW[cc][kk];
+          v[2 * cc] -= u * kd[1][kk] + w * kd[0][kk];
+          if (NB == 2) v[2 * cc + 1] -= u * kd[3][kk] + w * kd[2][kk];
+        }
+      }
+      block_sum_multi<4>(v, red);
+      if (tid < S.ncols) {
+        const int cc = tid;
+        const double pA = v[2 * cc], pB = v[2 * cc + 1];
+        const double uA = rowU[cc][S.kprev], uB = (NB == 2) ? rowU[cc][S.kprev + 1] : 0.0;
+        const double yA = tm[0] * pA, yB = tm[1] * pA + tm[2] * pB;
+        rowW[cc][S.kprev] = yA - 0.5 * (uA * tm[3] + uB * tm[5]);
+        if (NB == 2) rowW[cc][S.kprev + 1] = yB - 0.5 * (uA * tm[4] + uB * tm[6]);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---------------------------------------------------------------- row loop: slice partial sums
+  const int r = blockIdx.x * KA_ROWS + rr;
+  const int kp = S.has_prev ? S.kprev : 0;
+  const int kloop = S.has_prev ? S.kprev : S.k;
+  {
+    double pA = 0.0, pB = 0.0, x0 = 0.0, x1 = 0.0;
+    if (r < S.rows) {
+      for (int kk = ks; kk < kloop; kk += 8) {
+        const double u = Up[(size_t)kk * ldp + r];
+        const double w = Wp[(size_t)kk * ldp + r];
+        if (S.has_prev) {
+          pA -= u * kd[1][kk] + w * kd[0][kk];
+          if (NB == 2) pB -= u * kd[3][kk] + w * kd[2][kk];
+        }
+        if (S.ncols > 0) {
+          x0 += u * rowW[0][kk] + w * rowU[0][kk];
+          if (S.ncols > 1) x1 += u * rowW[1][kk] + w * rowU[1][kk];
+        }
+      }
+      if (S.has_prev && r < S.Lprev) {
+        const int ty = r / g.T;
+        for (int t = ks; t < g.nt + 1; t += 8) symv_part(r, t, ty, pA, pB);
+      }
+    }
+    slice[ks][rr][0] = pA; slice[ks][rr][1] = pB; slice[ks][rr][2] = x0; slice[ks][rr][3] = x1;
+  }
+  __syncthreads();
+  double gg[2] = {0.0, 0.0};
+  if (ks == 0 && r < S.rows) {
+    double pA = 0.0, pB = 0.0, x0 = 0.0, x1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      pA += slice[q][rr][0]; pB += slice[q][rr][1]; x0 += slice[q][rr][2]; x1 += slice[q][rr][3];
+    }
+    if (S.has_prev) {
+      const double uA = Up[(size_t)kp * ldp + r];
+      const double uB = (NB == 2) ? Up[(size_t)(kp + 1) * ldp + r] : 0.0;
+      const double yA = tm[0] * pA, yB = tm[1] * pA + tm[2] * pB;
+      double wA = yA - 0.5 * (uA * tm[3] + uB * tm[5]);
+      double wB = (NB == 2) ? yB - 0.5 * (uA * tm[4] + uB * tm[6]) : 0.0;
+      if (r >= S.Lprev) { wA = 0.0; wB = 0.0; }
+      Wp[(size_t)kp * ldp + r] = wA;
+      if (NB == 2) Wp[(size_t)(kp + 1) * ldp + r] = wB;
+      if (S.ncols > 0) {
+        x0 += uA * rowW[0][kp] + wA * rowU[0][kp];
+        if (NB == 2) x0 += uB * rowW[0][kp + 1] + wB * rowU[0][kp + 1];
+        if (S.ncols > 1) {
+          x1 += uA * rowW[1][kp] + wA * rowU[1][kp];
+          if (NB == 2) x1 += uB * rowW[1][kp + 1] + wB * rowU[1][kp + 1];
+        }
+      }
+    }
+    if (S.ncols > 0 && r <= S.i) {
+      const double xi = R.A[(size_t)S.i * R.lda + r] - x0;
+      R.X[r] = xi;
+      double xim = 0.0;
+      if (S.ncols > 1 && r <= S.i - 1) {
+        xim = R.A[(size_t)(S.i - 1) * R.lda + r] - x1;
+        R.X[ldp + r] = xim;
+      }
+      if (r < S.L) { gg[0] = xi * xi; gg[1] = xi * xim; }
+      if (r == S.i) R.d[S.i] = xi;
+      if (S.ncols > 1 && r == S.i - 1) { R.e[S.i] = xi; R.d[S.i - 1] = xim; }  // e(i,1) = A_eff(i-1,i)
+    }
+  }
+  if (S.ncols > 0) {
+    block_sum_multi<2>(gg, red);
+    if (tid == 0) { R.GP[blockIdx.x * 2 + 0] = gg[0]; R.GP[blockIdx.x * 2 + 1] = gg[1]; }
+  }
+}
+
+// =================================================================================================
+// K_M (NB=2): x1' = x1 - gamma uA ; partial norm of x1'(0:L-1) ; scalars of reflector A
+// =================================================================================================
+__global__ __launch_bounds__(256) void km_kernel(RedArgs R, int i, int L, int ngp) {
+  __shared__ double red[8];
+  const int tid = threadIdx.x;
+  double gv[2] = {0.0, 0.0};
+  for (int q = tid; q < ngp; q += 256) { gv[0] += R.GP[2 * q]; gv[1] += R.GP[2 * q + 1]; }
+  block_sum_multi<2>(gv, red);
+  const double g22 = gv[0], g12 = gv[1];
+  const double x2L = R.X[L - 1];
+  const double x1L = R.X[R.ldp + L - 1];
+  double s2 = 0.0, betaA = 0.0, gamma = 0.0;
+  if (g22 > 0.0) {
+    s2 = -sign_of(sqrt(g22), x2L);
+    betaA = g22 - s2 * x2L;
+    gamma = (g12 - s2 * x1L) / betaA;
+  } else {
+    s2 = x2L;  // = 0
+  }
+  const int r = blockIdx.x * KM_ROWS + tid;
+  double h[1] = {0.0};
+  if (r < L) {
+    const double uA = R.X[r] - (r == L - 1 ? s2 : 0.0);
+    const double x1 = R.X[R.ldp + r] - gamma * uA;
+    R.X[2 * R.ldp + r] = x1;
+    if (r < L - 1) h[0] = x1 * x1;
+    if (r == L - 1) R.e[i - 1] = x1;  // e(i-1,1) = T(i-2,i-1)
+  }
+  block_sum_multi<1>(h, red);
+  if (tid == 0) {
+    R.GP[R.gp2_off + blockIdx.x] = h[0];
+    if (blockIdx.x == 0) {
+      R.sc[SC_SA] = s2;
+      R.sc[SC_BETA_A] = betaA;
+      R.e[R.lde + i] = s2;  // e(i,2) = T(i-2,i)
+    }
+  }
+}
+
+// =================================================================================================
+// K_B : fused symmetric mat-vec on the upper triangle, NV vectors, plus (same launch, extra workgroup
+// rows) K_P : panel dot products and reflector store.
+// grid (gx, nt + npd):
+//   blockIdx.y <  nt : SYMV workgroup, tile (ty = blockIdx.y, tx = blockIdx.x), tx >= ty, T = 128*RB:
+//                      rows [ty*T, +T) x columns [tx*T, +T) of [0,L).  Wave w owns the tile columns
+//                      [w*T/4, +T/4) in groups of 8; a lane owns rows 2*lane, 2*lane+1 of each of the RB
+//                      128-row blocks (16-byte loads, 1 KiB per wave-instruction, down the columns).
+//                      Column sums: halving butterfly of wave shuffles once per column group.
+//                      Row sums: per-wave registers, combined over the 4 waves through LDS.
+//   blockIdx.y >= nt : panel workgroup, row chunk = blockIdx.y - nt, column group cg = blockIdx.x:
+//                      cg < ncg : panel columns [cg*PD_COLS, +PD_COLS) of U and W against the NV new vectors
+//                      cg == ncg: store the reflectors into the panel (both U copies) and into `a`, uA.uB
+// =================================================================================================
+struct KBArgs { int i, L, nt, ngp, k, ncg, toprows; };
+
+template <int K> struct IC { static constexpr int value = K; };
+
+template <int NV, int RB>
+__global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
+  constexpr int T = 128 * RB;
+  constexpr int DYN = (4 * NV * T > NV * PD_ROWS + NV * T) ? 4 * NV * T : NV * PD_ROWS + NV * T;
+  __shared__ __attribute__((aligned(16))) double dyn[DYN + NV * T];  // [4][NV][T] row sums | panel us ; then uc[NV][T]
+  __shared__ double red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ldp = R.ldp;
+  const int L = B.L, i = B.i;
+  const bool panel_role = (int)blockIdx.y >= B.nt;
+  if (!panel_role && ((int)blockIdx.x >= B.nt || blockIdx.x < blockIdx.y)) return;
+  if (panel_role && (int)blockIdx.x > B.ncg) return;
+
+  // ---- reflector scalars (every workgroup, same order) -------------------------------------------
+  double sA, sB = 0.0, betaA, betaB = 0.0;
+  const int pivA = L - 1, pivB = L - 2;
+  if (NV == 1) {
+    double gv[1] = {0.0};
+    for (int q = tid; q < B.ngp; q += 256) gv[0] += R.GP[2 * q];
+    block_sum_multi<1>(gv, red);
+    const double xL = R.X[L - 1];
+    if (gv[0] > 0.0) { sA = -sign_of(sqrt(gv[0]), xL); betaA = gv[0] - sA * xL; }
+    else { sA = xL; betaA = 0.0; }
+  } else {
+    sA = R.sc[SC_SA];
+    betaA = R.sc[SC_BETA_A];
+    double hv[1] = {0.0};
+    for (int q = tid; q < B.ngp; q += 256) hv[0] += R.GP[R.gp2_off + q];
+    block_sum_multi<1>(hv, red);
+    const double xL = (pivB >= 0) ? R.X[2 * ldp + pivB] : 0.0;
+    if (hv[0] > 0.0) { sB = -sign_of(sqrt(hv[0]), xL); betaB = hv[0] - sB * xL; }
+    else { sB = xL; betaB = 0.0; }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    if (NV == 1) {
+      R.sc[SC_SA] = sA; R.sc[SC_BETA_A] = betaA;
+      R.e[i] = sA;                               // e(i,1) = T(i-1,i)
+    } else {
+      R.sc[SC_SB] = sB; R.sc[SC_BETA_B] = betaB;
+      if (i - 1 >= 2) R.e[R.lde + i - 1] = sB;   // e(i-1,2) = T(i-3,i-1)
+    }
+  }
+  // u_a(j) = X_a(j) - [j == piv_a] s_a ;  uB(L-1) = 0 ; zero when the reflector is trivial or j >= L
+  auto uval = [&](int a, int j) -> double {
+    if (j >= L) return 0.0;
+    if (a == 0) return (betaA != 0.0) ? R.X[j] - (j == pivA ? sA : 0.0) : 0.0;
+    if (j >= L - 1 || betaB == 0.0) return 0.0;
+    return R.X[2 * ldp + j] - (j == pivB ? sB : 0.0);
+  };
+
+  if (panel_role) {
+    // ================================================================ K_P
+    const int m = R.m, k = B.k;
+    const int chunk = blockIdx.y - B.nt, cg = blockIdx.x;
+    const int rbase = chunk * PD_ROWS;
+    double* us = dyn;  // [NV][PD_ROWS]
+    for (int t = tid; t < PD_ROWS; t += 256) {
+      const int r = rbase + t;
+#pragma unroll
+      for (int a = 0; a < NV; ++a) us[a * PD_ROWS + t] = uval(a, r);
+    }
+    __syncthreads();
+    double* Up = R.UW;
+    double* Wp = R.UW + (size_t)ldp * m;
+    double* U2 = R.UW + (size_t)2 * ldp * m;
+    if (cg == B.ncg) {
+      double ab[1] = {0.0};
+      for (int t = tid; t < PD_ROWS; t += 256) {
+        const int r = rbase + t;
+        if (r >= B.toprows) continue;
+        const double uA = us[t];
+        const double uB = (NV == 2) ? us[(NV - 1) * PD_ROWS + t] : 0.0;
+        Up[(size_t)k * ldp + r] = uA;
+        U2[(size_t)k * ldp + r] = uA;
+        if (NV == 2) { Up[(size_t)(k + 1) * ldp + r] = uB; U2[(size_t)(k + 1) * ldp + r] = uB; }
+        if (r < L) {
+          R.A[(size_t)i * R.lda + r] = uA;
+          if (NV == 2) R.A[(size_t)(i - 1) * R.lda + r] = uB;  // row L-1 gets 0 (src/eigen_prd_t4x.F:333-343)
+        }
+        ab[0] += uA * uB;
+      }
+      if (NV == 2) {
+        block_sum_multi<1>(ab, red);
+        if (tid == 0) R.KD[R.kdab_off + chunk] = ab[0];
+      }
+      return;
+    }
+    // wave per panel column: lanes stride the chunk's rows
+    const int rows_here = (L - rbase < PD_ROWS) ? L - rbase : PD_ROWS;
+    for (int cc = wave; cc < PD_COLS; cc += 4) {
+      const int kk = cg * PD_COLS + cc;
+      if (kk >= k) break;
+      const double* ucol = Up + (size_t)kk * ldp + rbase;
+      const double* wcol = Wp + (size_t)kk * ldp + rbase;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      for (int t = lane; t < rows_here; t += 64) {
+        const double u = ucol[t], w = wcol[t];
+        const double a = us[t];
+        s0 += u * a; s1 += w * a;
+        if (NV == 2) { const double b = us[(NV - 1) * PD_ROWS + t]; s2 += u * b; s3 += w * b; }
+      }
+      s0 = wave_sum(s0); s1 = wave_sum(s1);
+      if (NV == 2) { s2 = wave_sum(s2); s3 = wave_sum(s3); }
+      if (lane == 0) {
+        double* kdp = R.KD + (size_t)chunk * 2 * NV * m;
+        kdp[0 * m + kk] = s0; kdp[1 * m + kk] = s1;
+        if (NV == 2) { kdp[2 * m + kk] = s2; kdp[3 * m + kk] = s3; }
+      }
+    }
+    return;
+  }
+
+  // ================================================================== K_B (SYMV tile)
+  const int ty = blockIdx.y, tx = blockIdx.x;
+  const int row0 = ty * T, col0 = tx * T;
+  const bool diag = (tx == ty);
+  double* yrs = dyn;            // [4 waves][NV][T]
+  double* ucs = dyn + DYN;      // [NV][T] : u_a at the tile's columns
+  for (int t = tid; t < T; t += 256) {
+#pragma unroll
+    for (int a = 0; a < NV; ++a) ucs[a * T + t] = uval(a, col0 + t);
+  }
+  __syncthreads();
+
+  double ux[NV][RB][2], yr[NV][RB][2];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int r0 = row0 + rb * 128 + lane * 2;
+#pragma unroll
+    for (int a = 0; a < NV; ++a) {
+      ux[a][rb][0] = uval(a, r0);
+      ux[a][rb][1] = uval(a, r0 + 1);
+      yr[a][rb][0] = 0.0; yr[a][rb][1] = 0.0;
+    }
+  }
+  const int wcol0 = wave * (T / 4);       // first tile column of this wave
+  constexpr int NG = T / 32;              // column groups of 8 per wave
+  double yc[NV][8];
+  double sp[3] = {0.0, 0.0, 0.0};
+
+  auto load8 = [&](double2 (&av)[8], int g, int rb) {
+    const int r0 = row0 + rb * 128 + lane * 2;
+    const bool rok = r0 < L;
+    const double* Ap = R.A + (rok ? r0 : 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = col0 + wcol0 + g * 8 + j;
+      if (rok && c < L) av[j] = *reinterpret_cast<const double2*>(Ap + (size_t)c * R.lda);
+      else av[j] = make_double2(0.0, 0.0);
+    }
+  };
+  // one unit = (column group g, row block rb): accumulate; after the last row block reduce the 8 column sums
+  auto compute8 = [&](const double2 (&av)[8], int g, auto rbc) {
+    constexpr int rb = decltype(rbc)::value;
+    const int r0 = row0 + rb * 128 + lane * 2, r1 = r0 + 1;
+    const int tc0 = wcol0 + g * 8;
+    if (rb == 0) {
+#pragma unroll
+      for (int a = 0; a < NV; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) yc[a][j] = 0.0;
+    }
+    if (!diag) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int a = 0; a < NV; ++a) {
+          const double uc = ucs[a * T + tc0 + j];
+          yr[a][rb][0] += av[j].x * uc;
+          yr[a][rb][1] += av[j].y * uc;
+          yc[a][j] += av[j].x * ux[a][rb][0] + av[j].y * ux[a][rb][1];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = col0 + tc0 + j;
+        const double ax_s = (r0 < c) ? av[j].x : 0.0, ay_s = (r1 < c) ? av[j].y : 0.0;     // strict upper
+        const double ax_d = (r0 <= c) ? av[j].x : 0.0, ay_d = (r1 <= c) ? av[j].y : 0.0;   // with diagonal
+#pragma unroll
+        for (int a = 0; a < NV; ++a) {
+          const double uc = ucs[a * T + tc0 + j];
+          yr[a][rb][0] += ax_s * uc;
+          yr[a][rb][1] += ay_s * uc;
+          yc[a][j] += ax_d * ux[a][rb][0] + ay_d * ux[a][rb][1];
+        }
+      }
+    }
+    if (rb == RB - 1) {
+      // halving butterfly: 8 column sums over 64 lanes in 4+2+1+3 shuffles
+      double fin[NV];
+#pragma unroll
+      for (int a = 0; a < NV; ++a) {
+        double v4[4], v2[2], v1;
+        const bool hi32 = lane & 32, hi16 = lane & 16, hi8 = lane & 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double keep = hi32 ? yc[a][j + 4] : yc[a][j];
+          const double send = hi32 ? yc[a][j] : yc[a][j + 4];
+          v4[j] = keep + __shfl_xor(send, 32, 64);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const double keep = hi16 ? v4[j + 2] : v4[j];
+          const double send = hi16 ? v4[j] : v4[j + 2];
+          v2[j] = keep + __shfl_xor(send, 16, 64);
+        }
+        {
+          const double keep = hi8 ? v2[1] : v2[0];
+          const double send = hi8 ? v2[0] : v2[1];
+          v1 = keep + __shfl_xor(send, 8, 64);
+        }
+        v1 += __shfl_xor(v1, 4, 64);
+        v1 += __shfl_xor(v1, 2, 64);
+        v1 += __shfl_xor(v1, 1, 64);
+        fin[a] = v1;
+      }
+      // lane with (lane&7)==0 holds column j = 4*bit5 + 2*bit4 + bit3 : complete over the tile's rows
+      if ((lane & 7) == 0) {
+        const int j = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+        const int c = col0 + tc0 + j;
+        if (c < L) {
+#pragma unroll
+          for (int a = 0; a < NV; ++a) R.YC[((size_t)ty * NV + a) * ldp + c] = fin[a];
+          const double ua = ucs[tc0 + j];
+          sp[0] += ua * fin[0];
+          if (NV == 2) { sp[1] += ua * fin[NV - 1]; sp[2] += ucs[(NV - 1) * T + tc0 + j] * fin[NV - 1]; }
+        }
+      }
+    }
+  };
+
+  // software pipeline, two units in flight, all register indices static
+  {
+    double2 av0[8], av1[8];
+    if (RB == 1) {
+      load8(av0, 0, 0);
+      for (int g = 0; g < NG; g += 2) {
+        load8(av1, g + 1, 0);
+        compute8(av0, g, IC<0>());
+        if (g + 2 < NG) load8(av0, g + 2, 0);
+        compute8(av1, g + 1, IC<0>());
+      }
+    } else if (RB == 2) {
+      load8(av0, 0, 0);
+      for (int g = 0; g < NG; ++g) {
+        load8(av1, g, 1);
+        compute8(av0, g, IC<0>());
+        if (g + 1 < NG) load8(av0, g + 1, 0);
+        compute8(av1, g, IC<(RB > 1 ? 1 : 0)>());
+      }
+    } else {
+      load8(av0, 0, 0);
+      for (int g = 0; g < NG; ++g) {
+        load8(av1, g, 1);
+        compute8(av0, g, IC<0>());
+        load8(av0, g, 2);
+        compute8(av1, g, IC<(RB > 1 ? 1 : 0)>());
+        load8(av1, g, 3);
+        compute8(av0, g, IC<(RB > 2 ? 2 : 0)>());
+        if (g + 1 < NG) load8(av0, g + 1, 0);
+        compute8(av1, g, IC<(RB > 3 ? 3 : 0)>());
+      }
+    }
+  }
+
+  // ---- row sums: combine the 4 waves through LDS; bilinear row part ----------------------------------
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+    for (int a = 0; a < NV; ++a) {
+      double* dst = yrs + ((size_t)wave * NV + a) * T + rb * 128 + lane * 2;
+      dst[0] = yr[a][rb][0];
+      dst[1] = yr[a][rb][1];
+    }
+    sp[0] += ux[0][rb][0] * yr[0][rb][0] + ux[0][rb][1] * yr[0][rb][1];
+    if (NV == 2) {
+      sp[1] += ux[0][rb][0] * yr[NV - 1][rb][0] + ux[0][rb][1] * yr[NV - 1][rb][1];
+      sp[2] += ux[NV - 1][rb][0] * yr[NV - 1][rb][0] + ux[NV - 1][rb][1] * yr[NV - 1][rb][1];
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < T; t += 256) {
+    const int r = row0 + t;
+    if (r < L) {
+#pragma unroll
+      for (int a = 0; a < NV; ++a) {
+        const double s = (yrs[((size_t)0 * NV + a) * T + t] + yrs[((size_t)1 * NV + a) * T + t]) +
+                         (yrs[((size_t)2 * NV + a) * T + t] + yrs[((size_t)3 * NV + a) * T + t]);
+        R.YR[((size_t)tx * NV + a) * ldp + r] = s;
+      }
+    }
+  }
+  block_sum_multi<3>(sp, red);
+  if (tid == 0) {
+    const size_t w = (size_t)ty * B.nt + tx;
+    R.SP[w * 3 + 0] = sp[0]; R.SP[w * 3 + 1] = sp[1]; R.SP[w * 3 + 2] = sp[2];
+  }
+}
+
+// zero-fill helper
+__global__ void fill_kernel(double* p, size_t n, double v) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+template <int NB>
+void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double* e, int lde, int m) {
+  hipStream_t st = ctx.stream;
+  if (m < NB) m = NB;
+  if (m > 256) m = 256;
+  if (NB == 2 && (m & 1)) ++m;
+  const int ldp = (n + 127) / 128 * 128 + 128;
+  RedArgs R;
+  R.A = A; R.lda = lda; R.n = n; R.ldp = ldp; R.m = m;
+  R.d = d; R.e = e; R.lde = lde;
+  int maxseg = 0;
+  for (int L = n; L >= 1; --L) {  // nt is not monotone in L: scan
+    const SymvGeom g = symv_geom(L);
+    if (g.nt > maxseg) maxseg = g.nt;
+  }
+  maxseg += 1;
+  R.maxseg = maxseg;
+  R.maxrs = maxseg;
+  R.maxchunk = (n + PD_ROWS - 1) / PD_ROWS + 1;
+  R.UW = ctx.pool.get_t<double>("red.UW", (size_t)ldp * m * 3);
+  R.X = ctx.pool.get_t<double>("red.X", (size_t)ldp * 3);
+  R.YR = ctx.pool.get_t<double>("red.YR", (size_t)maxseg * NB * ldp);
+  R.YC = ctx.pool.get_t<double>("red.YC", (size_t)R.maxrs * NB * ldp);
+  R.kdab_off = R.maxchunk * 2 * NB * m;
+  R.KD = ctx.pool.get_t<double>("red.KD", (size_t)R.kdab_off + R.maxchunk + 8);
+  R.SP = ctx.pool.get_t<double>("red.SP", (size_t)(maxseg * maxseg) * 3 + 8);
+  const int maxgp = (n + KA_ROWS - 1) / KA_ROWS + 2;
+  R.gp2_off = maxgp * 2;
+  R.GP = ctx.pool.get_t<double>("red.GP", (size_t)maxgp * 3 + 8);
+  R.sc = ctx.pool.get_t<double>("red.sc", SC_COUNT);
+  hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, st, R.UW, (size_t)ldp * m * 3, 0.0);
+  hipLaunchKernelGGL(fill_kernel, dim3(8), dim3(256), 0, st, e, (size_t)lde * NB, 0.0);
+  hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, R.sc, (size_t)SC_COUNT, 0.0);
+
+  KAArgs S;
+  S.has_prev = 0; S.iprev = 0; S.Lprev = 0; S.kprev = 0; S.nchunk_prev = 0;
+  int k = 0;        // panel fill
+  int i = n - 1;    // top column of the current block
+  double t_symv_bytes = 0.0;
+  long n_symv = 0, n_k1 = 0;
+  double k1_flops = 0.0;
+  while (true) {
+    const int L = i - NB + 1;  // rows above the block
+    const bool do_step = (L >= 1);
+    // columns to form: a full block while reflectors remain, otherwise the last <= NB columns
+    const int ncols = do_step ? NB : (i >= 0 ? (i + 1 < NB ? i + 1 : NB) : 0);
+    S.ncols = ncols;
+    S.i = i;
+    S.L = do_step ? L : 0;
+    S.k = k;
+    S.rows = i + 1;
+    if (S.has_prev && S.iprev + 1 > S.rows) S.rows = S.iprev + 1;
+    const int nb_ka = (S.rows + KA_ROWS - 1) / KA_ROWS;
+    if (S.rows > 0 && (S.has_prev || ncols > 0))
+      hipLaunchKernelGGL((ka_kernel<NB>), dim3(nb_ka), dim3(256), 0, st, R, S);
+    if (!do_step) break;
+    const SymvGeom g = symv_geom(L);
+    KBArgs B;
+    B.i = i; B.L = L; B.nt = g.nt; B.k = k;
+    B.ncg = (k + PD_COLS - 1) / PD_COLS;
+    B.toprows = i + 1;
+    const int npd = (B.toprows + PD_ROWS - 1) / PD_ROWS;
+    const int gx = g.nt > B.ncg + 1 ? g.nt : B.ncg + 1;
+    if (NB == 2) {
+      const int nbm = (L + KM_ROWS - 1) / KM_ROWS;
+      hipLaunchKernelGGL(km_kernel, dim3(nbm), dim3(256), 0, st, R, i, L, nb_ka);
+      B.ngp = nbm;
+    } else {
+      B.ngp = nb_ka;
+    }
+    if (g.T == 128) hipLaunchKernelGGL((symv_kernel<NB, 1>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
+    else if (g.T == 256) hipLaunchKernelGGL((symv_kernel<NB, 2>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
+    else hipLaunchKernelGGL((symv_kernel<NB, 4>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
+    t_symv_bytes += 8.0 * ((double)L * (L + 1) / 2);
+    ++n_symv;
+    // bookkeeping for the next K_A
+    S.has_prev = 1; S.iprev = i; S.Lprev = L; S.kprev = k;
+    S.nchunk_prev = npd;
+    k += NB;
+    i -= NB;
+    if (k >= m && i - NB + 1 >= 1) {
+      // panel full and more reflectors to come: finish W, trailing update, start a new panel
+      KAArgs F = S;
+      F.ncols = 0; F.i = i; F.L = 0; F.k = k; F.rows = S.iprev + 1;
+      hipLaunchKernelGGL((ka_kernel<NB>), dim3((F.rows + KA_ROWS - 1) / KA_ROWS), dim3(256), 0, st, R, F);
+      const int nr = i + 1;
+      dgemm_dev(st, 'N', 'T', nr, nr, 2 * m, -1.0, R.UW, ldp, R.UW + (size_t)ldp * m, ldp, 1.0, A, lda, 1,
+                &ctx.grid);
+      k1_flops += 2.0 * (double)nr * nr * m;  // 2*nr*nr*(2m)/2 : upper triangle only
+      ++n_k1;
+      hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, st, R.UW, (size_t)ldp * m * 3, 0.0);
+      S.has_prev = 0;
+      k = 0;
+    }
+  }
+  EIGX_HIP_CHECK(hipGetLastError());
+  ctx.timers[6] = (double)n_k1;
+  ctx.timers[7] = k1_flops;
+  ctx.timers[9] = (double)n_symv;
+  ctx.timers[10] = t_symv_bytes;
+}
+
+}  // namespace
+
+void band_reduce_dev(Context& ctx, int n, double* A, int lda, double* d, double* e, int lde, int m, int band) {
+  if (band == 1) band_reduce_impl<1>(ctx, n, A, lda, d, e, lde, m);
+  else band_reduce_impl<2>(ctx, n, A, lda, d, e, lde, m);
+}
+
+}  // namespace eigx

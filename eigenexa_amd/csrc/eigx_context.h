@@ -54,6 +54,9 @@ int comm_get_unique_id(void* out128);
 int comm_init(Context& ctx, const void* unique_id);
 void comm_free(Context& ctx);
 
+// band_reduce.hip: A (upper triangle) -> band (d, e(:,1..band)); reflectors left in A's columns
+void band_reduce_dev(Context& ctx, int n, double* A, int lda, double* d, double* e, int lde, int m, int band);
+
 // solver.hip
 int64_t solver_workspace_bytes(const Context& ctx, int n, int lda, int ldz, int mf, int mb);
 
