@@ -1,0 +1,698 @@
+// dc.hip -- divide and conquer for the symmetric band matrix (half-bandwidth 1 or 2), gfx950.
+//
+// Replaces (reference paths relative to RIKEN-RCCS/EigenExa 2.13):
+//   band=1 : eigen_dc2 / MX_PDSTEDC / MX_PDLAED0-3,Z      src/dc2.F, src/mx_pd*.F
+//            dc2_FS / FS_EDC / FS_PDLAED0-3 / FS_PDLAEDZ   src/dc2_FS.F, src/FS_*.F90
+//   band=2 : eigen_dcx / MY_PDSxEDC / MY_PDLAED0-3,Z       src/dcx.F:81-337, src/my_pd*.F
+//            (tear = SVD of the 2x2 coupling block, one rank-one merge per singular triplet,
+//             src/my_pdlaed0.F:213-266, :312-408)
+//   leaves : LAPACK_EIGEN2/DSYEVD src/lapack_eigen.F:31-61, DSTEQR src/mx_pdlaed0.F:182,
+//            DSTEDC src/FS_PDLAED0.F90:178
+//   sort   : MY_PDLASRT src/my_pdlasrt.F, FS_PDLASRT src/FS_PDLASRT.F90
+//
+// MI355X design: the whole tree lives on one GPU; Q (n x n) is block diagonal at every height, so a
+// height is processed as one batch:
+//   leaves         one workgroup per leaf: parallel cyclic Jacobi on the dense <=64x64 block in LDS
+//   z = Q^T w      gather of <= 4 rows of Q per merge
+//   deflation      the one inherently serial scan (DLAED2 logic: src/FS_PDLAED2.F90:232-233 tolerance,
+//                  :348-383 Givens) runs on the host on 2n doubles per height (the only host round trip)
+//   rotations      Givens rotations of eigenvector columns, one thread per row
+//   secular eq.    one thread per root, middle-way rational iteration + bisection safeguard
+//                  (role of DLAED4 at src/my_pdlaed3.F:276,490, src/FS_PDLAED3.F90:281,700,795)
+//   Loewner        Gu-Eisenstat z-hat: one wave per pole, product over the roots
+//   eigenvectors   one thread per root, normalised columns of S
+//   Q <- Q S       fp64 MFMA GEMM with a column-gather map on A (non-deflated columns) so that no
+//                  pack / permute pass touches HBM (role of PDGEMM src/my_pdlaed1.F:310-341 and of the
+//                  DGEMM ring src/FS_PDLAED3.F90:833-860)
+//   eigenvalues stay unsorted between merges (the next deflation sorts anyway); one final sort +
+//   column permutation writes z.
+#include "eigx_context.h"
+#include "../../include/eigenexa_amd.h"
+#include <algorithm>
+#include <cfloat>
+#include <cstring>
+
+namespace eigx {
+
+namespace {
+
+constexpr int LEAF = 64;
+
+// ================================================================================================
+// leaves: cyclic Jacobi with round-robin pairing, one workgroup per leaf
+// ================================================================================================
+__global__ __launch_bounds__(256) void jacobi_leaf_kernel(const double* __restrict__ d,
+                                                          const double* __restrict__ e, int lde, int band,
+                                                          const int* __restrict__ leaf_off,
+                                                          const int* __restrict__ leaf_n, double* __restrict__ D,
+                                                          double* __restrict__ Q, int ldq) {
+  __shared__ double A[LEAF][LEAF + 1];
+  __shared__ double V[LEAF][LEAF + 1];
+  __shared__ double cs[LEAF / 2][2];
+  __shared__ int pq[LEAF / 2][2];
+  __shared__ int nrot;
+  __shared__ double anorm_s;
+  __shared__ int perm[LEAF];
+  const int tid = threadIdx.x;
+  const int off = leaf_off[blockIdx.x], m = leaf_n[blockIdx.x];
+  for (int idx = tid; idx < LEAF * LEAF; idx += 256) {
+    const int r = idx / LEAF, c = idx % LEAF;
+    double v = 0.0;
+    if (r < m && c < m) {
+      const int lo = r < c ? r : c, hi = r < c ? c : r;
+      const int dist = hi - lo;
+      if (dist == 0) v = d[off + r];
+      else if (dist <= band) v = e[(size_t)(dist - 1) * lde + off + hi];  // e(hi, dist) = T(hi-dist, hi)
+    }
+    A[r][c] = v;
+    V[r][c] = (r == c) ? 1.0 : 0.0;
+  }
+  if (tid == 0) anorm_s = 0.0;
+  __syncthreads();
+  {
+    double mx = 0.0;
+    for (int idx = tid; idx < m * m; idx += 256) mx = fmax(mx, fabs(A[idx / m][idx % m]));
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0) atomicMax((unsigned long long*)&anorm_s, (unsigned long long)__double_as_longlong(mx));
+  }
+  __syncthreads();
+  const double thr = 2e-18 * anorm_s;
+  const int m2 = m + (m & 1);
+  const int np = m2 / 2;
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    if (tid == 0) nrot = 0;
+    __syncthreads();
+    for (int rnd = 0; rnd < m2 - 1; ++rnd) {
+      if (tid < np) {
+        int p, q;
+        if (tid == 0) { p = m2 - 1; q = rnd; }
+        else { p = (rnd + tid) % (m2 - 1); q = (rnd - tid + (m2 - 1)) % (m2 - 1); }
+        if (p > q) { const int t = p; p = q; q = t; }
+        double c = 1.0, s = 0.0;
+        if (q < m) {
+          const double apq = A[p][q];
+          if (fabs(apq) > thr) {
+            const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+            const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            c = 1.0 / sqrt(t * t + 1.0);
+            s = t * c;
+            atomicAdd(&nrot, 1);
+          }
+        }
+        cs[tid][0] = c; cs[tid][1] = s;
+        pq[tid][0] = p; pq[tid][1] = q;
+      }
+      __syncthreads();
+      // columns: A <- A J, V <- V J
+      for (int idx = tid; idx < np * m; idx += 256) {
+        const int t = idx / m, k = idx - t * m;
+        const double c = cs[t][0], s = cs[t][1];
+        if (s != 0.0) {
+          const int p = pq[t][0], q = pq[t][1];
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - s * akq;
+          A[k][q] = s * akp + c * akq;
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+      __syncthreads();
+      // rows: A <- J^T A
+      for (int idx = tid; idx < np * m; idx += 256) {
+        const int t = idx / m, k = idx - t * m;
+        const double c = cs[t][0], s = cs[t][1];
+        if (s != 0.0) {
+          const int p = pq[t][0], q = pq[t][1];
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - s * aqk;
+          A[q][k] = s * apk + c * aqk;
+        }
+      }
+      __syncthreads();
+    }
+    if (nrot == 0) break;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    for (int j = 0; j < m; ++j) perm[j] = j;
+    for (int j = 1; j < m; ++j) {  // insertion sort by eigenvalue
+      const int pj = perm[j];
+      const double v = A[pj][pj];
+      int t = j - 1;
+      while (t >= 0 && A[perm[t]][perm[t]] > v) { perm[t + 1] = perm[t]; --t; }
+      perm[t + 1] = pj;
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < m; j += 256) D[off + j] = A[perm[j]][perm[j]];
+  __syncthreads();
+  // one Newton-Schulz step V <- V - V (V^T V - I)/2 : removes the O(sqrt(#rotations) eps) loss of
+  // orthogonality that the rotation products accumulate (A is free now and holds E = V^T V - I)
+  for (int idx = tid; idx < m * m; idx += 256) {
+    const int r = idx / m, c = idx - r * m;
+    double acc = 0.0;
+    for (int k = 0; k < m; ++k) acc += V[k][r] * V[k][c];
+    A[r][c] = acc - (r == c ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < m * m; idx += 256) {
+    const int j = idx / m, r = idx - j * m;
+    const int pj = perm[j];
+    double acc = 0.0;
+    for (int k = 0; k < m; ++k) acc += V[r][k] * A[k][pj];
+    Q[(size_t)(off + j) * ldq + off + r] = V[r][pj] - 0.5 * acc;
+  }
+}
+
+// ================================================================================================
+// per-merge descriptors (device arrays, one entry per merge of the current height)
+// ================================================================================================
+struct MergeDev {
+  int off, nm, n1, K;
+  int rot_beg, rot_end;
+  double rho;
+  double wv[4];  // weights of rows off+n1-band .. off+n1+band-1 in z = Q^T w
+};
+
+__global__ void zgather_kernel(const MergeDev* __restrict__ md, int band, const double* __restrict__ Q, int ldq,
+                               double* __restrict__ z) {
+  const MergeDev M = md[blockIdx.y];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= M.nm) return;
+  const double* col = Q + (size_t)(M.off + j) * ldq + M.off + M.n1 - band;
+  double acc = 0.0;
+  for (int t = 0; t < 2 * band; ++t) acc += M.wv[t] * col[t];
+  z[M.off + j] = acc;
+}
+
+__global__ void rotate_kernel(const MergeDev* __restrict__ md, const int* __restrict__ rpj,
+                              const int* __restrict__ rjj, const double* __restrict__ rc,
+                              const double* __restrict__ rsn, double* __restrict__ Q, int ldq) {
+  const MergeDev M = md[blockIdx.y];
+  if (M.rot_end <= M.rot_beg) return;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= M.nm) return;
+  double* row = Q + M.off + r;
+  for (int t = M.rot_beg; t < M.rot_end; ++t) {
+    const size_t cp = (size_t)rpj[t] * ldq, cj = (size_t)rjj[t] * ldq;
+    const double c = rc[t], s = rsn[t];
+    const double x = row[cp], y = row[cj];
+    row[cp] = c * x + s * y;
+    row[cj] = c * y - s * x;
+  }
+}
+
+// ================================================================================================
+// secular equation: one thread per root.  f(x) = 1/rho + sum_i z_i^2/(d_i - x), d ascending, ||z|| = 1.
+// Writes lambda_j to Dn[off+j] and S'(j,i) = d_i - lambda_j (root index contiguous).
+// ================================================================================================
+__global__ __launch_bounds__(128) void secular_kernel(const MergeDev* __restrict__ md,
+                                                      const double* __restrict__ dlam,
+                                                      const double* __restrict__ wz, double* __restrict__ Dn,
+                                                      double* __restrict__ S, int lds) {
+  const MergeDev M = md[blockIdx.y];
+  const int K = M.K;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  const double* __restrict__ d = dlam + M.off;
+  const double* __restrict__ z = wz + M.off;
+  double* Sp = S + (size_t)M.off * lds + M.off;  // S'(j,i) at Sp[j + i*lds]
+  const double rho = M.rho, rhoinv = 1.0 / rho;
+  const double eps = DBL_EPSILON / 2.0;
+  if (K == 1) {
+    const double t = rho * z[0] * z[0];
+    Dn[M.off] = d[0] + t;
+    Sp[0] = -t;
+    return;
+  }
+  const bool last = (j == K - 1);
+  const int jl = last ? K - 2 : j, jr = jl + 1;
+  double origin, lo, hi, tau;
+  {
+    const double gap = last ? rho : d[j + 1] - d[j];
+    const double mid = last ? d[K - 1] + 0.5 * rho : 0.5 * (d[j] + d[j + 1]);
+    double c = rhoinv;
+    for (int i = 0; i < K; ++i)
+      if (i != jl && i != jr) c += z[i] * z[i] / (d[i] - mid);
+    const double zl2 = z[jl] * z[jl], zr2 = z[jr] * z[jr];
+    const double fmid = c + zl2 / (d[jl] - mid) + zr2 / (d[jr] - mid);
+    int org;
+    if (last) { org = K - 1; if (fmid <= 0.0) { lo = 0.5 * gap; hi = gap; } else { lo = 0.0; hi = 0.5 * gap; } }
+    else if (fmid > 0.0) { org = j; lo = 0.0; hi = 0.5 * gap; }
+    else { org = j + 1; lo = -0.5 * gap; hi = 0.0; }
+    origin = d[org];
+    const double dl = d[jl] - origin, dr = d[jr] - origin;
+    const double qa = c, qb = -(c * (dl + dr) + zl2 + zr2), qc = c * dl * dr + zl2 * dr + zr2 * dl;
+    tau = 0.5 * (lo + hi);
+    const double disc = qb * qb - 4.0 * qa * qc;
+    if (disc >= 0.0) {
+      const double sq = sqrt(disc);
+      const double qq = -0.5 * (qb + (qb >= 0.0 ? sq : -sq));
+      const double r1 = (qa != 0.0) ? qq / qa : NAN, r2 = (qq != 0.0) ? qc / qq : NAN;
+      if (r1 > lo && r1 < hi) tau = r1;
+      else if (r2 > lo && r2 < hi) tau = r2;
+    }
+  }
+  for (int iter = 0; iter < 100; ++iter) {
+    double psi = 0.0, dpsi = 0.0, phi = 0.0, dphi = 0.0, err = 0.0;
+    for (int i = 0; i <= jl; ++i) {
+      const double t = z[i] / ((d[i] - origin) - tau);
+      psi += z[i] * t; dpsi += t * t; err += psi;
+    }
+    err = fabs(err);
+    for (int i = K - 1; i > jl; --i) {
+      const double t = z[i] / ((d[i] - origin) - tau);
+      phi += z[i] * t; dphi += t * t; err += fabs(phi);
+    }
+    const double wv = rhoinv + phi + psi;
+    err = 8.0 * (fabs(phi) + fabs(psi)) + err + 2.0 * rhoinv + fabs(tau) * (dpsi + dphi);
+    if (fabs(wv) <= eps * err) break;
+    if (wv < 0.0) lo = tau; else hi = tau;
+    const double Dl = (d[jl] - origin) - tau, Dr = (d[jr] - origin) - tau;
+    const double aa = (Dl + Dr) * wv - Dl * Dr * (dpsi + dphi);
+    const double bb = Dl * Dr * wv;
+    const double cc = wv - Dl * dpsi - Dr * dphi;
+    double eta;
+    {
+      double disc = aa * aa - 4.0 * bb * cc;
+      if (disc < 0.0) disc = 0.0;
+      const double sq = sqrt(disc);
+      if (cc == 0.0) eta = (aa != 0.0) ? bb / aa : 0.0;
+      else if (aa <= 0.0) eta = (aa - sq) / (2.0 * cc);
+      else eta = 2.0 * bb / (aa + sq);
+    }
+    if (wv * eta >= 0.0) eta = -wv / (dpsi + dphi);
+    double tnew = tau + eta;
+    if (!(tnew > lo && tnew < hi)) tnew = 0.5 * (lo + hi);
+    if (tnew == tau) break;
+    tau = tnew;
+  }
+  Dn[M.off + j] = origin + tau;
+  for (int i = 0; i < K; ++i) Sp[j + (size_t)i * lds] = (d[i] - origin) - tau;
+}
+
+// Gu-Eisenstat: zhat_i^2 = prod_j (lam_j - d_i) / prod_{j != i} (d_j - d_i); one wave per pole i
+__global__ __launch_bounds__(256) void loewner_kernel(const MergeDev* __restrict__ md,
+                                                      const double* __restrict__ dlam,
+                                                      const double* __restrict__ wz, const double* __restrict__ S,
+                                                      int lds, double* __restrict__ zh) {
+  const MergeDev M = md[blockIdx.y];
+  const int K = M.K;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= K) return;
+  const double* d = dlam + M.off;
+  const double* Sp = S + (size_t)M.off * lds + M.off + (size_t)i * lds;  // S'(:, i)
+  const double di = d[i];
+  double prod = 1.0;
+  for (int j = lane; j < K; j += 64) {
+    const double num = -Sp[j];
+    prod *= (j == i) ? num : num / (d[j] - di);
+  }
+  for (int o = 32; o > 0; o >>= 1) prod *= __shfl_xor(prod, o, 64);
+  if (lane == 0) {
+    const double v = sqrt(fabs(prod));
+    zh[M.off + i] = (wz[M.off + i] >= 0.0) ? v : -v;
+  }
+}
+
+// eigenvectors of the rank-one problem: S'(j,i) <- zhat_i / (d_i - lam_j), normalised over i
+__global__ __launch_bounds__(128) void vectors_kernel(const MergeDev* __restrict__ md, const double* __restrict__ zh,
+                                                      double* __restrict__ S, int lds) {
+  const MergeDev M = md[blockIdx.y];
+  const int K = M.K;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  double* Sp = S + (size_t)M.off * lds + M.off + j;
+  const double* zz = zh + M.off;
+  double nrm = 0.0;
+  for (int i = 0; i < K; ++i) {
+    const double v = zz[i] / Sp[(size_t)i * lds];
+    Sp[(size_t)i * lds] = v;
+    nrm += v * v;
+  }
+  const double sc = 1.0 / sqrt(nrm);
+  for (int i = 0; i < K; ++i) Sp[(size_t)i * lds] *= sc;
+}
+
+// copy deflated columns Qa(:, src) -> Qb(:, dst) on the merge's row range
+__global__ void copycols_kernel(const int* __restrict__ src, const int* __restrict__ dst,
+                                const int* __restrict__ row0, const int* __restrict__ nrows,
+                                const double* __restrict__ Qa, double* __restrict__ Qb, int ldq) {
+  const int p = blockIdx.x;
+  const double* s = Qa + (size_t)src[p] * ldq + row0[p];
+  double* t = Qb + (size_t)dst[p] * ldq + row0[p];
+  for (int r = threadIdx.x; r < nrows[p]; r += blockDim.x) t[r] = s[r];
+}
+
+// final: z(:, p) = Q(:, perm[p]), w[p] = scale * D[perm[p]]
+__global__ void final_permute_kernel(const int* __restrict__ perm, const double* __restrict__ Q, int ldq, int n,
+                                     double* __restrict__ Z, int ldz, int nvec) {
+  const int p = blockIdx.y;
+  if (p >= nvec) return;
+  const double* s = Q + (size_t)perm[p] * ldq;
+  double* t = Z + (size_t)p * ldz;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) t[r] = s[r];
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+struct Node {
+  int off, n;
+  int left = -1, right = -1;  // children (node indices), -1 for a leaf
+  int height = 0;
+  int n1 = 0;
+  double sig[2] = {0, 0};
+  double wv[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+};
+
+// SVD of the band x band upper-triangular-in-(r<=c) coupling block, C = sum sig_k x_k y_k^T
+// (role of DGESVD at src/my_pdlaed0.F:226,353)
+void svd2(int band, const double* c, double* sig, double* x, double* y) {
+  if (band == 1) { sig[0] = fabs(c[0]); x[0] = (c[0] >= 0) ? 1.0 : -1.0; y[0] = 1.0; return; }
+  const double c00 = c[0], c10 = c[1], c01 = c[2], c11 = c[3];
+  const double g00 = c00 * c00 + c10 * c10, g01 = c00 * c01 + c10 * c11, g11 = c01 * c01 + c11 * c11;
+  double cs = 1.0, sn = 0.0;
+  if (g01 != 0.0) {
+    const double theta = (g11 - g00) / (2.0 * g01);
+    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    cs = 1.0 / sqrt(t * t + 1.0);
+    sn = t * cs;
+  }
+  const double ys[2][2] = {{cs, -sn}, {sn, cs}};
+  for (int k = 0; k < 2; ++k) {
+    const double u0 = c00 * ys[k][0] + c01 * ys[k][1], u1 = c10 * ys[k][0] + c11 * ys[k][1];
+    const double s = hypot(u0, u1);
+    sig[k] = s;
+    y[2 * k] = ys[k][0]; y[2 * k + 1] = ys[k][1];
+    if (s > 0.0) { x[2 * k] = u0 / s; x[2 * k + 1] = u1 / s; } else { x[2 * k] = 0.0; x[2 * k + 1] = 0.0; }
+  }
+}
+
+struct HostDC {
+  int n, band, lde;
+  std::vector<double> d, e;  // host copies, torn in place
+  std::vector<Node> nodes;
+  double& E(int i, int b) { return e[(size_t)(b - 1) * lde + i]; }
+
+  int build(int off, int nn) {
+    const int id = (int)nodes.size();
+    nodes.push_back(Node());
+    nodes[id].off = off; nodes[id].n = nn;
+    if (nn <= LEAF) return id;
+    const int n1 = nn / 2;
+    nodes[id].n1 = n1;
+    double c[4] = {0, 0, 0, 0}, sig[2] = {0, 0}, x[4] = {0, 0, 0, 0}, y[4] = {0, 0, 0, 0};
+    for (int r = 0; r < band; ++r)
+      for (int cc = r; cc < band; ++cc) {
+        const int gi = off + n1 + r, gj = off + n1 - band + cc;
+        c[r + band * cc] = E(gi, gi - gj);
+      }
+    svd2(band, c, sig, x, y);
+    for (int k = 0; k < band; ++k) {
+      for (int r = 0; r < band; ++r)
+        for (int cc = 0; cc < band; ++cc) {
+          const int i1 = off + n1 - band + r, j1 = off + n1 - band + cc;
+          const double v1 = sig[k] * y[band * k + r] * y[band * k + cc];
+          if (i1 == j1) d[i1] -= v1; else if (i1 < j1) E(j1, j1 - i1) -= v1;
+          const int i2 = off + n1 + r, j2 = off + n1 + cc;
+          const double v2 = sig[k] * x[band * k + r] * x[band * k + cc];
+          if (i2 == j2) d[i2] -= v2; else if (i2 < j2) E(j2, j2 - i2) -= v2;
+        }
+      nodes[id].sig[k] = sig[k];
+      for (int r = 0; r < band; ++r) {
+        nodes[id].wv[k][r] = y[band * k + r];
+        nodes[id].wv[k][band + r] = x[band * k + r];
+      }
+    }
+    const int l = build(off, n1);
+    const int r = build(off + n1, nn - n1);
+    nodes[id].left = l; nodes[id].right = r;
+    nodes[id].height = 1 + std::max(nodes[l].height, nodes[r].height);
+    return id;
+  }
+};
+
+// host deflation of one merge (DLAED2 logic).  Works on global-index arrays.
+struct DeflOut {
+  int K = 0;
+  double rho = 0.0;
+};
+
+}  // namespace
+
+void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const double* e_dev, int lde, int band,
+                 double* w_dev, double* z_dev, int ldz) {
+  hipStream_t st = ctx.stream;
+  const double eps = DBL_EPSILON / 2.0;
+  HostDC H;
+  H.n = n; H.band = band; H.lde = lde;
+  H.d.resize(n);
+  H.e.resize((size_t)lde * band);
+  EIGX_HIP_CHECK(hipMemcpyAsync(H.d.data(), d_dev, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  EIGX_HIP_CHECK(hipMemcpyAsync(H.e.data(), e_dev, (size_t)lde * band * 8, hipMemcpyDeviceToHost, st));
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  // scale to unit max-norm (MY_PDSxEDC scales by the DLANST norm, src/my_pdsxedc.F:277-290)
+  double nrm = 0.0;
+  for (int i = 0; i < n; ++i) {
+    nrm = std::max(nrm, fabs(H.d[i]));
+    for (int b = 1; b <= band; ++b) if (i >= b) nrm = std::max(nrm, fabs(H.E(i, b)));
+  }
+  const double scl = nrm > 0.0 ? 1.0 / nrm : 1.0;
+  for (int i = 0; i < n; ++i) {
+    H.d[i] *= scl;
+    for (int b = 1; b <= band; ++b) H.E(i, b) = (i >= b) ? H.E(i, b) * scl : 0.0;
+  }
+  H.nodes.reserve(2 * (n / (LEAF / 2) + 2));
+  const int root = H.build(0, n);
+  const int maxh = H.nodes[root].height;
+
+  // ---- device workspace --------------------------------------------------------------------------
+  const int ldq = (n + 31) / 32 * 32;
+  double* Qa = ctx.pool.get_t<double>("dc.Qa", (size_t)ldq * n);
+  double* Qb = ctx.pool.get_t<double>("dc.Qb", (size_t)ldq * n);
+  double* S = ctx.pool.get_t<double>("dc.S", (size_t)ldq * n);
+  double* dd = ctx.pool.get_t<double>("dc.d", (size_t)n);
+  double* de = ctx.pool.get_t<double>("dc.e", (size_t)lde * band);
+  double* Dcur = ctx.pool.get_t<double>("dc.D", (size_t)n);
+  double* zbuf = ctx.pool.get_t<double>("dc.z", (size_t)n);
+  double* dlam = ctx.pool.get_t<double>("dc.dlam", (size_t)n);
+  double* wz = ctx.pool.get_t<double>("dc.wz", (size_t)n);
+  double* zh = ctx.pool.get_t<double>("dc.zh", (size_t)n);
+  int* ibuf = ctx.pool.get_t<int>("dc.ibuf", (size_t)8 * n + 64);
+  double* rbuf = ctx.pool.get_t<double>("dc.rbuf", (size_t)2 * n + 64);
+  const int maxmerge = n / (LEAF / 2) + 8;
+  MergeDev* md_dev = ctx.pool.get_t<MergeDev>("dc.md", (size_t)maxmerge);
+  int* leafinfo = ctx.pool.get_t<int>("dc.leaf", (size_t)2 * maxmerge);
+  // int sub-buffers
+  int* nd_dev = ibuf;               // [n] non-deflated column (global) per merge range, dlam order
+  int* rpj_dev = ibuf + n;          // [n]
+  int* rjj_dev = ibuf + 2 * n;      // [n]
+  int* cps_dev = ibuf + 3 * n;      // [n] copy src
+  int* cpd_dev = ibuf + 4 * n;      // [n] copy dst
+  int* cpr_dev = ibuf + 5 * n;      // [n] copy row0
+  int* cpn_dev = ibuf + 6 * n;      // [n] copy nrows
+  int* perm_dev = ibuf + 7 * n;     // [n]
+  double* rc_dev = rbuf;            // [n]
+  double* rs_dev = rbuf + n;        // [n]
+
+  EIGX_HIP_CHECK(hipMemcpyAsync(dd, H.d.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+  EIGX_HIP_CHECK(hipMemcpyAsync(de, H.e.data(), (size_t)lde * band * 8, hipMemcpyHostToDevice, st));
+  EIGX_HIP_CHECK(hipMemsetAsync(Qa, 0, (size_t)ldq * n * 8, st));
+
+  // ---- leaves ---------------------------------------------------------------------------------------
+  {
+    std::vector<int> lo, ln;
+    for (const Node& nd : H.nodes)
+      if (nd.left < 0) { lo.push_back(nd.off); ln.push_back(nd.n); }
+    const int nl = (int)lo.size();
+    std::vector<int> both(lo);
+    both.insert(both.end(), ln.begin(), ln.end());
+    EIGX_HIP_CHECK(hipMemcpyAsync(leafinfo, both.data(), (size_t)2 * nl * 4, hipMemcpyHostToDevice, st));
+    EIGX_HIP_CHECK(hipStreamSynchronize(st));  // `both` is a stack vector
+    hipLaunchKernelGGL(jacobi_leaf_kernel, dim3(nl), dim3(256), 0, st, dd, de, lde, band, leafinfo, leafinfo + nl,
+                       Dcur, Qa, ldq);
+  }
+
+  // ---- merges, height by height ---------------------------------------------------------------------
+  std::vector<double> Dh(n), zhost(n), Dnew(n), dl_h(n), wz_h(n), rc_h(n), rs_h(n);
+  std::vector<int> nd_h(n), rpj_h(n), rjj_h(n), cps_h(n), cpd_h(n), cpr_h(n), cpn_h(n);
+  std::vector<MergeDev> mds;
+  std::vector<std::pair<double, int>> ord;
+  double gemm_flops = 0.0;
+  for (int h = 1; h <= maxh; ++h) {
+    std::vector<int> ids;
+    for (int id = 0; id < (int)H.nodes.size(); ++id)
+      if (H.nodes[id].left >= 0 && H.nodes[id].height == h) ids.push_back(id);
+    if (ids.empty()) continue;
+    for (int k = 0; k < band; ++k) {
+      // -- z = Q^T w ------------------------------------------------------------------------------------
+      mds.assign(ids.size(), MergeDev());
+      int maxnm = 0;
+      for (size_t q = 0; q < ids.size(); ++q) {
+        const Node& nd = H.nodes[ids[q]];
+        MergeDev& M = mds[q];
+        M.off = nd.off; M.nm = nd.n; M.n1 = nd.n1; M.K = 0; M.rot_beg = 0; M.rot_end = 0; M.rho = nd.sig[k];
+        for (int t = 0; t < 4; ++t) M.wv[t] = nd.wv[k][t];
+        maxnm = std::max(maxnm, nd.n);
+      }
+      EIGX_HIP_CHECK(hipMemcpyAsync(md_dev, mds.data(), mds.size() * sizeof(MergeDev), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(zgather_kernel, dim3((maxnm + 255) / 256, (unsigned)ids.size()), dim3(256), 0, st, md_dev,
+                         band, Qa, ldq, zbuf);
+      EIGX_HIP_CHECK(hipMemcpyAsync(zhost.data(), zbuf, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+      EIGX_HIP_CHECK(hipMemcpyAsync(Dh.data(), Dcur, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+      EIGX_HIP_CHECK(hipStreamSynchronize(st));
+      // -- host deflation -------------------------------------------------------------------------------
+      int nrot = 0, ncopy = 0;
+      Dnew = Dh;
+      for (size_t q = 0; q < ids.size(); ++q) {
+        MergeDev& M = mds[q];
+        const int off = M.off, nm = M.nm;
+        double* dloc = &Dh[off];
+        double* zloc = &zhost[off];
+        double zn = 0.0;
+        for (int i = 0; i < nm; ++i) zn += zloc[i] * zloc[i];
+        zn = sqrt(zn);
+        double rho = M.rho;
+        M.rot_beg = nrot;
+        int K = 0;
+        // output slots: roots first, then deflated columns
+        std::vector<int> defl;
+        if (zn > 0.0 && rho > 0.0) {
+          for (int i = 0; i < nm; ++i) zloc[i] /= zn;
+          rho *= zn * zn;
+          ord.resize(nm);
+          double dmax = 0.0, zmax = 0.0;
+          for (int i = 0; i < nm; ++i) {
+            ord[i] = std::make_pair(dloc[i], i);
+            dmax = std::max(dmax, fabs(dloc[i]));
+            zmax = std::max(zmax, fabs(zloc[i]));
+          }
+          std::sort(ord.begin(), ord.end());
+          const double tol = 8.0 * eps * std::max(dmax, zmax);
+          if (rho * zmax > tol) {
+            int pj = -1;
+            for (int t = 0; t < nm; ++t) {
+              const int jj = ord[t].second;
+              if (rho * fabs(zloc[jj]) <= tol) { defl.push_back(jj); continue; }
+              if (pj < 0) { pj = jj; continue; }
+              double s = zloc[pj], c = zloc[jj];
+              const double tau = hypot(c, s);
+              const double tt = dloc[jj] - dloc[pj];
+              c /= tau; s = -s / tau;
+              if (fabs(tt * c * s) <= tol) {
+                zloc[jj] = tau; zloc[pj] = 0.0;
+                rpj_h[nrot] = off + pj; rjj_h[nrot] = off + jj; rc_h[nrot] = c; rs_h[nrot] = s;
+                ++nrot;
+                const double dp = dloc[pj] * c * c + dloc[jj] * s * s;
+                dloc[jj] = dloc[pj] * s * s + dloc[jj] * c * c;
+                dloc[pj] = dp;
+                defl.push_back(pj);
+                pj = jj;
+              } else {
+                nd_h[off + K] = off + pj;
+                ++K;
+                pj = jj;
+              }
+            }
+            if (pj >= 0) { nd_h[off + K] = off + pj; ++K; }
+          } else {
+            for (int i = 0; i < nm; ++i) defl.push_back(i);
+          }
+        } else {
+          for (int i = 0; i < nm; ++i) defl.push_back(i);
+        }
+        M.rot_end = nrot;
+        // poles in strictly ascending order
+        for (int t = 0; t < K; ++t) { dl_h[off + t] = dloc[nd_h[off + t] - off]; wz_h[off + t] = zloc[nd_h[off + t] - off]; }
+        for (int t = 1; t < K; ++t) {
+          int u = t;
+          while (u > 0 && dl_h[off + u] < dl_h[off + u - 1]) {
+            std::swap(dl_h[off + u], dl_h[off + u - 1]);
+            std::swap(wz_h[off + u], wz_h[off + u - 1]);
+            std::swap(nd_h[off + u], nd_h[off + u - 1]);
+            --u;
+          }
+        }
+        M.K = K;
+        M.rho = rho;
+        // deflated columns go behind the K roots
+        for (size_t t = 0; t < defl.size(); ++t) {
+          const int src = off + defl[t], dst = off + K + (int)t;
+          cps_h[ncopy] = src; cpd_h[ncopy] = dst; cpr_h[ncopy] = off; cpn_h[ncopy] = nm;
+          ++ncopy;
+          Dnew[dst] = dloc[defl[t]];
+        }
+        for (int t = 0; t < K; ++t) Dnew[off + t] = 0.0;  // overwritten by the secular kernel
+      }
+      // -- upload and run the GPU part ---------------------------------------------------------------------
+      EIGX_HIP_CHECK(hipMemcpyAsync(md_dev, mds.data(), mds.size() * sizeof(MergeDev), hipMemcpyHostToDevice, st));
+      EIGX_HIP_CHECK(hipMemcpyAsync(nd_dev, nd_h.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+      EIGX_HIP_CHECK(hipMemcpyAsync(dlam, dl_h.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+      EIGX_HIP_CHECK(hipMemcpyAsync(wz, wz_h.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+      EIGX_HIP_CHECK(hipMemcpyAsync(Dcur, Dnew.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+      if (nrot > 0) {
+        EIGX_HIP_CHECK(hipMemcpyAsync(rpj_dev, rpj_h.data(), (size_t)nrot * 4, hipMemcpyHostToDevice, st));
+        EIGX_HIP_CHECK(hipMemcpyAsync(rjj_dev, rjj_h.data(), (size_t)nrot * 4, hipMemcpyHostToDevice, st));
+        EIGX_HIP_CHECK(hipMemcpyAsync(rc_dev, rc_h.data(), (size_t)nrot * 8, hipMemcpyHostToDevice, st));
+        EIGX_HIP_CHECK(hipMemcpyAsync(rs_dev, rs_h.data(), (size_t)nrot * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(rotate_kernel, dim3((maxnm + 255) / 256, (unsigned)ids.size()), dim3(256), 0, st, md_dev,
+                           rpj_dev, rjj_dev, rc_dev, rs_dev, Qa, ldq);
+      }
+      if (ncopy > 0) {
+        EIGX_HIP_CHECK(hipMemcpyAsync(cps_dev, cps_h.data(), (size_t)ncopy * 4, hipMemcpyHostToDevice, st));
+        EIGX_HIP_CHECK(hipMemcpyAsync(cpd_dev, cpd_h.data(), (size_t)ncopy * 4, hipMemcpyHostToDevice, st));
+        EIGX_HIP_CHECK(hipMemcpyAsync(cpr_dev, cpr_h.data(), (size_t)ncopy * 4, hipMemcpyHostToDevice, st));
+        EIGX_HIP_CHECK(hipMemcpyAsync(cpn_dev, cpn_h.data(), (size_t)ncopy * 4, hipMemcpyHostToDevice, st));
+      }
+      int maxK = 0;
+      for (const MergeDev& M : mds) maxK = std::max(maxK, M.K);
+      if (maxK > 0) {
+        const unsigned nmg = (unsigned)ids.size();
+        hipLaunchKernelGGL(secular_kernel, dim3((maxK + 127) / 128, nmg), dim3(128), 0, st, md_dev, dlam, wz, Dcur, S,
+                           ldq);
+        hipLaunchKernelGGL(loewner_kernel, dim3((maxK + 3) / 4, nmg), dim3(256), 0, st, md_dev, dlam, wz, S, ldq, zh);
+        hipLaunchKernelGGL(vectors_kernel, dim3((maxK + 127) / 128, nmg), dim3(128), 0, st, md_dev, zh, S, ldq);
+        for (const MergeDev& M : mds) {
+          if (M.K <= 0) continue;
+          // Qb(rows, off+j) = sum_i Qa(rows, nd[i]) * U(i,j),  U(i,j) = S'(j,i)
+          dgemm_dev(st, 'N', 'T', M.nm, M.K, M.K, 1.0, Qa + M.off, ldq, S + (size_t)M.off * ldq + M.off, ldq, 0.0,
+                    Qb + (size_t)M.off * ldq + M.off, ldq, 0, nullptr, nd_dev + M.off, nullptr);
+          gemm_flops += 2.0 * M.nm * (double)M.K * M.K;
+        }
+      }
+      if (ncopy > 0)
+        hipLaunchKernelGGL(copycols_kernel, dim3(ncopy), dim3(256), 0, st, cps_dev, cpd_dev, cpr_dev, cpn_dev, Qa, Qb,
+                           ldq);
+      // the host vectors are reused next round: wait for the uploads (tiny) before touching them
+      // merged blocks go back into Qa (blocks that do not merge at this height stay where they are)
+      for (const MergeDev& M : mds)
+        EIGX_HIP_CHECK(hipMemcpy2DAsync(Qa + (size_t)M.off * ldq + M.off, (size_t)ldq * 8,
+                                        Qb + (size_t)M.off * ldq + M.off, (size_t)ldq * 8, (size_t)M.nm * 8,
+                                        (size_t)M.nm, hipMemcpyDeviceToDevice, st));
+      EIGX_HIP_CHECK(hipStreamSynchronize(st));
+    }
+  }
+
+  // ---- final sort + copy-out ----------------------------------------------------------------------------
+  EIGX_HIP_CHECK(hipMemcpyAsync(Dh.data(), Dcur, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  ord.resize(n);
+  for (int i = 0; i < n; ++i) ord[i] = std::make_pair(Dh[i], i);
+  std::sort(ord.begin(), ord.end());
+  std::vector<int> perm(n);
+  std::vector<double> wh(n);
+  for (int i = 0; i < n; ++i) { perm[i] = ord[i].second; wh[i] = ord[i].first * nrm; }
+  if (nrm == 0.0) for (int i = 0; i < n; ++i) wh[i] = 0.0;
+  EIGX_HIP_CHECK(hipMemcpyAsync(perm_dev, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+  EIGX_HIP_CHECK(hipMemcpyAsync(w_dev, wh.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+  if (nvec > 0 && z_dev)
+    hipLaunchKernelGGL(final_permute_kernel, dim3(8, nvec), dim3(256), 0, st, perm_dev, Qa, ldq, n, z_dev, ldz, nvec);
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  EIGX_HIP_CHECK(hipGetLastError());
+  ctx.timers[11] = gemm_flops;
+}
+
+}  // namespace eigx

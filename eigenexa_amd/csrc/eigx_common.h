@@ -42,8 +42,11 @@ static inline int local_count(int n, int P, int p) { return n > p ? (n - p + P -
 // C = alpha*op(A)*op(B) + beta*C ; opA/opB in {'N','T'}.
 // tri_mode: 0 = full, 1 = only tiles that intersect the upper triangle (global row <= global col)
 // of a matrix whose local element (i,j) is global (i*Px+px, j*Py+py).
+// batch > 1: `batch` independent products, operand b at A + b*strideA etc. (elements).
+// kmapA (device, optional, opA='N'): A's column for k-index k; cmapC (device, optional): C's column for n.
 void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, double alpha,
                const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc,
-               int tri_mode = 0, const Grid* g = nullptr);
+               int tri_mode = 0, const Grid* g = nullptr, const int* kmapA = nullptr,
+               const int* cmapC = nullptr, int batch = 1, long strideA = 0, long strideB = 0, long strideC = 0);
 
 }  // namespace eigx

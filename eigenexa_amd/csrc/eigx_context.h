@@ -57,6 +57,10 @@ void comm_free(Context& ctx);
 // band_reduce.hip: A (upper triangle) -> band (d, e(:,1..band)); reflectors left in A's columns
 void band_reduce_dev(Context& ctx, int n, double* A, int lda, double* d, double* e, int lde, int m, int band);
 
+// dc.hip: eigen-decomposition of the band matrix (d, e(:,1..band)); w ascending, z(ldz, nvec)
+void band_dc_dev(Context& ctx, int n, int nvec, const double* d, const double* e, int lde, int band, double* w,
+                 double* z, int ldz);
+
 // solver.hip
 int64_t solver_workspace_bytes(const Context& ctx, int n, int lda, int ldz, int mf, int mb);
 

@@ -39,13 +39,17 @@ struct GemmArgs {
   int ldc;
   int tri_mode;
   int Px, px, Py, py;
+  const int* kmapA;  // optional: column of A that holds k-index k ('N' A only): A(:, kmapA[k])
+  const int* cmapC;  // optional: column of C that receives n-index n: C(:, cmapC[n])
+  long sA, sB, sC;   // batch strides in elements (blockIdx.y = batch index)
 };
 
 // Load this thread's 8 elements of a 128 x 16 operand slab (rows m0.., k-range k0..) into regs.
 //   MC: element (m,k) at P[m + k*ld]     KC: element (m,k) at P[k + m*ld]
 template <bool KC>
 __device__ __forceinline__ void load_slab(double (&r)[8], const double* __restrict__ P, int ld, int m0,
-                                          int k0, int Mmax, int Kmax, int tid) {
+                                          int k0, int Mmax, int Kmax, int tid,
+                                          const int* __restrict__ kmap = nullptr) {
   if (!KC) {
     const int m = m0 + (tid & 127);
     const int kb = k0 + (tid >> 7);  // 0..1, then +2 per pass
@@ -53,7 +57,12 @@ __device__ __forceinline__ void load_slab(double (&r)[8], const double* __restri
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int k = kb + 2 * p;
-      r[p] = (mok && k < Kmax) ? P[(size_t)m + (size_t)k * ld] : 0.0;
+      if (mok && k < Kmax) {
+        const int kc = kmap ? kmap[k] : k;
+        r[p] = P[(size_t)m + (size_t)kc * ld];
+      } else {
+        r[p] = 0.0;
+      }
     }
   } else {
     const int k = k0 + (tid & 15);
@@ -90,6 +99,9 @@ __device__ __forceinline__ double frag(const double* __restrict__ S, int m, int 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  g.A += (long)blockIdx.y * g.sA;
+  g.B += (long)blockIdx.y * g.sB;
+  g.C += (long)blockIdx.y * g.sC;
   // stage buffer b: A slab at smem + 2*b*OPER_DOUBLES, B slab right behind it
 
   const int tid = threadIdx.x;
@@ -137,7 +149,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = n0 + wn * 64 + j * 16 + fk + 4 * r;
-      const double* cp = g.C + (size_t)n * g.ldc;
+      const int nc = (g.cmapC && n < g.N) ? g.cmapC[n] : n;
+      const double* cp = g.C + (size_t)nc * g.ldc;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + fm;
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 
   double ra[8], rb[8];
   const int nk = (g.K + BK - 1) / BK;
-  load_slab<A_KC>(ra, g.A, g.lda, m0, 0, g.M, g.K, tid);
+  load_slab<A_KC>(ra, g.A, g.lda, m0, 0, g.M, g.K, tid, g.kmapA);
   load_slab<B_KC>(rb, g.B, g.ldb, n0, 0, g.N, g.K, tid);
   store_slab<A_KC>(ra, smem, tid);
   store_slab<B_KC>(rb, smem + OPER_DOUBLES, tid);
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      load_slab<A_KC>(ra, g.A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid);
+      load_slab<A_KC>(ra, g.A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid, g.kmapA);
       load_slab<B_KC>(rb, g.B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
     }
     const double* as = smem + cur * 2 * OPER_DOUBLES;
@@ -190,7 +203,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     for (int r = 0; r < 4; ++r) {
       const int n = n0 + wn * 64 + j * 16 + fk + 4 * r;
       if (n >= g.N) continue;
-      double* cp = g.C + (size_t)n * g.ldc;
+      const int nc = g.cmapC ? g.cmapC[n] : n;
+      double* cp = g.C + (size_t)nc * g.ldc;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + fm;
@@ -208,19 +222,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 
 void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, double alpha, const double* A,
                int lda, const double* B, int ldb, double beta, double* C, int ldc, int tri_mode,
-               const Grid* grid) {
-  if (M <= 0 || N <= 0) return;
+               const Grid* grid, const int* kmapA, const int* cmapC, int batch, long strideA, long strideB,
+               long strideC) {
+  if (M <= 0 || N <= 0 || batch <= 0) return;
   GemmArgs g;
   g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.tri_mode = tri_mode;
+  g.kmapA = (opA == 'N' || opA == 'n') ? kmapA : nullptr;
+  g.cmapC = cmapC;
+  g.sA = strideA; g.sB = strideB; g.sC = strideC;
   g.Px = grid ? grid->Px : 1; g.px = grid ? grid->px : 0;
   g.Py = grid ? grid->Py : 1; g.py = grid ? grid->py : 0;
   const bool a_kc = (opA == 'T' || opA == 't');   // op(A)(m,k) = A[k + m*lda]
   const bool b_kc = (opB == 'N' || opB == 'n');   // op(B)(k,n) = B[k + n*ldb]
   const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
   const size_t shmem = (size_t)4 * OPER_DOUBLES * sizeof(double);
-  dim3 grd(tiles), blk(256);
+  dim3 grd(tiles, batch), blk(256);
 #define EIGX_LAUNCH(AK, BK_)                                                                       \
   do {                                                                                             \
     static bool attr_set = false;                                                                  \

@@ -1,21 +1,210 @@
-// solver.hip -- drivers eigx_sx / eigx_s (placeholder until the stages land).
+// solver.hip -- drivers: eigx_sx (pentadiagonal route) and eigx_s (tridiagonal route).
+//
+// Replaces eigen_sx (src/eigen_sx.F:30-308) and eigen_s -> eigen_FS / eigen_s0
+// (src/eigen_libs.F:150-202, src/eigen_FS.F:29-300, src/eigen_s.F:30-307):
+//   guards -> eigen_scaling -> band reduction -> band D&C -> back-transformation -> unscale ->
+//   a(1:3,1) = flops, seconds, comm seconds (src/eigen_sx.F:285-296).
 #include "eigx_context.h"
 #include "../../include/eigenexa_amd.h"
+#include <chrono>
+#include <cfloat>
+#include <limits>
 
 namespace eigx {
-int64_t solver_workspace_bytes(const Context&, int n, int lda, int ldz, int mf, int mb) {
-  (void)lda; (void)ldz; (void)mf; (void)mb;
-  return (int64_t)n * n * 8 * 3;
-}
+
+void trbak_dev(Context& ctx, int n, int nvec, const double* A, int lda, double* Z, int ldz, const double* e,
+               int lde, int mb, int band);
+
+namespace {
+
+// max |a_ij| over the upper triangle and a non-finite flag (eigen_scaling, src/eigen_scaling.F:86-150)
+__global__ __launch_bounds__(256) void absmax_kernel(const double* __restrict__ A, int lda, int n,
+                                                     double* __restrict__ out /* [gridDim.x][2] */) {
+  __shared__ double smax[4], sbad[4];
+  double mx = 0.0, bad = 0.0;
+  for (int j = blockIdx.x; j < n; j += gridDim.x) {
+    const double* col = A + (size_t)j * lda;
+    for (int i = threadIdx.x; i <= j; i += 256) {
+      const double v = fabs(col[i]);
+      if (!(v <= DBL_MAX)) bad = 1.0;
+      else mx = fmax(mx, v);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { mx = fmax(mx, __shfl_xor(mx, o, 64)); bad = fmax(bad, __shfl_xor(bad, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = mx; sbad[threadIdx.x >> 6] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+    out[2 * blockIdx.x + 1] = fmax(fmax(sbad[0], sbad[1]), fmax(sbad[2], sbad[3]));
+  }
 }
 
+__global__ void scale_upper_kernel(double* __restrict__ A, int lda, int n, double s) {
+  for (int j = blockIdx.x; j < n; j += gridDim.x) {
+    double* col = A + (size_t)j * lda;
+    for (int i = threadIdx.x; i <= j; i += blockDim.x) col[i] *= s;
+  }
+}
+
+__global__ void scale_vec_kernel(double* __restrict__ w, int n, double s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w[i] *= s;
+}
+
+__global__ void fill_vec_kernel(double* __restrict__ w, int n, double v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w[i] = v;
+}
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb,
+              char mode, int band) {
+  if (!ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  if (n <= 0) {
+    fprintf(stderr, "[eigx] warning: non-positive dimension is invalid\n");  // src/eigen_sx.F:95-98
+    return EIGX_ERR_BAD_ARG;
+  }
+  if (ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;  // multi-rank path: see DESIGN.md (e)
+  if (lda < n || (lda & 1) || !a || !w) return EIGX_ERR_BAD_ARG;
+  if (mode >= 'a' && mode <= 'z') mode = (char)(mode - 'a' + 'A');
+  if (nvec == 0) mode = 'N';                      // src/eigen_sx.F:108-110
+  if (nvec < 0) nvec = -nvec;
+  if (nvec > n) nvec = n;
+  const bool want_vec = (mode != 'N');
+  if (want_vec && (!z || ldz < n)) return EIGX_ERR_BAD_ARG;
+  if (mf <= 0) mf = 128;
+  if (mb <= 0) mb = 128;
+  EIGX_HIP_CHECK(hipSetDevice(ctx.device));
+  hipStream_t st = ctx.stream;
+  ctx.errinfo = 0;
+  for (int q = 0; q < 16; ++q) ctx.timers[q] = 0.0;
+  const double t0 = now_s();
+
+  // ---- eigen_scaling ---------------------------------------------------------------------------
+  double sigma = 1.0;
+  {
+    const int nb = 512;
+    double* part = ctx.pool.get_t<double>("sol.absmax", (size_t)2 * nb);
+    hipLaunchKernelGGL(absmax_kernel, dim3(nb), dim3(256), 0, st, a, lda, n, part);
+    std::vector<double> hp(2 * nb);
+    EIGX_HIP_CHECK(hipMemcpyAsync(hp.data(), part, hp.size() * 8, hipMemcpyDeviceToHost, st));
+    EIGX_HIP_CHECK(hipStreamSynchronize(st));
+    double anrm = 0.0, bad = 0.0;
+    for (int q = 0; q < nb; ++q) { anrm = std::max(anrm, hp[2 * q]); bad = std::max(bad, hp[2 * q + 1]); }
+    if (bad != 0.0) {  // NaN/Inf in the input: w(:) = NaN and return (src/eigen_sx.F:151-155)
+      hipLaunchKernelGGL(fill_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, n,
+                         std::numeric_limits<double>::quiet_NaN());
+      EIGX_HIP_CHECK(hipStreamSynchronize(st));
+      ctx.errinfo = -1;
+      return EIGX_ERR_NONFINITE;
+    }
+    const double safmin = DBL_MIN, epsm = DBL_EPSILON / 2.0;
+    const double smlnum = safmin / epsm, rmin = sqrt(smlnum);
+    const double rmax = std::min(sqrt(1.0 / smlnum), 1.0 / sqrt(sqrt(safmin)));
+    if (anrm > 0.0 && anrm < rmin) sigma = rmin / anrm;
+    else if (anrm > rmax) sigma = rmax / anrm;
+    if (sigma != 1.0) hipLaunchKernelGGL(scale_upper_kernel, dim3(1024), dim3(256), 0, st, a, lda, n, sigma);
+  }
+
+  // ---- forward reduction --------------------------------------------------------------------------
+  const int lde = (n + 3) / 4 * 4;  // nme of src/eigen_sx.F:139
+  double* d = ctx.pool.get_t<double>("sol.d", (size_t)n);
+  double* e = ctx.pool.get_t<double>("sol.e", (size_t)lde * 2);
+  const double t1 = now_s();
+  band_reduce_dev(ctx, n, a, lda, d, e, lde, mf, band);
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  const double t2 = now_s();
+
+  // ---- divide and conquer --------------------------------------------------------------------------
+  band_dc_dev(ctx, n, want_vec ? nvec : 0, d, e, lde, band, w, want_vec ? z : nullptr, ldz);
+  const double t3 = now_s();
+
+  // ---- back-transformation ---------------------------------------------------------------------------
+  const bool do_bt = want_vec && mode != 'T' && mode != 'C' && mode != 'R';  // src/eigen_sx.F:240
+  if (do_bt) trbak_dev(ctx, n, nvec, a, lda, z, ldz, e, lde, mb, band);
+  if (sigma != 1.0 && sigma != 0.0)
+    hipLaunchKernelGGL(scale_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, n, 1.0 / sigma);
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  const double t4 = now_s();
+
+  // ---- statistics (src/eigen_sx.F:285-296) -----------------------------------------------------------
+  const double f_red = 4.0 / 3.0 * (double)n * n * n;
+  const double f_dc = ctx.timers[11];
+  const double f_bt = do_bt ? 2.0 * (double)nvec * n * n : 0.0;
+  double ret = f_red + f_dc + f_bt;
+  if (f_dc == 0.0) ret = -ret;
+  ctx.timers[0] = t4 - t0; ctx.timers[1] = t2 - t1; ctx.timers[2] = t3 - t2; ctx.timers[3] = t4 - t3;
+  ctx.timers[4] = 0.0; ctx.timers[12] = ret;
+  const double stats[3] = {ret, t4 - t0, -1.0};
+  const int nst = n >= 3 ? 3 : n;  // a(1:3,1) lives in the first column
+  EIGX_HIP_CHECK(hipMemcpyAsync(a, stats, (size_t)nst * 8, hipMemcpyHostToDevice, st));
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  return EIGX_OK;
+}
+
+int solve_host(Context& ctx, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb,
+               char mode, int band) {
+  if (!ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  if (n <= 0 || !a || !w || lda < n) return EIGX_ERR_BAD_ARG;
+  if (ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;
+  EIGX_HIP_CHECK(hipSetDevice(ctx.device));
+  const int ldd = (n + 1) / 2 * 2;  // device leading dimension: even for the 16-byte column loads
+  double* ad = ctx.pool.get_t<double>("host.a", (size_t)ldd * n);
+  double* zd = ctx.pool.get_t<double>("host.z", (size_t)ldd * n);
+  double* wd = ctx.pool.get_t<double>("host.w", (size_t)n);
+  EIGX_HIP_CHECK(hipMemcpy2D(ad, (size_t)ldd * 8, a, (size_t)lda * 8, (size_t)n * 8, (size_t)n,
+                             hipMemcpyHostToDevice));
+  const int rc = solve_dev(ctx, n, nvec, ad, ldd, wd, zd, ldd, mf, mb, mode, band);
+  EIGX_HIP_CHECK(hipMemcpy(w, wd, (size_t)n * 8, hipMemcpyDeviceToHost));
+  if (rc != EIGX_OK) return rc;
+  char md = mode;
+  if (md >= 'a' && md <= 'z') md = (char)(md - 'a' + 'A');
+  int nv = nvec < 0 ? -nvec : nvec;
+  if (nv > n) nv = n;
+  if (z && nv > 0 && md != 'N')
+    EIGX_HIP_CHECK(hipMemcpy2D(z, (size_t)ldz * 8, zd, (size_t)ldd * 8, (size_t)n * 8, (size_t)nv,
+                               hipMemcpyDeviceToHost));
+  // `a` is destroyed by contract; only the statistics come back
+  const int nst = n >= 3 ? 3 : n;
+  EIGX_HIP_CHECK(hipMemcpy(a, ad, (size_t)nst * 8, hipMemcpyDeviceToHost));
+  return EIGX_OK;
+}
+
+}  // namespace
+
+int64_t solver_workspace_bytes(const Context&, int n, int lda, int ldz, int mf, int mb) {
+  (void)lda; (void)ldz;
+  if (mf <= 0) mf = 128;
+  if (mb <= 0) mb = 128;
+  const int64_t nn = (int64_t)((n + 31) / 32 * 32) * n;
+  // D&C: Qa, Qb, S ; reduction: panels + partials ; back-transform: V, W, X
+  return 8 * (3 * nn + (int64_t)(n + 256) * (3 * mf + 2 * (n / 128 + 2) * 2 + 8) + (int64_t)(n + 512) * mb +
+              2 * (int64_t)mb * n);
+}
+
+}  // namespace eigx
+
+using namespace eigx;
+
 extern "C" {
-int eigx_sx(int, int, double*, int, double*, double*, int, int, int, char) { return EIGX_ERR_INTERNAL; }
-int eigx_s(int, int, double*, int, double*, double*, int, int, int, char) { return EIGX_ERR_INTERNAL; }
-int eigx_sx_dev(int, int, double*, int, double*, double*, int, int, int, char) { return EIGX_ERR_INTERNAL; }
-int eigx_s_dev(int, int, double*, int, double*, double*, int, int, int, char) { return EIGX_ERR_INTERNAL; }
+
+int eigx_sx(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb, char mode) {
+  return solve_host(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 2);
+}
+int eigx_s(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb, char mode) {
+  return solve_host(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 1);
+}
+int eigx_sx_dev(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb, char mode) {
+  return solve_dev(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 2);
+}
+int eigx_s_dev(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb, char mode) {
+  return solve_dev(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 1);
+}
+
 int eigx_band_reduce_dev(int n, double* a, int lda, double* d, double* e, int lde, int mf, int band) {
-  using namespace eigx;
   if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
   if (n <= 0 || lda < n || (lda & 1) || lde < n || (band != 1 && band != 2)) return EIGX_ERR_BAD_ARG;
   if (g_ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;
@@ -23,6 +212,25 @@ int eigx_band_reduce_dev(int n, double* a, int lda, double* d, double* e, int ld
   EIGX_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
   return EIGX_OK;
 }
-int eigx_band_dc_dev(int, int, const double*, const double*, int, int, double*, double*, int) { return EIGX_ERR_INTERNAL; }
-int eigx_trbak_dev(int, int, const double*, int, double*, int, const double*, int, int, int) { return EIGX_ERR_INTERNAL; }
+
+int eigx_band_dc_dev(int n, int nvec, const double* d, const double* e, int lde, int band, double* w, double* z,
+                     int ldz) {
+  if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  if (n <= 0 || nvec < 0 || nvec > n || lde < n || (band != 1 && band != 2) || (nvec > 0 && ldz < n))
+    return EIGX_ERR_BAD_ARG;
+  if (g_ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;
+  band_dc_dev(g_ctx, n, nvec, d, e, lde, band, w, z, ldz);
+  return EIGX_OK;
 }
+
+int eigx_trbak_dev(int n, int nvec, const double* a, int lda, double* z, int ldz, const double* e, int lde, int mb,
+                   int band) {
+  if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  if (n <= 0 || nvec < 0 || lda < n || ldz < n || lde < n || (band != 1 && band != 2)) return EIGX_ERR_BAD_ARG;
+  if (g_ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;
+  trbak_dev(g_ctx, n, nvec, a, lda, z, ldz, e, lde, mb > 0 ? mb : 128, band);
+  EIGX_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+  return EIGX_OK;
+}
+
+}  // extern "C"
