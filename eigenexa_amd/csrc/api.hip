@@ -68,6 +68,7 @@ int eigx_free(void) {
   EIGX_HIP_CHECK(hipDeviceSynchronize());
   if (g_ctx.grid.nranks > 1) comm_free(g_ctx);
   g_ctx.pool.release();
+  for (hipEvent_t e : g_ctx.prof_ev) EIGX_HIP_CHECK(hipEventDestroy(e));
   EIGX_HIP_CHECK(hipStreamDestroy(g_ctx.stream));
   EIGX_HIP_CHECK(hipStreamDestroy(g_ctx.side_stream));
   g_ctx = Context();
@@ -163,6 +164,32 @@ int64_t eigx_memory_internal(int n, int lda, int ldz, int m_forward, int m_backw
 int eigx_get_timers(double* out16) {
   if (!out16) return EIGX_ERR_BAD_ARG;
   for (int i = 0; i < 16; ++i) out16[i] = g_ctx.timers[i];
+  return EIGX_OK;
+}
+
+int eigx_profile(int stride) {
+  if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  g_ctx.prof_stride = stride > 0 ? stride : 0;
+  g_ctx.prof_used = 0;
+  g_ctx.prof_kind.clear();
+  g_ctx.prof_units.clear();
+  return EIGX_OK;
+}
+
+int eigx_profile_read(double* out6) {
+  if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  if (!out6) return EIGX_ERR_BAD_ARG;
+  EIGX_HIP_CHECK(hipSetDevice(g_ctx.device));
+  EIGX_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+  for (int q = 0; q < 6; ++q) out6[q] = 0.0;
+  for (size_t q = 0; q < g_ctx.prof_kind.size(); ++q) {
+    float ms = 0.f;
+    EIGX_HIP_CHECK(hipEventElapsedTime(&ms, g_ctx.prof_ev[2 * q], g_ctx.prof_ev[2 * q + 1]));
+    const int k = g_ctx.prof_kind[q] ? 3 : 0;
+    out6[k + 0] += 1.0;
+    out6[k + 1] += g_ctx.prof_units[q];
+    out6[k + 2] += 1e-3 * ms;
+  }
   return EIGX_OK;
 }
 

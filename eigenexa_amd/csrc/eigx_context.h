@@ -3,6 +3,7 @@
 #pragma once
 #include "eigx_common.h"
 #include <map>
+#include <vector>
 #include <string>
 
 namespace eigx {
@@ -45,6 +46,25 @@ struct Context {
   CommState* comm = nullptr;
   int64_t errinfo = 0;
   double timers[16] = {0};
+  // sampled HIP-event timing of the two roofline kernels (bench.py): every prof_stride-th launch of the
+  // fused SYMV kernel and every trailing-update GEMM is bracketed by events on the compute stream
+  int prof_stride = 0;  // 0 = off
+  std::vector<hipEvent_t> prof_ev;   // pairs
+  std::vector<double> prof_units;    // bytes (kind 0) or flops (kind 1) of the bracketed launch
+  std::vector<int> prof_kind;
+  size_t prof_used = 0;
+  void prof_begin(int kind, double units, hipStream_t st) {
+    if (prof_used + 2 > prof_ev.size()) {
+      for (int q = 0; q < 2; ++q) { hipEvent_t e; EIGX_HIP_CHECK(hipEventCreate(&e)); prof_ev.push_back(e); }
+    }
+    prof_kind.push_back(kind);
+    prof_units.push_back(units);
+    EIGX_HIP_CHECK(hipEventRecord(prof_ev[prof_used], st));
+  }
+  void prof_end(hipStream_t st) {
+    EIGX_HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], st));
+    prof_used += 2;
+  }
 };
 
 extern Context g_ctx;

@@ -101,11 +101,15 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
       ctx.errinfo = -1;
       return EIGX_ERR_NONFINITE;
     }
-    const double safmin = DBL_MIN, epsm = DBL_EPSILON / 2.0;
-    const double smlnum = safmin / epsm, rmin = sqrt(smlnum);
-    const double rmax = std::min(sqrt(1.0 / smlnum), 1.0 / sqrt(sqrt(safmin)));
-    if (anrm > 0.0 && anrm < rmin) sigma = rmin / anrm;
-    else if (anrm > rmax) sigma = rmax / anrm;
+    // eigen_scaling (src/eigen_scaling.F:76-81,:127-147) rescales only when max|a| leaves the safe range,
+    // to RMIN/RMAX ~ 1e-146/1e+146.  This implementation forms reflector quantities that are cubic in the
+    // matrix scale (u^T A u with un-normalised u), so its safe range is narrower and the target is O(1):
+    // outside [1e-90, 1e90] the matrix is scaled by the exact power of two nearest to 1/max|a|.
+    if (anrm > 0.0 && (anrm < 1e-90 || anrm > 1e90)) {
+      int ex = 0;
+      (void)frexp(anrm, &ex);
+      sigma = ldexp(1.0, -ex);
+    }
     if (sigma != 1.0) hipLaunchKernelGGL(scale_upper_kernel, dim3(1024), dim3(256), 0, st, a, lda, n, sigma);
   }
 

@@ -1,0 +1,101 @@
+"""2-D cyclic layout helpers and the benchmark's synthetic matrices (host logic, numpy only).
+
+Layout rules of the reference (src/eigen_libs0.F:526-570 grid shape, :1825-2258 index maps):
+global (i, j), 0-based, lives on grid coordinate (i % Px, j % Py) at local (i // Px, j // Py);
+ranks are numbered column-major over the grid (rank = px + py*Px) unless order == 'R'.
+Matrix generators follow benchmark/mat_set.f (Frank :117-132, analytic spectrum :638-647) with a
+counter-based random generator keyed on global indices so every layout sees the same matrix
+(SURVEY.md 8d).
+"""
+import numpy as np
+
+
+def grid_shape(nranks):
+    """Px = largest divisor of nranks that is <= sqrt(nranks); Py = nranks // Px."""
+    px = 1
+    x = 1
+    while x * x <= nranks:
+        if nranks % x == 0:
+            px = x
+        x += 1
+    return px, nranks // px
+
+
+def rank_coords(rank, nranks, order="C"):
+    px, py = grid_shape(nranks)
+    if str(order)[:1].upper() == "R":
+        return rank // py, rank % py
+    return rank % px, rank // px
+
+
+def local_count(n, p, nprocs):
+    """number of global indices g < n with g % nprocs == p"""
+    return (n - p + nprocs - 1) // nprocs if n > p else 0
+
+
+def scatter_cyclic(a_global, nranks, rank, order="C", nx=None, ny=None):
+    """local block (Fortran order, shape (nx, ny)) of a global matrix for `rank`."""
+    n0, n1 = a_global.shape
+    Px, Py = grid_shape(nranks)
+    px, py = rank_coords(rank, nranks, order)
+    loc = a_global[px::Px, py::Py]
+    nx = nx or loc.shape[0]
+    ny = ny or loc.shape[1]
+    out = np.zeros((nx, ny), dtype=a_global.dtype, order="F")
+    out[: loc.shape[0], : loc.shape[1]] = loc
+    return out
+
+
+def gather_cyclic(blocks, n0, n1, order="C"):
+    """inverse of scatter_cyclic: blocks[rank] -> global (n0, n1) matrix."""
+    nranks = len(blocks)
+    Px, Py = grid_shape(nranks)
+    out = np.zeros((n0, n1), dtype=blocks[0].dtype)
+    for rank, b in enumerate(blocks):
+        px, py = rank_coords(rank, nranks, order)
+        r = local_count(n0, px, Px)
+        c = local_count(n1, py, Py)
+        out[px::Px, py::Py] = b[:r, :c]
+    return out
+
+
+# ---- synthetic matrices -------------------------------------------------------------------------
+
+def frank(n, rows=None, cols=None):
+    """Frank matrix a_ij = min(i, j), 1-based (benchmark/mat_set.f:117-132); optional index subsets."""
+    i = (np.arange(n) if rows is None else np.asarray(rows)) + 1
+    j = (np.arange(n) if cols is None else np.asarray(cols)) + 1
+    return np.minimum.outer(i, j).astype(np.float64)
+
+
+def frank_eigenvalues(n):
+    """analytic spectrum 1/(2(1-cos((2k-1)pi/(2n+1)))), ascending (benchmark/mat_set.f:638-647)."""
+    k = np.arange(1, n + 1)
+    return np.sort(1.0 / (2.0 * (1.0 - np.cos((2 * k - 1) * np.pi / (2 * n + 1)))))
+
+
+def _mix64(x):
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def random_symmetric(n, seed=20240807, rows=None, cols=None):
+    """A = R + R^T with r_ij uniform [0,1) from a counter-based generator keyed (seed, i, j)."""
+    i = (np.arange(n) if rows is None else np.asarray(rows)).astype(np.uint64)
+    j = (np.arange(n) if cols is None else np.asarray(cols)).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        def r(ii, jj):
+            key = (ii[:, None] * np.uint64(n) + jj[None, :]) + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15)
+            return (_mix64(key) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        return r(i, j) + r(j, i).T
+
+
+def accuracy_metrics(A, w, Z):
+    """the reference's three gates: residual ||AZ-ZW||_F/(N eps ||A||_F) (< 768), orthogonality
+    ||Z^T Z - I||_F/(N eps) (< 8)  (benchmark/ev_test.f:181-204)."""
+    n = A.shape[0]
+    eps = np.finfo(np.float64).eps
+    res = np.linalg.norm(A @ Z - Z * w[None, : Z.shape[1]]) / (n * eps * np.linalg.norm(A))
+    orth = np.linalg.norm(Z.T @ Z - np.eye(Z.shape[1])) / (n * eps)
+    return res, orth

@@ -131,6 +131,14 @@ int eigx_dgemm_dev(char opa, char opb, int m, int n, int k, double alpha, const 
  * [8] symv kernel seconds [9] its launch count [10] its algorithmic bytes */
 int eigx_get_timers(double* out16);
 
+/* Sampled in-library profiling for bench.py (the reference prints per-kernel timers under TIMER_PRINT=2,
+ * src/eigen_trd.F:710-714): eigx_profile(stride>0) brackets every stride-th launch of the fused symmetric
+ * mat-vec kernel and every trailing-update GEMM launch with HIP events on the library's compute stream;
+ * eigx_profile_read returns {symv launches sampled, their algorithmic bytes, their seconds,
+ * trailing-update launches, their flops, their seconds} accumulated since the last eigx_profile call. */
+int eigx_profile(int stride);
+int eigx_profile_read(double* out6);
+
 /* device synchronisation helper for hosts without a HIP binding */
 int eigx_device_synchronize(void);
 

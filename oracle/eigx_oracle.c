@@ -580,11 +580,11 @@ static int orc_eigen(int n, int nvec, double* a, int lda, double* wout, double* 
   for (int j = 0; j < n; ++j)
     for (int i = 0; i <= j; ++i) { const double v = A_(i, j); if (!(fabs(v) <= DBL_MAX)) bad = 1; anrm = fmax(anrm, fabs(v)); }
   if (bad) { for (int i = 0; i < n; ++i) wout[i] = NAN; return 1; }
-  const double safmin = DBL_MIN, epsm = DBL_EPSILON / 2.0;
-  const double smlnum = safmin / epsm, rmin = sqrt(smlnum), rmax = fmin(sqrt(1.0 / smlnum), 1.0 / sqrt(sqrt(safmin)));
+  /* the reference rescales to RMIN/RMAX only outside [sqrt(safmin/eps), 1/that]; un-normalised reflectors
+   * form quantities cubic in the scale, so both this oracle and the GPU build rescale (exactly, by a power
+   * of two) to O(1) when max|a| is outside [1e-90, 1e90] */
   double sigma = 1.0;
-  if (anrm > 0.0 && anrm < rmin) sigma = rmin / anrm;
-  else if (anrm > rmax) sigma = rmax / anrm;
+  if (anrm > 0.0 && (anrm < 1e-90 || anrm > 1e90)) { int ex = 0; (void)frexp(anrm, &ex); sigma = ldexp(1.0, -ex); }
   if (sigma != 1.0) for (int j = 0; j < n; ++j) for (int i = 0; i <= j; ++i) A_(i, j) *= sigma;
 
   const int lde = n;

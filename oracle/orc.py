@@ -1,0 +1,77 @@
+"""ctypes wrapper of the CPU oracle (oracle/eigx_oracle.c).  TEST INFRASTRUCTURE ONLY:
+importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never from eigenexa_amd."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liborc.so")
+_lib = None
+_dp = C.POINTER(C.c_double)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _SO
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        lib = C.CDLL(_SO)
+        lib.orc_eigen_sx.argtypes = lib.orc_eigen_s.argtypes = [C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, C.c_int,
+                                                                C.c_char, _dp]
+        lib.orc_band_reduce.argtypes = [C.c_int, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int]
+        lib.orc_band_dc.argtypes = [C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]
+        lib.orc_trbak.argtypes = [C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int]
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def eigen(A, route="sx", mode="A"):
+    """full solve of the symmetric matrix A (numpy, any order): returns (w, Z, stats, stage_seconds)."""
+    lib = load()
+    n = A.shape[0]
+    a = np.asfortranarray(A, dtype=np.float64).copy(order="F")
+    w = np.zeros(n)
+    z = np.zeros((n, n), order="F")
+    t = np.zeros(3)
+    fn = lib.orc_eigen_sx if route == "sx" else lib.orc_eigen_s
+    rc = fn(n, n, _p(a), n, _p(w), _p(z), n, mode.encode()[:1], _p(t))
+    if rc not in (0, 1):
+        raise RuntimeError(f"oracle failed rc={rc}")
+    return w, z, a[: min(3, n), 0].copy(), t
+
+
+def band_reduce(A, band):
+    """returns d, e(band, n) with e[b-1, i] = T(i-b, i), and the matrix holding the reflectors."""
+    lib = load()
+    n = A.shape[0]
+    a = np.asfortranarray(A, dtype=np.float64).copy(order="F")
+    d = np.zeros(n)
+    e = np.zeros((band, n))
+    rc = lib.orc_band_reduce(n, _p(a), n, _p(d), _p(e), n, band)
+    if rc != 0:
+        raise RuntimeError(f"oracle band_reduce rc={rc}")
+    return d, e, a
+
+
+def band_dc(d, e, band):
+    lib = load()
+    n = len(d)
+    w = np.zeros(n)
+    z = np.zeros((n, n), order="F")
+    fl = np.zeros(1)
+    ee = np.ascontiguousarray(e, dtype=np.float64)
+    rc = lib.orc_band_dc(n, _p(np.ascontiguousarray(d)), _p(ee), ee.shape[1], band, _p(w), _p(z), n, _p(fl))
+    if rc != 0:
+        raise RuntimeError(f"oracle band_dc rc={rc}")
+    return w, z

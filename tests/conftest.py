@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import orc as o
+
+    o.load()
+    return o
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import eigenexa_amd as ee
+
+    ee.eigen_init()
+    from eigenexa_amd import _lib
+
+    yield _lib.load()
+    ee.eigen_free()

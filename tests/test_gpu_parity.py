@@ -1,0 +1,326 @@
+"""GPU parity tests: the HIP path through the C-ABI against the CPU oracle on the same seeded inputs,
+the reference's known-answer tests, and size-independent properties at BASELINE.json sizes."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "known_answers.json")))
+GATE_RES = GOLD["gates"]["residual"]
+GATE_ORTH = GOLD["gates"]["orthogonality"]
+EPS = np.finfo(np.float64).eps
+
+
+def _dev():
+    import torch
+
+    return torch.device("cuda:0")
+
+
+def _to_colmajor(A, ld=None):
+    """numpy (r x c) -> torch tensor t[c, ld] whose memory is the column-major (ld x c) array"""
+    import torch
+
+    r, c = A.shape
+    ld = ld or (r + (r & 1))
+    t = torch.zeros(c, ld, dtype=torch.float64, device=_dev())
+    t[:, :r] = torch.from_numpy(np.ascontiguousarray(A.T)).to(_dev())
+    return t, ld
+
+
+def _band_matrix(d, e, band):
+    n = len(d)
+    T = np.diag(d)
+    for b in range(1, min(band, n - 1) + 1):
+        T += np.diag(e[b - 1, b:n], b) + np.diag(e[b - 1, b:n], -b)
+    return T
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("opa,opb", [("N", "N"), ("N", "T"), ("T", "N"), ("T", "T")])
+def test_gemm_vs_torch_fp64(gpu_lib, opa, opb):
+    import torch
+
+    torch.manual_seed(0)
+    M, N, K = 257, 131, 75
+    A = torch.randn((M, K) if opa == "N" else (K, M), dtype=torch.float64, device=_dev())
+    B = torch.randn((K, N) if opb == "N" else (N, K), dtype=torch.float64, device=_dev())
+    Cm = torch.randn(M, N, dtype=torch.float64, device=_dev())
+    At, lda = _to_colmajor(A.cpu().numpy(), A.shape[0] + 3)
+    Bt, ldb = _to_colmajor(B.cpu().numpy(), B.shape[0] + 1)
+    Ct, ldc = _to_colmajor(Cm.cpu().numpy(), M + 5)
+    rc = gpu_lib.eigx_dgemm_dev(opa.encode(), opb.encode(), M, N, K, -0.5, At.data_ptr(), lda, Bt.data_ptr(), ldb,
+                                2.0, Ct.data_ptr(), ldc, 0)
+    assert rc == 0
+    ref = -0.5 * ((A if opa == "N" else A.T) @ (B if opb == "N" else B.T)) + 2.0 * Cm
+    got = Ct[:, :M].T
+    assert (got - ref).abs().max().item() < 1e-12 * K  # fp64 tolerance: K rounding steps of O(1) products
+
+
+def test_gemm_upper_triangle_mode(gpu_lib):
+    import torch
+
+    torch.manual_seed(1)
+    n, K = 700, 64
+    U = torch.randn(n, K, dtype=torch.float64, device=_dev())
+    V = torch.randn(n, K, dtype=torch.float64, device=_dev())
+    Cm = torch.randn(n, n, dtype=torch.float64, device=_dev())
+    Ut, ldu = _to_colmajor(U.cpu().numpy())
+    Vt, ldv = _to_colmajor(V.cpu().numpy())
+    Ct, ldc = _to_colmajor(Cm.cpu().numpy())
+    assert gpu_lib.eigx_dgemm_dev(b"N", b"T", n, n, K, -1.0, Ut.data_ptr(), ldu, Vt.data_ptr(), ldv, 1.0,
+                                  Ct.data_ptr(), ldc, 1) == 0
+    ref = Cm - U @ V.T
+    mask = torch.triu(torch.ones(n, n, dtype=torch.bool, device=_dev()))
+    assert ((Ct[:, :n].T - ref) * mask).abs().max().item() < 1e-12 * K
+
+
+# ---------------------------------------------------------------------------------- band reduction
+@pytest.mark.parametrize("n,m", [(1, 8), (2, 8), (3, 8), (5, 4), (64, 16), (200, 32), (513, 48), (700, 128)])
+def test_tridiagonal_matches_oracle(gpu_lib, orc, n, m):
+    """(d, |e|) of the bottom-up Householder tridiagonal is unique: element-wise parity with the oracle"""
+    import torch
+    from eigenexa_amd import layout
+
+    A = layout.random_symmetric(n, seed=11)
+    do, eo, _ = orc.band_reduce(A, 1)
+    a, lda = _to_colmajor(A)
+    il = torch.tril_indices(n, n, -1, device=_dev())
+    a[il[1], il[0]] = float("nan")  # the strict lower triangle must never be read (src/eigen_trd_t8.F:84-94)
+    d = torch.zeros(n, dtype=torch.float64, device=_dev())
+    e = torch.zeros(n, dtype=torch.float64, device=_dev())
+    assert gpu_lib.eigx_band_reduce_dev(n, a.data_ptr(), lda, d.data_ptr(), e.data_ptr(), n, m, 1) == 0
+    # single entries of T are not backward-stable quantities (errors accumulate along the n-1 similarity
+    # steps); 1e-9 ||A|| element-wise, while the spectrum of T is held to 1e-13 n ||A||
+    scale = np.abs(A).max() * n
+    dg, eg = d.cpu().numpy(), e.cpu().numpy()
+    assert np.abs(dg - do).max() < 1e-9 * scale
+    assert np.abs(np.abs(eg) - np.abs(eo[0])).max() < 1e-9 * scale
+    wr = np.linalg.eigvalsh(A)
+    assert np.abs(np.linalg.eigvalsh(_band_matrix(dg, eg.reshape(1, n), 1)) - wr).max() < 1e-13 * n * np.abs(wr).max()
+
+
+@pytest.mark.parametrize("n,m", [(1, 8), (2, 8), (3, 8), (4, 8), (5, 4), (64, 16), (201, 32), (513, 48), (700, 128)])
+def test_pentadiagonal_is_similarity(gpu_lib, n, m):
+    """the pentadiagonal is not unique (2x2 block rotations); its spectrum is"""
+    import torch
+    from eigenexa_amd import layout
+
+    A = layout.random_symmetric(n, seed=12)
+    a, lda = _to_colmajor(A)
+    d = torch.zeros(n, dtype=torch.float64, device=_dev())
+    e = torch.zeros(2 * n, dtype=torch.float64, device=_dev())
+    assert gpu_lib.eigx_band_reduce_dev(n, a.data_ptr(), lda, d.data_ptr(), e.data_ptr(), n, m, 2) == 0
+    T = _band_matrix(d.cpu().numpy(), e.cpu().numpy().reshape(2, n), 2)
+    wr = np.linalg.eigvalsh(A)
+    assert np.abs(np.linalg.eigvalsh(T) - wr).max() < 1e-13 * n * np.abs(wr).max()
+
+
+# ------------------------------------------------------------------------------------------- D&C
+@pytest.mark.parametrize("band", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 33, 65, 129, 300, 1000])
+def test_band_dc_matches_oracle(gpu_lib, orc, band, n):
+    import torch
+
+    rng = np.random.default_rng(n)
+    d = rng.standard_normal(n)
+    e = np.zeros((band, n))
+    for b in range(1, band + 1):
+        if n > b:
+            e[b - 1, b:] = rng.standard_normal(n - b)
+    wo, _ = orc.band_dc(d, e, band)
+    dd = torch.from_numpy(d).to(_dev())
+    ee = torch.from_numpy(e.reshape(-1).copy()).to(_dev())
+    ldz = n + (n & 1)
+    z = torch.zeros(n, ldz, dtype=torch.float64, device=_dev())
+    w = torch.zeros(n, dtype=torch.float64, device=_dev())
+    assert gpu_lib.eigx_band_dc_dev(n, n, dd.data_ptr(), ee.data_ptr(), n, band, w.data_ptr(), z.data_ptr(),
+                                    ldz) == 0
+    wg = w.cpu().numpy()
+    T = _band_matrix(d, e, band)
+    tn = max(np.abs(T).max(), 1e-300)
+    assert np.abs(wg - wo).max() < 1e-12 * tn * max(1, n / 100)
+    from eigenexa_amd import layout
+
+    res, orth = layout.accuracy_metrics(T, wg, z[:, :n].T.cpu().numpy())
+    assert res < GATE_RES and orth < GATE_ORTH
+
+
+# ------------------------------------------------------------------------------------ back-transform
+@pytest.mark.parametrize("band", [1, 2])
+@pytest.mark.parametrize("n,nvec,mb", [(5, 5, 8), (130, 130, 16), (300, 77, 128), (517, 517, 48)])
+def test_trbak_matches_oracle_elementwise(gpu_lib, orc, band, n, nvec, mb):
+    """same reflectors, same Z in -> same Z out (blocked WY on the GPU vs reflector-by-reflector oracle)"""
+    import torch
+    from eigenexa_amd import layout
+
+    A = layout.random_symmetric(n, seed=5)
+    d, e, refl = orc.band_reduce(A, band)
+    rng = np.random.default_rng(0)
+    Z0 = np.asfortranarray(rng.standard_normal((n, nvec)))
+    Zo = Z0.copy(order="F")
+    lib = orc.load()
+    p = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    ee = np.ascontiguousarray(e)
+    assert lib.orc_trbak(n, nvec, p(refl), n, p(Zo), n, p(ee), n, band) == 0
+    a, lda = _to_colmajor(refl)
+    zt, ldz = _to_colmajor(Z0)
+    et = torch.from_numpy(ee.reshape(-1).copy()).to(_dev())
+    assert gpu_lib.eigx_trbak_dev(n, nvec, a.data_ptr(), lda, zt.data_ptr(), ldz, et.data_ptr(), n, mb, band) == 0
+    got = zt[:, :n].T.cpu().numpy()
+    assert np.abs(got - Zo).max() < 1e-11
+
+
+# ---------------------------------------------------------------------------------------- full solve
+@pytest.mark.parametrize("route", ["sx", "s"])
+@pytest.mark.parametrize("n", [3, 4, 5, 7, 64, 200, 255, 256, 257, 1000, 1024])
+def test_frank_known_answer(gpu_lib, route, n):
+    """benchmark/w_test.f:141-151 + benchmark/ev_test.f:181-204 on the Frank matrix (N=3 was a historical bug,
+    ReleaseNotes.txt:172); device-resident API"""
+    import torch
+    import eigenexa_amd as ee
+    from eigenexa_amd import api, layout
+
+    A = layout.frank(n)
+    nx, ny = ee.eigen_get_matdims(n)
+    assert nx >= n and ny >= n
+    a = torch.zeros(ny, nx, dtype=torch.float64, device=_dev())
+    a[:n, :n] = torch.from_numpy(A.T.copy()).to(_dev())
+    z = torch.zeros(ny, nx, dtype=torch.float64, device=_dev())
+    w = torch.zeros(n, dtype=torch.float64, device=_dev())
+    (ee.eigen_sx if route == "sx" else ee.eigen_s)(n, n, a, nx, w, z, nx)
+    assert api.last_status() == 0
+    wg = w.cpu().numpy()
+    lam = layout.frank_eigenvalues(n)
+    assert np.abs((wg - lam) / lam).max() < GOLD["gates"]["frank_rel_err"]
+    res, orth = layout.accuracy_metrics(A, wg, z[:n, :n].T.cpu().numpy())
+    assert res < GATE_RES and orth < GATE_ORTH
+    st = a[0, :3].cpu().numpy()  # a(1:3,1) = flops, seconds, comm seconds (src/eigen_sx.F:285-296)
+    if n >= 3:
+        assert abs(st[0]) >= 4.0 / 3.0 * n ** 3 and st[1] > 0 and st[2] == -1.0
+
+
+@pytest.mark.parametrize("route", ["sx", "s"])
+@pytest.mark.parametrize("n", [1, 2, 129, 300, 777])
+def test_random_matches_oracle_host_api(gpu_lib, orc, route, n):
+    """host arrays in / out exactly like the Fortran API; eigenvalues against the oracle"""
+    import eigenexa_amd as ee
+    from eigenexa_amd import api, layout
+
+    A = layout.random_symmetric(n)
+    wo, _, _, _ = orc.eigen(A, route)
+    nx, ny = ee.eigen_get_matdims(n)
+    a = np.zeros((nx, ny), order="F")
+    a[:n, :n] = np.triu(A)  # only the upper triangle is significant
+    z = np.zeros((nx, ny), order="F")
+    w = np.zeros(n)
+    (ee.eigen_sx if route == "sx" else ee.eigen_s)(n, n, a, nx, w, z, nx, mode="A")
+    assert api.last_status() == 0
+    assert np.abs(w - wo).max() < 1e-12 * max(1.0, np.abs(wo).max())
+    res, orth = layout.accuracy_metrics(A, w, z[:n, :n])
+    assert res < GATE_RES and orth < GATE_ORTH
+
+
+def test_c_test_matrix(gpu_lib):
+    """C/c_test.c:5-77"""
+    import eigenexa_amd as ee
+
+    A = np.array(GOLD["c_test"]["matrix"])
+    a = np.asfortranarray(A.copy())
+    z = np.zeros((2, 2), order="F")
+    w = np.zeros(2)
+    ee.eigen_sx(2, 2, a, 2, w, z, 2)
+    assert np.allclose(w, GOLD["c_test"]["eigenvalues"], atol=1e-14)
+    assert np.allclose(np.abs(z), np.sqrt(0.5), atol=1e-14)
+
+
+def test_modes_and_partial_vectors(gpu_lib, orc):
+    import eigenexa_amd as ee
+    from eigenexa_amd import layout
+
+    n = 400
+    A = layout.random_symmetric(n, seed=9)
+    wr = np.linalg.eigvalsh(A)
+    # mode 'N': eigenvalues only, z untouched (src/eigen_sx.F:219-221)
+    a = np.asfortranarray(A.copy())
+    z = np.full((n, n), 7.0, order="F")
+    w = np.zeros(n)
+    ee.eigen_sx(n, n, a, n, w, z, n, mode="N")
+    assert np.abs(w - wr).max() < 1e-12 * np.abs(wr).max() and (z == 7.0).all()
+    # nvec = 0 behaves like mode 'N' (src/eigen_sx.F:108-110)
+    a = np.asfortranarray(A.copy())
+    ee.eigen_s(n, 0, a, n, w, z, n)
+    assert np.abs(w - wr).max() < 1e-12 * np.abs(wr).max() and (z == 7.0).all()
+    # nvec < n: the first nvec eigenvectors
+    a = np.asfortranarray(A.copy())
+    z = np.zeros((n, n), order="F")
+    ee.eigen_sx(n, 40, a, n, w, z, n)
+    Z = z[:, :40]
+    assert np.linalg.norm(A @ Z - Z * w[:40]) / (n * EPS * np.linalg.norm(A)) < GATE_RES
+
+
+def test_error_behaviour(gpu_lib):
+    """NaN input -> w = NaN (src/eigen_sx.F:151-155); n <= 0 -> warning + return (:95-98)"""
+    import eigenexa_amd as ee
+    from eigenexa_amd import api, layout
+
+    n = 50
+    A = layout.random_symmetric(n)
+    A[3, 7] = np.inf
+    a = np.asfortranarray(A.copy())
+    z = np.zeros((n, n), order="F")
+    w = np.zeros(n)
+    ee.eigen_sx(n, n, a, n, w, z, n)
+    assert np.isnan(w).all() and api.last_status() == -5
+    ee.eigen_sx(0, 0, a, n, w, z, n)
+    assert api.last_status() == -2
+    assert ee.eigen_get_matdims(70000) == (-1, -1)  # 32-bit guard (src/eigen_libs0.F:1349-1365)
+    assert ee.eigen_get_procs() == (1, 1, 1) and ee.eigen_get_id() == (1, 1, 1)
+
+
+def test_scaling_extremes(gpu_lib):
+    """eigen_scaling (src/eigen_scaling.F:127-147): tiny / huge matrices are rescaled, w unscaled"""
+    import eigenexa_amd as ee
+    from eigenexa_amd import layout
+
+    n = 120
+    A0 = layout.random_symmetric(n, seed=4)
+    wr = np.linalg.eigvalsh(A0)
+    for f in (1e-200, 1e200):
+        a = np.asfortranarray(A0 * f)
+        z = np.zeros((n, n), order="F")
+        w = np.zeros(n)
+        ee.eigen_sx(n, n, a, n, w, z, n)
+        assert np.abs(w / f - wr).max() < 1e-12 * np.abs(wr).max()
+
+
+@pytest.mark.parametrize("route", ["sx", "s"])
+def test_baseline_size_properties(gpu_lib, route):
+    """BASELINE.json configs[1] (N=8192 random symmetric): size-independent properties on the GPU --
+    residual ||AZ-ZW||/||A|| <= 1e-12 N, the reference's 768 / 8 gates, trace and Frobenius invariants."""
+    import torch
+    import eigenexa_amd as ee
+    from eigenexa_amd import api, layout
+
+    n = 8192
+    A = torch.from_numpy(layout.random_symmetric(n)).to(_dev())
+    nx, ny = ee.eigen_get_matdims(n)
+    a = torch.zeros(ny, nx, dtype=torch.float64, device=_dev())
+    a[:n, :n] = A.T
+    z = torch.zeros(ny, nx, dtype=torch.float64, device=_dev())
+    w = torch.zeros(n, dtype=torch.float64, device=_dev())
+    (ee.eigen_sx if route == "sx" else ee.eigen_s)(n, n, a, nx, w, z, nx, m_forward=128)
+    assert api.last_status() == 0
+    Z = z[:n, :n].T
+    anorm = torch.linalg.norm(A).item()
+    r = torch.linalg.norm(A @ Z - Z * w[None, :]).item()
+    assert r / anorm <= 1e-12 * n
+    assert r / (n * EPS * anorm) < GATE_RES
+    assert torch.linalg.norm(Z.T @ Z - torch.eye(n, dtype=torch.float64, device=_dev())).item() / (n * EPS) < GATE_ORTH
+    assert abs(w.sum().item() - torch.trace(A).item()) < 1e-9 * anorm          # trace invariant
+    assert abs(torch.linalg.norm(w).item() - anorm) < 1e-10 * anorm            # Frobenius invariant
+    assert (w[1:] >= w[:-1]).all()                                             # ascending

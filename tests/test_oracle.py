@@ -1,0 +1,102 @@
+"""CPU tests that pin the oracle (oracle/eigx_oracle.c) against the reference's own known-answer tests."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from eigenexa_amd import layout
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "known_answers.json")))
+GATE_RES = GOLD["gates"]["residual"]
+GATE_ORTH = GOLD["gates"]["orthogonality"]
+
+
+@pytest.mark.parametrize("route", ["sx", "s"])
+@pytest.mark.parametrize("n", [3, 4, 5, 7, 64, 200, 257])
+def test_frank_analytic(orc, route, n):
+    """benchmark/w_test.f:141-151: max relative eigenvalue error < sqrt(eps) on the Frank matrix"""
+    A = layout.frank(n)
+    w, Z, stats, _ = orc.eigen(A, route)
+    lam = layout.frank_eigenvalues(n)
+    g = GOLD["frank"][str(n)]
+    assert np.allclose([lam[0], lam[n // 2], lam[-1], lam.sum()], g, rtol=1e-13)  # fixture == formula
+    assert np.abs((w - lam) / lam).max() < GOLD["gates"]["frank_rel_err"]
+    res, orth = layout.accuracy_metrics(A, w, Z)
+    assert res < GATE_RES and orth < GATE_ORTH
+    assert stats[0] > 0  # a(1,1) = flop count (src/eigen_sx.F:285-296)
+
+
+@pytest.mark.parametrize("route", ["sx", "s"])
+def test_c_test_matrix(orc, route):
+    """C/c_test.c:5-77"""
+    A = np.array(GOLD["c_test"]["matrix"])
+    w, Z, _, _ = orc.eigen(A, route)
+    assert np.allclose(w, GOLD["c_test"]["eigenvalues"], atol=1e-14)
+
+
+@pytest.mark.parametrize("route", ["sx", "s"])
+@pytest.mark.parametrize("n", [1, 2, 33, 65, 100, 300, 513])
+def test_random_vs_lapack(orc, route, n):
+    A = layout.random_symmetric(n)
+    w, Z, _, _ = orc.eigen(A, route)
+    wr = np.linalg.eigvalsh(A)
+    assert np.abs(w - wr).max() <= 1e-12 * max(1.0, np.abs(wr).max())
+    res, orth = layout.accuracy_metrics(A, w, Z)
+    assert res < GATE_RES and orth < GATE_ORTH
+
+
+@pytest.mark.parametrize("band", [1, 2])
+def test_band_reduce_is_similarity(orc, band):
+    n = 150
+    A = layout.random_symmetric(n, seed=7)
+    d, e, _ = orc.band_reduce(A, band)
+    T = np.diag(d)
+    for b in range(1, band + 1):
+        T += np.diag(e[b - 1, b:], b) + np.diag(e[b - 1, b:], -b)
+    assert np.abs(np.linalg.eigvalsh(T) - np.linalg.eigvalsh(A)).max() < 1e-12 * n
+
+
+def test_tridiagonal_matches_independent_householder(orc):
+    """the bottom-up Householder tridiagonal is unique up to signs of e: compare (d, |e|) with a plain numpy
+    implementation of the same similarity"""
+    n = 40
+    A = layout.random_symmetric(n, seed=3)
+    d, e, _ = orc.band_reduce(A, 1)
+    W = A.copy()
+    for i in range(n - 1, 0, -1):
+        x = W[:i, i].copy()
+        s = -np.copysign(np.linalg.norm(x), x[-1])
+        u = x.copy()
+        u[-1] -= s
+        beta = -u[-1] * s
+        H = np.eye(n)
+        H[:i, :i] -= np.outer(u, u) / beta
+        W = H @ W @ H
+    assert np.allclose(np.diag(W), d, atol=1e-12 * n)
+    assert np.allclose(np.abs(np.diag(W, 1)), np.abs(e[0, 1:]), atol=1e-12 * n)
+
+
+@pytest.mark.parametrize("band", [1, 2])
+def test_band_dc_heavy_deflation(orc, band):
+    n = 200
+    rng = np.random.default_rng(1)
+    d = np.tile(rng.standard_normal(8), n // 8)
+    e = np.zeros((band, n))
+    for b in range(1, band + 1):
+        e[b - 1, b:] = 1e-3 * np.tile(rng.standard_normal(8), n // 8 + 1)[: n - b]
+    T = np.diag(d)
+    for b in range(1, band + 1):
+        T += np.diag(e[b - 1, b:], b) + np.diag(e[b - 1, b:], -b)
+    w, Z = orc.band_dc(d, e, band)
+    assert np.abs(w - np.linalg.eigvalsh(T)).max() < 1e-13
+    res, orth = layout.accuracy_metrics(T, w, Z)
+    assert res < GATE_RES and orth < GATE_ORTH
+
+
+def test_nan_input_sets_w_nan(orc):
+    """src/eigen_sx.F:151-155"""
+    A = layout.random_symmetric(10)
+    A[2, 5] = np.nan
+    w, _, _, _ = orc.eigen(A, "sx")
+    assert np.isnan(w).all()
