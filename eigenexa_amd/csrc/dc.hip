@@ -204,26 +204,40 @@ __global__ void rotate_kernel(const MergeDev* __restrict__ md, const int* __rest
 }
 
 // ================================================================================================
-// secular equation: one thread per root.  f(x) = 1/rho + sum_i z_i^2/(d_i - x), d ascending, ||z|| = 1.
+// secular equation: 8 lanes per root (32 roots per 256-thread workgroup).  f(x) = 1/rho + sum_i z_i^2/(d_i - x),
+// d ascending, ||z|| = 1.  Lane `sub` of a root's 8-lane group owns the poles i = sub (mod 8); sums are
+// combined with an xor butterfly (bit-identical in all 8 lanes, so the group branches uniformly).
 // Writes lambda_j to Dn[off+j] and S'(j,i) = d_i - lambda_j (root index contiguous).
 // ================================================================================================
-__global__ __launch_bounds__(128) void secular_kernel(const MergeDev* __restrict__ md,
+__device__ __forceinline__ double group8_sum(double v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void secular_kernel(const MergeDev* __restrict__ md,
                                                       const double* __restrict__ dlam,
                                                       const double* __restrict__ wz, double* __restrict__ Dn,
                                                       double* __restrict__ S, int lds) {
   const MergeDev M = md[blockIdx.y];
   const int K = M.K;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= K) return;
+  if ((int)(blockIdx.x * 32) >= K) return;
+  const int sub = threadIdx.x & 7;
+  const int jraw = blockIdx.x * 32 + (threadIdx.x >> 3);
+  const bool act = jraw < K;
+  const int j = act ? jraw : K - 1;  // idle groups recompute the last root (keeps every lane in the shuffles)
   const double* __restrict__ d = dlam + M.off;
   const double* __restrict__ z = wz + M.off;
   double* Sp = S + (size_t)M.off * lds + M.off;  // S'(j,i) at Sp[j + i*lds]
   const double rho = M.rho, rhoinv = 1.0 / rho;
   const double eps = DBL_EPSILON / 2.0;
   if (K == 1) {
-    const double t = rho * z[0] * z[0];
-    Dn[M.off] = d[0] + t;
-    Sp[0] = -t;
+    if (threadIdx.x == 0) {
+      const double t = rho * z[0] * z[0];
+      Dn[M.off] = d[0] + t;
+      Sp[0] = -t;
+    }
     return;
   }
   const bool last = (j == K - 1);
@@ -232,9 +246,10 @@ __global__ __launch_bounds__(128) void secular_kernel(const MergeDev* __restrict
   {
     const double gap = last ? rho : d[j + 1] - d[j];
     const double mid = last ? d[K - 1] + 0.5 * rho : 0.5 * (d[j] + d[j + 1]);
-    double c = rhoinv;
-    for (int i = 0; i < K; ++i)
+    double c = 0.0;
+    for (int i = sub; i < K; i += 8)
       if (i != jl && i != jr) c += z[i] * z[i] / (d[i] - mid);
+    c = group8_sum(c) + rhoinv;
     const double zl2 = z[jl] * z[jl], zr2 = z[jr] * z[jr];
     const double fmid = c + zl2 / (d[jl] - mid) + zr2 / (d[jr] - mid);
     int org;
@@ -256,15 +271,15 @@ __global__ __launch_bounds__(128) void secular_kernel(const MergeDev* __restrict
   }
   for (int iter = 0; iter < 100; ++iter) {
     double psi = 0.0, dpsi = 0.0, phi = 0.0, dphi = 0.0, err = 0.0;
-    for (int i = 0; i <= jl; ++i) {
+    for (int i = sub; i < K; i += 8) {
       const double t = z[i] / ((d[i] - origin) - tau);
-      psi += z[i] * t; dpsi += t * t; err += psi;
+      const double zt = z[i] * t, tt = t * t;
+      if (i <= jl) { psi += zt; dpsi += tt; err += fabs(psi); }
+      else { phi += zt; dphi += tt; err += fabs(phi); }
     }
-    err = fabs(err);
-    for (int i = K - 1; i > jl; --i) {
-      const double t = z[i] / ((d[i] - origin) - tau);
-      phi += z[i] * t; dphi += t * t; err += fabs(phi);
-    }
+    psi = group8_sum(psi); dpsi = group8_sum(dpsi);
+    phi = group8_sum(phi); dphi = group8_sum(dphi);
+    err = group8_sum(err);
     const double wv = rhoinv + phi + psi;
     err = 8.0 * (fabs(phi) + fabs(psi)) + err + 2.0 * rhoinv + fabs(tau) * (dpsi + dphi);
     if (fabs(wv) <= eps * err) break;
@@ -288,8 +303,10 @@ __global__ __launch_bounds__(128) void secular_kernel(const MergeDev* __restrict
     if (tnew == tau) break;
     tau = tnew;
   }
-  Dn[M.off + j] = origin + tau;
-  for (int i = 0; i < K; ++i) Sp[j + (size_t)i * lds] = (d[i] - origin) - tau;
+  if (act) {
+    if (sub == 0) Dn[M.off + j] = origin + tau;
+    for (int i = sub; i < K; i += 8) Sp[j + (size_t)i * lds] = (d[i] - origin) - tau;
+  }
 }
 
 // Gu-Eisenstat: zhat_i^2 = prod_j (lam_j - d_i) / prod_{j != i} (d_j - d_i); one wave per pole i
@@ -317,23 +334,32 @@ __global__ __launch_bounds__(256) void loewner_kernel(const MergeDev* __restrict
   }
 }
 
-// eigenvectors of the rank-one problem: S'(j,i) <- zhat_i / (d_i - lam_j), normalised over i
-__global__ __launch_bounds__(128) void vectors_kernel(const MergeDev* __restrict__ md, const double* __restrict__ zh,
+// eigenvectors of the rank-one problem: S'(j,i) <- zhat_i / (d_i - lam_j), normalised over i.
+// workgroup = 64 roots (lanes) x 4 waves (wave w owns the poles i = w mod 4): coalesced along j.
+__global__ __launch_bounds__(256) void vectors_kernel(const MergeDev* __restrict__ md, const double* __restrict__ zh,
                                                       double* __restrict__ S, int lds) {
+  __shared__ double part[4][64];
   const MergeDev M = md[blockIdx.y];
   const int K = M.K;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= K) return;
+  if ((int)(blockIdx.x * 64) >= K) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const bool act = j < K;
   double* Sp = S + (size_t)M.off * lds + M.off + j;
   const double* zz = zh + M.off;
   double nrm = 0.0;
-  for (int i = 0; i < K; ++i) {
-    const double v = zz[i] / Sp[(size_t)i * lds];
-    Sp[(size_t)i * lds] = v;
-    nrm += v * v;
+  if (act)
+    for (int i = wave; i < K; i += 4) {
+      const double v = zz[i] / Sp[(size_t)i * lds];
+      Sp[(size_t)i * lds] = v;
+      nrm += v * v;
+    }
+  part[wave][lane] = nrm;
+  __syncthreads();
+  if (act) {
+    const double sc = 1.0 / sqrt((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+    for (int i = wave; i < K; i += 4) Sp[(size_t)i * lds] *= sc;
   }
-  const double sc = 1.0 / sqrt(nrm);
-  for (int i = 0; i < K; ++i) Sp[(size_t)i * lds] *= sc;
 }
 
 // copy deflated columns Qa(:, src) -> Qb(:, dst) on the merge's row range
@@ -651,10 +677,10 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
       for (const MergeDev& M : mds) maxK = std::max(maxK, M.K);
       if (maxK > 0) {
         const unsigned nmg = (unsigned)ids.size();
-        hipLaunchKernelGGL(secular_kernel, dim3((maxK + 127) / 128, nmg), dim3(128), 0, st, md_dev, dlam, wz, Dcur, S,
+        hipLaunchKernelGGL(secular_kernel, dim3((maxK + 31) / 32, nmg), dim3(256), 0, st, md_dev, dlam, wz, Dcur, S,
                            ldq);
         hipLaunchKernelGGL(loewner_kernel, dim3((maxK + 3) / 4, nmg), dim3(256), 0, st, md_dev, dlam, wz, S, ldq, zh);
-        hipLaunchKernelGGL(vectors_kernel, dim3((maxK + 127) / 128, nmg), dim3(128), 0, st, md_dev, zh, S, ldq);
+        hipLaunchKernelGGL(vectors_kernel, dim3((maxK + 63) / 64, nmg), dim3(256), 0, st, md_dev, zh, S, ldq);
         for (const MergeDev& M : mds) {
           if (M.K <= 0) continue;
           // Qb(rows, off+j) = sum_i Qa(rows, nd[i]) * U(i,j),  U(i,j) = S'(j,i)

@@ -47,6 +47,7 @@ static inline int local_count(int n, int P, int p) { return n > p ? (n - p + P -
 void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, double alpha,
                const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc,
                int tri_mode = 0, const Grid* g = nullptr, const int* kmapA = nullptr,
-               const int* cmapC = nullptr, int batch = 1, long strideA = 0, long strideB = 0, long strideC = 0);
+               const int* cmapC = nullptr, int batch = 1, long strideA = 0, long strideB = 0, long strideC = 0,
+               int batch2 = 1, long strideA2 = 0, long strideB2 = 0, long strideC2 = 0);
 
 }  // namespace eigx

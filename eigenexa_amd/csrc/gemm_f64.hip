@@ -23,10 +23,17 @@ namespace eigx {
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LD_MC = BM + 16;  // doubles; (LD_MC*2) % 64 == 32 -> lanes 16..31 land on the other bank half
+constexpr int BK = 16;
 constexpr int LD_KC = BK + 1;
-constexpr int OPER_DOUBLES = (BK * LD_MC > BM * LD_KC) ? BK * LD_MC : BM * LD_KC;
+// tile geometry for a wave tile of WT x WT (WT = 64: 128x128 workgroup tile; WT = 32: 64x64, used when the
+// output is too small to fill 256 CUs with 128x128 tiles)
+template <int WT> struct Geo {
+  static constexpr int BM = 2 * WT, BN = 2 * WT;
+  static constexpr int LD_MC = BM + 16;  // doubles; (LD_MC*2) % 64 == 32 -> lanes 16..31 land on the other bank half
+  static constexpr int OPER = (BK * LD_MC > BM * LD_KC) ? BK * LD_MC : BM * LD_KC;
+  static constexpr int NL = BM * BK / 256;  // slab elements per thread
+  static constexpr int NF = WT / 16;        // MFMA tiles per wave per dimension
+};
 
 struct GemmArgs {
   int M, N, K;
@@ -41,22 +48,24 @@ struct GemmArgs {
   int Px, px, Py, py;
   const int* kmapA;  // optional: column of A that holds k-index k ('N' A only): A(:, kmapA[k])
   const int* cmapC;  // optional: column of C that receives n-index n: C(:, cmapC[n])
-  long sA, sB, sC;   // batch strides in elements (blockIdx.y = batch index)
+  long sA, sB, sC;     // batch strides in elements (blockIdx.y = batch index)
+  long sA2, sB2, sC2;  // second-level batch strides (blockIdx.z)
 };
 
-// Load this thread's 8 elements of a 128 x 16 operand slab (rows m0.., k-range k0..) into regs.
+// Load this thread's NL elements of a BM x 16 operand slab (rows m0.., k-range k0..) into regs.
 //   MC: element (m,k) at P[m + k*ld]     KC: element (m,k) at P[k + m*ld]
-template <bool KC>
-__device__ __forceinline__ void load_slab(double (&r)[8], const double* __restrict__ P, int ld, int m0,
+template <bool KC, int WT>
+__device__ __forceinline__ void load_slab(double (&r)[Geo<WT>::NL], const double* __restrict__ P, int ld, int m0,
                                           int k0, int Mmax, int Kmax, int tid,
                                           const int* __restrict__ kmap = nullptr) {
+  constexpr int BM = Geo<WT>::BM, NL = Geo<WT>::NL;
   if (!KC) {
-    const int m = m0 + (tid & 127);
-    const int kb = k0 + (tid >> 7);  // 0..1, then +2 per pass
+    const int m = m0 + (tid & (BM - 1));
+    const int kb = k0 + tid / BM;  // 0..256/BM-1, then +256/BM per pass
     const bool mok = m < Mmax;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int k = kb + 2 * p;
+    for (int p = 0; p < NL; ++p) {
+      const int k = kb + (256 / BM) * p;
       if (mok && k < Kmax) {
         const int kc = kmap ? kmap[k] : k;
         r[p] = P[(size_t)m + (size_t)kc * ld];
@@ -69,39 +78,41 @@ __device__ __forceinline__ void load_slab(double (&r)[8], const double* __restri
     const int mb = m0 + (tid >> 4);  // 0..15, then +16 per pass
     const bool kok = k < Kmax;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < NL; ++p) {
       const int m = mb + 16 * p;
       r[p] = (kok && m < Mmax) ? P[(size_t)k + (size_t)m * ld] : 0.0;
     }
   }
 }
 
-template <bool KC>
-__device__ __forceinline__ void store_slab(const double (&r)[8], double* __restrict__ S, int tid) {
+template <bool KC, int WT>
+__device__ __forceinline__ void store_slab(const double (&r)[Geo<WT>::NL], double* __restrict__ S, int tid) {
+  constexpr int BM = Geo<WT>::BM, NL = Geo<WT>::NL, LD_MC = Geo<WT>::LD_MC;
   if (!KC) {
-    const int m = tid & 127;
-    const int kb = tid >> 7;
+    const int m = tid & (BM - 1);
+    const int kb = tid / BM;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) S[(kb + 2 * p) * LD_MC + m] = r[p];
+    for (int p = 0; p < NL; ++p) S[(kb + (256 / BM) * p) * LD_MC + m] = r[p];
   } else {
     const int k = tid & 15;
     const int mb = tid >> 4;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) S[(mb + 16 * p) * LD_KC + k] = r[p];
+    for (int p = 0; p < NL; ++p) S[(mb + 16 * p) * LD_KC + k] = r[p];
   }
 }
 
-template <bool KC>
+template <bool KC, int WT>
 __device__ __forceinline__ double frag(const double* __restrict__ S, int m, int k) {
-  return KC ? S[m * LD_KC + k] : S[k * LD_MC + m];
+  return KC ? S[m * LD_KC + k] : S[k * Geo<WT>::LD_MC + m];
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int WT>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  g.A += (long)blockIdx.y * g.sA;
-  g.B += (long)blockIdx.y * g.sB;
-  g.C += (long)blockIdx.y * g.sC;
+  constexpr int BM = Geo<WT>::BM, BN = Geo<WT>::BN, OPER_DOUBLES = Geo<WT>::OPER, NL = Geo<WT>::NL, NF = Geo<WT>::NF;
+  g.A += (long)blockIdx.y * g.sA + (long)blockIdx.z * g.sA2;
+  g.B += (long)blockIdx.y * g.sB + (long)blockIdx.z * g.sB2;
+  g.C += (long)blockIdx.y * g.sC + (long)blockIdx.z * g.sC2;
   // stage buffer b: A slab at smem + 2*b*OPER_DOUBLES, B slab right behind it
 
   const int tid = threadIdx.x;
@@ -141,56 +152,56 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   // Accumulators start from (beta/alpha)*C so the C tile is fetched while the first operand slabs are
   // in flight and the epilogue is store-only (result = alpha*acc).  acc[i][j][r] holds
   // C(m = m0+wm*64+i*16+(lane&15), n = n0+wn*64+j*16+(lane>>4)+4r).
-  d4_t acc[4][4];
+  d4_t acc[NF][NF];
   const bool use_c = (g.beta != 0.0) && (g.alpha != 0.0);
   const double cscale = use_c ? g.beta / g.alpha : 0.0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NF; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wn * 64 + j * 16 + fk + 4 * r;
+      const int n = n0 + wn * WT + j * 16 + fk + 4 * r;
       const int nc = (g.cmapC && n < g.N) ? g.cmapC[n] : n;
       const double* cp = g.C + (size_t)nc * g.ldc;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + fm;
+      for (int i = 0; i < NF; ++i) {
+        const int m = m0 + wm * WT + i * 16 + fm;
         acc[i][j][r] = (use_c && n < g.N && m < g.M) ? cscale * cp[m] : 0.0;
       }
     }
 
-  double ra[8], rb[8];
+  double ra[NL], rb[NL];
   const int nk = (g.K + BK - 1) / BK;
-  load_slab<A_KC>(ra, g.A, g.lda, m0, 0, g.M, g.K, tid, g.kmapA);
-  load_slab<B_KC>(rb, g.B, g.ldb, n0, 0, g.N, g.K, tid);
-  store_slab<A_KC>(ra, smem, tid);
-  store_slab<B_KC>(rb, smem + OPER_DOUBLES, tid);
+  load_slab<A_KC, WT>(ra, g.A, g.lda, m0, 0, g.M, g.K, tid, g.kmapA);
+  load_slab<B_KC, WT>(rb, g.B, g.ldb, n0, 0, g.N, g.K, tid);
+  store_slab<A_KC, WT>(ra, smem, tid);
+  store_slab<B_KC, WT>(rb, smem + OPER_DOUBLES, tid);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      load_slab<A_KC>(ra, g.A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid, g.kmapA);
-      load_slab<B_KC>(rb, g.B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
+      load_slab<A_KC, WT>(ra, g.A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid, g.kmapA);
+      load_slab<B_KC, WT>(rb, g.B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
     }
     const double* as = smem + cur * 2 * OPER_DOUBLES;
     const double* bs = as + OPER_DOUBLES;
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
-      double fa[4], fb[4];
+      double fa[NF], fb[NF];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = frag<A_KC>(as, wm * 64 + i * 16 + fm, ks * 4 + fk);
+      for (int i = 0; i < NF; ++i) fa[i] = frag<A_KC, WT>(as, wm * WT + i * 16 + fm, ks * 4 + fk);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = frag<B_KC>(bs, wn * 64 + j * 16 + fm, ks * 4 + fk);
+      for (int j = 0; j < NF; ++j) fb[j] = frag<B_KC, WT>(bs, wn * WT + j * 16 + fm, ks * 4 + fk);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NF; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NF; ++i)
           // D[x][y] = sum_k opB(k, n=x) * opA(m=y, k)  ->  lane&15 <-> m (contiguous in C)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) {
-      store_slab<A_KC>(ra, smem + (cur ^ 1) * 2 * OPER_DOUBLES, tid);
-      store_slab<B_KC>(rb, smem + (cur ^ 1) * 2 * OPER_DOUBLES + OPER_DOUBLES, tid);
+      store_slab<A_KC, WT>(ra, smem + (cur ^ 1) * 2 * OPER_DOUBLES, tid);
+      store_slab<B_KC, WT>(rb, smem + (cur ^ 1) * 2 * OPER_DOUBLES + OPER_DOUBLES, tid);
     }
     __syncthreads();
   }
@@ -198,16 +209,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   // epilogue (store-only unless alpha == 0)
   const double alpha = g.alpha, beta = g.beta;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NF; ++j) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wn * 64 + j * 16 + fk + 4 * r;
+      const int n = n0 + wn * WT + j * 16 + fk + 4 * r;
       if (n >= g.N) continue;
       const int nc = g.cmapC ? g.cmapC[n] : n;
       double* cp = g.C + (size_t)nc * g.ldc;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + fm;
+      for (int i = 0; i < NF; ++i) {
+        const int m = m0 + wm * WT + i * 16 + fm;
         if (m < g.M) {
           double v = alpha * acc[i][j][r];
           if (alpha == 0.0 && beta != 0.0) v = beta * cp[m];
@@ -223,8 +234,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, double alpha, const double* A,
                int lda, const double* B, int ldb, double beta, double* C, int ldc, int tri_mode,
                const Grid* grid, const int* kmapA, const int* cmapC, int batch, long strideA, long strideB,
-               long strideC) {
-  if (M <= 0 || N <= 0 || batch <= 0) return;
+               long strideC, int batch2, long strideA2, long strideB2, long strideC2) {
+  if (M <= 0 || N <= 0 || batch <= 0 || batch2 <= 0) return;
   GemmArgs g;
   g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
@@ -232,27 +243,34 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
   g.kmapA = (opA == 'N' || opA == 'n') ? kmapA : nullptr;
   g.cmapC = cmapC;
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
+  g.sA2 = strideA2; g.sB2 = strideB2; g.sC2 = strideC2;
   g.Px = grid ? grid->Px : 1; g.px = grid ? grid->px : 0;
   g.Py = grid ? grid->Py : 1; g.py = grid ? grid->py : 0;
   const bool a_kc = (opA == 'T' || opA == 't');   // op(A)(m,k) = A[k + m*lda]
   const bool b_kc = (opB == 'N' || opB == 'n');   // op(B)(k,n) = B[k + n*ldb]
-  const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
-  const size_t shmem = (size_t)4 * OPER_DOUBLES * sizeof(double);
-  dim3 grd(tiles, batch), blk(256);
-#define EIGX_LAUNCH(AK, BK_)                                                                       \
+  // 64x64 tiles when 128x128 tiles would leave most of the 256 CUs idle
+  const long tiles128 = (long)ceil_div(M, 128) * ceil_div(N, 128) * batch * batch2;
+  const bool small = (tri_mode == 0) && tiles128 < 192;
+  const int bm = small ? 64 : 128;
+  const int tiles = ceil_div(M, bm) * ceil_div(N, bm);
+  dim3 grd(tiles, batch, batch2), blk(256);
+#define EIGX_LAUNCH(AK, BK_, WT_)                                                                  \
   do {                                                                                             \
+    const size_t shmem = (size_t)4 * Geo<WT_>::OPER * sizeof(double);                              \
     static bool attr_set = false;                                                                  \
     if (!attr_set) {                                                                               \
-      EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f64_kernel<AK, BK_>,                    \
+      EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f64_kernel<AK, BK_, WT_>,               \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
       attr_set = true;                                                                             \
     }                                                                                              \
-    hipLaunchKernelGGL((gemm_f64_kernel<AK, BK_>), grd, blk, shmem, stream, g);                    \
+    hipLaunchKernelGGL((gemm_f64_kernel<AK, BK_, WT_>), grd, blk, shmem, stream, g);               \
   } while (0)
-  if (a_kc && b_kc) EIGX_LAUNCH(true, true);
-  else if (a_kc && !b_kc) EIGX_LAUNCH(true, false);
-  else if (!a_kc && b_kc) EIGX_LAUNCH(false, true);
-  else EIGX_LAUNCH(false, false);
+#define EIGX_LAUNCH_T(AK, BK_) do { if (small) EIGX_LAUNCH(AK, BK_, 32); else EIGX_LAUNCH(AK, BK_, 64); } while (0)
+  if (a_kc && b_kc) EIGX_LAUNCH_T(true, true);
+  else if (a_kc && !b_kc) EIGX_LAUNCH_T(true, false);
+  else if (!a_kc && b_kc) EIGX_LAUNCH_T(false, true);
+  else EIGX_LAUNCH_T(false, false);
+#undef EIGX_LAUNCH_T
 #undef EIGX_LAUNCH
   EIGX_HIP_CHECK(hipGetLastError());
 }

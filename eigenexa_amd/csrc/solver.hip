@@ -12,7 +12,7 @@
 
 namespace eigx {
 
-void trbak_dev(Context& ctx, int n, int nvec, const double* A, int lda, double* Z, int ldz, const double* e,
+void trbak_dev(Context& ctx, int n, int nvec, double* A, int lda, double* Z, int ldz, const double* e,
                int lde, int mb, int band);
 
 namespace {
@@ -232,7 +232,7 @@ int eigx_trbak_dev(int n, int nvec, const double* a, int lda, double* z, int ldz
   if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
   if (n <= 0 || nvec < 0 || lda < n || ldz < n || lde < n || (band != 1 && band != 2)) return EIGX_ERR_BAD_ARG;
   if (g_ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;
-  trbak_dev(g_ctx, n, nvec, a, lda, z, ldz, e, lde, mb > 0 ? mb : 128, band);
+  trbak_dev(g_ctx, n, nvec, const_cast<double*>(a), lda, z, ldz, e, lde, mb > 0 ? mb : 128, band);
   EIGX_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
   return EIGX_OK;
 }

@@ -8,10 +8,11 @@
 //   (src/trbakwy4_body.F:573-577, :305-313, :687), beta_j = -a(j-band, j) * e(j, band)
 //   (src/trbakwy4.F:309-335).
 // MI355X re-design (one stream, no panel broadcast / triple buffering needed on one GPU):
-//   1. mask-copy the block's reflectors out of `a` into a zero-padded panel V (rows x mb)
-//   2. Gram partials G_c = V_c^T V_c over 512-row chunks: one batched fp64 MFMA GEMM launch
-//   3. T = S^{-1} by the row recurrence T(k,:) = -(1/beta_k) G(k,0:k) T(0:k,:) in LDS (packed lower
-//      triangles of G and T, one workgroup) -- replaces the DTRSM of the reference
+//   1. zero `a` below every reflector: `a` itself is then the zero-padded panel V of every block
+//   2. Gram partials G_c = V_c^T V_c over 512-row chunks of ALL blocks: one two-level batched fp64 MFMA
+//      GEMM launch
+//   3. T = S^{-1} of ALL blocks in one launch (one workgroup per block): row recurrence
+//      T(k,:) = -(1/beta_k) G(k,0:k) T(0:k,:) on packed lower triangles in LDS -- replaces the DTRSM
 //   4. W = V^T Z,  X = T W,  Z -= V X : three fp64 MFMA GEMMs (the reference's dgemm('T','N') +
 //      dtrsm + dgemm('N','N'))
 #include "eigx_context.h"
@@ -23,25 +24,32 @@ namespace {
 
 constexpr int GCH = 512;  // rows per Gram chunk
 
-// V(r, c) = a(r, j0+c) for r <= j0+c-band, else 0 ; rows [0, rows_pad)
-__global__ void maskcopy_kernel(const double* __restrict__ A, int lda, int j0, int mbk, int band, int rows_pad,
-                                double* __restrict__ V, int ldv) {
-  const int c = blockIdx.y;
-  if (c >= mbk) return;
-  const int len = j0 + c - band + 1;
-  const double* src = A + (size_t)(j0 + c) * lda;
-  double* dst = V + (size_t)c * ldv;
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows_pad; r += gridDim.x * blockDim.x)
-    dst[r] = (r < len) ? src[r] : 0.0;
+// After the reduction the part of column j below its reflector (rows > j-band) holds stale matrix / band
+// entries that nobody reads again (d, e were extracted; `a` is destroyed by contract, src/eigen_sx.F:30-308).
+// Zeroing it turns `a` itself into the zero-padded reflector panel V of every block: no copies.
+__global__ void zero_below_kernel(double* __restrict__ A, int lda, int n, int band, int rows_pad) {
+  const int j = blockIdx.y;
+  const int len = j - band + 1;  // reflector length (<= 0: no reflector in this column)
+  double* col = A + (size_t)j * lda;
+  const int lo = len > 0 ? len : 0;
+  const int hi = rows_pad < lda ? rows_pad : lda;
+  for (int r = lo + blockIdx.x * blockDim.x + threadIdx.x; r < hi; r += gridDim.x * blockDim.x) col[r] = 0.0;
 }
 
 __device__ __forceinline__ int tri_idx(int r, int c) { return r * (r + 1) / 2 + c; }  // c <= r
 
 // T = S^{-1}, S = strict_lower(G) + diag(beta); Gpart: [nchunks][mb x mb] column-major partial Grams
-__global__ __launch_bounds__(256) void tbuild_kernel(const double* __restrict__ Gpart, int nchunks, int mb, int mbk,
+__global__ __launch_bounds__(256) void tbuild_kernel(const double* __restrict__ Gall, int maxchunks, int mb, int n,
                                                      const double* __restrict__ A, int lda,
-                                                     const double* __restrict__ e, int lde, int band, int j0,
-                                                     double* __restrict__ T) {
+                                                     const double* __restrict__ e, int lde, int band,
+                                                     double* __restrict__ Tall) {
+  // block b = blockIdx.x: reflectors j0 .. j0+mbk-1
+  const int j0 = band + blockIdx.x * mb;
+  const int mbk = (n - j0 < mb) ? n - j0 : mb;
+  const int rows = j0 + mbk - band;
+  const int nchunks = (rows + GCH - 1) / GCH;
+  const double* Gpart = Gall + (size_t)blockIdx.x * maxchunks * mb * mb;
+  double* T = Tall + (size_t)blockIdx.x * mb * mb;
   extern __shared__ double sm[];  // Gl[mb(mb+1)/2] | Tl[mb(mb+1)/2] | binv[mb]
   const int tri = mb * (mb + 1) / 2;
   double* Gl = sm;
@@ -80,18 +88,29 @@ __global__ __launch_bounds__(256) void tbuild_kernel(const double* __restrict__ 
 
 }  // namespace
 
-void trbak_dev(Context& ctx, int n, int nvec, const double* A, int lda, double* Z, int ldz, const double* e,
+void trbak_dev(Context& ctx, int n, int nvec, double* A, int lda, double* Z, int ldz, const double* e,
                int lde, int mb, int band) {
   if (nvec <= 0 || n <= band) return;
   hipStream_t st = ctx.stream;
   if (mb < 8) mb = 8;
   if (mb > 128) mb = 128;  // T-builder keeps two packed mb x mb triangles in LDS
-  const int rows_max = n;
-  const int ldv = (rows_max + GCH - 1) / GCH * GCH;
-  const int maxchunks = ldv / GCH;
-  double* V = ctx.pool.get_t<double>("bt.V", (size_t)ldv * mb);
-  double* Gpart = ctx.pool.get_t<double>("bt.G", (size_t)maxchunks * mb * mb);
-  double* T = ctx.pool.get_t<double>("bt.T", (size_t)mb * mb);
+  const int nblk = (n - band + mb - 1) / mb;
+  const int rows_all = n - band;                       // longest reflector
+  int rows_pad = (rows_all + GCH - 1) / GCH * GCH;     // Gram chunks read up to here: must stay inside lda
+  const int maxchunks = (rows_all + GCH - 1) / GCH;
+  const bool inplace = rows_pad <= lda;
+  double* V = A;
+  int ldv = lda;
+  if (!inplace) {
+    // lda too small for the zero padding of the last Gram chunk: work on a padded copy of the reflectors
+    ldv = rows_pad;
+    V = ctx.pool.get_t<double>("bt.Vall", (size_t)ldv * n);
+    EIGX_HIP_CHECK(hipMemcpy2DAsync(V, (size_t)ldv * 8, A, (size_t)lda * 8, (size_t)n * 8, (size_t)n,
+                                    hipMemcpyDeviceToDevice, st));
+  }
+  hipLaunchKernelGGL(zero_below_kernel, dim3(8, n), dim3(256), 0, st, V, ldv, n, band, rows_pad);
+  double* Gall = ctx.pool.get_t<double>("bt.G", (size_t)nblk * maxchunks * mb * mb);
+  double* Tall = ctx.pool.get_t<double>("bt.T", (size_t)nblk * mb * mb);
   double* W = ctx.pool.get_t<double>("bt.W", (size_t)mb * nvec);
   double* X = ctx.pool.get_t<double>("bt.X", (size_t)mb * nvec);
   const size_t tshm = ((size_t)mb * (mb + 1) + mb) * sizeof(double);
@@ -101,21 +120,30 @@ void trbak_dev(Context& ctx, int n, int nvec, const double* A, int lda, double* 
                                        (int)(((size_t)128 * 129 + 128) * sizeof(double))));
     attr = true;
   }
-  for (int j0 = band; j0 < n; j0 += mb) {
+  // Gram partials of every block in one launch: batch = chunk (stride GCH rows), batch2 = block
+  // (stride mb columns); chunks beyond a block's reflector length multiply zeros.
+  const int nfull = (n - band) / mb;  // full blocks; a trailing partial block gets its own launch
+  if (nfull > 0)
+    dgemm_dev(st, 'T', 'N', mb, mb, GCH, 1.0, V + (size_t)band * ldv, ldv, V + (size_t)band * ldv, ldv, 0.0, Gall, mb,
+              0, nullptr, nullptr, nullptr, maxchunks, GCH, GCH, (long)mb * mb, nfull, (long)mb * ldv, (long)mb * ldv,
+              (long)maxchunks * mb * mb);
+  if (nfull < nblk) {
+    const int j0 = band + nfull * mb, mbk = n - j0;
+    dgemm_dev(st, 'T', 'N', mbk, mbk, GCH, 1.0, V + (size_t)j0 * ldv, ldv, V + (size_t)j0 * ldv, ldv, 0.0,
+              Gall + (size_t)nfull * maxchunks * mb * mb, mb, 0, nullptr, nullptr, nullptr, maxchunks, GCH, GCH,
+              (long)mb * mb);
+  }
+  hipLaunchKernelGGL(tbuild_kernel, dim3(nblk), dim3(256), tshm, st, Gall, maxchunks, mb, n, V, ldv, e, lde, band,
+                     Tall);
+  for (int b = 0; b < nblk; ++b) {
+    const int j0 = band + b * mb;
     const int mbk = (n - j0 < mb) ? n - j0 : mb;
-    const int rows = j0 + mbk - 1 - band + 1;  // length of the longest reflector of the block
-    const int nchunks = (rows + GCH - 1) / GCH;
-    const int rows_pad = nchunks * GCH;
-    hipLaunchKernelGGL(maskcopy_kernel, dim3((rows_pad + 255) / 256 > 64 ? 64 : (rows_pad + 255) / 256, mbk),
-                       dim3(256), 0, st, A, lda, j0, mbk, band, rows_pad, V, ldv);
-    // Gram partials: batch of nchunks products (mbk x mbk, K = GCH)
-    dgemm_dev(st, 'T', 'N', mbk, mbk, GCH, 1.0, V, ldv, V, ldv, 0.0, Gpart, mb, 0, nullptr, nullptr, nullptr,
-              nchunks, GCH, GCH, (long)mb * mb);
-    hipLaunchKernelGGL(tbuild_kernel, dim3(1), dim3(256), tshm, st, Gpart, nchunks, mb, mbk, A, lda, e, lde, band,
-                       j0, T);
-    dgemm_dev(st, 'T', 'N', mbk, nvec, rows, 1.0, V, ldv, Z, ldz, 0.0, W, mb);
+    const int rows = j0 + mbk - band;  // length of the longest reflector of the block
+    const double* Vb = V + (size_t)j0 * ldv;
+    const double* T = Tall + (size_t)b * mb * mb;
+    dgemm_dev(st, 'T', 'N', mbk, nvec, rows, 1.0, Vb, ldv, Z, ldz, 0.0, W, mb);
     dgemm_dev(st, 'N', 'N', mbk, nvec, mbk, 1.0, T, mb, W, mb, 0.0, X, mb);
-    dgemm_dev(st, 'N', 'N', rows, nvec, mbk, -1.0, V, ldv, X, mb, 1.0, Z, ldz);
+    dgemm_dev(st, 'N', 'N', rows, nvec, mbk, -1.0, Vb, ldv, X, mb, 1.0, Z, ldz);
   }
   EIGX_HIP_CHECK(hipGetLastError());
 }
