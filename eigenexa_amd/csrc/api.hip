@@ -47,9 +47,11 @@ int eigx_init_multi(int device, int rank, int nranks, const void* uid, char orde
   if (order == 'R' || order == 'r') {  // row-major rank order (src/eigen_libs0.F:2336-2356)
     g.px = rank / g.Py;
     g.py = rank % g.Py;
+    g.row_major = 1;
   } else {
     g.px = rank % g.Px;
     g.py = rank / g.Px;
+    g.row_major = 0;
   }
   EIGX_HIP_CHECK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
   EIGX_HIP_CHECK(hipStreamCreateWithFlags(&g_ctx.side_stream, hipStreamNonBlocking));

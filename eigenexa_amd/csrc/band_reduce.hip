@@ -28,6 +28,7 @@
 //     K_P  panel dot products U^T u, W^T u (tall-skinny), reflector store into `a` and the panel
 //   per panel: A(0:nr,0:nr) -= [U W][W U]^T on upper-triangle tiles with the fp64 MFMA GEMM.
 #include "eigx_context.h"
+#include "eigx_comm.h"
 #include "../../include/eigenexa_amd.h"
 
 namespace eigx {
@@ -53,6 +54,11 @@ struct RedArgs {
   double* sc;                     // scalars
   double* d; double* e; int lde;
   int maxseg, maxrs, maxchunk, gp2_off, kdab_off;
+  // multi-GPU (P > 1): A is the full matrix, replicated; this rank owns the 128-column tile columns
+  // tx with tx % P == p.  RB = [pA(0:Lp) | pB(0:Lp) | 3 bilinear scalars]: locally reduced SYMV partials,
+  // allreduced over the ranks once per step.
+  int P, p;
+  double* RB;
 };
 
 // SYMV tiling: square tiles of T = 128*RB rows/cols (RB = 1,2,4); tile (ty,tx) with tx >= ty is one
@@ -60,10 +66,10 @@ struct RedArgs {
 // so that the number of partial sums per row (nt+1) stays ~100.
 struct SymvGeom { int L, T, nt; };
 
-__host__ __device__ inline SymvGeom symv_geom(int L) {
+__host__ __device__ inline SymvGeom symv_geom(int L, int P = 1) {
   SymvGeom g;
   g.L = L;
-  g.T = (L <= 6000) ? 128 : (L <= 14000 ? 256 : 512);
+  g.T = (L <= 6000 || P > 1) ? 128 : (L <= 14000 ? 256 : 512);  // P > 1: ownership granularity = 128 columns
   g.nt = (L + g.T - 1) / g.T;
   return g;
 }
@@ -121,7 +127,9 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   const int ldp = R.ldp, m = R.m;
   double* Up = R.UW;
   double* Wp = R.UW + (size_t)ldp * m;
-  const SymvGeom g = symv_geom(S.Lprev);
+  const SymvGeom g = symv_geom(S.Lprev, R.P);
+  const bool mg = R.P > 1;
+  const int Lp = (S.Lprev + 7) / 8 * 8;  // RB stride
 
   // ---------------------------------------------------------------- prologue: previous step scalars
   if (S.has_prev) {
@@ -136,12 +144,16 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
     // [0..2] bilinear forms of the stale matrix (SYMV workgroups, fixed order), [3..5] their panel
     // corrections, [6] uA.uB
     double v[7] = {0, 0, 0, 0, 0, 0, 0};
-    const int tot = g.nt * g.nt;
-    for (int w = tid; w < tot; w += 256) {
-      const int ty = w / g.nt, tx = w - ty * g.nt;
-      if (tx >= ty) {
-        v[0] += R.SP[(size_t)w * 3 + 0];
-        if (NB == 2) { v[1] += R.SP[(size_t)w * 3 + 1]; v[2] += R.SP[(size_t)w * 3 + 2]; }
+    if (mg) {
+      if (tid == 0) { v[0] = R.RB[NB * Lp + 0]; if (NB == 2) { v[1] = R.RB[NB * Lp + 1]; v[2] = R.RB[NB * Lp + 2]; } }
+    } else {
+      const int tot = g.nt * g.nt;
+      for (int w = tid; w < tot; w += 256) {
+        const int ty = w / g.nt, tx = w - ty * g.nt;
+        if (tx >= ty) {
+          v[0] += R.SP[(size_t)w * 3 + 0];
+          if (NB == 2) { v[1] += R.SP[(size_t)w * 3 + 1]; v[2] += R.SP[(size_t)w * 3 + 2]; }
+        }
       }
     }
     for (int kk = tid; kk < kp; kk += 256) {
@@ -198,7 +210,11 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       for (int cc = 0; cc < S.ncols; ++cc) {
         const int c = S.i - cc;
         const int ty = c / g.T;
-        for (int t = tid; t < g.nt + 1; t += 256) symv_part(c, t, ty, v[2 * cc], v[2 * cc + 1]);
+        if (mg) {
+          if (tid == 0) { v[2 * cc] += R.RB[c]; if (NB == 2) v[2 * cc + 1] += R.RB[Lp + c]; }
+        } else {
+          for (int t = tid; t < g.nt + 1; t += 256) symv_part(c, t, ty, v[2 * cc], v[2 * cc + 1]);
+        }
         for (int kk = tid; kk < S.kprev; kk += 256) {
           const double u = rowU[cc][kk], w = rowW[cc][kk];
           v[2 * cc] -= u * kd[1][kk] + w * kd[0][kk];
@@ -239,7 +255,11 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       }
       if (S.has_prev && r < S.Lprev) {
         const int ty = r / g.T;
-        for (int t = ks; t < g.nt + 1; t += 8) symv_part(r, t, ty, pA, pB);
+        if (mg) {
+          if (ks == 0) { pA += R.RB[r]; if (NB == 2) pB += R.RB[Lp + r]; }
+        } else {
+          for (int t = ks; t < g.nt + 1; t += 8) symv_part(r, t, ty, pA, pB);
+        }
       }
     }
     slice[ks][rr][0] = pA; slice[ks][rr][1] = pB; slice[ks][rr][2] = x0; slice[ks][rr][3] = x1;
@@ -345,6 +365,44 @@ __global__ __launch_bounds__(256) void km_kernel(RedArgs R, int i, int L, int ng
 // =================================================================================================
 struct KBArgs { int i, L, nt, ngp, k, ncg, toprows; };
 
+// K_L (multi-GPU only): reduce this rank's SYMV partials (owned tile columns) into RB before the allreduce
+template <int NB>
+__global__ __launch_bounds__(256) void kl_kernel(RedArgs R, int L, int nt) {
+  __shared__ double red[16];
+  const int Lp = (L + 7) / 8 * 8;
+  const int ldp = R.ldp;
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < Lp) {
+    double pA = 0.0, pB = 0.0;
+    if (r < L) {
+      const int ty = r / 128;
+      if (ty % R.P == R.p)  // column r belongs to an owned tile column: column sums of tiles (t, ty)
+        for (int t = 0; t <= ty; ++t) {
+          pA += R.YC[((size_t)t * NB + 0) * ldp + r];
+          if (NB == 2) pB += R.YC[((size_t)t * NB + 1) * ldp + r];
+        }
+      for (int tx = ty; tx < nt; ++tx)
+        if (tx % R.P == R.p) {  // row sums of owned tiles (ty, tx)
+          pA += R.YR[((size_t)tx * NB + 0) * ldp + r];
+          if (NB == 2) pB += R.YR[((size_t)tx * NB + 1) * ldp + r];
+        }
+    }
+    R.RB[r] = pA;
+    if (NB == 2) R.RB[Lp + r] = pB;
+  }
+  if (blockIdx.x == 0) {
+    double v[3] = {0.0, 0.0, 0.0};
+    for (int w = threadIdx.x; w < nt * nt; w += 256) {
+      const int ty = w / nt, tx = w - ty * nt;
+      if (tx >= ty && tx % R.P == R.p) {
+        v[0] += R.SP[(size_t)w * 3 + 0]; v[1] += R.SP[(size_t)w * 3 + 1]; v[2] += R.SP[(size_t)w * 3 + 2];
+      }
+    }
+    block_sum_multi<3>(v, red);
+    if (threadIdx.x < 8) R.RB[NB * Lp + threadIdx.x] = threadIdx.x < 3 ? v[threadIdx.x] : 0.0;
+  }
+}
+
 template <int K> struct IC { static constexpr int value = K; };
 
 template <int NV, int RB>
@@ -358,6 +416,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   const int L = B.L, i = B.i;
   const bool panel_role = (int)blockIdx.y >= B.nt;
   if (!panel_role && ((int)blockIdx.x >= B.nt || blockIdx.x < blockIdx.y)) return;
+  if (!panel_role && R.P > 1 && ((int)blockIdx.x % R.P) != R.p) return;  // not my tile column
   if (panel_role && (int)blockIdx.x > B.ncg) return;
 
   // ---- reflector scalars (every workgroup, same order) -------------------------------------------
@@ -380,7 +439,8 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
     if (hv[0] > 0.0) { sB = -sign_of(sqrt(hv[0]), xL); betaB = hv[0] - sB * xL; }
     else { sB = xL; betaB = 0.0; }
   }
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+  // the store-role panel workgroup of chunk 0 publishes the scalars (it exists on every rank)
+  if (panel_role && (int)blockIdx.x == B.ncg && (int)blockIdx.y == B.nt && tid == 0) {
     if (NV == 1) {
       R.sc[SC_SA] = sA; R.sc[SC_BETA_A] = betaA;
       R.e[i] = sA;                               // e(i,1) = T(i-1,i)
@@ -662,9 +722,10 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   RedArgs R;
   R.A = A; R.lda = lda; R.n = n; R.ldp = ldp; R.m = m;
   R.d = d; R.e = e; R.lde = lde;
+  R.P = ctx.grid.nranks; R.p = ctx.grid.rank;
   int maxseg = 0;
   for (int L = n; L >= 1; --L) {  // nt is not monotone in L: scan
-    const SymvGeom g = symv_geom(L);
+    const SymvGeom g = symv_geom(L, R.P);
     if (g.nt > maxseg) maxseg = g.nt;
   }
   maxseg += 1;
@@ -682,6 +743,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   R.gp2_off = maxgp * 2;
   R.GP = ctx.pool.get_t<double>("red.GP", (size_t)maxgp * 3 + 8);
   R.sc = ctx.pool.get_t<double>("red.sc", SC_COUNT);
+  R.RB = ctx.pool.get_t<double>("red.RB", (size_t)NB * (n + 8) + 16);
   hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, st, R.UW, (size_t)ldp * m * 3, 0.0);
   hipLaunchKernelGGL(fill_kernel, dim3(8), dim3(256), 0, st, e, (size_t)lde * NB, 0.0);
   hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, R.sc, (size_t)SC_COUNT, 0.0);
@@ -708,7 +770,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     if (S.rows > 0 && (S.has_prev || ncols > 0))
       hipLaunchKernelGGL((ka_kernel<NB>), dim3(nb_ka), dim3(256), 0, st, R, S);
     if (!do_step) break;
-    const SymvGeom g = symv_geom(L);
+    const SymvGeom g = symv_geom(L, R.P);
     KBArgs B;
     B.i = i; B.L = L; B.nt = g.nt; B.k = k;
     B.ncg = (k + PD_COLS - 1) / PD_COLS;
@@ -728,6 +790,11 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     else if (g.T == 256) hipLaunchKernelGGL((symv_kernel<NB, 2>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
     else hipLaunchKernelGGL((symv_kernel<NB, 4>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
     if (prof) ctx.prof_end(st);
+    if (R.P > 1) {
+      const int Lp = (L + 7) / 8 * 8;
+      hipLaunchKernelGGL((kl_kernel<NB>), dim3((Lp + 255) / 256), dim3(256), 0, st, R, L, g.nt);
+      comm_allreduce_sum(ctx, COMM_WORLD, R.RB, (size_t)NB * Lp + 8, st);
+    }
     t_symv_bytes += 8.0 * ((double)L * (L + 1) / 2);
     ++n_symv;
     // bookkeeping for the next K_A
@@ -743,7 +810,17 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       const int nr = i + 1;
       if (ctx.prof_stride > 0) ctx.prof_begin(1, 2.0 * (double)nr * nr * m, st);
       dgemm_dev(st, 'N', 'T', nr, nr, 2 * m, -1.0, R.UW, ldp, R.UW + (size_t)ldp * m, ldp, 1.0, A, lda, 1,
-                &ctx.grid);
+                nullptr, nullptr, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, R.P, R.p);
+      if (R.P > 1) {
+        // next panel = columns (i-m, i]: fetch each 128-column block from its owner (the reference's
+        // panel-load allgather, src/eigen_prd_t7.F:74-250); whole blocks, so already-reduced columns that
+        // share a block are simply re-sent unchanged
+        const int clo = (i - m + 1 > 0) ? i - m + 1 : 0;
+        for (int b = clo / 128; b <= i / 128; ++b) {
+          const int c0 = b * 128, c1 = (c0 + 128 < n) ? c0 + 128 : n;
+          comm_bcast(ctx, COMM_WORLD, A + (size_t)c0 * lda, (size_t)(c1 - c0) * lda, b % R.P, st);
+        }
+      }
       if (ctx.prof_stride > 0) ctx.prof_end(st);
       k1_flops += 2.0 * (double)nr * nr * m;  // 2*nr*nr*(2m)/2 : upper triangle only
       ++n_k1;

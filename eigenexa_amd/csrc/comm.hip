@@ -14,6 +14,7 @@
 #include "../../include/eigenexa_amd.h"
 #include <dlfcn.h>
 #include <cstring>
+#include <vector>
 
 namespace eigx {
 
@@ -74,7 +75,19 @@ bool load_rccl() {
 
 constexpr int kNcclFloat64 = 8;  // ncclDouble
 constexpr int kNcclSum = 0, kNcclMax = 2;
+
+// Host-staged test transport: the collectives are delegated to callbacks (tests register gloo-backed
+// Python functions), so the distributed algorithm can be exercised with several processes on ONE GPU,
+// where RCCL refuses duplicate devices.  Never used by bench.py.
+struct Callbacks {
+  eigx_allreduce_cb allreduce = nullptr;  // (buf, count, op: 0 sum / 2 max, group)
+  eigx_bcast_cb bcast = nullptr;          // (buf, count, root, group)
+  eigx_allgather_cb allgather = nullptr;  // (send, recv, count, group)
+} cbs;
+std::vector<double> stage_a, stage_b;
 }  // namespace
+
+bool comm_uses_callbacks(const Context& ctx) { return ctx.comm && ctx.comm->callbacks; }
 
 int comm_get_unique_id(void* out128) {
   if (!out128) return EIGX_ERR_BAD_ARG;
@@ -84,24 +97,27 @@ int comm_get_unique_id(void* out128) {
 }
 
 int comm_init(Context& ctx, const void* uid) {
-  if (!uid) return EIGX_ERR_BAD_ARG;
+  if (!uid) {
+    if (!cbs.allreduce || !cbs.bcast || !cbs.allgather) return EIGX_ERR_BAD_ARG;
+    CommState* cs = new CommState();
+    cs->callbacks = true;
+    ctx.comm = cs;
+    return EIGX_OK;
+  }
   if (!load_rccl()) return EIGX_ERR_INTERNAL;
   CommState* cs = new CommState();
   ncclUniqueIdBlob id;
   memcpy(id.internal, uid, 128);
   const Grid& g = ctx.grid;
   EIGX_NCCL_CHECK(api.CommInitRank(&cs->world, g.nranks, id, g.rank));
-  // X group: same py, ordered by px.  Y group: same px, ordered by py.
-  if (g.Px > 1) EIGX_NCCL_CHECK(api.CommSplit(cs->world, g.py, g.px, &cs->x, nullptr));
-  else EIGX_NCCL_CHECK(api.CommSplit(cs->world, g.rank, 0, &cs->x, nullptr));
-  if (g.Py > 1) EIGX_NCCL_CHECK(api.CommSplit(cs->world, g.px, g.py, &cs->y, nullptr));
-  else EIGX_NCCL_CHECK(api.CommSplit(cs->world, g.rank, 0, &cs->y, nullptr));
+  // round 1 uses the world communicator only; X / Y groups are split on demand
   ctx.comm = cs;
   return EIGX_OK;
 }
 
 void comm_free(Context& ctx) {
   if (!ctx.comm) return;
+  if (ctx.comm->callbacks) { delete ctx.comm; ctx.comm = nullptr; return; }
   if (ctx.comm->x) api.CommDestroy(ctx.comm->x);
   if (ctx.comm->y) api.CommDestroy(ctx.comm->y);
   if (ctx.comm->world) api.CommDestroy(ctx.comm->world);
@@ -116,16 +132,44 @@ int comm_size(const Context& ctx, CommGroup grp) {
   return grp == COMM_X ? ctx.grid.Px : grp == COMM_Y ? ctx.grid.Py : ctx.grid.nranks;
 }
 
+static void cb_roundtrip_begin(double* dev, size_t count, std::vector<double>& h, hipStream_t s) {
+  h.resize(count);
+  EIGX_HIP_CHECK(hipMemcpyAsync(h.data(), dev, count * 8, hipMemcpyDeviceToHost, s));
+  EIGX_HIP_CHECK(hipStreamSynchronize(s));
+}
+static void cb_roundtrip_end(double* dev, size_t count, std::vector<double>& h, hipStream_t s) {
+  EIGX_HIP_CHECK(hipMemcpyAsync(dev, h.data(), count * 8, hipMemcpyHostToDevice, s));
+  EIGX_HIP_CHECK(hipStreamSynchronize(s));
+}
+
 void comm_allreduce_sum(const Context& ctx, CommGroup grp, double* buf, size_t count, hipStream_t s) {
   if (comm_size(ctx, grp) == 1 || count == 0) return;
+  if (ctx.comm->callbacks) {
+    cb_roundtrip_begin(buf, count, stage_a, s);
+    cbs.allreduce(stage_a.data(), (long)count, 0, (int)grp);
+    cb_roundtrip_end(buf, count, stage_a, s);
+    return;
+  }
   EIGX_NCCL_CHECK(api.AllReduce(buf, buf, count, kNcclFloat64, kNcclSum, pick(ctx, grp), s));
 }
 void comm_allreduce_max(const Context& ctx, CommGroup grp, double* buf, size_t count, hipStream_t s) {
   if (comm_size(ctx, grp) == 1 || count == 0) return;
+  if (ctx.comm->callbacks) {
+    cb_roundtrip_begin(buf, count, stage_a, s);
+    cbs.allreduce(stage_a.data(), (long)count, 2, (int)grp);
+    cb_roundtrip_end(buf, count, stage_a, s);
+    return;
+  }
   EIGX_NCCL_CHECK(api.AllReduce(buf, buf, count, kNcclFloat64, kNcclMax, pick(ctx, grp), s));
 }
 void comm_bcast(const Context& ctx, CommGroup grp, double* buf, size_t count, int root, hipStream_t s) {
   if (comm_size(ctx, grp) == 1 || count == 0) return;
+  if (ctx.comm->callbacks) {
+    cb_roundtrip_begin(buf, count, stage_a, s);
+    cbs.bcast(stage_a.data(), (long)count, root, (int)grp);
+    cb_roundtrip_end(buf, count, stage_a, s);
+    return;
+  }
   EIGX_NCCL_CHECK(api.Broadcast(buf, buf, count, kNcclFloat64, root, pick(ctx, grp), s));
 }
 void comm_allgather(const Context& ctx, CommGroup grp, const double* send, double* recv, size_t count,
@@ -135,7 +179,26 @@ void comm_allgather(const Context& ctx, CommGroup grp, const double* send, doubl
       EIGX_HIP_CHECK(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
     return;
   }
+  if (ctx.comm->callbacks) {
+    const size_t np = (size_t)comm_size(ctx, grp);
+    cb_roundtrip_begin(const_cast<double*>(send), count, stage_a, s);
+    stage_b.resize(count * np);
+    cbs.allgather(stage_a.data(), stage_b.data(), (long)count, (int)grp);
+    cb_roundtrip_end(recv, count * np, stage_b, s);
+    return;
+  }
   EIGX_NCCL_CHECK(api.AllGather(send, recv, count, kNcclFloat64, pick(ctx, grp), s));
 }
+
+}  // namespace eigx
+
+extern "C" int eigx_set_comm_callbacks(eigx_allreduce_cb ar, eigx_bcast_cb bc, eigx_allgather_cb ag) {
+  eigx::cbs.allreduce = ar;
+  eigx::cbs.bcast = bc;
+  eigx::cbs.allgather = ag;
+  return 0;
+}
+
+namespace eigx {
 
 }  // namespace eigx

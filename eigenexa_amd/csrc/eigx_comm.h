@@ -10,7 +10,10 @@ struct CommState {
   void* world = nullptr;  // ncclComm_t
   void* x = nullptr;      // ranks sharing my py (size Px)
   void* y = nullptr;      // ranks sharing my px (size Py)
+  bool callbacks = false; // host-staged test transport (see comm.hip)
 };
+
+bool comm_uses_callbacks(const Context& ctx);
 
 enum CommGroup { COMM_WORLD = 0, COMM_X = 1, COMM_Y = 2 };
 

@@ -29,6 +29,7 @@ struct Grid {
   int Px = 1, Py = 1;  // grid shape (x: rows, y: columns)
   int px = 0, py = 0;  // my coordinates
   int rank = 0, nranks = 1;
+  int row_major = 0;   // rank order 'R' (src/eigen_libs0.F:2336-2356)
 };
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -48,6 +49,7 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
                const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc,
                int tri_mode = 0, const Grid* g = nullptr, const int* kmapA = nullptr,
                const int* cmapC = nullptr, int batch = 1, long strideA = 0, long strideB = 0, long strideC = 0,
-               int batch2 = 1, long strideA2 = 0, long strideB2 = 0, long strideC2 = 0);
+               int batch2 = 1, long strideA2 = 0, long strideB2 = 0, long strideC2 = 0, int ownP = 1,
+               int ownp = 0);
 
 }  // namespace eigx

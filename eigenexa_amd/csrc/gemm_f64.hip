@@ -50,6 +50,7 @@ struct GemmArgs {
   const int* cmapC;  // optional: column of C that receives n-index n: C(:, cmapC[n])
   long sA, sB, sC;     // batch strides in elements (blockIdx.y = batch index)
   long sA2, sB2, sC2;  // second-level batch strides (blockIdx.z)
+  int ownP, ownp;      // tri mode, multi-GPU: this rank updates tile columns tn with tn % ownP == ownp
 };
 
 // Load this thread's NL elements of a BM x 16 operand slab (rows m0.., k-range k0..) into regs.
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   const int m0 = tm * BM, n0 = tn * BN;
 
   if (g.tri_mode == 1) {
+    if (g.ownP > 1 && (tn % g.ownP) != g.ownp) return;
     // skip tiles strictly below the diagonal: min global row > max global col
     const long grow_min = (long)m0 * g.Px + g.px;
     const int jmax = (n0 + BN - 1 < g.N - 1) ? n0 + BN - 1 : g.N - 1;
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, double alpha, const double* A,
                int lda, const double* B, int ldb, double beta, double* C, int ldc, int tri_mode,
                const Grid* grid, const int* kmapA, const int* cmapC, int batch, long strideA, long strideB,
-               long strideC, int batch2, long strideA2, long strideB2, long strideC2) {
+               long strideC, int batch2, long strideA2, long strideB2, long strideC2, int ownP, int ownp) {
   if (M <= 0 || N <= 0 || batch <= 0 || batch2 <= 0) return;
   GemmArgs g;
   g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
@@ -244,6 +246,7 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
   g.cmapC = cmapC;
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
   g.sA2 = strideA2; g.sB2 = strideB2; g.sC2 = strideC2;
+  g.ownP = ownP; g.ownp = ownp;
   g.Px = grid ? grid->Px : 1; g.px = grid ? grid->px : 0;
   g.Py = grid ? grid->Py : 1; g.py = grid ? grid->py : 0;
   const bool a_kc = (opA == 'T' || opA == 't');   // op(A)(m,k) = A[k + m*lda]

@@ -5,6 +5,7 @@
 //   guards -> eigen_scaling -> band reduction -> band D&C -> back-transformation -> unscale ->
 //   a(1:3,1) = flops, seconds, comm seconds (src/eigen_sx.F:285-296).
 #include "eigx_context.h"
+#include "eigx_comm.h"
 #include "../../include/eigenexa_amd.h"
 #include <chrono>
 #include <cfloat>
@@ -56,6 +57,38 @@ __global__ void fill_vec_kernel(double* __restrict__ w, int n, double v) {
   if (i < n) w[i] = v;
 }
 
+// recv = [rank q][li + lj*bx] : local cyclic blocks of all ranks -> full matrix F(gi, gj), gi = li*Px+qx, ...
+__global__ void cyclic_to_full_kernel(const double* __restrict__ recv, int bx, int by, int Px, int Py, int order_r,
+                                      int n, double* __restrict__ F, int ldf) {
+  const int q = blockIdx.z;
+  const int qx = order_r ? q / Py : q % Px, qy = order_r ? q % Py : q / Px;
+  const int lj = blockIdx.y;
+  const int gj = lj * Py + qy;
+  if (gj >= n) return;
+  const double* src = recv + (size_t)q * bx * by + (size_t)lj * bx;
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < bx; li += gridDim.x * blockDim.x) {
+    const int gi = li * Px + qx;
+    if (gi < n) F[(size_t)gj * ldf + gi] = src[li];
+  }
+}
+
+// local (nloc_r x nloc_c) cyclic block of the full matrix: dst(li, lj) = F(li*Px+px, lj*Py+py)
+__global__ void full_to_cyclic_kernel(const double* __restrict__ F, int ldf, int nrows, int ncols, int Px, int px,
+                                      int Py, int py, double* __restrict__ dst, int ldd) {
+  const int lj = blockIdx.y;
+  const int gj = lj * Py + py;
+  if (gj >= ncols) return;
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li * Px + px < nrows; li += gridDim.x * blockDim.x)
+    dst[(size_t)lj * ldd + li] = F[(size_t)gj * ldf + li * Px + px];
+}
+
+__global__ void pack_block_kernel(const double* __restrict__ a, int lda, int nr, int nc, double* __restrict__ out,
+                                  int bx, int by) {
+  const int lj = blockIdx.y;
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < bx; li += gridDim.x * blockDim.x)
+    out[(size_t)lj * bx + li] = (li < nr && lj < nc) ? a[(size_t)lj * lda + li] : 0.0;
+}
+
 double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -67,14 +100,20 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
     fprintf(stderr, "[eigx] warning: non-positive dimension is invalid\n");  // src/eigen_sx.F:95-98
     return EIGX_ERR_BAD_ARG;
   }
-  if (ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;  // multi-rank path: see DESIGN.md (e)
-  if (lda < n || (lda & 1) || !a || !w) return EIGX_ERR_BAD_ARG;
+  const Grid& G = ctx.grid;
+  const int P = G.nranks;
+  const int nloc_r = local_count(n, G.Px, G.px), nloc_c = local_count(n, G.Py, G.py);
+  if (P == 1) {
+    if (lda < n || (lda & 1) || !a || !w) return EIGX_ERR_BAD_ARG;
+  } else {
+    if (lda < nloc_r || !a || !w) return EIGX_ERR_BAD_ARG;
+  }
   if (mode >= 'a' && mode <= 'z') mode = (char)(mode - 'a' + 'A');
   if (nvec == 0) mode = 'N';                      // src/eigen_sx.F:108-110
   if (nvec < 0) nvec = -nvec;
   if (nvec > n) nvec = n;
   const bool want_vec = (mode != 'N');
-  if (want_vec && (!z || ldz < n)) return EIGX_ERR_BAD_ARG;
+  if (want_vec && (!z || ldz < (P == 1 ? n : nloc_r))) return EIGX_ERR_BAD_ARG;
   if (mf <= 0) mf = 128;
   if (mb <= 0) mb = 128;
   EIGX_HIP_CHECK(hipSetDevice(ctx.device));
@@ -82,6 +121,32 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   ctx.errinfo = 0;
   for (int q = 0; q < 16; ++q) ctx.timers[q] = 0.0;
   const double t0 = now_s();
+
+  // ---- multi-GPU: gather the 2-D cyclic blocks into a replicated full matrix;
+  // the solver below then works in global indices and shards the reduction by tile-column ownership.
+  double* a_user = a;
+  double* z_user = z;
+  const int lda_user = lda, ldz_user = ldz;
+  int zcols_per_rank = 0;
+  if (P > 1) {
+    const int bx = ceil_div(n, G.Px), by = ceil_div(n, G.Py);
+    const int ldf = (n + 1) / 2 * 2;
+    double* sendb = ctx.pool.get_t<double>("mg.send", (size_t)bx * by);
+    double* recvb = ctx.pool.get_t<double>("mg.recv", (size_t)bx * by * P);
+    double* Afull = ctx.pool.get_t<double>("mg.A", (size_t)ldf * n);
+    hipLaunchKernelGGL(pack_block_kernel, dim3(8, by), dim3(256), 0, st, a, lda, nloc_r, nloc_c, sendb, bx, by);
+    comm_allgather(ctx, COMM_WORLD, sendb, recvb, (size_t)bx * by, st);
+    const int order_r = G.row_major;
+    hipLaunchKernelGGL(cyclic_to_full_kernel, dim3(8, by, P), dim3(256), 0, st, recvb, bx, by, G.Px, G.Py, order_r, n,
+                       Afull, ldf);
+    a = Afull;
+    lda = ldf;
+    zcols_per_rank = ceil_div(nvec > 0 ? nvec : 1, P);
+    if (want_vec) {
+      z = ctx.pool.get_t<double>("mg.Z", (size_t)ldf * (size_t)zcols_per_rank * P);
+      ldz = ldf;
+    }
+  }
 
   // ---- eigen_scaling ---------------------------------------------------------------------------
   double sigma = 1.0;
@@ -128,7 +193,23 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
 
   // ---- back-transformation ---------------------------------------------------------------------------
   const bool do_bt = want_vec && mode != 'T' && mode != 'C' && mode != 'R';  // src/eigen_sx.F:240
-  if (do_bt) trbak_dev(ctx, n, nvec, a, lda, z, ldz, e, lde, mb, band);
+  if (do_bt) {
+    if (P == 1) {
+      trbak_dev(ctx, n, nvec, a, lda, z, ldz, e, lde, mb, band);
+    } else {
+      // eigenvector columns are split over the ranks; every rank holds all reflectors (replicated panels)
+      const int c0 = G.rank * zcols_per_rank;
+      const int cnt = (nvec - c0 < zcols_per_rank) ? nvec - c0 : zcols_per_rank;
+      if (cnt > 0) trbak_dev(ctx, n, cnt, a, lda, z + (size_t)c0 * ldz, ldz, e, lde, mb, band);
+      comm_allgather(ctx, COMM_WORLD, z + (size_t)c0 * ldz, z, (size_t)zcols_per_rank * ldz, st);
+    }
+  }
+  if (P > 1 && want_vec) {
+    const int nzc = local_count(nvec, G.Py, G.py);
+    if (nzc > 0 && nloc_r > 0)
+      hipLaunchKernelGGL(full_to_cyclic_kernel, dim3(8, nzc), dim3(256), 0, st, z, ldz, n, nvec, G.Px, G.px, G.Py,
+                         G.py, z_user, ldz_user);
+  }
   if (sigma != 1.0 && sigma != 0.0)
     hipLaunchKernelGGL(scale_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, n, 1.0 / sigma);
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
@@ -143,8 +224,10 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   ctx.timers[0] = t4 - t0; ctx.timers[1] = t2 - t1; ctx.timers[2] = t3 - t2; ctx.timers[3] = t4 - t3;
   ctx.timers[4] = 0.0; ctx.timers[12] = ret;
   const double stats[3] = {ret, t4 - t0, -1.0};
-  const int nst = n >= 3 ? 3 : n;  // a(1:3,1) lives in the first column
-  EIGX_HIP_CHECK(hipMemcpyAsync(a, stats, (size_t)nst * 8, hipMemcpyHostToDevice, st));
+  int nst = n >= 3 ? 3 : n;  // a(1:3,1) lives in the first column
+  if (P > 1) { nst = nloc_r >= 3 ? 3 : nloc_r; if (nloc_c == 0) nst = 0; }
+  (void)lda_user;
+  if (nst > 0) EIGX_HIP_CHECK(hipMemcpyAsync(a_user, stats, (size_t)nst * 8, hipMemcpyHostToDevice, st));
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
   return EIGX_OK;
 }
@@ -152,15 +235,17 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
 int solve_host(Context& ctx, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb,
                char mode, int band) {
   if (!ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
-  if (n <= 0 || !a || !w || lda < n) return EIGX_ERR_BAD_ARG;
-  if (ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;
+  const int nr = local_count(n, ctx.grid.Px, ctx.grid.px), nc = local_count(n, ctx.grid.Py, ctx.grid.py);
+  if (n <= 0 || !a || !w || lda < nr) return EIGX_ERR_BAD_ARG;
   EIGX_HIP_CHECK(hipSetDevice(ctx.device));
-  const int ldd = (n + 1) / 2 * 2;  // device leading dimension: even for the 16-byte column loads
-  double* ad = ctx.pool.get_t<double>("host.a", (size_t)ldd * n);
-  double* zd = ctx.pool.get_t<double>("host.z", (size_t)ldd * n);
+  const int ldd = (nr + 1) / 2 * 2 + 2;  // device leading dimension: even for the 16-byte column loads
+  const int ncd = nc > 0 ? nc : 1;
+  double* ad = ctx.pool.get_t<double>("host.a", (size_t)ldd * ncd);
+  double* zd = ctx.pool.get_t<double>("host.z", (size_t)ldd * ncd);
   double* wd = ctx.pool.get_t<double>("host.w", (size_t)n);
-  EIGX_HIP_CHECK(hipMemcpy2D(ad, (size_t)ldd * 8, a, (size_t)lda * 8, (size_t)n * 8, (size_t)n,
-                             hipMemcpyHostToDevice));
+  if (nr > 0 && nc > 0)
+    EIGX_HIP_CHECK(hipMemcpy2D(ad, (size_t)ldd * 8, a, (size_t)lda * 8, (size_t)nr * 8, (size_t)nc,
+                               hipMemcpyHostToDevice));
   const int rc = solve_dev(ctx, n, nvec, ad, ldd, wd, zd, ldd, mf, mb, mode, band);
   EIGX_HIP_CHECK(hipMemcpy(w, wd, (size_t)n * 8, hipMemcpyDeviceToHost));
   if (rc != EIGX_OK) return rc;
@@ -168,12 +253,13 @@ int solve_host(Context& ctx, int n, int nvec, double* a, int lda, double* w, dou
   if (md >= 'a' && md <= 'z') md = (char)(md - 'a' + 'A');
   int nv = nvec < 0 ? -nvec : nvec;
   if (nv > n) nv = n;
-  if (z && nv > 0 && md != 'N')
-    EIGX_HIP_CHECK(hipMemcpy2D(z, (size_t)ldz * 8, zd, (size_t)ldd * 8, (size_t)n * 8, (size_t)nv,
+  const int nzc = local_count(nv, ctx.grid.Py, ctx.grid.py);
+  if (z && nzc > 0 && nr > 0 && md != 'N')
+    EIGX_HIP_CHECK(hipMemcpy2D(z, (size_t)ldz * 8, zd, (size_t)ldd * 8, (size_t)nr * 8, (size_t)nzc,
                                hipMemcpyDeviceToHost));
   // `a` is destroyed by contract; only the statistics come back
-  const int nst = n >= 3 ? 3 : n;
-  EIGX_HIP_CHECK(hipMemcpy(a, ad, (size_t)nst * 8, hipMemcpyDeviceToHost));
+  const int nst = (nc > 0) ? (nr >= 3 ? 3 : nr) : 0;
+  if (nst > 0) EIGX_HIP_CHECK(hipMemcpy(a, ad, (size_t)nst * 8, hipMemcpyDeviceToHost));
   return EIGX_OK;
 }
 

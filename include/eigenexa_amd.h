@@ -54,6 +54,15 @@ int eigx_init(int device);
 int eigx_init_multi(int device, int rank, int nranks, const void* rccl_unique_id, char order);
 int eigx_get_rccl_unique_id(void* out128);
 
+/* Test transport for the N>1 path on machines where RCCL cannot be used (several ranks sharing one GPU):
+ * the collectives of the multi-rank solvers are delegated to host callbacks (buffers are host pointers;
+ * op 0 = sum, 2 = max; group 0 = world, 1 = X, 2 = Y).  Register them, then call
+ * eigx_init_multi(..., rccl_unique_id = NULL, ...).  tests/ use gloo-backed callbacks; bench.py never does. */
+typedef void (*eigx_allreduce_cb)(double* buf, long count, int op, int group);
+typedef void (*eigx_bcast_cb)(double* buf, long count, int root, int group);
+typedef void (*eigx_allgather_cb)(const double* send, double* recv, long count, int group);
+int eigx_set_comm_callbacks(eigx_allreduce_cb allreduce, eigx_bcast_cb bcast, eigx_allgather_cb allgather);
+
 /* replaces eigen_free  src/eigen_libs.F:204-216 */
 int eigx_free(void);
 

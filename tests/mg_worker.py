@@ -1,0 +1,50 @@
+"""Worker of the multi-rank GPU test: `world` processes share GPU 0, collectives go through the host-staged
+gloo transport (RCCL refuses duplicate devices).  argv: rank world port n route"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import torch.distributed as dist
+
+rank, world, port, n, route = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+import eigenexa_amd as ee
+from eigenexa_amd import api, layout
+
+ee.eigen_init(comm=True, device=0)
+procs, xp, yp = ee.eigen_get_procs()
+idn, xi, yi = ee.eigen_get_id()
+assert (xp, yp) == layout.grid_shape(world) and idn == rank + 1
+px, py = xi - 1, yi - 1
+A = layout.random_symmetric(n)
+nx, ny = ee.eigen_get_matdims(n)
+# fill the local cyclic block with the reference's index helpers (benchmark/main2.f style)
+a = np.zeros((nx, ny), order="F")
+rows = np.arange(px, n, xp)
+cols = np.arange(py, n, yp)
+a[: len(rows), : len(cols)] = layout.random_symmetric(n, rows=rows, cols=cols)
+z = np.zeros((nx, ny), order="F")
+w = np.zeros(n)
+(ee.eigen_sx if route == "sx" else ee.eigen_s)(n, n, a, nx, w, z, nx, m_forward=32, mode="A")
+assert api.last_status() == 0, api.last_status()
+# gather the cyclic eigenvector blocks
+zl = np.zeros(((n + xp - 1) // xp, (n + yp - 1) // yp))
+zl[: len(rows), : len(cols)] = z[: len(rows), : len(cols)]
+blocks = [torch.zeros(zl.shape, dtype=torch.float64) for _ in range(world)]
+dist.all_gather(blocks, torch.from_numpy(np.ascontiguousarray(zl)))
+Z = layout.gather_cyclic([b.numpy() for b in blocks], n, n)
+wr = np.linalg.eigvalsh(A)
+werr = np.abs(w - wr).max() / np.abs(wr).max()
+res, orth = layout.accuracy_metrics(A, w, Z)
+wt = torch.from_numpy(w.copy())
+dist.broadcast(wt, src=0)
+assert np.array_equal(wt.numpy(), w), "w must be bit-identical on every rank (replicated)"
+assert werr < 1e-12 and res < 768 and orth < 8, (werr, res, orth)
+assert abs(a[0, 0]) > 0 if (px == 0 and py == 0) else True
+ee.eigen_free()
+dist.barrier()
+dist.destroy_process_group()
+print(f"OK rank {rank}/{world} n={n} {route}: werr {werr:.2e} res {res:.3e} orth {orth:.3e}", flush=True)

@@ -324,3 +324,30 @@ def test_baseline_size_properties(gpu_lib, route):
     assert abs(w.sum().item() - torch.trace(A).item()) < 1e-9 * anorm          # trace invariant
     assert abs(torch.linalg.norm(w).item() - anorm) < 1e-10 * anorm            # Frobenius invariant
     assert (w[1:] >= w[:-1]).all()                                             # ascending
+
+
+@pytest.mark.parametrize("world,n,route", [(2, 300, "sx"), (4, 517, "sx"), (4, 300, "s"), (3, 260, "sx")])
+def test_multi_rank_solver_on_one_gpu(world, n, route):
+    """the N>1 path (tile-column sharded reduction, replicated D&C, column-parallel back-transform, 2-D cyclic
+    API layout) with `world` ranks sharing the GPU over the host-staged gloo transport"""
+    import socket
+    import subprocess
+    import sys
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = os.path.join(os.path.dirname(__file__), "mg_worker.py")
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port), str(n), route],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"OK rank {r}/{world}" in o, o[-3000:]
