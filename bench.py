@@ -10,8 +10,9 @@ already resident in HBM when the timed region starts (K pristine copies are made
 solver destroys `a`, exactly like the reference).  value = flops credited by the reference's own model
 (4/3 N^3 + counted D&C GEMM flops + 2 nvec N^2, src/eigen_sx.F:165,:248,:285-296) / wall time.
 
-N > 1 in round 1: the 2-D cyclic multi-GPU path (DESIGN.md section e) is not built yet, so every rank solves
-an independent replica ("replicas", scaling "weak"); value is the aggregate over replicas and the JSON says so.
+N > 1: the sharded multi-GPU path on the 2-D cyclic API layout, weak scaling at fixed memory
+per GPU (N = 8192*sqrt(P), rounded to 128); a small sanity solve runs first and, if the multi-GPU path raises, the
+run falls back to independent replicas and says so in config.parallelism.
 """
 import argparse
 import ctypes as C
@@ -35,10 +36,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--size", dest="n", type=int, default=8192)
     ap.add_argument("--route", default="sx", choices=["sx", "s"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=2048)
+    ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of the sharded path")
+    ap.add_argument("--n-fixed", action="store_true", help="N>1: keep --size (strong scaling) instead of size*sqrt(P)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -50,28 +53,82 @@ def main():
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # EIGX_BENCH_BACKEND=gloo: functional rehearsal of the N>1 code path with all ranks on GPU 0 and the
+        # host-staged transport (RCCL refuses duplicate devices); never used for reported numbers
+        backend = os.environ.get("EIGX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo")
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
     import eigenexa_amd as ee
-    from eigenexa_amd import _lib, layout
+    from eigenexa_amd import _lib, api, layout
 
     lib = _lib.load()
-    # replicas: every rank owns a 1x1 grid on its own GPU
-    _lib.check(lib.eigx_init(dev.index), "eigx_init")
-
+    replicas = args.replicas or world == 1
     n = args.n
+    if world > 1 and not args.replicas and not args.n_fixed:
+        # weak scaling at fixed memory per GPU: N_P = N_1 * sqrt(P), rounded to the 128-column tile
+        n = int(round(args.n * (world ** 0.5) / 128.0)) * 128
+
+    def gen_local(nn, Px, Py, px, py):
+        rows = np.arange(px, nn, Px)
+        cols = np.arange(py, nn, Py)
+        return layout.random_symmetric(nn, rows=rows, cols=cols), rows, cols
+
+    mg_note = ""
+    if not replicas:
+        try:
+            ee.eigen_init(comm=True, device=dev.index)   # RCCL world communicator from a broadcast unique id
+            procs, Px, Py = ee.eigen_get_procs()
+            _, xi, yi = ee.eigen_get_id()
+            px, py = xi - 1, yi - 1
+            # sanity solve through the multi-GPU path before anything is timed
+            ns = 1024
+            loc, rows, cols = gen_local(ns, Px, Py, px, py)
+            nxs, nys = ee.eigen_get_matdims(ns)
+            a_s = torch.zeros(nys, nxs, dtype=torch.float64, device=dev)
+            a_s[: len(cols), : len(rows)] = torch.from_numpy(np.ascontiguousarray(loc.T)).to(dev)
+            z_s = torch.zeros(nys, nxs, dtype=torch.float64, device=dev)
+            w_s = torch.zeros(ns, dtype=torch.float64, device=dev)
+            ee.eigen_sx(ns, ns, a_s, nxs, w_s, z_s, nxs, m_forward=128, m_backward=128)
+            if api.last_status() != 0:
+                raise RuntimeError(f"sanity solve status {api.last_status()}")
+            wref = np.linalg.eigvalsh(layout.random_symmetric(ns))
+            werr = float(np.abs(w_s.cpu().numpy() - wref).max() / np.abs(wref).max())
+            ok = torch.tensor([1.0 if werr < 1e-12 else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() != 1.0:
+                raise RuntimeError(f"multi-GPU sanity solve inaccurate (werr {werr:.2e})")
+            mg_note = f"multi-GPU sanity N={ns}: max eigenvalue error {werr:.1e}"
+        except Exception as exc:  # fall back to replicas, and say so
+            print(f"[bench] multi-GPU path unavailable ({exc}); falling back to replicas", file=sys.stderr, flush=True)
+            replicas = True
+            n = args.n
+            try:
+                ee.eigen_free()
+            except Exception:
+                pass
+    if replicas:
+        _lib.check(lib.eigx_init(dev.index), "eigx_init")   # every rank owns a 1x1 grid on its own GPU
+        Px = Py = 1
+        px = py = 0
+
     nx, ny = ee.eigen_get_matdims(n)
-    A_host = layout.random_symmetric(n)
-    A_dev = torch.from_numpy(np.ascontiguousarray(A_host.T)).to(dev)  # A_dev[j, i] = A(i, j)
+    loc, rows, cols = gen_local(n, Px, Py, px, py)
+    A_loc_T = torch.from_numpy(np.ascontiguousarray(loc.T)).to(dev)   # [local col, local row]
+    del loc
     nrun = args.warmup + args.steps
     a_bufs = []
     for _ in range(nrun):
         a = torch.zeros(ny, nx, dtype=torch.float64, device=dev)
-        a[:n, :n] = A_dev
+        a[: len(cols), : len(rows)] = A_loc_T
         a_bufs.append(a)
     z = torch.zeros(ny, nx, dtype=torch.float64, device=dev)
     w = torch.zeros(n, dtype=torch.float64, device=dev)
@@ -87,6 +144,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()
     for i in range(args.warmup):
         solve(a_bufs[i])
     lib.eigx_profile(8)  # bracket every 8th SYMV launch and every trailing-update launch with HIP events
@@ -101,7 +159,7 @@ def main():
     lib.eigx_profile(0)
     tm = np.zeros(16)
     lib.eigx_get_timers(tm.ctypes.data_as(C.POINTER(C.c_double)))
-    flops_one = abs(float(a_bufs[-1][0, 0].item()))  # a(1,1) = flops credited by the reference model
+    flops_one = abs(float(tm[12]))  # = a(1,1): flops credited by the reference model
 
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -109,17 +167,38 @@ def main():
         dt = float(t.item())
 
     # accuracy of the last solve (outside the timed region): the reference's gates
-    Z = z[:n, :n].T
     eps = np.finfo(np.float64).eps
-    Afull = A_dev.T
-    anorm = torch.linalg.norm(Afull).item()
-    res_abs = torch.linalg.norm(Afull @ Z - Z * w[None, :]).item()
-    res_metric = res_abs / (n * eps * anorm)
-    orth_metric = torch.linalg.norm(Z.T @ Z - torch.eye(n, dtype=torch.float64, device=dev)).item() / (n * eps)
+    acc = {}
+    if replicas:
+        Z = z[:n, :n].T
+        Afull = A_loc_T.T
+        anorm = torch.linalg.norm(Afull).item()
+        res_abs = torch.linalg.norm(Afull @ Z - Z * w[None, :]).item()
+        acc = {"residual_over_anorm": res_abs / anorm,
+               "residual_metric_lt_768": round(res_abs / (n * eps * anorm), 5),
+               "orthogonality_metric_lt_8": round(
+                   torch.linalg.norm(Z.T @ Z - torch.eye(n, dtype=torch.float64, device=dev)).item() / (n * eps), 5)}
+    else:
+        # distributed invariants: trace and Frobenius norm of A against the eigenvalues; Z^T Z diagonal sample
+        tr = torch.zeros(2, dtype=torch.float64, device=dev)
+        rr = torch.from_numpy(rows).to(dev)
+        cc = torch.from_numpy(cols).to(dev)
+        Aloc = A_loc_T.T  # [local row, local col]
+        diag_mask = rr[:, None] == cc[None, :]
+        tr[0] = (Aloc * diag_mask).sum()
+        tr[1] = (Aloc * Aloc).sum()
+        dist.all_reduce(tr)
+        anorm = float(tr[1].sqrt().item())
+        acc = {"trace_error_over_anorm": abs(float(w.sum().item()) - float(tr[0].item())) / anorm,
+               "frobenius_error_over_anorm": abs(float(torch.linalg.norm(w).item()) - anorm) / anorm,
+               "sanity": mg_note}
+    if replicas:
+        total_flops_all = flops_one * args.steps * world
+    else:
+        total_flops_all = flops_one * args.steps
 
     if rank == 0:
-        total_flops = flops_one * args.steps * world
-        value = total_flops / dt / 1e9
+        value = total_flops_all / dt / 1e9
         out = {
             "metric": "eigen_sx full-solve throughput (reference flop model: 4/3 N^3 + D&C GEMM + 2 nvec N^2)"
             if args.route == "sx" else "eigen_s full-solve throughput (reference flop model)",
@@ -137,13 +216,14 @@ def main():
             "config": {
                 "workload": f"N={n} random symmetric fp64 (counter-based R+R^T, seed 20240807), eigen_{args.route} "
                             f"all eigenpairs, m_forward=128, m_backward=128",
-                "parallelism": "1 GPU (1x1 grid)" if world == 1 else
-                               f"{world} independent replicas (2-D cyclic multi-GPU path not built in round 1)",
+                "parallelism": "1 GPU (1x1 grid)" if world == 1 else (
+                    f"{world} independent replicas (fallback)" if replicas else
+                    f"{world} GPUs, {Px}x{Py} 2-D cyclic API layout; reduction sharded by 128-column tile ownership "
+                    f"(1 RCCL allreduce/step + panel bcast), D&C replicated, back-transform column-parallel; "
+                    f"weak scaling N = {args.n}*sqrt(P)"),
                 "stage_ms": {"reduction": round(tm[1] * 1e3, 2), "dc": round(tm[2] * 1e3, 2),
                              "backtransform": round(tm[3] * 1e3, 2)},
-                "residual_over_anorm": res_abs / anorm,
-                "residual_metric_lt_768": round(res_metric, 5),
-                "orthogonality_metric_lt_8": round(orth_metric, 5),
+                **acc,
             },
         }
         if prof[0] > 0 and prof[2] > 0:

@@ -785,7 +785,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       B.ngp = nb_ka;
     }
     const bool prof = ctx.prof_stride > 0 && (n_symv % ctx.prof_stride) == 0;
-    if (prof) ctx.prof_begin(0, 8.0 * ((double)L * (L + 1) / 2), st);
+    if (prof) ctx.prof_begin(0, 8.0 * ((double)L * (L + 1) / 2) / R.P, st);  // this rank's share of the triangle
     if (g.T == 128) hipLaunchKernelGGL((symv_kernel<NB, 1>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
     else if (g.T == 256) hipLaunchKernelGGL((symv_kernel<NB, 2>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
     else hipLaunchKernelGGL((symv_kernel<NB, 4>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
@@ -808,7 +808,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       F.ncols = 0; F.i = i; F.L = 0; F.k = k; F.rows = S.iprev + 1;
       hipLaunchKernelGGL((ka_kernel<NB>), dim3((F.rows + KA_ROWS - 1) / KA_ROWS), dim3(256), 0, st, R, F);
       const int nr = i + 1;
-      if (ctx.prof_stride > 0) ctx.prof_begin(1, 2.0 * (double)nr * nr * m, st);
+      if (ctx.prof_stride > 0) ctx.prof_begin(1, 2.0 * (double)nr * nr * m / R.P, st);
       dgemm_dev(st, 'N', 'T', nr, nr, 2 * m, -1.0, R.UW, ldp, R.UW + (size_t)ldp * m, ldp, 1.0, A, lda, 1,
                 nullptr, nullptr, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, R.P, R.p);
       if (R.P > 1) {
