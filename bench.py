@@ -78,9 +78,11 @@ def main():
         n = int(round(args.n * (world ** 0.5) / 128.0)) * 128
 
     def gen_local(nn, Px, Py, px, py):
+        # this rank's 2-D cyclic block of the global matrix, generated on the GPU (bit-identical to the numpy
+        # generator layout.random_symmetric, see tests/test_host.py)
         rows = np.arange(px, nn, Px)
         cols = np.arange(py, nn, Py)
-        return layout.random_symmetric(nn, rows=rows, cols=cols), rows, cols
+        return layout.random_symmetric_torch(nn, dev, rows=rows, cols=cols), rows, cols
 
     mg_note = ""
     if not replicas:
@@ -94,7 +96,7 @@ def main():
             loc, rows, cols = gen_local(ns, Px, Py, px, py)
             nxs, nys = ee.eigen_get_matdims(ns)
             a_s = torch.zeros(nys, nxs, dtype=torch.float64, device=dev)
-            a_s[: len(cols), : len(rows)] = torch.from_numpy(np.ascontiguousarray(loc.T)).to(dev)
+            a_s[: len(cols), : len(rows)] = loc.T
             z_s = torch.zeros(nys, nxs, dtype=torch.float64, device=dev)
             w_s = torch.zeros(ns, dtype=torch.float64, device=dev)
             ee.eigen_sx(ns, ns, a_s, nxs, w_s, z_s, nxs, m_forward=128, m_backward=128)
@@ -122,7 +124,7 @@ def main():
 
     nx, ny = ee.eigen_get_matdims(n)
     loc, rows, cols = gen_local(n, Px, Py, px, py)
-    A_loc_T = torch.from_numpy(np.ascontiguousarray(loc.T)).to(dev)   # [local col, local row]
+    A_loc_T = loc.T.contiguous()   # [local col, local row]
     del loc
     nrun = args.warmup + args.steps
     a_bufs = []

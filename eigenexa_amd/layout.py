@@ -99,3 +99,40 @@ def accuracy_metrics(A, w, Z):
     res = np.linalg.norm(A @ Z - Z * w[None, : Z.shape[1]]) / (n * eps * np.linalg.norm(A))
     orth = np.linalg.norm(Z.T @ Z - np.eye(Z.shape[1])) / (n * eps)
     return res, orth
+
+
+def random_symmetric_torch(n, device, seed=20240807, rows=None, cols=None, chunk=2048):
+    """same matrix as random_symmetric(), generated on `device` with torch int64 arithmetic (wrap-around
+    multiplication, logical shifts emulated), in column chunks; returns the (len(rows) x len(cols)) block."""
+    import torch
+
+    M64 = (1 << 64) - 1
+
+    def to_i64(u):  # python unsigned 64-bit constant -> signed value with the same bits
+        u &= M64
+        return u - (1 << 64) if u >= (1 << 63) else u
+
+    C1, C2 = to_i64(0xBF58476D1CE4E5B9), to_i64(0x94D049BB133111EB)
+    base = to_i64(seed * 0x9E3779B97F4A7C15)
+
+    def lsr(x, k):
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    def mix(x):
+        x = (x ^ lsr(x, 30)) * C1
+        x = (x ^ lsr(x, 27)) * C2
+        return x ^ lsr(x, 31)
+
+    def r(ii, jj):
+        key = ii[:, None] * n + jj[None, :] + base
+        return lsr(mix(key), 11).to(torch.float64) * (1.0 / 9007199254740992.0)
+
+    ri = torch.arange(n, device=device) if rows is None else torch.as_tensor(rows, device=device)
+    ci = torch.arange(n, device=device) if cols is None else torch.as_tensor(cols, device=device)
+    ri = ri.to(torch.int64)
+    ci = ci.to(torch.int64)
+    out = torch.empty(len(ri), len(ci), dtype=torch.float64, device=device)
+    for c0 in range(0, len(ci), chunk):
+        cj = ci[c0:c0 + chunk]
+        out[:, c0:c0 + chunk] = r(ri, cj) + r(cj, ri).T
+    return out

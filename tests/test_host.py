@@ -106,6 +106,16 @@ def test_cyclic_scatter_gather_roundtrip(nranks):
         assert np.array_equal(loc, blocks[r][: loc.shape[0], : loc.shape[1]])
 
 
+def test_torch_generator_is_bit_identical():
+    from eigenexa_amd import layout
+
+    n = 131
+    assert np.array_equal(layout.random_symmetric(n), layout.random_symmetric_torch(n, "cpu", chunk=50).numpy())
+    rows, cols = np.arange(1, n, 2), np.arange(0, n, 4)
+    assert np.array_equal(layout.random_symmetric(n, rows=rows, cols=cols),
+                          layout.random_symmetric_torch(n, "cpu", rows=rows, cols=cols).numpy())
+
+
 def test_frank_formula():
     from eigenexa_amd import layout
 

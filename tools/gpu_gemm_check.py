@@ -56,6 +56,23 @@ def run(opa, opb, M, N, K, tri=0, alpha=-1.0, beta=1.0, reps=0):
     assert err < 1e-10 * max(1.0, scale) * max(1, K) ** 0.5 and pad_ok
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "pmc":
+    run("N", "T", 16384, 16384, 256, tri=1, reps=2)
+    run("N", "T", 16384, 16384, 1024, tri=0, alpha=-1.0, beta=0.0, reps=2)
+    run("N", "N", 8192, 8192, 8192, reps=2)
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "exp":
+    for kk in (256, 512, 1024):
+        run("N", "T", 16384, 16384, kk, tri=0, alpha=-1.0, beta=1.0, reps=4)
+        run("N", "T", 16384, 16384, kk, tri=0, alpha=-1.0, beta=0.0, reps=4)
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "k1":
+    run("N", "T", 1000, 1000, 96, tri=1)
+    run("N", "T", 3000, 3000, 64, tri=1)
+    for nn in (8192, 16384, 32768):
+        for kk in (256, 512):
+            run("N", "T", nn, nn, kk, tri=1, reps=4)
+    sys.exit(0)
 for opa in "NT":
     for opb in "NT":
         run(opa, opb, 300, 200, 77)
