@@ -117,7 +117,7 @@ struct KAArgs {
 
 template <int NB>
 __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
-  __shared__ double red[32];
+  __shared__ double red[48];
   __shared__ double kd[4][256];        // reduced panel-dot vectors: [UuA, WuA, UuB, WuB][kk]  (m <= 256)
   __shared__ double rowU[2][258], rowW[2][258];  // U(c, kk), W(c, kk) for the new block columns c
   __shared__ double tm[8];             // T (tAA,tAB,tBB) and M (m11,m12,m21,m22)
@@ -129,21 +129,41 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   double* Wp = R.UW + (size_t)ldp * m;
   const SymvGeom g = symv_geom(S.Lprev, R.P);
   const bool mg = R.P > 1;
+  const bool hp = S.has_prev != 0;
   const int Lp = (S.Lprev + 7) / 8 * 8;  // RB stride
+  const int kp = hp ? S.kprev : 0;
+  const int kloop = hp ? S.kprev : S.k;
+  const int kold = hp ? S.kprev : S.k;  // panel slots that are final in memory
+  const int r = blockIdx.x * KA_ROWS + rr;
 
-  // ---------------------------------------------------------------- prologue: previous step scalars
-  if (S.has_prev) {
-    const int kp = S.kprev;
-    for (int idx = tid; idx < 2 * NB * kp; idx += 256) {
-      const int kind = idx / kp, kk = idx - kind * kp;
-      double v = 0.0;
-      for (int c = 0; c < S.nchunk_prev; ++c) v += R.KD[((size_t)c * 2 * NB + kind) * m + kk];
-      kd[kind][kk] = v;
+  // t-th SYMV partial of row q (tile row ty = q/T), t in [0, nt]: t <= ty -> column result of tile row t
+  // (column q of tile (t, ty)) ; t > ty -> row result of tile column t-1 (row q of tile (ty, t-1))
+  auto symv_part = [&](int q, int t, int ty, double& pA, double& pB) {
+    const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
+    pA += base[q];
+    if (NB == 2) pB += base[ldp + q];
+  };
+
+  // ============ phase 0: every load that depends on nothing computed in this kernel ==================
+  double bA = 0.0, bB = 0.0;
+  double kdv[4] = {0.0, 0.0, 0.0, 0.0};          // my (kind,kk) entries of the reduced panel dots
+  double v[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [0..2] SP, [3..5] corrections, [6] uA.uB, [7..10] P(c,a)
+  double ru[2] = {0.0, 0.0}, rw[2] = {0.0, 0.0};
+  double prA = 0.0, prB = 0.0;                   // my share of this row's SYMV partial sums
+  double uA_r = 0.0, uB_r = 0.0, a_i = 0.0, a_im = 0.0;
+  if (hp) {
+    bA = R.sc[SC_BETA_A];
+    if (NB == 2) bB = R.sc[SC_BETA_B];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + 256 * q;
+      if (idx < 2 * NB * kp) {
+        const int kind = idx / kp, kk = idx - kind * kp;
+        double acc = 0.0;
+        for (int c = 0; c < S.nchunk_prev; ++c) acc += R.KD[((size_t)c * 2 * NB + kind) * m + kk];
+        kdv[q] = acc;
+      }
     }
-    __syncthreads();
-    // [0..2] bilinear forms of the stale matrix (SYMV workgroups, fixed order), [3..5] their panel
-    // corrections, [6] uA.uB
-    double v[7] = {0, 0, 0, 0, 0, 0, 0};
     if (mg) {
       if (tid == 0) { v[0] = R.RB[NB * Lp + 0]; if (NB == 2) { v[1] = R.RB[NB * Lp + 1]; v[2] = R.RB[NB * Lp + 2]; } }
     } else {
@@ -156,19 +176,75 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
         }
       }
     }
+    if (NB == 2)
+      for (int c = tid; c < S.nchunk_prev; c += 256) v[6] += R.KD[R.kdab_off + c];
+    // P(c, a) partial sums for the new block columns (rows c of the previous step's SYMV result)
+    for (int cc = 0; cc < S.ncols; ++cc) {
+      const int c = S.i - cc;
+      if (mg) {
+        if (tid == 0) { v[7 + 2 * cc] += R.RB[c]; if (NB == 2) v[8 + 2 * cc] += R.RB[Lp + c]; }
+      } else {
+        const int ty = c / g.T;
+        for (int t = tid; t < g.nt + 1; t += 256) symv_part(c, t, ty, v[7 + 2 * cc], v[8 + 2 * cc]);
+      }
+    }
+    if (r < S.rows && r < S.Lprev) {
+      if (mg) {
+        if (ks == 0) { prA = R.RB[r]; if (NB == 2) prB = R.RB[Lp + r]; }
+      } else {
+        const int ty = r / g.T;
+        for (int t = ks; t < g.nt + 1; t += 8) symv_part(r, t, ty, prA, prB);
+      }
+    }
+    if (ks == 0 && r < S.rows) {
+      uA_r = Up[(size_t)kp * ldp + r];
+      if (NB == 2) uB_r = Up[(size_t)(kp + 1) * ldp + r];
+    }
+  }
+  if (S.ncols > 0) {
+    for (int cc = 0; cc < S.ncols; ++cc) {
+      const int c = S.i - cc;
+      if (tid < S.k) {
+        ru[cc] = Up[(size_t)tid * ldp + c];
+        rw[cc] = (tid < kold) ? Wp[(size_t)tid * ldp + c] : 0.0;
+      }
+    }
+    if (ks == 0 && r <= S.i) {
+      a_i = R.A[(size_t)S.i * R.lda + r];
+      if (S.ncols > 1 && r <= S.i - 1) a_im = R.A[(size_t)(S.i - 1) * R.lda + r];
+    }
+  }
+
+  // ============ phase 1: publish kd / rowU / rowW in LDS ============================================
+  if (hp) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + 256 * q;
+      if (idx < 2 * NB * kp) { const int kind = idx / kp; kd[kind][idx - kind * kp] = kdv[q]; }
+    }
+  }
+  if (S.ncols > 0 && tid < S.k) {
+    for (int cc = 0; cc < S.ncols; ++cc) { rowU[cc][tid] = ru[cc]; rowW[cc][tid] = rw[cc]; }
+  }
+  __syncthreads();
+
+  // ============ phase 2: one block reduction for all replicated scalars ================================
+  if (hp) {
     for (int kk = tid; kk < kp; kk += 256) {
       v[3] += 2.0 * kd[0][kk] * kd[1][kk];
       if (NB == 2) {
         v[4] += kd[0][kk] * kd[3][kk] + kd[1][kk] * kd[2][kk];
         v[5] += 2.0 * kd[2][kk] * kd[3][kk];
       }
+      for (int cc = 0; cc < S.ncols; ++cc) {
+        const double u = rowU[cc][kk], w = rowW[cc][kk];
+        v[7 + 2 * cc] -= u * kd[1][kk] + w * kd[0][kk];
+        if (NB == 2) v[8 + 2 * cc] -= u * kd[3][kk] + w * kd[2][kk];
+      }
     }
-    if (NB == 2)
-      for (int c = tid; c < S.nchunk_prev; c += 256) v[6] += R.KD[R.kdab_off + c];
-    block_sum_multi<7>(v, red);
+    block_sum_multi<11>(v, red);
     if (tid == 0) {
       const double gAA = v[0] - v[3], gAB = v[1] - v[4], gBB = v[2] - v[5], uab = v[6];
-      const double bA = R.sc[SC_BETA_A], bB = (NB == 2) ? R.sc[SC_BETA_B] : 0.0;
       const double tAA = bA != 0.0 ? 1.0 / bA : 0.0;
       const double tBB = bB != 0.0 ? 1.0 / bB : 0.0;
       const double tAB = -uab * tAA * tBB;
@@ -180,85 +256,32 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       tm[4] = tAA * gt12;               // m12
       tm[5] = tAB * gt11 + tBB * gt21;  // m21
       tm[6] = tAB * gt12 + tBB * gt22;  // m22
-    }
-    __syncthreads();
-  }
-
-  // t-th SYMV partial of row r (tile row ty = r/T), t in [0, nt]: t <= ty -> column result of tile row t
-  // (column r of tile (t, ty)) ; t > ty -> row result of tile column t-1 (row r of tile (ty, t-1))
-  auto symv_part = [&](int r, int t, int ty, double& pA, double& pB) {
-    const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
-    pA += base[r];
-    if (NB == 2) pB += base[ldp + r];
-  };
-
-  // ---------------------------------------------------------------- rows U(c,:), W(c,:) of the new block
-  const int kold = S.has_prev ? S.kprev : S.k;  // panel slots that are final in memory
-  if (S.ncols > 0) {
-    for (int cc = 0; cc < S.ncols; ++cc) {
-      const int c = S.i - cc;
-      for (int kk = tid; kk < S.k; kk += 256) {
-        rowU[cc][kk] = Up[(size_t)kk * ldp + c];
-        rowW[cc][kk] = (kk < kold) ? Wp[(size_t)kk * ldp + c] : 0.0;
-      }
-    }
-    __syncthreads();
-    if (S.has_prev) {
-      // W(c, new slots) = row c of the previous step's W, computed redundantly by every workgroup:
-      // P(c,a) = sum of SYMV partials - panel corrections, all summed in one block reduction
-      double v[4] = {0, 0, 0, 0};
+      // W(c, new slots) = row c of the previous step's W (same formula as the row loop below)
       for (int cc = 0; cc < S.ncols; ++cc) {
-        const int c = S.i - cc;
-        const int ty = c / g.T;
-        if (mg) {
-          if (tid == 0) { v[2 * cc] += R.RB[c]; if (NB == 2) v[2 * cc + 1] += R.RB[Lp + c]; }
-        } else {
-          for (int t = tid; t < g.nt + 1; t += 256) symv_part(c, t, ty, v[2 * cc], v[2 * cc + 1]);
-        }
-        for (int kk = tid; kk < S.kprev; kk += 256) {
-          const double u = rowU[cc][kk], w = rowW[cc][kk];
-          v[2 * cc] -= u * kd[1][kk] + w * kd[0][kk];
-          if (NB == 2) v[2 * cc + 1] -= u * kd[3][kk] + w * kd[2][kk];
-        }
-      }
-      block_sum_multi<4>(v, red);
-      if (tid < S.ncols) {
-        const int cc = tid;
-        const double pA = v[2 * cc], pB = v[2 * cc + 1];
-        const double uA = rowU[cc][S.kprev], uB = (NB == 2) ? rowU[cc][S.kprev + 1] : 0.0;
+        const double pA = v[7 + 2 * cc], pB = v[8 + 2 * cc];
+        const double uA = rowU[cc][kp], uB = (NB == 2) ? rowU[cc][kp + 1] : 0.0;
         const double yA = tm[0] * pA, yB = tm[1] * pA + tm[2] * pB;
-        rowW[cc][S.kprev] = yA - 0.5 * (uA * tm[3] + uB * tm[5]);
-        if (NB == 2) rowW[cc][S.kprev + 1] = yB - 0.5 * (uA * tm[4] + uB * tm[6]);
+        rowW[cc][kp] = yA - 0.5 * (uA * tm[3] + uB * tm[5]);
+        if (NB == 2) rowW[cc][kp + 1] = yB - 0.5 * (uA * tm[4] + uB * tm[6]);
       }
-      __syncthreads();
     }
+    __syncthreads();
   }
 
-  // ---------------------------------------------------------------- row loop: slice partial sums
-  const int r = blockIdx.x * KA_ROWS + rr;
-  const int kp = S.has_prev ? S.kprev : 0;
-  const int kloop = S.has_prev ? S.kprev : S.k;
+  // ============ phase 3: row loop: slice partial sums ================================================
   {
-    double pA = 0.0, pB = 0.0, x0 = 0.0, x1 = 0.0;
+    double pA = prA, pB = prB, x0 = 0.0, x1 = 0.0;
     if (r < S.rows) {
       for (int kk = ks; kk < kloop; kk += 8) {
         const double u = Up[(size_t)kk * ldp + r];
         const double w = Wp[(size_t)kk * ldp + r];
-        if (S.has_prev) {
+        if (hp) {
           pA -= u * kd[1][kk] + w * kd[0][kk];
           if (NB == 2) pB -= u * kd[3][kk] + w * kd[2][kk];
         }
         if (S.ncols > 0) {
           x0 += u * rowW[0][kk] + w * rowU[0][kk];
           if (S.ncols > 1) x1 += u * rowW[1][kk] + w * rowU[1][kk];
-        }
-      }
-      if (S.has_prev && r < S.Lprev) {
-        const int ty = r / g.T;
-        if (mg) {
-          if (ks == 0) { pA += R.RB[r]; if (NB == 2) pB += R.RB[Lp + r]; }
-        } else {
-          for (int t = ks; t < g.nt + 1; t += 8) symv_part(r, t, ty, pA, pB);
         }
       }
     }
@@ -272,9 +295,8 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
     for (int q = 0; q < 8; ++q) {
       pA += slice[q][rr][0]; pB += slice[q][rr][1]; x0 += slice[q][rr][2]; x1 += slice[q][rr][3];
     }
-    if (S.has_prev) {
-      const double uA = Up[(size_t)kp * ldp + r];
-      const double uB = (NB == 2) ? Up[(size_t)(kp + 1) * ldp + r] : 0.0;
+    if (hp) {
+      const double uA = uA_r, uB = uB_r;
       const double yA = tm[0] * pA, yB = tm[1] * pA + tm[2] * pB;
       double wA = yA - 0.5 * (uA * tm[3] + uB * tm[5]);
       double wB = (NB == 2) ? yB - 0.5 * (uA * tm[4] + uB * tm[6]) : 0.0;
@@ -291,11 +313,11 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       }
     }
     if (S.ncols > 0 && r <= S.i) {
-      const double xi = R.A[(size_t)S.i * R.lda + r] - x0;
+      const double xi = a_i - x0;
       R.X[r] = xi;
       double xim = 0.0;
       if (S.ncols > 1 && r <= S.i - 1) {
-        xim = R.A[(size_t)(S.i - 1) * R.lda + r] - x1;
+        xim = a_im - x1;
         R.X[ldp + r] = xim;
       }
       if (r < S.L) { gg[0] = xi * xi; gg[1] = xi * xim; }
