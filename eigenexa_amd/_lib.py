@@ -46,6 +46,9 @@ SIGNATURES = {
                                  C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "eigx_dgemm_dev": (C.c_int, [C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p,
                                  C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_int]),
+    "eigx_dgemm_gather_dev": (C.c_int, [C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p,
+                                        C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.c_void_p]),
     "eigx_get_timers": (C.c_int, [_c_double_p]),
     "eigx_profile": (C.c_int, [C.c_int]),
     "eigx_profile_read": (C.c_int, [_c_double_p]),

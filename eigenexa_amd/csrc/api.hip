@@ -55,6 +55,10 @@ int eigx_init_multi(int device, int rank, int nranks, const void* uid, char orde
   }
   EIGX_HIP_CHECK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
   EIGX_HIP_CHECK(hipStreamCreateWithFlags(&g_ctx.side_stream, hipStreamNonBlocking));
+  for (int q = 0; q < Context::kAux; ++q)
+    EIGX_HIP_CHECK(hipStreamCreateWithFlags(&g_ctx.aux[q], hipStreamNonBlocking));
+  for (int q = 0; q <= Context::kAux; ++q)
+    EIGX_HIP_CHECK(hipEventCreateWithFlags(&g_ctx.aux_ev[q], hipEventDisableTiming));
   if (nranks > 1) {
     int rc = comm_init(g_ctx, uid);
     if (rc != 0) return rc;
@@ -73,6 +77,8 @@ int eigx_free(void) {
   for (hipEvent_t e : g_ctx.prof_ev) EIGX_HIP_CHECK(hipEventDestroy(e));
   EIGX_HIP_CHECK(hipStreamDestroy(g_ctx.stream));
   EIGX_HIP_CHECK(hipStreamDestroy(g_ctx.side_stream));
+  for (int q = 0; q < Context::kAux; ++q) EIGX_HIP_CHECK(hipStreamDestroy(g_ctx.aux[q]));
+  for (int q = 0; q <= Context::kAux; ++q) EIGX_HIP_CHECK(hipEventDestroy(g_ctx.aux_ev[q]));
   g_ctx = Context();
   return EIGX_OK;
 }
@@ -226,6 +232,16 @@ int eigx_dgemm_dev(char opa, char opb, int m, int n, int k, double alpha, const 
   if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
   dgemm_dev(g_ctx.stream, opa, opb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, tri_upper ? 1 : 0,
             &g_ctx.grid);
+  EIGX_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+  return EIGX_OK;
+}
+
+int eigx_dgemm_gather_dev(char opa, char opb, int m, int n, int k, double alpha, const double* a, int lda,
+                          const double* b, int ldb, double beta, double* c, int ldc, const int* kmap_a,
+                          const int* kmap_b) {
+  if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  dgemm_dev(g_ctx.stream, opa, opb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, 0, nullptr, kmap_a, nullptr, 1, 0,
+            0, 0, 1, 0, 0, 0, 1, 0, kmap_b);
   EIGX_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
   return EIGX_OK;
 }

@@ -740,7 +740,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   if (m < NB) m = NB;
   if (m > 256) m = 256;
   if (NB == 2 && (m & 1)) ++m;
-  const int ldp = (n + 127) / 128 * 128 + 128;
+  const int ldp = pad_ld((n + 127) / 128 * 128 + 128);
   RedArgs R;
   R.A = A; R.lda = lda; R.n = n; R.ldp = ldp; R.m = m;
   R.d = d; R.e = e; R.lde = lde;

@@ -496,7 +496,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   const int maxh = H.nodes[root].height;
 
   // ---- device workspace --------------------------------------------------------------------------
-  const int ldq = (n + 31) / 32 * 32;
+  const int ldq = pad_ld(n);
   double* Qa = ctx.pool.get_t<double>("dc.Qa", (size_t)ldq * n);
   double* Qb = ctx.pool.get_t<double>("dc.Qb", (size_t)ldq * n);
   double* S = ctx.pool.get_t<double>("dc.S", (size_t)ldq * n);
@@ -507,7 +507,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   double* dlam = ctx.pool.get_t<double>("dc.dlam", (size_t)n);
   double* wz = ctx.pool.get_t<double>("dc.wz", (size_t)n);
   double* zh = ctx.pool.get_t<double>("dc.zh", (size_t)n);
-  int* ibuf = ctx.pool.get_t<int>("dc.ibuf", (size_t)8 * n + 64);
+  int* ibuf = ctx.pool.get_t<int>("dc.ibuf", (size_t)13 * n + 64);
   double* rbuf = ctx.pool.get_t<double>("dc.rbuf", (size_t)2 * n + 64);
   const int maxmerge = n / (LEAF / 2) + 8;
   MergeDev* md_dev = ctx.pool.get_t<MergeDev>("dc.md", (size_t)maxmerge);
@@ -521,12 +521,23 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   int* cpr_dev = ibuf + 5 * n;      // [n] copy row0
   int* cpn_dev = ibuf + 6 * n;      // [n] copy nrows
   int* perm_dev = ibuf + 7 * n;     // [n]
+  int* topA_dev = ibuf + 8 * n;     // [n] first update: columns with a non-zero top part (global index)
+  int* topB_dev = ibuf + 9 * n;     // [n]   ... and their pole indices
+  int* botA_dev = ibuf + 10 * n;    // [n] same for the bottom part
+  int* botB_dev = ibuf + 11 * n;    // [n]
+  int* iota_dev = ibuf + 12 * n;    // [n] 0,1,2,...: identity map for the pole index of dense updates
   double* rc_dev = rbuf;            // [n]
   double* rs_dev = rbuf + n;        // [n]
 
   EIGX_HIP_CHECK(hipMemcpyAsync(dd, H.d.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
   EIGX_HIP_CHECK(hipMemcpyAsync(de, H.e.data(), (size_t)lde * band * 8, hipMemcpyHostToDevice, st));
   EIGX_HIP_CHECK(hipMemsetAsync(Qa, 0, (size_t)ldq * n * 8, st));
+  {
+    std::vector<int> iota(n);
+    for (int q = 0; q < n; ++q) iota[q] = q;
+    EIGX_HIP_CHECK(hipMemcpyAsync(iota_dev, iota.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  }
 
   // ---- leaves ---------------------------------------------------------------------------------------
   {
@@ -545,6 +556,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   // ---- merges, height by height ---------------------------------------------------------------------
   std::vector<double> Dh(n), zhost(n), Dnew(n), dl_h(n), wz_h(n), rc_h(n), rs_h(n);
   std::vector<int> nd_h(n), rpj_h(n), rjj_h(n), cps_h(n), cpd_h(n), cpr_h(n), cpn_h(n);
+  std::vector<int> topA_h(n), topB_h(n), botA_h(n), botB_h(n), ctype(n), ktop(n / 2 + 8), kbot(n / 2 + 8);
   std::vector<MergeDev> mds;
   std::vector<std::pair<double, int>> ord;
   double gemm_flops = 0.0;
@@ -584,6 +596,8 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
         double rho = M.rho;
         M.rot_beg = nrot;
         int K = 0;
+        // column types for the first update: 1 = non-zero only in block 1's rows, 2 = only block 2's, 3 = both
+        for (int i2 = 0; i2 < nm; ++i2) ctype[off + i2] = (k == 0) ? (i2 < M.n1 ? 1 : 2) : 3;
         // output slots: roots first, then deflated columns
         std::vector<int> defl;
         if (zn > 0.0 && rho > 0.0) {
@@ -612,6 +626,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
                 zloc[jj] = tau; zloc[pj] = 0.0;
                 rpj_h[nrot] = off + pj; rjj_h[nrot] = off + jj; rc_h[nrot] = c; rs_h[nrot] = s;
                 ++nrot;
+                if (ctype[off + pj] != ctype[off + jj]) { ctype[off + pj] = 3; ctype[off + jj] = 3; }
                 const double dp = dloc[pj] * c * c + dloc[jj] * s * s;
                 dloc[jj] = dloc[pj] * s * s + dloc[jj] * c * c;
                 dloc[pj] = dp;
@@ -644,6 +659,15 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
         }
         M.K = K;
         M.rho = rho;
+        {
+          int nt_ = 0, nb_ = 0;
+          for (int t = 0; t < K; ++t) {
+            const int col = nd_h[off + t], ty = ctype[col];
+            if (ty != 2) { topA_h[off + nt_] = col; topB_h[off + nt_] = t; ++nt_; }
+            if (ty != 1) { botA_h[off + nb_] = col; botB_h[off + nb_] = t; ++nb_; }
+          }
+          ktop[q] = nt_; kbot[q] = nb_;
+        }
         // deflated columns go behind the K roots
         for (size_t t = 0; t < defl.size(); ++t) {
           const int src = off + defl[t], dst = off + K + (int)t;
@@ -656,6 +680,12 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
       // -- upload and run the GPU part ---------------------------------------------------------------------
       EIGX_HIP_CHECK(hipMemcpyAsync(md_dev, mds.data(), mds.size() * sizeof(MergeDev), hipMemcpyHostToDevice, st));
       EIGX_HIP_CHECK(hipMemcpyAsync(nd_dev, nd_h.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+      if (k == 0) {
+        EIGX_HIP_CHECK(hipMemcpyAsync(topA_dev, topA_h.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        EIGX_HIP_CHECK(hipMemcpyAsync(topB_dev, topB_h.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        EIGX_HIP_CHECK(hipMemcpyAsync(botA_dev, botA_h.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        EIGX_HIP_CHECK(hipMemcpyAsync(botB_dev, botB_h.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+      }
       EIGX_HIP_CHECK(hipMemcpyAsync(dlam, dl_h.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
       EIGX_HIP_CHECK(hipMemcpyAsync(wz, wz_h.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
       EIGX_HIP_CHECK(hipMemcpyAsync(Dcur, Dnew.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
@@ -681,13 +711,51 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
                            ldq);
         hipLaunchKernelGGL(loewner_kernel, dim3((maxK + 3) / 4, nmg), dim3(256), 0, st, md_dev, dlam, wz, S, ldq, zh);
         hipLaunchKernelGGL(vectors_kernel, dim3((maxK + 63) / 64, nmg), dim3(256), 0, st, md_dev, zh, S, ldq);
-        for (const MergeDev& M : mds) {
-          if (M.K <= 0) continue;
-          // Qb(rows, off+j) = sum_i Qa(rows, nd[i]) * U(i,j),  U(i,j) = S'(j,i)
-          dgemm_dev(st, 'N', 'T', M.nm, M.K, M.K, 1.0, Qa + M.off, ldq, S + (size_t)M.off * ldq + M.off, ldq, 0.0,
-                    Qb + (size_t)M.off * ldq + M.off, ldq, 0, nullptr, nd_dev + M.off, nullptr);
-          gemm_flops += 2.0 * M.nm * (double)M.K * M.K;
+        // the merges of one height are independent: when there are several, spread their GEMMs over the aux
+        // streams so that small products run side by side instead of one after another
+        const bool fan = mds.size() > 1;
+        if (fan) {
+          EIGX_HIP_CHECK(hipEventRecord(ctx.aux_ev[Context::kAux], st));
+          for (int q = 0; q < Context::kAux; ++q) EIGX_HIP_CHECK(hipStreamWaitEvent(ctx.aux[q], ctx.aux_ev[Context::kAux], 0));
         }
+        int rr = 0;
+        for (size_t q = 0; q < mds.size(); ++q) {
+          const MergeDev& M = mds[q];
+          if (M.K <= 0) continue;
+          const double* Sb = S + (size_t)M.off * ldq + M.off;
+          double* Cb = Qb + (size_t)M.off * ldq + M.off;
+          // Qb(rows, off+j) = sum_i Qa(rows, nd[i]) * U(i,j),  U(i,j) = S'(j,i)
+          if (k == 0) {
+            // first update: Q = diag(Q1, Q2) up to the Givens-mixed columns, so the top rows only see the
+            // columns of type 1/3 and the bottom rows those of type 2/3 (DLAED3's compressed Q2 idea)
+            hipStream_t g1 = fan ? ctx.aux[rr++ % Context::kAux] : st;
+            hipStream_t g2 = fan ? ctx.aux[rr++ % Context::kAux] : (mds.size() == 1 ? ctx.aux[0] : st);
+            if (!fan && g2 != st) {
+              EIGX_HIP_CHECK(hipEventRecord(ctx.aux_ev[Context::kAux], st));
+              EIGX_HIP_CHECK(hipStreamWaitEvent(g2, ctx.aux_ev[Context::kAux], 0));
+            }
+            dgemm_dev(g1, 'N', 'T', M.n1, M.K, ktop[q], 1.0, Qa + M.off, ldq, Sb, ldq, 0.0, Cb, ldq, 0, nullptr,
+                      topA_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, topB_dev + M.off);
+            dgemm_dev(g2, 'N', 'T', M.nm - M.n1, M.K, kbot[q], 1.0, Qa + M.off + M.n1, ldq, Sb, ldq, 0.0,
+                      Cb + M.n1, ldq, 0, nullptr, botA_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0,
+                      botB_dev + M.off);
+            if (!fan && g2 != st) {
+              EIGX_HIP_CHECK(hipEventRecord(ctx.aux_ev[0], g2));
+              EIGX_HIP_CHECK(hipStreamWaitEvent(st, ctx.aux_ev[0], 0));
+            }
+            gemm_flops += 2.0 * (double)M.K * ((double)M.n1 * ktop[q] + (double)(M.nm - M.n1) * kbot[q]);
+          } else {
+            hipStream_t gs = fan ? ctx.aux[rr++ % Context::kAux] : st;
+            dgemm_dev(gs, 'N', 'T', M.nm, M.K, M.K, 1.0, Qa + M.off, ldq, Sb, ldq, 0.0, Cb, ldq, 0, nullptr,
+                      nd_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, iota_dev);
+            gemm_flops += 2.0 * M.nm * (double)M.K * M.K;
+          }
+        }
+        if (fan)
+          for (int q = 0; q < Context::kAux; ++q) {
+            EIGX_HIP_CHECK(hipEventRecord(ctx.aux_ev[q], ctx.aux[q]));
+            EIGX_HIP_CHECK(hipStreamWaitEvent(st, ctx.aux_ev[q], 0));
+          }
       }
       if (ncopy > 0)
         hipLaunchKernelGGL(copycols_kernel, dim3(ncopy), dim3(256), 0, st, cps_dev, cpd_dev, cpr_dev, cpn_dev, Qa, Qb,

@@ -33,6 +33,11 @@ struct Grid {
 };
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Leading dimension >= n that is an odd multiple of 32 doubles (256 B): column strides that are multiples of
+// large powers of two camp on a few HBM channels (measured: fp64 GEMM 60 -> 45 TFLOP/s at ld = 8192).  Same
+// rule as the reference's CSTAB_get_optdim (src/CSTAB.F:73-131) for a different memory system.
+static inline int pad_ld(int n) { int l = (n + 31) / 32; if ((l & 1) == 0) ++l; return l * 32; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // number of local indices l with global index l*P+p < n
@@ -50,6 +55,6 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
                int tri_mode = 0, const Grid* g = nullptr, const int* kmapA = nullptr,
                const int* cmapC = nullptr, int batch = 1, long strideA = 0, long strideB = 0, long strideC = 0,
                int batch2 = 1, long strideA2 = 0, long strideB2 = 0, long strideC2 = 0, int ownP = 1,
-               int ownp = 0);
+               int ownp = 0, const int* kmapB = nullptr);
 
 }  // namespace eigx

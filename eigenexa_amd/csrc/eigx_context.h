@@ -42,6 +42,9 @@ struct Context {
   Grid grid;
   hipStream_t stream = nullptr;       // compute stream
   hipStream_t side_stream = nullptr;  // collectives / copies overlapped with compute
+  static constexpr int kAux = 6;
+  hipStream_t aux[kAux] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // concurrent small GEMMs (D&C levels)
+  hipEvent_t aux_ev[kAux + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   Pool pool;
   CommState* comm = nullptr;
   int64_t errinfo = 0;

@@ -48,6 +48,7 @@ struct GemmArgs {
   int Px, px, Py, py;
   const int* kmapA;  // optional: column of A that holds k-index k ('N' A only): A(:, kmapA[k])
   const int* cmapC;  // optional: column of C that receives n-index n: C(:, cmapC[n])
+  const int* kmapB;  // optional: column of B that holds k-index k ('T' B only): B(:, kmapB[k])
   long sA, sB, sC;     // batch strides in elements (blockIdx.y = batch index)
   long sA2, sB2, sC2;  // second-level batch strides (blockIdx.z)
   int ownP, ownp;      // tri mode, multi-GPU: this rank updates tile columns tn with tn % ownP == ownp
@@ -55,23 +56,33 @@ struct GemmArgs {
 
 // Load this thread's NL elements of a BM x 16 operand slab (rows m0.., k-range k0..) into regs.
 //   MC: element (m,k) at P[m + k*ld]     KC: element (m,k) at P[k + m*ld]
-template <bool KC, int WT>
+template <bool KC, int WT, bool MAP>
 __device__ __forceinline__ void load_slab(double (&r)[Geo<WT>::NL], const double* __restrict__ P, int ld, int m0,
-                                          int k0, int Mmax, int Kmax, int tid,
-                                          const int* __restrict__ kmap = nullptr) {
+                                          int k0, int Mmax, int Kmax, int tid, const int* __restrict__ kmap) {
   constexpr int BM = Geo<WT>::BM, NL = Geo<WT>::NL;
   if (!KC) {
     const int m = m0 + (tid & (BM - 1));
     const int kb = k0 + tid / BM;  // 0..256/BM-1, then +256/BM per pass
     const bool mok = m < Mmax;
+    if (MAP) {
+      // gather variant (its own kernel instantiation: a run-time "map or not" select inside this unrolled
+      // loop makes hipcc branch around every load and serialise them)
+      int kc[NL];
 #pragma unroll
-    for (int p = 0; p < NL; ++p) {
-      const int k = kb + (256 / BM) * p;
-      if (mok && k < Kmax) {
-        const int kc = kmap ? kmap[k] : k;
-        r[p] = P[(size_t)m + (size_t)kc * ld];
-      } else {
-        r[p] = 0.0;
+      for (int p = 0; p < NL; ++p) {
+        const int k = kb + (256 / BM) * p;
+        kc[p] = kmap[k < Kmax ? k : 0];
+      }
+#pragma unroll
+      for (int p = 0; p < NL; ++p) {
+        const int k = kb + (256 / BM) * p;
+        r[p] = (mok && k < Kmax) ? P[(size_t)m + (size_t)kc[p] * ld] : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < NL; ++p) {
+        const int k = kb + (256 / BM) * p;
+        r[p] = (mok && k < Kmax) ? P[(size_t)m + (size_t)k * ld] : 0.0;
       }
     }
   } else {
@@ -107,7 +118,7 @@ __device__ __forceinline__ double frag(const double* __restrict__ S, int m, int 
   return KC ? S[m * LD_KC + k] : S[k * Geo<WT>::LD_MC + m];
 }
 
-template <bool A_KC, bool B_KC, int WT>
+template <bool A_KC, bool B_KC, int WT, bool GATHER>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int BM = Geo<WT>::BM, BN = Geo<WT>::BN, OPER_DOUBLES = Geo<WT>::OPER, NL = Geo<WT>::NL, NF = Geo<WT>::NF;
@@ -156,25 +167,32 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   // C(m = m0+wm*64+i*16+(lane&15), n = n0+wn*64+j*16+(lane>>4)+4r).
   d4_t acc[NF][NF];
   const bool use_c = (g.beta != 0.0) && (g.alpha != 0.0);
-  const double cscale = use_c ? g.beta / g.alpha : 0.0;
+  if (use_c) {
+    const double cscale = g.beta / g.alpha;
 #pragma unroll
-  for (int j = 0; j < NF; ++j)
+    for (int j = 0; j < NF; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wn * WT + j * 16 + fk + 4 * r;
-      const int nc = (g.cmapC && n < g.N) ? g.cmapC[n] : n;
-      const double* cp = g.C + (size_t)nc * g.ldc;
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * WT + j * 16 + fk + 4 * r;
+        const int nc = (g.cmapC && n < g.N) ? g.cmapC[n] : n;
+        const double* cp = g.C + (size_t)nc * g.ldc;
 #pragma unroll
-      for (int i = 0; i < NF; ++i) {
-        const int m = m0 + wm * WT + i * 16 + fm;
-        acc[i][j][r] = (use_c && n < g.N && m < g.M) ? cscale * cp[m] : 0.0;
+        for (int i = 0; i < NF; ++i) {
+          const int m = m0 + wm * WT + i * 16 + fm;
+          acc[i][j][r] = (n < g.N && m < g.M) ? cscale * cp[m] : 0.0;
+        }
       }
-    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+      for (int i = 0; i < NF; ++i) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+  }
 
   double ra[NL], rb[NL];
   const int nk = (g.K + BK - 1) / BK;
-  load_slab<A_KC, WT>(ra, g.A, g.lda, m0, 0, g.M, g.K, tid, g.kmapA);
-  load_slab<B_KC, WT>(rb, g.B, g.ldb, n0, 0, g.N, g.K, tid);
+  load_slab<A_KC, WT, GATHER>(ra, g.A, g.lda, m0, 0, g.M, g.K, tid, g.kmapA);
+  load_slab<B_KC, WT, GATHER>(rb, g.B, g.ldb, n0, 0, g.N, g.K, tid, g.kmapB);
   store_slab<A_KC, WT>(ra, smem, tid);
   store_slab<B_KC, WT>(rb, smem + OPER_DOUBLES, tid);
   __syncthreads();
@@ -182,8 +200,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      load_slab<A_KC, WT>(ra, g.A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid, g.kmapA);
-      load_slab<B_KC, WT>(rb, g.B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
+      load_slab<A_KC, WT, GATHER>(ra, g.A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid, g.kmapA);
+      load_slab<B_KC, WT, GATHER>(rb, g.B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid, g.kmapB);
     }
     const double* as = smem + cur * 2 * OPER_DOUBLES;
     const double* bs = as + OPER_DOUBLES;
@@ -236,7 +254,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, double alpha, const double* A,
                int lda, const double* B, int ldb, double beta, double* C, int ldc, int tri_mode,
                const Grid* grid, const int* kmapA, const int* cmapC, int batch, long strideA, long strideB,
-               long strideC, int batch2, long strideA2, long strideB2, long strideC2, int ownP, int ownp) {
+               long strideC, int batch2, long strideA2, long strideB2, long strideC2, int ownP, int ownp,
+               const int* kmapB) {
   if (M <= 0 || N <= 0 || batch <= 0 || batch2 <= 0) return;
   GemmArgs g;
   g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
@@ -244,6 +263,7 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
   g.tri_mode = tri_mode;
   g.kmapA = (opA == 'N' || opA == 'n') ? kmapA : nullptr;
   g.cmapC = cmapC;
+  g.kmapB = (opB == 'T' || opB == 't') ? kmapB : nullptr;
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
   g.sA2 = strideA2; g.sB2 = strideB2; g.sC2 = strideC2;
   g.ownP = ownP; g.ownp = ownp;
@@ -257,19 +277,26 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
   const int bm = small ? 64 : 128;
   const int tiles = ceil_div(M, bm) * ceil_div(N, bm);
   dim3 grd(tiles, batch, batch2), blk(256);
-#define EIGX_LAUNCH(AK, BK_, WT_)                                                                  \
+#define EIGX_LAUNCH(AK, BK_, WT_, GA_)                                                             \
   do {                                                                                             \
     const size_t shmem = (size_t)4 * Geo<WT_>::OPER * sizeof(double);                              \
     static bool attr_set = false;                                                                  \
     if (!attr_set) {                                                                               \
-      EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f64_kernel<AK, BK_, WT_>,               \
+      EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f64_kernel<AK, BK_, WT_, GA_>,          \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
       attr_set = true;                                                                             \
     }                                                                                              \
-    hipLaunchKernelGGL((gemm_f64_kernel<AK, BK_, WT_>), grd, blk, shmem, stream, g);               \
+    hipLaunchKernelGGL((gemm_f64_kernel<AK, BK_, WT_, GA_>), grd, blk, shmem, stream, g);          \
   } while (0)
-#define EIGX_LAUNCH_T(AK, BK_) do { if (small) EIGX_LAUNCH(AK, BK_, 32); else EIGX_LAUNCH(AK, BK_, 64); } while (0)
-  if (a_kc && b_kc) EIGX_LAUNCH_T(true, true);
+#define EIGX_LAUNCH_T(AK, BK_) do { if (small) EIGX_LAUNCH(AK, BK_, 32, false); else EIGX_LAUNCH(AK, BK_, 64, false); } while (0)
+  if (g.kmapA || g.kmapB) {
+    // gather variant: only the D&C product Q(:, map) * S^T ('N','T') uses it; both maps are required
+    if (a_kc || b_kc || !g.kmapA || !g.kmapB) {
+      fprintf(stderr, "[eigx] dgemm gather needs opA='N', opB='T' and both maps\n");
+      abort();
+    }
+    if (small) EIGX_LAUNCH(false, false, 32, true); else EIGX_LAUNCH(false, false, 64, true);
+  } else if (a_kc && b_kc) EIGX_LAUNCH_T(true, true);
   else if (a_kc && !b_kc) EIGX_LAUNCH_T(true, false);
   else if (!a_kc && b_kc) EIGX_LAUNCH_T(false, true);
   else EIGX_LAUNCH_T(false, false);

@@ -130,7 +130,7 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   int zcols_per_rank = 0;
   if (P > 1) {
     const int bx = ceil_div(n, G.Px), by = ceil_div(n, G.Py);
-    const int ldf = (n + 1) / 2 * 2;
+    const int ldf = pad_ld(n);
     double* sendb = ctx.pool.get_t<double>("mg.send", (size_t)bx * by);
     double* recvb = ctx.pool.get_t<double>("mg.recv", (size_t)bx * by * P);
     double* Afull = ctx.pool.get_t<double>("mg.A", (size_t)ldf * n);
@@ -238,7 +238,7 @@ int solve_host(Context& ctx, int n, int nvec, double* a, int lda, double* w, dou
   const int nr = local_count(n, ctx.grid.Px, ctx.grid.px), nc = local_count(n, ctx.grid.Py, ctx.grid.py);
   if (n <= 0 || !a || !w || lda < nr) return EIGX_ERR_BAD_ARG;
   EIGX_HIP_CHECK(hipSetDevice(ctx.device));
-  const int ldd = (nr + 1) / 2 * 2 + 2;  // device leading dimension: even for the 16-byte column loads
+  const int ldd = pad_ld(nr + 2);  // device leading dimension: even (16-byte column loads), odd multiple of 32
   const int ncd = nc > 0 ? nc : 1;
   double* ad = ctx.pool.get_t<double>("host.a", (size_t)ldd * ncd);
   double* zd = ctx.pool.get_t<double>("host.z", (size_t)ldd * ncd);
@@ -269,7 +269,7 @@ int64_t solver_workspace_bytes(const Context&, int n, int lda, int ldz, int mf, 
   (void)lda; (void)ldz;
   if (mf <= 0) mf = 128;
   if (mb <= 0) mb = 128;
-  const int64_t nn = (int64_t)((n + 31) / 32 * 32) * n;
+  const int64_t nn = (int64_t)pad_ld(n) * n;
   // D&C: Qa, Qb, S ; reduction: panels + partials ; back-transform: V, W, X
   return 8 * (3 * nn + (int64_t)(n + 256) * (3 * mf + 2 * (n / 128 + 2) * 2 + 8) + (int64_t)(n + 512) * mb +
               2 * (int64_t)mb * n);

@@ -103,7 +103,7 @@ void trbak_dev(Context& ctx, int n, int nvec, double* A, int lda, double* Z, int
   int ldv = lda;
   if (!inplace) {
     // lda too small for the zero padding of the last Gram chunk: work on a padded copy of the reflectors
-    ldv = rows_pad;
+    ldv = pad_ld(rows_pad);
     V = ctx.pool.get_t<double>("bt.Vall", (size_t)ldv * n);
     EIGX_HIP_CHECK(hipMemcpy2DAsync(V, (size_t)ldv * 8, A, (size_t)lda * 8, (size_t)n * 8, (size_t)n,
                                     hipMemcpyDeviceToDevice, st));

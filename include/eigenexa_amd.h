@@ -134,6 +134,14 @@ int eigx_trbak_dev(int n, int nvec, const double* a_dev, int lda, double* z_dev,
 int eigx_dgemm_dev(char opa, char opb, int m, int n, int k, double alpha, const double* a_dev, int lda,
                    const double* b_dev, int ldb, double beta, double* c_dev, int ldc, int tri_upper);
 
+/* same product with column gathers, as used by the D&C eigenvector update Q <- Q(:, nondeflated) * S
+ * (replaces the copy into the compressed Q2 + PDGEMM of src/my_pdlaed2.F / src/my_pdlaed1.F:310-341):
+ * A(:, kmap_a[k]) supplies k-index k (opa = 'N' only), B(:, kmap_b[k]) likewise (opb = 'T' only);
+ * either map may be NULL.  Maps are device int arrays of length k. */
+int eigx_dgemm_gather_dev(char opa, char opb, int m, int n, int k, double alpha, const double* a_dev, int lda,
+                          const double* b_dev, int ldb, double beta, double* c_dev, int ldc,
+                          const int* kmap_a_dev, const int* kmap_b_dev);
+
 /* timers of the last solve, seconds: [0] total [1] reduction [2] d&c [3] back-transform [4] comm
  * (reference: TIMER_PRINT lines, src/eigen_sx.F:167-174, :300-304).  kernel-level stats for bench.py:
  * [5] trailing-update kernel seconds (sum of launches) [6] its launch count [7] its flops

@@ -351,3 +351,22 @@ def test_multi_rank_solver_on_one_gpu(world, n, route):
             raise
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"OK rank {r}/{world}" in o, o[-3000:]
+
+
+def test_gemm_gather_vs_torch(gpu_lib):
+    """the D&C product Q(:, map_a) * S(:, map_b)^T with column gathers on both operands"""
+    import torch
+
+    torch.manual_seed(3)
+    M, N, K, na, nb = 333, 210, 190, 400, 260
+    A = torch.randn(M, na, dtype=torch.float64, device=_dev())
+    B = torch.randn(N, nb, dtype=torch.float64, device=_dev())   # op(B)(k, n) = B[n, map_b[k]]
+    ma = torch.randperm(na, device=_dev())[:K].to(torch.int32)
+    mb = torch.randperm(nb, device=_dev())[:K].to(torch.int32)
+    At, lda = _to_colmajor(A.cpu().numpy())
+    Bt, ldb = _to_colmajor(B.cpu().numpy())
+    Ct, ldc = _to_colmajor(np.zeros((M, N)))
+    assert gpu_lib.eigx_dgemm_gather_dev(b"N", b"T", M, N, K, 1.0, At.data_ptr(), lda, Bt.data_ptr(), ldb, 0.0,
+                                         Ct.data_ptr(), ldc, ma.data_ptr(), mb.data_ptr()) == 0
+    ref = A[:, ma.long()] @ B[:, mb.long()].T
+    assert (Ct[:, :M].T - ref).abs().max().item() < 1e-12 * K
