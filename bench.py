@@ -221,7 +221,8 @@ def main():
                 "parallelism": "1 GPU (1x1 grid)" if world == 1 else (
                     f"{world} independent replicas (fallback)" if replicas else
                     f"{world} GPUs, {Px}x{Py} 2-D cyclic API layout; reduction sharded by 128-column tile ownership "
-                    f"(1 RCCL allreduce/step + panel bcast), D&C replicated, back-transform column-parallel; "
+                    f"(1 RCCL allreduce/step + panel bcast), D&C GEMMs row-distributed (z allreduce per merge), "
+                    f"back-transform column-parallel; "
                     f"weak scaling N = {args.n}*sqrt(P)"),
                 "stage_ms": {"reduction": round(tm[1] * 1e3, 2), "dc": round(tm[2] * 1e3, 2),
                              "backtransform": round(tm[3] * 1e3, 2)},
@@ -245,6 +246,16 @@ def main():
                 "frac": round(ach / FP64_MFMA_PEAK_TF, 4), "traffic": None,
                 "launches": int(prof[3]), "avg_launch_us": round(prof[5] / prof[3] * 1e6, 2),
             }
+            # HBM traffic of this kernel from the committed PMC passes (profiles/r01_trailing_update_traffic.json:
+            # separate --pmc FETCH_SIZE / WRITE_SIZE runs); reported as measured/algorithmic bytes at the nearest size
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_trailing_update_traffic.json")))
+                row = min((r for r in tj["rows"] if r["K"] == 256), key=lambda r: abs(r["n"] - n))
+                out["roofline_trailing_update"]["traffic"] = {
+                    "fetch_over_algorithmic": row["fetch_over_algorithmic"],
+                    "write_over_algorithmic": row["write_over_algorithmic"], "measured_at_n": row["n"]}
+            except Exception:
+                pass
         if world == 1 and not args.no_cpu_baseline:
             from oracle import orc
 

@@ -27,6 +27,7 @@
 //   eigenvalues stay unsorted between merges (the next deflation sorts anyway); one final sort +
 //   column permutation writes z.
 #include "eigx_context.h"
+#include "eigx_comm.h"
 #include "../../include/eigenexa_amd.h"
 #include <algorithm>
 #include <cfloat>
@@ -176,23 +177,25 @@ struct MergeDev {
 };
 
 __global__ void zgather_kernel(const MergeDev* __restrict__ md, int band, const double* __restrict__ Q, int ldq,
-                               double* __restrict__ z) {
+                               double* __restrict__ z, int r0, int r1) {
   const MergeDev M = md[blockIdx.y];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= M.nm) return;
-  const double* col = Q + (size_t)(M.off + j) * ldq + M.off + M.n1 - band;
+  const int row0 = M.off + M.n1 - band;
+  const double* col = Q + (size_t)(M.off + j) * ldq + row0;
   double acc = 0.0;
-  for (int t = 0; t < 2 * band; ++t) acc += M.wv[t] * col[t];
+  for (int t = 0; t < 2 * band; ++t)
+    if (row0 + t >= r0 && row0 + t < r1) acc += M.wv[t] * col[t];  // rows owned by this rank (all rows if P = 1)
   z[M.off + j] = acc;
 }
 
 __global__ void rotate_kernel(const MergeDev* __restrict__ md, const int* __restrict__ rpj,
                               const int* __restrict__ rjj, const double* __restrict__ rc,
-                              const double* __restrict__ rsn, double* __restrict__ Q, int ldq) {
+                              const double* __restrict__ rsn, double* __restrict__ Q, int ldq, int r0, int r1) {
   const MergeDev M = md[blockIdx.y];
   if (M.rot_end <= M.rot_beg) return;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= M.nm) return;
+  if (r >= M.nm || M.off + r < r0 || M.off + r >= r1) return;
   double* row = Q + M.off + r;
   for (int t = M.rot_beg; t < M.rot_end; ++t) {
     const size_t cp = (size_t)rpj[t] * ldq, cj = (size_t)rjj[t] * ldq;
@@ -201,6 +204,20 @@ __global__ void rotate_kernel(const MergeDev* __restrict__ md, const int* __rest
     row[cp] = c * x + s * y;
     row[cj] = c * y - s * x;
   }
+}
+
+// row-block exchange of the multi-GPU D&C: pack rows [r0, r0+nr) of Q(:, 0:n) / unpack all ranks' blocks
+__global__ void pack_rows_kernel(const double* __restrict__ Q, int ldq, int n, int r0, int nr, int rp,
+                                 double* __restrict__ out) {
+  const int j = blockIdx.y;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rp; r += gridDim.x * blockDim.x)
+    out[(size_t)j * rp + r] = (r < nr) ? Q[(size_t)j * ldq + r0 + r] : 0.0;
+}
+__global__ void unpack_rows_kernel(const double* __restrict__ in, int n, int rp, double* __restrict__ Q, int ldq) {
+  const int j = blockIdx.y, q = blockIdx.z;
+  const double* src = in + (size_t)q * rp * n + (size_t)j * rp;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rp; r += gridDim.x * blockDim.x)
+    if (q * rp + r < n) Q[(size_t)j * ldq + q * rp + r] = src[r];
 }
 
 // ================================================================================================
@@ -473,6 +490,13 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
                  double* w_dev, double* z_dev, int ldz) {
   hipStream_t st = ctx.stream;
   const double eps = DBL_EPSILON / 2.0;
+  // multi-GPU: Q is row-distributed in contiguous blocks of rp rows; everything that is O(n) or O(K^2)
+  // (leaves, z, deflation, secular equation, S) is replicated, the O(n K^2) GEMMs touch only the rank's rows
+  const int P = ctx.grid.nranks;
+  const int rp = (n + P - 1) / P;
+  const int r0 = P > 1 ? std::min(n, ctx.grid.rank * rp) : 0;
+  const int r1 = P > 1 ? std::min(n, r0 + rp) : n;
+  auto clip = [&](int lo, int hi, int& a, int& b) { a = std::max(lo, r0); b = std::min(hi, r1); return b > a; };
   HostDC H;
   H.n = n; H.band = band; H.lde = lde;
   H.d.resize(n);
@@ -578,7 +602,8 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
       }
       EIGX_HIP_CHECK(hipMemcpyAsync(md_dev, mds.data(), mds.size() * sizeof(MergeDev), hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(zgather_kernel, dim3((maxnm + 255) / 256, (unsigned)ids.size()), dim3(256), 0, st, md_dev,
-                         band, Qa, ldq, zbuf);
+                         band, Qa, ldq, zbuf, r0, r1);
+      if (P > 1) comm_allreduce_sum(ctx, COMM_WORLD, zbuf, (size_t)n, st);
       EIGX_HIP_CHECK(hipMemcpyAsync(zhost.data(), zbuf, (size_t)n * 8, hipMemcpyDeviceToHost, st));
       EIGX_HIP_CHECK(hipMemcpyAsync(Dh.data(), Dcur, (size_t)n * 8, hipMemcpyDeviceToHost, st));
       EIGX_HIP_CHECK(hipStreamSynchronize(st));
@@ -671,8 +696,11 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
         // deflated columns go behind the K roots
         for (size_t t = 0; t < defl.size(); ++t) {
           const int src = off + defl[t], dst = off + K + (int)t;
-          cps_h[ncopy] = src; cpd_h[ncopy] = dst; cpr_h[ncopy] = off; cpn_h[ncopy] = nm;
-          ++ncopy;
+          int ca, cb;
+          if (clip(off, off + nm, ca, cb)) {
+            cps_h[ncopy] = src; cpd_h[ncopy] = dst; cpr_h[ncopy] = ca; cpn_h[ncopy] = cb - ca;
+            ++ncopy;
+          }
           Dnew[dst] = dloc[defl[t]];
         }
         for (int t = 0; t < K; ++t) Dnew[off + t] = 0.0;  // overwritten by the secular kernel
@@ -695,7 +723,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
         EIGX_HIP_CHECK(hipMemcpyAsync(rc_dev, rc_h.data(), (size_t)nrot * 8, hipMemcpyHostToDevice, st));
         EIGX_HIP_CHECK(hipMemcpyAsync(rs_dev, rs_h.data(), (size_t)nrot * 8, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(rotate_kernel, dim3((maxnm + 255) / 256, (unsigned)ids.size()), dim3(256), 0, st, md_dev,
-                           rpj_dev, rjj_dev, rc_dev, rs_dev, Qa, ldq);
+                           rpj_dev, rjj_dev, rc_dev, rs_dev, Qa, ldq, r0, r1);
       }
       if (ncopy > 0) {
         EIGX_HIP_CHECK(hipMemcpyAsync(cps_dev, cps_h.data(), (size_t)ncopy * 4, hipMemcpyHostToDevice, st));
@@ -734,11 +762,13 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
               EIGX_HIP_CHECK(hipEventRecord(ctx.aux_ev[Context::kAux], st));
               EIGX_HIP_CHECK(hipStreamWaitEvent(g2, ctx.aux_ev[Context::kAux], 0));
             }
-            dgemm_dev(g1, 'N', 'T', M.n1, M.K, ktop[q], 1.0, Qa + M.off, ldq, Sb, ldq, 0.0, Cb, ldq, 0, nullptr,
-                      topA_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, topB_dev + M.off);
-            dgemm_dev(g2, 'N', 'T', M.nm - M.n1, M.K, kbot[q], 1.0, Qa + M.off + M.n1, ldq, Sb, ldq, 0.0,
-                      Cb + M.n1, ldq, 0, nullptr, botA_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0,
-                      botB_dev + M.off);
+            int ga, gb;
+            if (clip(M.off, M.off + M.n1, ga, gb))
+              dgemm_dev(g1, 'N', 'T', gb - ga, M.K, ktop[q], 1.0, Qa + ga, ldq, Sb, ldq, 0.0, Cb + (ga - M.off), ldq, 0,
+                        nullptr, topA_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, topB_dev + M.off);
+            if (clip(M.off + M.n1, M.off + M.nm, ga, gb))
+              dgemm_dev(g2, 'N', 'T', gb - ga, M.K, kbot[q], 1.0, Qa + ga, ldq, Sb, ldq, 0.0, Cb + (ga - M.off), ldq, 0,
+                        nullptr, botA_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, botB_dev + M.off);
             if (!fan && g2 != st) {
               EIGX_HIP_CHECK(hipEventRecord(ctx.aux_ev[0], g2));
               EIGX_HIP_CHECK(hipStreamWaitEvent(st, ctx.aux_ev[0], 0));
@@ -746,8 +776,10 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
             gemm_flops += 2.0 * (double)M.K * ((double)M.n1 * ktop[q] + (double)(M.nm - M.n1) * kbot[q]);
           } else {
             hipStream_t gs = fan ? ctx.aux[rr++ % Context::kAux] : st;
-            dgemm_dev(gs, 'N', 'T', M.nm, M.K, M.K, 1.0, Qa + M.off, ldq, Sb, ldq, 0.0, Cb, ldq, 0, nullptr,
-                      nd_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, iota_dev);
+            int ga, gb;
+            if (clip(M.off, M.off + M.nm, ga, gb))
+              dgemm_dev(gs, 'N', 'T', gb - ga, M.K, M.K, 1.0, Qa + ga, ldq, Sb, ldq, 0.0, Cb + (ga - M.off), ldq, 0,
+                        nullptr, nd_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, iota_dev);
             gemm_flops += 2.0 * M.nm * (double)M.K * M.K;
           }
         }
@@ -762,12 +794,25 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
                            ldq);
       // the host vectors are reused next round: wait for the uploads (tiny) before touching them
       // merged blocks go back into Qa (blocks that do not merge at this height stay where they are)
-      for (const MergeDev& M : mds)
-        EIGX_HIP_CHECK(hipMemcpy2DAsync(Qa + (size_t)M.off * ldq + M.off, (size_t)ldq * 8,
-                                        Qb + (size_t)M.off * ldq + M.off, (size_t)ldq * 8, (size_t)M.nm * 8,
+      for (const MergeDev& M : mds) {
+        int ca, cb;
+        if (!clip(M.off, M.off + M.nm, ca, cb)) continue;
+        EIGX_HIP_CHECK(hipMemcpy2DAsync(Qa + (size_t)M.off * ldq + ca, (size_t)ldq * 8,
+                                        Qb + (size_t)M.off * ldq + ca, (size_t)ldq * 8, (size_t)(cb - ca) * 8,
                                         (size_t)M.nm, hipMemcpyDeviceToDevice, st));
+      }
       EIGX_HIP_CHECK(hipStreamSynchronize(st));
     }
+  }
+
+  // ---- multi-GPU: every rank needs all rows of Q for its slice of the back-transformation ----------------
+  if (P > 1) {
+    double* packb = ctx.pool.get_t<double>("dc.pack", (size_t)rp * n);
+    double* allb = Qb;  // free now: P * rp * n <= ldq * n + slack? use a dedicated buffer to be safe
+    allb = ctx.pool.get_t<double>("dc.packall", (size_t)rp * n * P);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(8, n), dim3(256), 0, st, Qa, ldq, n, r0, r1 - r0, rp, packb);
+    comm_allgather(ctx, COMM_WORLD, packb, allb, (size_t)rp * n, st);
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3(8, n, P), dim3(256), 0, st, allb, n, rp, Qa, ldq);
   }
 
   // ---- final sort + copy-out ----------------------------------------------------------------------------
