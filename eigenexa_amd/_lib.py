@@ -17,6 +17,7 @@ SIGNATURES = {
     "eigx_init_multi": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_char]),
     "eigx_get_rccl_unique_id": (C.c_int, [C.c_void_p]),
     "eigx_set_comm_callbacks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eigx_rccl_selftest": (C.c_int, []),
     "eigx_free": (C.c_int, []),
     "eigx_get_version": (C.c_int, [_c_int_p, C.c_char_p, C.c_char_p]),
     "eigx_get_procs": (C.c_int, [_c_int_p, _c_int_p, _c_int_p]),

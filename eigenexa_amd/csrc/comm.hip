@@ -192,6 +192,39 @@ void comm_allgather(const Context& ctx, CommGroup grp, const double* send, doubl
 
 }  // namespace eigx
 
+// 1-rank RCCL self-test: exercises dlopen, ncclCommInitRank from a unique id and the three collectives the
+// multi-GPU solvers use, on the library's compute stream (a one-GPU box cannot host more RCCL ranks)
+extern "C" int eigx_rccl_selftest(void) {
+  using namespace eigx;
+  if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  if (!load_rccl()) return EIGX_ERR_INTERNAL;
+  EIGX_HIP_CHECK(hipSetDevice(g_ctx.device));
+  ncclUniqueIdBlob id;
+  EIGX_NCCL_CHECK(api.GetUniqueId(&id));
+  void* comm = nullptr;
+  EIGX_NCCL_CHECK(api.CommInitRank(&comm, 1, id, 0));
+  const int cnt = 1000;
+  double *a = nullptr, *b = nullptr;
+  EIGX_HIP_CHECK(hipMalloc(&a, cnt * 8));
+  EIGX_HIP_CHECK(hipMalloc(&b, cnt * 8));
+  std::vector<double> h(cnt), r(cnt);
+  for (int i = 0; i < cnt; ++i) h[i] = 0.5 * i - 3.0;
+  EIGX_HIP_CHECK(hipMemcpy(a, h.data(), cnt * 8, hipMemcpyHostToDevice));
+  hipStream_t s = g_ctx.stream;
+  EIGX_NCCL_CHECK(api.AllReduce(a, a, cnt, kNcclFloat64, kNcclSum, comm, s));
+  EIGX_NCCL_CHECK(api.Broadcast(a, a, cnt, kNcclFloat64, 0, comm, s));
+  EIGX_NCCL_CHECK(api.AllGather(a, b, cnt, kNcclFloat64, comm, s));
+  EIGX_NCCL_CHECK(api.AllGather(b, b, cnt, kNcclFloat64, comm, s));  // in-place form used for Z
+  EIGX_HIP_CHECK(hipStreamSynchronize(s));
+  EIGX_HIP_CHECK(hipMemcpy(r.data(), b, cnt * 8, hipMemcpyDeviceToHost));
+  int bad = 0;
+  for (int i = 0; i < cnt; ++i) bad += (r[i] != h[i]);
+  EIGX_NCCL_CHECK(api.CommDestroy(comm));
+  EIGX_HIP_CHECK(hipFree(a));
+  EIGX_HIP_CHECK(hipFree(b));
+  return bad == 0 ? EIGX_OK : EIGX_ERR_INTERNAL;
+}
+
 extern "C" int eigx_set_comm_callbacks(eigx_allreduce_cb ar, eigx_bcast_cb bc, eigx_allgather_cb ag) {
   eigx::cbs.allreduce = ar;
   eigx::cbs.bcast = bc;

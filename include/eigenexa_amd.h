@@ -63,6 +63,10 @@ typedef void (*eigx_bcast_cb)(double* buf, long count, int root, int group);
 typedef void (*eigx_allgather_cb)(const double* send, double* recv, long count, int group);
 int eigx_set_comm_callbacks(eigx_allreduce_cb allreduce, eigx_bcast_cb bcast, eigx_allgather_cb allgather);
 
+/* 1-rank RCCL self-test (dlopen, communicator from a unique id, allreduce / broadcast / allgather on the
+ * library stream): validates the RCCL plumbing on a one-GPU box.  Returns 0 on success. */
+int eigx_rccl_selftest(void);
+
 /* replaces eigen_free  src/eigen_libs.F:204-216 */
 int eigx_free(void);
 

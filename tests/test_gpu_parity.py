@@ -370,3 +370,9 @@ def test_gemm_gather_vs_torch(gpu_lib):
                                          Ct.data_ptr(), ldc, ma.data_ptr(), mb.data_ptr()) == 0
     ref = A[:, ma.long()] @ B[:, mb.long()].T
     assert (Ct[:, :M].T - ref).abs().max().item() < 1e-12 * K
+
+
+def test_rccl_plumbing_single_rank(gpu_lib):
+    """RCCL call path of comm.hip with a 1-rank communicator (the N>1 transport cannot be exercised with
+    more ranks on a one-GPU box; the algorithm itself is covered by test_multi_rank_solver_on_one_gpu)"""
+    assert gpu_lib.eigx_rccl_selftest() == 0
