@@ -54,11 +54,24 @@ struct GemmArgs {
   int ownP, ownp;      // tri mode, multi-GPU: this rank updates tile columns tn with tn % ownP == ownp
 };
 
+// column indices (gather map) of the slab starting at k0 for this thread's NL elements
+template <int WT>
+__device__ __forceinline__ void load_map(int (&kc)[Geo<WT>::NL], const int* __restrict__ kmap, int k0, int Kmax,
+                                         int tid) {
+  constexpr int BM = Geo<WT>::BM, NL = Geo<WT>::NL;
+  const int kb = k0 + tid / BM;
+#pragma unroll
+  for (int p = 0; p < NL; ++p) {
+    const int k = kb + (256 / BM) * p;
+    kc[p] = kmap[k < Kmax ? k : 0];
+  }
+}
+
 // Load this thread's NL elements of a BM x 16 operand slab (rows m0.., k-range k0..) into regs.
 //   MC: element (m,k) at P[m + k*ld]     KC: element (m,k) at P[k + m*ld]
 template <bool KC, int WT, bool MAP>
 __device__ __forceinline__ void load_slab(double (&r)[Geo<WT>::NL], const double* __restrict__ P, int ld, int m0,
-                                          int k0, int Mmax, int Kmax, int tid, const int* __restrict__ kmap) {
+                                          int k0, int Mmax, int Kmax, int tid, const int (&kc)[Geo<WT>::NL]) {
   constexpr int BM = Geo<WT>::BM, NL = Geo<WT>::NL;
   if (!KC) {
     const int m = m0 + (tid & (BM - 1));
@@ -66,13 +79,8 @@ __device__ __forceinline__ void load_slab(double (&r)[Geo<WT>::NL], const double
     const bool mok = m < Mmax;
     if (MAP) {
       // gather variant (its own kernel instantiation: a run-time "map or not" select inside this unrolled
-      // loop makes hipcc branch around every load and serialise them)
-      int kc[NL];
-#pragma unroll
-      for (int p = 0; p < NL; ++p) {
-        const int k = kb + (256 / BM) * p;
-        kc[p] = kmap[k < Kmax ? k : 0];
-      }
+      // loop makes hipcc branch around every load and serialise them).  kc[] = column indices of this slab,
+      // loaded one slab ahead by load_map so that map and data loads are not two dependent round trips.
 #pragma unroll
       for (int p = 0; p < NL; ++p) {
         const int k = kb + (256 / BM) * p;
@@ -190,9 +198,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   }
 
   double ra[NL], rb[NL];
+  int kca[NL], kcb[NL];
+#pragma unroll
+  for (int p = 0; p < NL; ++p) { kca[p] = 0; kcb[p] = 0; }
   const int nk = (g.K + BK - 1) / BK;
-  load_slab<A_KC, WT, GATHER>(ra, g.A, g.lda, m0, 0, g.M, g.K, tid, g.kmapA);
-  load_slab<B_KC, WT, GATHER>(rb, g.B, g.ldb, n0, 0, g.N, g.K, tid, g.kmapB);
+  if (GATHER) { load_map<WT>(kca, g.kmapA, 0, g.K, tid); load_map<WT>(kcb, g.kmapB, 0, g.K, tid); }
+  load_slab<A_KC, WT, GATHER>(ra, g.A, g.lda, m0, 0, g.M, g.K, tid, kca);
+  load_slab<B_KC, WT, GATHER>(rb, g.B, g.ldb, n0, 0, g.N, g.K, tid, kcb);
+  if (GATHER && nk > 1) { load_map<WT>(kca, g.kmapA, BK, g.K, tid); load_map<WT>(kcb, g.kmapB, BK, g.K, tid); }
   store_slab<A_KC, WT>(ra, smem, tid);
   store_slab<B_KC, WT>(rb, smem + OPER_DOUBLES, tid);
   __syncthreads();
@@ -200,8 +213,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      load_slab<A_KC, WT, GATHER>(ra, g.A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid, g.kmapA);
-      load_slab<B_KC, WT, GATHER>(rb, g.B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid, g.kmapB);
+      load_slab<A_KC, WT, GATHER>(ra, g.A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid, kca);
+      load_slab<B_KC, WT, GATHER>(rb, g.B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid, kcb);
+      if (GATHER && kt + 2 < nk) {  // maps of the slab after next: in flight during this slab's MFMAs
+        load_map<WT>(kca, g.kmapA, (kt + 2) * BK, g.K, tid);
+        load_map<WT>(kcb, g.kmapB, (kt + 2) * BK, g.K, tid);
+      }
     }
     const double* as = smem + cur * 2 * OPER_DOUBLES;
     const double* bs = as + OPER_DOUBLES;
