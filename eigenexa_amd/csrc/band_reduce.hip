@@ -441,6 +441,45 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   if (!panel_role && R.P > 1 && ((int)blockIdx.x % R.P) != R.p) return;  // not my tile column
   if (panel_role && (int)blockIdx.x > B.ncg) return;
 
+  // ---- SYMV role: issue everything that needs no scalar before the (latency-bound) scalar reduction:
+  // raw x values of this tile's columns / this lane's rows and the first 8-column unit of A
+  const int ty = blockIdx.y, tx = blockIdx.x;
+  const int row0 = ty * T, col0 = tx * T;
+  const int wcol0 = wave * (T / 4);       // first tile column of this wave
+  double craw[NV][(T + 255) / 256];       // raw x at the tile's columns (thread t -> column t, t+256)
+  double rraw[NV][RB][2];                 // raw x at this lane's rows
+  double2 av0[8], av1[8];
+  if (!panel_role) {
+#pragma unroll
+    for (int q = 0; q < (T + 255) / 256; ++q) {
+      const int c = col0 + tid + 256 * q;
+      const bool ok = (tid + 256 * q < T) && c < L;
+      craw[0][q] = ok ? R.X[c] : 0.0;
+      if (NV == 2) craw[NV - 1][q] = ok ? R.X[2 * ldp + c] : 0.0;
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int r0 = row0 + rb * 128 + lane * 2;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool ok = r0 + h < L;
+        rraw[0][rb][h] = ok ? R.X[r0 + h] : 0.0;
+        if (NV == 2) rraw[NV - 1][rb][h] = ok ? R.X[2 * ldp + r0 + h] : 0.0;
+      }
+    }
+    {
+      const int r0 = row0 + lane * 2;
+      const bool rok = r0 < L;
+      const double* Ap = R.A + (rok ? r0 : 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = col0 + wcol0 + j;
+        if (rok && c < L) av0[j] = *reinterpret_cast<const double2*>(Ap + (size_t)c * R.lda);
+        else av0[j] = make_double2(0.0, 0.0);
+      }
+    }
+  }
+
   // ---- reflector scalars (every workgroup, same order) -------------------------------------------
   double sA, sB = 0.0, betaA, betaB = 0.0;
   const int pivA = L - 1, pivB = L - 2;
@@ -542,14 +581,23 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   }
 
   // ================================================================== K_B (SYMV tile)
-  const int ty = blockIdx.y, tx = blockIdx.x;
-  const int row0 = ty * T, col0 = tx * T;
   const bool diag = (tx == ty);
   double* yrs = dyn;            // [4 waves][NV][T]
   double* ucs = dyn + DYN;      // [NV][T] : u_a at the tile's columns
-  for (int t = tid; t < T; t += 256) {
+  // u_a(j) from the pre-loaded raw x value: pivot shift, trivial-reflector and range rules of uval()
+  auto ufix = [&](int a, int j, double raw) -> double {
+    if (j >= L) return 0.0;
+    if (a == 0) return (betaA != 0.0) ? raw - (j == pivA ? sA : 0.0) : 0.0;
+    if (j >= L - 1 || betaB == 0.0) return 0.0;
+    return raw - (j == pivB ? sB : 0.0);
+  };
 #pragma unroll
-    for (int a = 0; a < NV; ++a) ucs[a * T + t] = uval(a, col0 + t);
+  for (int q = 0; q < (T + 255) / 256; ++q) {
+    const int t = tid + 256 * q;
+    if (t < T) {
+#pragma unroll
+      for (int a = 0; a < NV; ++a) ucs[a * T + t] = ufix(a, col0 + t, craw[a][q]);
+    }
   }
   __syncthreads();
 
@@ -559,12 +607,11 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
     const int r0 = row0 + rb * 128 + lane * 2;
 #pragma unroll
     for (int a = 0; a < NV; ++a) {
-      ux[a][rb][0] = uval(a, r0);
-      ux[a][rb][1] = uval(a, r0 + 1);
+      ux[a][rb][0] = ufix(a, r0, rraw[a][rb][0]);
+      ux[a][rb][1] = ufix(a, r0 + 1, rraw[a][rb][1]);
       yr[a][rb][0] = 0.0; yr[a][rb][1] = 0.0;
     }
   }
-  const int wcol0 = wave * (T / 4);       // first tile column of this wave
   constexpr int NG = T / 32;              // column groups of 8 per wave
   double yc[NV][8];
   double sp[3] = {0.0, 0.0, 0.0};
@@ -663,9 +710,8 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
 
   // software pipeline, two units in flight, all register indices static
   {
-    double2 av0[8], av1[8];
+    // av0 holds unit (g = 0, rb = 0), loaded at kernel entry
     if (RB == 1) {
-      load8(av0, 0, 0);
       for (int g = 0; g < NG; g += 2) {
         load8(av1, g + 1, 0);
         compute8(av0, g, IC<0>());
@@ -673,7 +719,6 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
         compute8(av1, g + 1, IC<0>());
       }
     } else if (RB == 2) {
-      load8(av0, 0, 0);
       for (int g = 0; g < NG; ++g) {
         load8(av1, g, 1);
         compute8(av0, g, IC<0>());
@@ -681,7 +726,6 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
         compute8(av1, g, IC<(RB > 1 ? 1 : 0)>());
       }
     } else {
-      load8(av0, 0, 0);
       for (int g = 0; g < NG; ++g) {
         load8(av1, g, 1);
         compute8(av0, g, IC<0>());
