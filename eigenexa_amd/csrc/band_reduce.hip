@@ -30,6 +30,7 @@
 #include "eigx_context.h"
 #include "eigx_comm.h"
 #include "../../include/eigenexa_amd.h"
+#include <chrono>
 
 namespace eigx {
 
@@ -37,7 +38,8 @@ namespace {
 
 constexpr int PD_ROWS = 512;   // rows per panel-dot chunk
 constexpr int PD_COLS = 16;    // panel columns per panel-dot workgroup
-constexpr int KA_ROWS = 32;    // rows per K_A workgroup (x 8 panel slices = 256 threads)
+constexpr int KA_ROWS = 16;    // rows per K_A workgroup
+constexpr int KA_SL = 256 / KA_ROWS;  // panel slices per row (KA_ROWS x KA_SL = 256 threads)
 constexpr int KM_ROWS = 256;   // rows per K_M workgroup
 
 // scalar slots in the small device array `sc`
@@ -121,9 +123,9 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   __shared__ double kd[4][256];        // reduced panel-dot vectors: [UuA, WuA, UuB, WuB][kk]  (m <= 256)
   __shared__ double rowU[2][258], rowW[2][258];  // U(c, kk), W(c, kk) for the new block columns c
   __shared__ double tm[8];             // T (tAA,tAB,tBB) and M (m11,m12,m21,m22)
-  __shared__ double slice[8][KA_ROWS][4];
+  __shared__ double slice[KA_SL][KA_ROWS][4];
   const int tid = threadIdx.x;
-  const int rr = tid & (KA_ROWS - 1), ks = tid >> 5;
+  const int rr = tid & (KA_ROWS - 1), ks = tid / KA_ROWS;
   const int ldp = R.ldp, m = R.m;
   double* Up = R.UW;
   double* Wp = R.UW + (size_t)ldp * m;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
         if (ks == 0) { prA = R.RB[r]; if (NB == 2) prB = R.RB[Lp + r]; }
       } else {
         const int ty = r / g.T;
-        for (int t = ks; t < g.nt + 1; t += 8) symv_part(r, t, ty, prA, prB);
+        for (int t = ks; t < g.nt + 1; t += KA_SL) symv_part(r, t, ty, prA, prB);
       }
     }
     if (ks == 0 && r < S.rows) {
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   {
     double pA = prA, pB = prB, x0 = 0.0, x1 = 0.0;
     if (r < S.rows) {
-      for (int kk = ks; kk < kloop; kk += 8) {
+      for (int kk = ks; kk < kloop; kk += KA_SL) {
         const double u = Up[(size_t)kk * ldp + r];
         const double w = Wp[(size_t)kk * ldp + r];
         if (hp) {
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   if (ks == 0 && r < S.rows) {
     double pA = 0.0, pB = 0.0, x0 = 0.0, x1 = 0.0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < KA_SL; ++q) {
       pA += slice[q][rr][0]; pB += slice[q][rr][1]; x0 += slice[q][rr][2]; x1 += slice[q][rr][3];
     }
     if (hp) {
@@ -814,6 +816,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   hipLaunchKernelGGL(fill_kernel, dim3(8), dim3(256), 0, st, e, (size_t)lde * NB, 0.0);
   hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, R.sc, (size_t)SC_COUNT, 0.0);
 
+  const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   KAArgs S;
   S.has_prev = 0; S.iprev = 0; S.Lprev = 0; S.kprev = 0; S.nchunk_prev = 0;
   int k = 0;        // panel fill
@@ -894,6 +897,12 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       S.has_prev = 0;
       k = 0;
     }
+  }
+  if (getenv("EIGX_TRACE_ENQUEUE")) {
+    const double te = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    EIGX_HIP_CHECK(hipStreamSynchronize(st));
+    const double ts = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    fprintf(stderr, "[eigx] reduction: enqueue loop %.1f ms, then %.1f ms until the stream drained\n", (te - t_begin) * 1e3, (ts - te) * 1e3);
   }
   EIGX_HIP_CHECK(hipGetLastError());
   ctx.timers[6] = (double)n_k1;
