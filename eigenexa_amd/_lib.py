@@ -53,6 +53,7 @@ SIGNATURES = {
     "eigx_get_timers": (C.c_int, [_c_double_p]),
     "eigx_profile": (C.c_int, [C.c_int]),
     "eigx_profile_read": (C.c_int, [_c_double_p]),
+    "eigx_tune": (C.c_int, [C.c_int, C.c_int]),
     "eigx_device_synchronize": (C.c_int, []),
     "eigx_malloc_dev": (C.c_void_p, [C.c_int64]),
     "eigx_free_dev": (C.c_int, [C.c_void_p]),

@@ -227,6 +227,11 @@ int eigx_memcpy_d2h(void* dst, const void* src, int64_t bytes) {
   return EIGX_OK;
 }
 
+int eigx_tune(int key, int value) {
+  if (key == 0) return set_gemm_variant(value);
+  return -1;
+}
+
 int eigx_dgemm_dev(char opa, char opb, int m, int n, int k, double alpha, const double* a, int lda,
                    const double* b, int ldb, double beta, double* c, int ldc, int tri_upper) {
   if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;

@@ -57,4 +57,7 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
                int batch2 = 1, long strideA2 = 0, long strideB2 = 0, long strideC2 = 0, int ownP = 1,
                int ownp = 0, const int* kmapB = nullptr);
 
+// tuning hook (eigx_tune key 0): 2 = LDS-DMA ring GEMM where supported, 1 = register-staged GEMM only
+int set_gemm_variant(int v);
+
 }  // namespace eigx

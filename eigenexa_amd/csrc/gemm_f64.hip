@@ -52,6 +52,7 @@ struct GemmArgs {
   long sA, sB, sC;     // batch strides in elements (blockIdx.y = batch index)
   long sA2, sB2, sC2;  // second-level batch strides (blockIdx.z)
   int ownP, ownp;      // tri mode, multi-GPU: this rank updates tile columns tn with tn % ownP == ownp
+  int tri_gb;          // gemm2 tri mode: tile-block edge of the XCD-aware order
 };
 
 // column indices (gather map) of the slab starting at k0 for this thread's NL elements
@@ -266,7 +267,278 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   }
 }
 
+
+// =================================================================================================
+// gemm2: LDS-DMA ring version of the same 128x128 tile (the default for every shape it supports).
+//
+// Why: with register staging the next K-slab is requested only one slab ahead; under load a slab arrives
+// later than one slab of MFMA time, so every slab stalled (49 % of the fp64 MFMA peak on the K = 256 trailing
+// update).  Here the operand slabs go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no
+// ds_write) into a ring of S = 4 stages of BK = 8, three slabs in flight across the barrier (counted vmcnt,
+// raw s_barrier), and the C tile moves in 16-byte accesses:
+//   * "MC" operands (contiguous along the tile's m/n index): image [k][128], one 1-KiB row per wave
+//     instruction; fragments of two adjacent rows come from ONE ds_read_b128 (conflict-free unpadded), the
+//     two rows go to MFMA tiles 2p and 2p+1, so acc[2p] and acc[2p+1] hold adjacent rows of C.
+//   * "KC" operands (contiguous along k): image [m][8] with the 16-byte chunks XOR-swizzled by (m>>2)&3 on
+//     the SOURCE address (the DMA destination stays lane-linear); fragments by ds_read_b64, conflict-free.
+//   * rows/columns beyond M/N read clamped (valid) addresses and are never stored; k >= K reads a zero page.
+// =================================================================================================
+constexpr int G2_BK = 8;
+constexpr int G2_STAGE = 2 * G2_BK * 128;  // doubles per ring stage (A image | B image)
+
+__device__ double g_zero_page[128];        // 1 KiB of zeros: source of every k >= K slab row
+
+__device__ __forceinline__ void glds16(const double* gp, double* lp) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                   (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+}
+
+// Issue this wave's share (2 wave-instructions) of one operand slab [k0, k0+8).
+//   MC: P(x, k) = P[x + col(k)*ld]; wave w loads k-rows 2w, 2w+1; lane l carries x = x0 + 2l, 2l+1
+//   KC: P(x, k) = P[k + x*ld];      wave w loads row blocks 2w, 2w+1 (16 rows each); lane l carries row
+//       16q + (l>>2), chunk (l&3) ^ ((l>>4)&3)
+template <bool KC, bool MAP>
+__device__ __forceinline__ void g2_issue(const double* __restrict__ P, int ld, int x0, int Xmax, int k0, int K,
+                                         double* img, int wave, int lane, const int* __restrict__ kmap) {
+  if (!KC) {
+    int x = x0 + 2 * lane;
+    if (x + 1 >= Xmax) x = (Xmax - 1) & ~1;   // clamp to the last aligned pair that starts inside the matrix
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int kr = 2 * wave + q;
+      const int k = k0 + kr;
+      const double* src;
+      if (k < K) {
+        const int col = MAP ? __builtin_amdgcn_readfirstlane(kmap[k]) : k;
+        src = P + (size_t)x + (size_t)col * ld;
+      } else {
+        src = g_zero_page + 2 * lane;
+      }
+      glds16(src, img + kr * 128);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int blk = 2 * wave + q;
+      int x = x0 + blk * 16 + (lane >> 2);
+      if (x >= Xmax) x = Xmax - 1;
+      const int ch = (lane & 3) ^ ((lane >> 4) & 3);
+      const int k = k0 + 2 * ch;
+      const double* src = (k < K) ? P + (size_t)k + (size_t)x * ld : g_zero_page + 2 * lane;
+      glds16(src, img + blk * 128);
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC, bool GATHER>
+__global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int S = 4;                    // ring stages
+  constexpr int GI = 4;                   // LDS-DMA instructions per wave per slab (2 per operand)
+  g.A += (long)blockIdx.y * g.sA + (long)blockIdx.z * g.sA2;
+  g.B += (long)blockIdx.y * g.sB + (long)blockIdx.z * g.sB2;
+  g.C += (long)blockIdx.y * g.sC + (long)blockIdx.z * g.sC2;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+
+  // Tile order (speed only).  Workgroups are dealt round-robin over the 8 XCDs (bid % 8 labels the XCD) and an
+  // XCD runs ~64 of them at a time, so each XCD walks its own sequence in blocks of GB x GB tiles: the
+  // 2*GB operand panels of a block are then shared by GB workgroups through that XCD's L2 instead of every
+  // workgroup streaming its own A panel from beyond L2.
+  //   full mode: row groups of 8 tile rows, columns inside a group, contiguous share of that list per XCD
+  //   tri mode : GB x GB blocks of the upper block triangle (column-major), dealt round-robin to the XCDs
+  const int tiles_m = (g.M + 127) / 128;
+  const int tiles_n = (g.N + 127) / 128;
+  int tm, tn;
+  if (g.tri_mode == 1) {
+    const int GB = g.tri_gb;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int blk = (seq / (GB * GB)) * 8 + xcd;        // block number in the column-major upper block triangle
+    const int w = seq % (GB * GB);
+    // blk = bj*(bj+1)/2 + bi, bi <= bj
+    int bj = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
+    while ((bj + 1) * (bj + 2) / 2 <= blk) ++bj;
+    while (bj * (bj + 1) / 2 > blk) --bj;
+    const int bi = blk - bj * (bj + 1) / 2;
+    tm = bi * GB + (w % GB);
+    tn = bj * GB + (w / GB);
+    if (tm >= tiles_m || tn >= tiles_n) return;
+  } else {
+    const int ntiles = tiles_m * tiles_n;
+    int o = blockIdx.x;
+    {  // contiguous share of the ordered list per XCD (bijective for any ntiles)
+      const int q = ntiles >> 3, r = ntiles & 7, xcd = o & 7;
+      o = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (o >> 3);
+    }
+    const int rg = o / (8 * tiles_n);
+    const int rem = o - rg * 8 * tiles_n;
+    const int rows = (tiles_m - rg * 8 < 8) ? tiles_m - rg * 8 : 8;
+    tn = rem / rows;
+    tm = rg * 8 + rem - tn * rows;
+  }
+  const int m0 = tm * 128, n0 = tn * 128;
+  if (g.tri_mode == 1) {
+    if (g.ownP > 1 && (tn % g.ownP) != g.ownp) return;
+    const long grow_min = (long)m0 * g.Px + g.px;
+    const int jmax = (n0 + 127 < g.N - 1) ? n0 + 127 : g.N - 1;
+    const long gcol_max = (long)jmax * g.Py + g.py;
+    if (grow_min > gcol_max) return;
+  }
+
+  const int fm = lane & 15, fk = lane >> 4;
+  const int nk = (g.K + G2_BK - 1) / G2_BK;
+
+  // tile-local column of MFMA tile j at accumulator row rho (rows: (i>>1)*32 + 2*fm + (i&1) for MC A, i*16 + fm for KC A)
+  auto ncol = [&](int j, int rho) { return B_KC ? j * 16 + rho : (j >> 1) * 32 + 2 * rho + (j & 1); };
+
+  d4_t acc[4][4];
+  const bool use_c = (g.beta != 0.0) && (g.alpha != 0.0);
+  if (use_c) {
+    const double cscale = g.beta / g.alpha;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + ncol(j, fk + 4 * r);
+        const double* cp = g.C + (size_t)n * g.ldc;
+        if (!A_KC) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const int m = m0 + wm * 64 + p * 32 + 2 * fm;
+            double2 v = make_double2(0.0, 0.0);
+            if (n < g.N) {
+              if (m + 1 < g.M) v = *reinterpret_cast<const double2*>(cp + m);
+              else if (m < g.M) v.x = cp[m];
+            }
+            acc[2 * p][j][r] = cscale * v.x;
+            acc[2 * p + 1][j][r] = cscale * v.y;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + fm;
+            acc[i][j][r] = (n < g.N && m < g.M) ? cscale * cp[m] : 0.0;
+          }
+        }
+      }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+  }
+
+  // ---- prologue: the C tile is requested first (above), then S-1 operand slabs; the first counted wait
+  // below therefore covers exactly "C tile + slab 0"
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s) {
+    double* st = smem + s * G2_STAGE;
+    g2_issue<A_KC, GATHER>(g.A, g.lda, m0, g.M, s * G2_BK, g.K, st, wave, lane, g.kmapA);
+    g2_issue<B_KC, GATHER>(g.B, g.ldb, n0, g.N, s * G2_BK, g.K, st + G2_BK * 128, wave, lane, g.kmapB);
+  }
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // my DMAs of slab kt have landed (the 2 younger slabs may still be in flight); after the barrier
+    // everybody's have, and everybody has finished reading slab kt-1, whose stage is refilled next
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((S - 2) * GI) : "memory");
+    {
+      const int ks = kt + S - 1;
+      double* st = smem + (ks % S) * G2_STAGE;
+      g2_issue<A_KC, GATHER>(g.A, g.lda, m0, g.M, ks * G2_BK, g.K, st, wave, lane, g.kmapA);
+      g2_issue<B_KC, GATHER>(g.B, g.ldb, n0, g.N, ks * G2_BK, g.K, st + G2_BK * 128, wave, lane, g.kmapB);
+    }
+    const double* as = smem + (kt % S) * G2_STAGE;
+    const double* bs = as + G2_BK * 128;
+#pragma unroll
+    for (int ks = 0; ks < G2_BK / 4; ++ks) {
+      const int k = ks * 4 + fk;
+      double fa[4], fb[4];
+      if (!A_KC) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const double2 v = *reinterpret_cast<const double2*>(as + k * 128 + wm * 64 + p * 32 + 2 * fm);
+          fa[2 * p] = v.x; fa[2 * p + 1] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = wm * 64 + i * 16 + fm;
+          fa[i] = as[m * 8 + (((k >> 1) ^ ((m >> 2) & 3)) << 1) + (k & 1)];
+        }
+      }
+      if (!B_KC) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const double2 v = *reinterpret_cast<const double2*>(bs + k * 128 + wn * 64 + p * 32 + 2 * fm);
+          fb[2 * p] = v.x; fb[2 * p + 1] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = wn * 64 + j * 16 + fm;
+          fb[j] = bs[n * 8 + (((k >> 1) ^ ((n >> 2) & 3)) << 1) + (k & 1)];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  // drain the (zero-page) DMAs still in flight before the LDS allocation is released
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const double alpha = g.alpha;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wn * 64 + ncol(j, fk + 4 * r);
+      if (n >= g.N) continue;
+      double* cp = g.C + (size_t)n * g.ldc;
+      if (!A_KC) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int m = m0 + wm * 64 + p * 32 + 2 * fm;
+          const double2 v = make_double2(alpha * acc[2 * p][j][r], alpha * acc[2 * p + 1][j][r]);
+          if (m + 1 < g.M) *reinterpret_cast<double2*>(cp + m) = v;
+          else if (m < g.M) cp[m] = v.x;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = m0 + wm * 64 + i * 16 + fm;
+          if (m < g.M) cp[m] = alpha * acc[i][j][r];
+        }
+      }
+    }
+  }
+}
+
+int g_gemm_variant = 2;   // 2 = gemm2 where supported and worthwhile, 3 = wherever supported (tests), 1 = never
+
+// gemm2 needs 16-byte aligned operand columns (even leading dimensions, aligned bases, even batch strides);
+// KC operands additionally need an even K (a 16-byte chunk must not straddle K)
+static bool gemm2_ok(const GemmArgs& g, bool a_kc, bool b_kc, int batch, int batch2) {
+  if (g_gemm_variant < 2) return false;
+  if (g.M < 2 || g.N < 2 || g.K < 1 || g.alpha == 0.0 || g.cmapC) return false;
+  if ((g.lda | g.ldb | g.ldc) & 1) return false;
+  if (((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.C) & 15) return false;
+  if (batch > 1 && ((g.sA | g.sB | g.sC) & 1)) return false;
+  if (batch2 > 1 && ((g.sA2 | g.sB2 | g.sC2) & 1)) return false;
+  if ((a_kc || b_kc) && (g.K & 1)) return false;
+  if (a_kc && g.lda < g.K) return false;
+  if (b_kc && g.ldb < g.K) return false;
+  return true;
+}
+
 }  // namespace
+
+int set_gemm_variant(int v) { const int old = g_gemm_variant; g_gemm_variant = v; return old; }
 
 void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, double alpha, const double* A,
                int lda, const double* B, int ldb, double beta, double* C, int ldc, int tri_mode,
@@ -283,11 +555,44 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
   g.kmapB = (opB == 'T' || opB == 't') ? kmapB : nullptr;
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
   g.sA2 = strideA2; g.sB2 = strideB2; g.sC2 = strideC2;
-  g.ownP = ownP; g.ownp = ownp;
+  g.ownP = ownP; g.ownp = ownp; g.tri_gb = 1;
   g.Px = grid ? grid->Px : 1; g.px = grid ? grid->px : 0;
   g.Py = grid ? grid->Py : 1; g.py = grid ? grid->py : 0;
   const bool a_kc = (opA == 'T' || opA == 't');   // op(A)(m,k) = A[k + m*lda]
   const bool b_kc = (opB == 'N' || opB == 'n');   // op(B)(k,n) = B[k + n*ldb]
+  if (!g.kmapA && !g.kmapB && gemm2_ok(g, a_kc, b_kc, batch, batch2)) {
+    const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128) * batch * batch2;
+    if (tri_mode != 0 || t128 >= 192 || g_gemm_variant == 3) {
+      int gx2 = ceil_div(M, 128) * ceil_div(N, 128);
+      if (tri_mode != 0) {
+        // block-triangular order: needs a square tile grid; GB x GB tile blocks, dealt to the 8 XCDs
+        const int t = ceil_div(N > M ? N : M, 128);
+        g.tri_gb = (t >= 96) ? 8 : (t >= 24 ? 4 : (t >= 8 ? 2 : 1));
+        const int nb = ceil_div(t, g.tri_gb);
+        const int nblk = nb * (nb + 1) / 2;
+        gx2 = 8 * ceil_div(nblk, 8) * g.tri_gb * g.tri_gb;
+      }
+      dim3 grd2(gx2, batch, batch2), blk2(256);
+      const size_t shmem2 = getenv("EIGX_G2_LDS") ? (size_t)atoi(getenv("EIGX_G2_LDS")) : (size_t)4 * G2_STAGE * sizeof(double);
+#define EIGX_LAUNCH2(AK, BK_)                                                                      \
+  do {                                                                                             \
+    static bool attr_set2 = false;                                                                 \
+    if (!attr_set2) {                                                                              \
+      EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<AK, BK_, false>,                \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2)); \
+      attr_set2 = true;                                                                            \
+    }                                                                                              \
+    hipLaunchKernelGGL((gemm2_kernel<AK, BK_, false>), grd2, blk2, shmem2, stream, g);             \
+  } while (0)
+      if (a_kc && b_kc) EIGX_LAUNCH2(true, true);
+      else if (a_kc) EIGX_LAUNCH2(true, false);
+      else if (b_kc) EIGX_LAUNCH2(false, true);
+      else EIGX_LAUNCH2(false, false);
+#undef EIGX_LAUNCH2
+      EIGX_HIP_CHECK(hipGetLastError());
+      return;
+    }
+  }
   // 64x64 tiles when 128x128 tiles would leave most of the 256 CUs idle
   const long tiles128 = (long)ceil_div(M, 128) * ceil_div(N, 128) * batch * batch2;
   const bool small = (tri_mode == 0) && tiles128 < 192;

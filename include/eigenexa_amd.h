@@ -160,6 +160,11 @@ int eigx_get_timers(double* out16);
 int eigx_profile(int stride);
 int eigx_profile_read(double* out6);
 
+/* Tuning hook for A/B measurements (tools/, tests/): key 0 = GEMM kernel (2 = LDS-DMA ring kernel where it
+ * applies [default], 1 = register-staged kernel everywhere).  Returns the previous value, or -1 for an
+ * unknown key.  Not part of the reference's interface. */
+int eigx_tune(int key, int value);
+
 /* device synchronisation helper for hosts without a HIP binding */
 int eigx_device_synchronize(void);
 

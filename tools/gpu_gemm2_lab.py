@@ -1,0 +1,147 @@
+"""GPU lab for the LDS-DMA ring GEMM (gemm2): correctness on awkward shapes, then interleaved A/B timing of
+gemm2 vs the register-staged kernel vs rocBLAS (torch.matmul, reference only) on the hot-path shapes."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from eigenexa_amd import _lib
+
+lib = _lib.load()
+_lib.check(lib.eigx_init(0), "eigx_init")
+dev = torch.device("cuda:0")
+torch.manual_seed(1)
+b = lambda s: s.encode()
+
+
+def even(x):
+    return x + (x & 1)
+
+
+def mk(rows, cols, pad):
+    ld = even(rows + pad)
+    t = torch.randn(cols, ld, dtype=torch.float64, device=dev)
+    return t, ld
+
+
+def call(opa, opb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri):
+    _lib.check(lib.eigx_dgemm_dev(b(opa), b(opb), M, N, K, alpha, A.data_ptr(), lda, B.data_ptr(), ldb, beta,
+                                  C.data_ptr(), ldc, tri), "dgemm")
+
+
+def check(opa, opb, M, N, K, tri=0, alpha=-1.0, beta=1.0, variant=3):
+    Ar, Ac = (M, K) if opa == "N" else (K, M)
+    Br, Bc = (K, N) if opb == "N" else (N, K)
+    A, lda = mk(Ar, Ac, 4)
+    B, ldb = mk(Br, Bc, 2)
+    C, ldc = mk(M, N, 6)
+    C0 = C.clone()
+    torch.cuda.synchronize()   # the library runs on its own (non-blocking) stream
+    lib.eigx_tune(0, variant)
+    call(opa, opb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri)
+    Am, Bm = A[:, :Ar].T, B[:, :Br].T
+    opA = Am if opa == "N" else Am.T
+    opB = Bm if opb == "N" else Bm.T
+    ref = alpha * (opA @ opB) + beta * C0[:, :M].T
+    got = C[:, :M].T
+    if tri:
+        tm = torch.arange(M, device=dev)[:, None] // 128
+        tn = torch.arange(N, device=dev)[None, :] // 128
+        mask = tm <= tn                       # tiles that intersect the upper triangle are updated
+        err = ((got - ref) * mask).abs().max().item()
+        keep = torch.equal(got[~mask], C0[:, :M].T[~mask])
+    else:
+        err = (got - ref).abs().max().item()
+        keep = True
+    pad_ok = torch.equal(C[:, M:], C0[:, M:])
+    scale = ref.abs().max().item()
+    ok = err < 1e-10 * max(1.0, scale) * max(1, K) ** 0.5 and pad_ok and keep
+    print(f"v{variant} {opa}{opb} M={M} N={N} K={K} tri={tri} beta={beta}: err {err:.2e} pad_ok={pad_ok} keep={keep} "
+          f"{'OK' if ok else 'FAIL'}", flush=True)
+    assert ok
+
+
+def timeit(fn, reps):
+    torch.cuda.synchronize()
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def perf(opa, opb, M, N, K, tri=0, alpha=-1.0, beta=1.0, reps=5, rounds=3):
+    Ar, Ac = (M, K) if opa == "N" else (K, M)
+    Br, Bc = (K, N) if opb == "N" else (N, K)
+    A, lda = mk(Ar, Ac, 32)
+    B, ldb = mk(Br, Bc, 32)
+    C, ldc = mk(M, N, 32)
+    Am, Bm, Cm = A[:, :Ar].T, B[:, :Br].T, C[:, :M].T
+    opA = Am if opa == "N" else Am.T
+    opB = Bm if opb == "N" else Bm.T
+    fl = 2.0 * M * N * K * (0.5 if tri else 1.0)
+    torch.cuda.synchronize()
+    best = {}
+    for _ in range(rounds):
+        for v in (1, 2):
+            lib.eigx_tune(0, v)
+            dt = timeit(lambda: call(opa, opb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri), reps)
+            best[v] = min(best.get(v, 1e9), dt)
+        if not tri:
+            if beta == 0.0:
+                dt = timeit(lambda: torch.mm(opA, opB, out=Cm) if False else torch.matmul(opA, opB), reps)
+            else:
+                dt = timeit(lambda: torch.addmm(Cm, opA, opB, beta=beta, alpha=alpha), reps)
+            best["rocblas"] = min(best.get("rocblas", 1e9), dt)
+    lib.eigx_tune(0, 2)
+    msg = " ".join(f"{k}: {v*1e3:8.3f} ms {fl/v/1e12:6.2f} TF |" for k, v in best.items())
+    print(f"{opa}{opb} M={M} N={N} K={K} tri={tri} beta={beta}: {msg}", flush=True)
+
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "all"
+if mode in ("all", "check"):
+    for opa in "NT":
+        for opb in "NT":
+            kk = 78 if (opa == "T" or opb == "N") else 77
+            check(opa, opb, 300, 200, kk)
+            check(opa, opb, 129, 257, 16)
+            check(opa, opb, 5, 3, 2)
+            check(opa, opb, 131, 130, 8, beta=0.0, alpha=1.0)
+            check(opa, opb, 640, 515, 130)
+    check("N", "T", 1000, 1000, 96, tri=1)
+    check("N", "T", 1153, 1153, 256, tri=1)
+    check("N", "T", 2048, 2048, 256, tri=1)
+    check("N", "T", 3000, 3000, 64, tri=1, variant=2)
+    print("GEMM2 CHECK PASSED", flush=True)
+if mode in ("all", "perf"):
+    perf("N", "T", 8192, 8192, 256, tri=1)
+    perf("N", "T", 16384, 16384, 256, tri=1)
+    perf("N", "T", 32768, 32768, 256, tri=1, reps=3)
+    perf("N", "T", 32768, 32768, 512, tri=1, reps=3)
+    perf("N", "T", 16384, 16384, 256)
+    perf("N", "N", 8192, 8192, 8192, reps=2)
+    perf("N", "T", 8192, 8192, 8192, reps=2)
+    perf("T", "N", 512, 8192, 8192)
+    perf("T", "N", 128, 8192, 8192, alpha=1.0, beta=0.0)
+    perf("N", "N", 8192, 8192, 128)
+    perf("N", "N", 8192, 8192, 512)
+if mode == "pmc":
+    # one launch per variant and shape for rocprofv3 --pmc (no timing loops)
+    def once(opa, opb, M, N, K, tri=0, alpha=-1.0, beta=1.0):
+        Ar, Ac = (M, K) if opa == "N" else (K, M)
+        Br, Bc = (K, N) if opb == "N" else (N, K)
+        A, lda = mk(Ar, Ac, 32); B, ldb = mk(Br, Bc, 32); C, ldc = mk(M, N, 32)
+        Am, Bm, Cm = A[:, :Ar].T, B[:, :Br].T, C[:, :M].T
+        opA = Am if opa == "N" else Am.T
+        opB = Bm if opb == "N" else Bm.T
+        torch.cuda.synchronize()
+        for v in (1, 2):
+            lib.eigx_tune(0, v)
+            for _ in range(2):
+                call(opa, opb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri)
+        if not tri:
+            for _ in range(2):
+                torch.addmm(Cm, opA, opB, beta=beta, alpha=alpha)
+        torch.cuda.synchronize()
+    once("N", "T", 32768, 32768, 256, tri=1)
+    once("N", "T", 8192, 8192, 8192)
