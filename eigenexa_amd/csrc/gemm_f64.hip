@@ -288,9 +288,13 @@ constexpr int G2_STAGE = 2 * G2_BK * 128;  // doubles per ring stage (A image | 
 
 __device__ double g_zero_page[128];        // 1 KiB of zeros: source of every k >= K slab row
 
+// One LDS-DMA wave instruction: lane l copies 16 bytes from its own global address to LDS byte lds_off + 16*l.
+// Written as inline asm on purpose: for the builtin form hipcc (ROCm 7.2) makes every later ds_read wait
+// vmcnt(0) for ALL outstanding LDS-DMA (no alias information), which drains the ring once per slab; with asm
+// the compiler sees no LDS-DMA and the ring is ordered by the counted s_waitcnt vmcnt + s_barrier below.
 __device__ __forceinline__ void glds16(const double* gp, double* lp) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                   (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+  const unsigned lds_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lp;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lds_off) : "m0", "memory");
 }
 
 // Issue this wave's share (2 wave-instructions) of one operand slab [k0, k0+8).
