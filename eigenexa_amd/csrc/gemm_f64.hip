@@ -301,9 +301,9 @@ __device__ __forceinline__ void glds16(const double* gp, double* lp) {
 //   MC: P(x, k) = P[x + col(k)*ld]; wave w loads k-rows 2w, 2w+1; lane l carries x = x0 + 2l, 2l+1
 //   KC: P(x, k) = P[k + x*ld];      wave w loads row blocks 2w, 2w+1 (16 rows each); lane l carries row
 //       16q + (l>>2), chunk (l&3) ^ ((l>>4)&3)
-template <bool KC, bool MAP>
+template <bool KC>
 __device__ __forceinline__ void g2_issue(const double* __restrict__ P, int ld, int x0, int Xmax, int k0, int K,
-                                         double* img, int wave, int lane, const int* __restrict__ kmap) {
+                                         double* img, int wave, int lane, int col0, int col1) {
   if (!KC) {
     int x = x0 + 2 * lane;
     if (x + 1 >= Xmax) x = (Xmax - 1) & ~1;   // clamp to the last aligned pair that starts inside the matrix
@@ -311,13 +311,8 @@ __device__ __forceinline__ void g2_issue(const double* __restrict__ P, int ld, i
     for (int q = 0; q < 2; ++q) {
       const int kr = 2 * wave + q;
       const int k = k0 + kr;
-      const double* src;
-      if (k < K) {
-        const int col = MAP ? __builtin_amdgcn_readfirstlane(kmap[k]) : k;
-        src = P + (size_t)x + (size_t)col * ld;
-      } else {
-        src = g_zero_page + 2 * lane;
-      }
+      const int col = q ? col1 : col0;        // column of P that holds k-index k (k itself without a gather map)
+      const double* src = (k < K) ? P + (size_t)x + (size_t)col * ld : g_zero_page + 2 * lane;
       glds16(src, img + kr * 128);
     }
   } else {
@@ -331,6 +326,26 @@ __device__ __forceinline__ void g2_issue(const double* __restrict__ P, int ld, i
       const double* src = (k < K) ? P + (size_t)k + (size_t)x * ld : g_zero_page + 2 * lane;
       glds16(src, img + blk * 128);
     }
+  }
+}
+
+// gather maps: columns of this wave's two k-rows of slab k0.  k is wave-uniform, so these are scalar loads --
+// written as asm because hipcc emits vector loads for them, which would sit in the same vmcnt queue as the
+// LDS-DMA ring and drain it.  The values are valid only after the s_waitcnt lgkmcnt(0) of g2_cols_wait().
+__device__ __forceinline__ int g2_sload(const int* p, int idx) {
+  int v;
+  asm volatile("s_load_dword %0, %1, %2" : "=s"(v) : "s"(p), "s"(idx * 4) : "memory");
+  return v;
+}
+template <bool MAP>
+__device__ __forceinline__ void g2_cols(const int* __restrict__ kmap, int k0, int K, int wave, int& c0, int& c1) {
+  const int k = k0 + 2 * wave;
+  if (MAP) {
+    c0 = 0; c1 = 0;
+    if (k < K) c0 = g2_sload(kmap, k);
+    if (k + 1 < K) c1 = g2_sload(kmap, k + 1);
+  } else {
+    c0 = k; c1 = k + 1;
   }
 }
 
@@ -437,22 +452,34 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmArgs g) {
 
   // ---- prologue: the C tile is requested first (above), then S-1 operand slabs; the first counted wait
   // below therefore covers exactly "C tile + slab 0"
+  int ca0, ca1, cb0, cb1;   // columns of the slab issued next (gather variant: fetched one iteration ahead)
 #pragma unroll
   for (int s = 0; s < S - 1; ++s) {
     double* st = smem + s * G2_STAGE;
-    g2_issue<A_KC, GATHER>(g.A, g.lda, m0, g.M, s * G2_BK, g.K, st, wave, lane, g.kmapA);
-    g2_issue<B_KC, GATHER>(g.B, g.ldb, n0, g.N, s * G2_BK, g.K, st + G2_BK * 128, wave, lane, g.kmapB);
+    g2_cols<GATHER && !A_KC>(g.kmapA, s * G2_BK, g.K, wave, ca0, ca1);
+    g2_cols<GATHER && !B_KC>(g.kmapB, s * G2_BK, g.K, wave, cb0, cb1);
+    if (GATHER) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ca0), "+s"(ca1), "+s"(cb0), "+s"(cb1)::"memory");
+    g2_issue<A_KC>(g.A, g.lda, m0, g.M, s * G2_BK, g.K, st, wave, lane, ca0, ca1);
+    g2_issue<B_KC>(g.B, g.ldb, n0, g.N, s * G2_BK, g.K, st + G2_BK * 128, wave, lane, cb0, cb1);
   }
+  g2_cols<GATHER && !A_KC>(g.kmapA, (S - 1) * G2_BK, g.K, wave, ca0, ca1);
+  g2_cols<GATHER && !B_KC>(g.kmapB, (S - 1) * G2_BK, g.K, wave, cb0, cb1);
 
   for (int kt = 0; kt < nk; ++kt) {
     // my DMAs of slab kt have landed (the 2 younger slabs may still be in flight); after the barrier
     // everybody's have, and everybody has finished reading slab kt-1, whose stage is refilled next
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((S - 2) * GI) : "memory");
+    if (GATHER)  // also: the map entries fetched during the previous iteration are in their SGPRs now
+      asm volatile("s_waitcnt vmcnt(%4) lgkmcnt(0)\n\ts_barrier"
+                   : "+s"(ca0), "+s"(ca1), "+s"(cb0), "+s"(cb1) : "n"((S - 2) * GI) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((S - 2) * GI) : "memory");
     {
       const int ks = kt + S - 1;
       double* st = smem + (ks % S) * G2_STAGE;
-      g2_issue<A_KC, GATHER>(g.A, g.lda, m0, g.M, ks * G2_BK, g.K, st, wave, lane, g.kmapA);
-      g2_issue<B_KC, GATHER>(g.B, g.ldb, n0, g.N, ks * G2_BK, g.K, st + G2_BK * 128, wave, lane, g.kmapB);
+      g2_issue<A_KC>(g.A, g.lda, m0, g.M, ks * G2_BK, g.K, st, wave, lane, ca0, ca1);
+      g2_issue<B_KC>(g.B, g.ldb, n0, g.N, ks * G2_BK, g.K, st + G2_BK * 128, wave, lane, cb0, cb1);
+      g2_cols<GATHER && !A_KC>(g.kmapA, (ks + 1) * G2_BK, g.K, wave, ca0, ca1);
+      g2_cols<GATHER && !B_KC>(g.kmapB, (ks + 1) * G2_BK, g.K, wave, cb0, cb1);
     }
     const double* as = smem + (kt % S) * G2_STAGE;
     const double* bs = as + G2_BK * 128;
@@ -564,7 +591,8 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
   g.Py = grid ? grid->Py : 1; g.py = grid ? grid->py : 0;
   const bool a_kc = (opA == 'T' || opA == 't');   // op(A)(m,k) = A[k + m*lda]
   const bool b_kc = (opB == 'N' || opB == 'n');   // op(B)(k,n) = B[k + n*ldb]
-  if (!g.kmapA && !g.kmapB && gemm2_ok(g, a_kc, b_kc, batch, batch2)) {
+  const bool gather = g.kmapA || g.kmapB;
+  if ((!gather || (g.kmapA && g.kmapB && !a_kc && !b_kc)) && gemm2_ok(g, a_kc, b_kc, batch, batch2)) {
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128) * batch * batch2;
     if (tri_mode != 0 || t128 >= 192 || g_gemm_variant == 3) {
       int gx2 = ceil_div(M, 128) * ceil_div(N, 128);
@@ -577,21 +605,22 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
         gx2 = 8 * ceil_div(nblk, 8) * g.tri_gb * g.tri_gb;
       }
       dim3 grd2(gx2, batch, batch2), blk2(256);
-      const size_t shmem2 = getenv("EIGX_G2_LDS") ? (size_t)atoi(getenv("EIGX_G2_LDS")) : (size_t)4 * G2_STAGE * sizeof(double);
-#define EIGX_LAUNCH2(AK, BK_)                                                                      \
+      const size_t shmem2 = (size_t)4 * G2_STAGE * sizeof(double);
+#define EIGX_LAUNCH2(AK, BK_, GA_)                                                                 \
   do {                                                                                             \
     static bool attr_set2 = false;                                                                 \
     if (!attr_set2) {                                                                              \
-      EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<AK, BK_, false>,                \
+      EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<AK, BK_, GA_>,                  \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2)); \
       attr_set2 = true;                                                                            \
     }                                                                                              \
-    hipLaunchKernelGGL((gemm2_kernel<AK, BK_, false>), grd2, blk2, shmem2, stream, g);             \
+    hipLaunchKernelGGL((gemm2_kernel<AK, BK_, GA_>), grd2, blk2, shmem2, stream, g);               \
   } while (0)
-      if (a_kc && b_kc) EIGX_LAUNCH2(true, true);
-      else if (a_kc) EIGX_LAUNCH2(true, false);
-      else if (b_kc) EIGX_LAUNCH2(false, true);
-      else EIGX_LAUNCH2(false, false);
+      if (gather) EIGX_LAUNCH2(false, false, true);
+      else if (a_kc && b_kc) EIGX_LAUNCH2(true, true, false);
+      else if (a_kc) EIGX_LAUNCH2(true, false, false);
+      else if (b_kc) EIGX_LAUNCH2(false, true, false);
+      else EIGX_LAUNCH2(false, false, false);
 #undef EIGX_LAUNCH2
       EIGX_HIP_CHECK(hipGetLastError());
       return;

@@ -98,6 +98,36 @@ def perf(opa, opb, M, N, K, tri=0, alpha=-1.0, beta=1.0, reps=5, rounds=3):
     print(f"{opa}{opb} M={M} N={N} K={K} tri={tri} beta={beta}: {msg}", flush=True)
 
 
+def gather(M, N, K, ncolsA, ncolsB, variant=3, reps=0):
+    """C = A(:, mapA) * B(:, mapB)^T  ('N','T' with column gather maps, the D&C eigenvector update)"""
+    A, lda = mk(M, ncolsA, 4)
+    B, ldb = mk(N, ncolsB, 2)
+    C, ldc = mk(M, N, 6)
+    mapA = torch.randperm(ncolsA, device=dev)[:K].to(torch.int32).contiguous()
+    mapB = torch.randperm(ncolsB, device=dev)[:K].to(torch.int32).contiguous()
+    C0 = C.clone()
+    torch.cuda.synchronize()
+    def run():
+        _lib.check(lib.eigx_dgemm_gather_dev(b"N", b"T", M, N, K, 1.0, A.data_ptr(), lda, B.data_ptr(), ldb, 0.0,
+                                             C.data_ptr(), ldc, mapA.data_ptr(), mapB.data_ptr()), "gather")
+    lib.eigx_tune(0, variant)
+    run()
+    ref = A[:, :M].T[:, mapA.long()] @ B[:, :N].T[:, mapB.long()].T
+    got = C[:, :M].T
+    err = (got - ref).abs().max().item()
+    pad_ok = torch.equal(C[:, M:], C0[:, M:])
+    ok = err < 1e-10 * max(1.0, ref.abs().max().item()) * K ** 0.5 and pad_ok
+    msg = f"gather v{variant} M={M} N={N} K={K}: err {err:.2e} pad_ok={pad_ok} {'OK' if ok else 'FAIL'}"
+    if reps:
+        for v in (1, 2):
+            lib.eigx_tune(0, v)
+            dt = timeit(run, reps)
+            msg += f" | v{v} {dt*1e3:.3f} ms {2.0*M*N*K/dt/1e12:.2f} TF"
+    lib.eigx_tune(0, 2)
+    print(msg, flush=True)
+    assert ok
+
+
 mode = sys.argv[1] if len(sys.argv) > 1 else "all"
 if mode in ("all", "check"):
     for opa in "NT":
@@ -112,8 +142,14 @@ if mode in ("all", "check"):
     check("N", "T", 1153, 1153, 256, tri=1)
     check("N", "T", 2048, 2048, 256, tri=1)
     check("N", "T", 3000, 3000, 64, tri=1, variant=2)
+    gather(300, 200, 77, 100, 90)
+    gather(129, 257, 16, 16, 40)
+    gather(640, 515, 131, 200, 300)
+    gather(1000, 1000, 1, 5, 5)
     print("GEMM2 CHECK PASSED", flush=True)
 if mode in ("all", "perf"):
+    gather(8192, 6912, 6912, 8192, 8192, variant=2, reps=3)
+    gather(4096, 3500, 3500, 4096, 4096, variant=2, reps=3)
     perf("N", "T", 8192, 8192, 256, tri=1)
     perf("N", "T", 16384, 16384, 256, tri=1)
     perf("N", "T", 32768, 32768, 256, tri=1, reps=3)
