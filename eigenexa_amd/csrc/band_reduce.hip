@@ -40,7 +40,6 @@ constexpr int PD_ROWS = 512;   // rows per panel-dot chunk
 constexpr int PD_COLS = 16;    // panel columns per panel-dot workgroup
 constexpr int KA_ROWS = 16;    // rows per K_A workgroup
 constexpr int KA_SL = 256 / KA_ROWS;  // panel slices per row (KA_ROWS x KA_SL = 256 threads)
-constexpr int KM_ROWS = 256;   // rows per K_M workgroup
 
 // scalar slots in the small device array `sc`
 enum { SC_SA = 0, SC_BETA_A = 1, SC_SB = 2, SC_BETA_B = 3, SC_COUNT = 8 };
@@ -52,7 +51,7 @@ struct RedArgs {
   double* YR; double* YC;         // SYMV partials [tile col | tile row][a][ldp]
   double* KD;                     // panel-dot partials [chunk][kind 2*NB][m], then [chunk] uA.uB at the end
   double* SP;                     // [wg][3] bilinear partials
-  double* GP;                     // [wg][2] Gram partials (K_A), GP2 = GP + gp2_off : [wg] (K_M)
+  double* GP;                     // [K_A workgroup][3] Gram partials of the new columns
   double* sc;                     // scalars
   double* d; double* e; int lde;
   int maxseg, maxrs, maxchunk, gp2_off, kdab_off;
@@ -137,44 +136,113 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   const int kloop = hp ? S.kprev : S.k;
   const int kold = hp ? S.kprev : S.k;  // panel slots that are final in memory
   const int r = blockIdx.x * KA_ROWS + rr;
-
-  // t-th SYMV partial of row q (tile row ty = q/T), t in [0, nt]: t <= ty -> column result of tile row t
-  // (column q of tile (t, ty)) ; t > ty -> row result of tile column t-1 (row q of tile (ty, t-1))
-  auto symv_part = [&](int q, int t, int ty, double& pA, double& pB) {
-    const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
-    pA += base[q];
-    if (NB == 2) pB += base[ldp + q];
-  };
+  const bool rowok = r < S.rows;
 
   // ============ phase 0: every load that depends on nothing computed in this kernel ==================
+  // The kernel is a latency chain (a few hundred bytes per thread), so ALL loads are issued up front in
+  // straight-line batches with clamped indices (values of out-of-range entries are dropped by a select
+  // afterwards, never by a branch around the load): the chain costs about one memory round trip.
+  // --- the panel rows of phase 3 first: the longest batch, consumed last
+  constexpr int KB = 8;                 // kk per slice and batch (8 * KA_SL = 128 panel columns)
+  double tu[KB], tw[KB];
+  {
+    const int rc = rowok ? r : 0;
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+      const int kk = (ks + j * KA_SL < kloop) ? ks + j * KA_SL : 0;
+      tu[j] = Up[(size_t)kk * ldp + rc];
+      tw[j] = Wp[(size_t)kk * ldp + rc];
+    }
+  }
   double bA = 0.0, bB = 0.0;
   double kdv[4] = {0.0, 0.0, 0.0, 0.0};          // my (kind,kk) entries of the reduced panel dots
   double v[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [0..2] SP, [3..5] corrections, [6] uA.uB, [7..10] P(c,a)
   double ru[2] = {0.0, 0.0}, rw[2] = {0.0, 0.0};
   double prA = 0.0, prB = 0.0;                   // my share of this row's SYMV partial sums
   double uA_r = 0.0, uB_r = 0.0, a_i = 0.0, a_im = 0.0;
+  if (S.ncols > 0) {
+    for (int cc = 0; cc < S.ncols; ++cc) {
+      const int c = S.i - cc;
+      if (tid < S.k) {
+        ru[cc] = Up[(size_t)tid * ldp + c];
+        rw[cc] = (tid < kold) ? Wp[(size_t)tid * ldp + c] : 0.0;
+      }
+    }
+    if (ks == 0 && r <= S.i) {
+      a_i = R.A[(size_t)S.i * R.lda + r];
+      if (S.ncols > 1 && r <= S.i - 1) a_im = R.A[(size_t)(S.i - 1) * R.lda + r];
+    }
+  }
   if (hp) {
     bA = R.sc[SC_BETA_A];
     if (NB == 2) bB = R.sc[SC_BETA_B];
+    if (ks == 0 && rowok) {
+      uA_r = Up[(size_t)kp * ldp + r];
+      if (NB == 2) uB_r = Up[(size_t)(kp + 1) * ldp + r];
+    }
+    // --- SYMV partial sums of my row: t-th partial, t in [0, nt]: t <= ty -> column result of tile row t
+    // (column r of tile (t, ty)); t > ty -> row result of tile column t-1 (row r of tile (ty, t-1))
+    constexpr int RPB = 5;              // partials per slice and batch (5 * KA_SL = 80)
+    double ta[2][RPB], tb[2][RPB];
+    const bool rowp = rowok && r < S.Lprev;
+    if (mg) {
+      if (ks == 0 && rowp) { prA = R.RB[r]; if (NB == 2) prB = R.RB[Lp + r]; }
+    } else {
+      const int rc = rowp ? r : 0;
+      const int ty = rc / g.T;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < RPB; ++j) {
+          const int tt = ks + (b * RPB + j) * KA_SL;
+          const int t = (tt < g.nt + 1) ? tt : 0;
+          const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
+          ta[b][j] = base[rc];
+          if (NB == 2) tb[b][j] = base[ldp + rc];
+        }
+    }
+    // --- reduced panel dots: entry (kind, kk) summed over the K_P row chunks
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int idx = tid + 256 * q;
       if (idx < 2 * NB * kp) {
         const int kind = idx / kp, kk = idx - kind * kp;
         double acc = 0.0;
-        for (int c = 0; c < S.nchunk_prev; ++c) acc += R.KD[((size_t)c * 2 * NB + kind) * m + kk];
+        for (int c0 = 0; c0 < S.nchunk_prev; c0 += 4) {
+          double t[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int c = (c0 + j < S.nchunk_prev) ? c0 + j : 0;
+            t[j] = R.KD[((size_t)c * 2 * NB + kind) * m + kk];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc += (c0 + j < S.nchunk_prev) ? t[j] : 0.0;
+        }
         kdv[q] = acc;
       }
     }
+    // --- bilinear partials of the SYMV tiles.  SP is laid out [ty][tx] with the fixed stride maxseg;
+    // entries below the tile diagonal are never written and stay zero, so the sum runs unconditionally
+    // over the nt x nt square, 8 entries per thread and batch
     if (mg) {
       if (tid == 0) { v[0] = R.RB[NB * Lp + 0]; if (NB == 2) { v[1] = R.RB[NB * Lp + 1]; v[2] = R.RB[NB * Lp + 2]; } }
     } else {
       const int tot = g.nt * g.nt;
-      for (int w = tid; w < tot; w += 256) {
-        const int ty = w / g.nt, tx = w - ty * g.nt;
-        if (tx >= ty) {
-          v[0] += R.SP[(size_t)w * 3 + 0];
-          if (NB == 2) { v[1] += R.SP[(size_t)w * 3 + 1]; v[2] += R.SP[(size_t)w * 3 + 2]; }
+      for (int w0 = tid; w0 < tot; w0 += 2048) {
+        double t[8][3];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int w = (w0 + 256 * j < tot) ? w0 + 256 * j : 0;
+          const int ty = w / g.nt, tx = w - ty * g.nt;
+          const double* sp = R.SP + ((size_t)ty * R.maxseg + tx) * 3;
+          t[j][0] = sp[0];
+          if (NB == 2) { t[j][1] = sp[1]; t[j][2] = sp[2]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool ok = w0 + 256 * j < tot;
+          v[0] += ok ? t[j][0] : 0.0;
+          if (NB == 2) { v[1] += ok ? t[j][1] : 0.0; v[2] += ok ? t[j][2] : 0.0; }
         }
       }
     }
@@ -187,33 +255,31 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
         if (tid == 0) { v[7 + 2 * cc] += R.RB[c]; if (NB == 2) v[8 + 2 * cc] += R.RB[Lp + c]; }
       } else {
         const int ty = c / g.T;
-        for (int t = tid; t < g.nt + 1; t += 256) symv_part(c, t, ty, v[7 + 2 * cc], v[8 + 2 * cc]);
+        for (int t = tid; t < g.nt + 1; t += 256) {
+          const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
+          v[7 + 2 * cc] += base[c];
+          if (NB == 2) v[8 + 2 * cc] += base[ldp + c];
+        }
       }
     }
-    if (r < S.rows && r < S.Lprev) {
-      if (mg) {
-        if (ks == 0) { prA = R.RB[r]; if (NB == 2) prB = R.RB[Lp + r]; }
-      } else {
+    if (!mg) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < RPB; ++j) {
+          const bool ok = rowp && (ks + (b * RPB + j) * KA_SL < g.nt + 1);
+          prA += ok ? ta[b][j] : 0.0;
+          if (NB == 2) prB += ok ? tb[b][j] : 0.0;
+        }
+      // more than 2*RPB*KA_SL = 160 partials per row (not reached by symv_geom's tile choice below N ~ 80000)
+      if (rowp) {
         const int ty = r / g.T;
-        for (int t = ks; t < g.nt + 1; t += KA_SL) symv_part(r, t, ty, prA, prB);
+        for (int t = ks + 2 * RPB * KA_SL; t < g.nt + 1; t += KA_SL) {
+          const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
+          prA += base[r];
+          if (NB == 2) prB += base[ldp + r];
+        }
       }
-    }
-    if (ks == 0 && r < S.rows) {
-      uA_r = Up[(size_t)kp * ldp + r];
-      if (NB == 2) uB_r = Up[(size_t)(kp + 1) * ldp + r];
-    }
-  }
-  if (S.ncols > 0) {
-    for (int cc = 0; cc < S.ncols; ++cc) {
-      const int c = S.i - cc;
-      if (tid < S.k) {
-        ru[cc] = Up[(size_t)tid * ldp + c];
-        rw[cc] = (tid < kold) ? Wp[(size_t)tid * ldp + c] : 0.0;
-      }
-    }
-    if (ks == 0 && r <= S.i) {
-      a_i = R.A[(size_t)S.i * R.lda + r];
-      if (S.ncols > 1 && r <= S.i - 1) a_im = R.A[(size_t)(S.i - 1) * R.lda + r];
     }
   }
 
@@ -273,25 +339,40 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   // ============ phase 3: row loop: slice partial sums ================================================
   {
     double pA = prA, pB = prB, x0 = 0.0, x1 = 0.0;
-    if (r < S.rows) {
-      for (int kk = ks; kk < kloop; kk += KA_SL) {
-        const double u = Up[(size_t)kk * ldp + r];
-        const double w = Wp[(size_t)kk * ldp + r];
-        if (hp) {
-          pA -= u * kd[1][kk] + w * kd[0][kk];
-          if (NB == 2) pB -= u * kd[3][kk] + w * kd[2][kk];
+    auto accum = [&](int kk, double u, double w) {
+      if (hp) {
+        pA -= u * kd[1][kk] + w * kd[0][kk];
+        if (NB == 2) pB -= u * kd[3][kk] + w * kd[2][kk];
+      }
+      if (S.ncols > 0) {
+        x0 += u * rowW[0][kk] + w * rowU[0][kk];
+        if (S.ncols > 1) x1 += u * rowW[1][kk] + w * rowU[1][kk];
+      }
+    };
+    if (rowok) {
+#pragma unroll
+      for (int j = 0; j < KB; ++j) {
+        const int kk = ks + j * KA_SL;
+        if (kk < kloop) accum(kk, tu[j], tw[j]);
+      }
+      for (int k0 = ks + KB * KA_SL; k0 < kloop; k0 += KB * KA_SL) {   // m > 128 only
+        double xu[KB], xw[KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+          const int kk = (k0 + j * KA_SL < kloop) ? k0 + j * KA_SL : 0;
+          xu[j] = Up[(size_t)kk * ldp + r];
+          xw[j] = Wp[(size_t)kk * ldp + r];
         }
-        if (S.ncols > 0) {
-          x0 += u * rowW[0][kk] + w * rowU[0][kk];
-          if (S.ncols > 1) x1 += u * rowW[1][kk] + w * rowU[1][kk];
-        }
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+          if (k0 + j * KA_SL < kloop) accum(k0 + j * KA_SL, xu[j], xw[j]);
       }
     }
     slice[ks][rr][0] = pA; slice[ks][rr][1] = pB; slice[ks][rr][2] = x0; slice[ks][rr][3] = x1;
   }
   __syncthreads();
-  double gg[2] = {0.0, 0.0};
-  if (ks == 0 && r < S.rows) {
+  double gg[3] = {0.0, 0.0, 0.0};
+  if (ks == 0 && rowok) {
     double pA = 0.0, pB = 0.0, x0 = 0.0, x1 = 0.0;
 #pragma unroll
     for (int q = 0; q < KA_SL; ++q) {
@@ -322,54 +403,15 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
         xim = a_im - x1;
         R.X[ldp + r] = xim;
       }
-      if (r < S.L) { gg[0] = xi * xi; gg[1] = xi * xim; }
+      if (r < S.L) { gg[0] = xi * xi; gg[1] = xi * xim; gg[2] = xim * xim; }
       if (r == S.i) R.d[S.i] = xi;
       if (S.ncols > 1 && r == S.i - 1) { R.e[S.i] = xi; R.d[S.i - 1] = xim; }  // e(i,1) = A_eff(i-1,i)
     }
   }
   if (S.ncols > 0) {
-    block_sum_multi<2>(gg, red);
-    if (tid == 0) { R.GP[blockIdx.x * 2 + 0] = gg[0]; R.GP[blockIdx.x * 2 + 1] = gg[1]; }
-  }
-}
-
-// =================================================================================================
-// K_M (NB=2): x1' = x1 - gamma uA ; partial norm of x1'(0:L-1) ; scalars of reflector A
-// =================================================================================================
-__global__ __launch_bounds__(256) void km_kernel(RedArgs R, int i, int L, int ngp) {
-  __shared__ double red[8];
-  const int tid = threadIdx.x;
-  double gv[2] = {0.0, 0.0};
-  for (int q = tid; q < ngp; q += 256) { gv[0] += R.GP[2 * q]; gv[1] += R.GP[2 * q + 1]; }
-  block_sum_multi<2>(gv, red);
-  const double g22 = gv[0], g12 = gv[1];
-  const double x2L = R.X[L - 1];
-  const double x1L = R.X[R.ldp + L - 1];
-  double s2 = 0.0, betaA = 0.0, gamma = 0.0;
-  if (g22 > 0.0) {
-    s2 = -sign_of(sqrt(g22), x2L);
-    betaA = g22 - s2 * x2L;
-    gamma = (g12 - s2 * x1L) / betaA;
-  } else {
-    s2 = x2L;  // = 0
-  }
-  const int r = blockIdx.x * KM_ROWS + tid;
-  double h[1] = {0.0};
-  if (r < L) {
-    const double uA = R.X[r] - (r == L - 1 ? s2 : 0.0);
-    const double x1 = R.X[R.ldp + r] - gamma * uA;
-    R.X[2 * R.ldp + r] = x1;
-    if (r < L - 1) h[0] = x1 * x1;
-    if (r == L - 1) R.e[i - 1] = x1;  // e(i-1,1) = T(i-2,i-1)
-  }
-  block_sum_multi<1>(h, red);
-  if (tid == 0) {
-    R.GP[R.gp2_off + blockIdx.x] = h[0];
-    if (blockIdx.x == 0) {
-      R.sc[SC_SA] = s2;
-      R.sc[SC_BETA_A] = betaA;
-      R.e[R.lde + i] = s2;  // e(i,2) = T(i-2,i)
-    }
+    // Gram partials of the new columns over the rows above the block: x_i.x_i, x_i.x_{i-1}, x_{i-1}.x_{i-1}
+    block_sum_multi<3>(gg, red);
+    if (tid == 0) { R.GP[blockIdx.x * 3 + 0] = gg[0]; R.GP[blockIdx.x * 3 + 1] = gg[1]; R.GP[blockIdx.x * 3 + 2] = gg[2]; }
   }
 }
 
@@ -419,7 +461,8 @@ __global__ __launch_bounds__(256) void kl_kernel(RedArgs R, int L, int nt) {
     for (int w = threadIdx.x; w < nt * nt; w += 256) {
       const int ty = w / nt, tx = w - ty * nt;
       if (tx >= ty && tx % R.P == R.p) {
-        v[0] += R.SP[(size_t)w * 3 + 0]; v[1] += R.SP[(size_t)w * 3 + 1]; v[2] += R.SP[(size_t)w * 3 + 2];
+        const double* sp = R.SP + ((size_t)ty * R.maxseg + tx) * 3;
+        v[0] += sp[0]; v[1] += sp[1]; v[2] += sp[2];
       }
     }
     block_sum_multi<3>(v, red);
@@ -457,7 +500,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
       const int c = col0 + tid + 256 * q;
       const bool ok = (tid + 256 * q < T) && c < L;
       craw[0][q] = ok ? R.X[c] : 0.0;
-      if (NV == 2) craw[NV - 1][q] = ok ? R.X[2 * ldp + c] : 0.0;
+      if (NV == 2) craw[NV - 1][q] = ok ? R.X[ldp + c] : 0.0;
     }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -466,7 +509,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
       for (int h = 0; h < 2; ++h) {
         const bool ok = r0 + h < L;
         rraw[0][rb][h] = ok ? R.X[r0 + h] : 0.0;
-        if (NV == 2) rraw[NV - 1][rb][h] = ok ? R.X[2 * ldp + r0 + h] : 0.0;
+        if (NV == 2) rraw[NV - 1][rb][h] = ok ? R.X[ldp + r0 + h] : 0.0;
       }
     }
     {
@@ -483,41 +526,80 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   }
 
   // ---- reflector scalars (every workgroup, same order) -------------------------------------------
-  double sA, sB = 0.0, betaA, betaB = 0.0;
+  // NV = 1: s = -sign(||x||, x_piv), beta = ||x||^2 - s x_piv from the Gram partials of K_A.
+  // NV = 2: two sequential Householder steps on the column pair (x0 = column i, x1 = column i-1) without a
+  // kernel in between: reflector A from g00 = x0.x0; gamma = uA.x1 / betaA from g01; the reflected second
+  // column x1' = x1 - gamma uA is formed on the fly wherever it is needed; its norm above the pivot row
+  // follows from the isometry of H_A: ||x1'(0:L-1)||^2 = g11 - x1'(L-1)^2.  If that difference cancels
+  // (more than 3/4 of the column's weight in the pivot row) the sum is taken explicitly instead -- same
+  // order in every workgroup, so the replicas stay bit-identical either way.
+  double sA, sB = 0.0, betaA, betaB = 0.0, gammaB = 0.0, eL1 = 0.0;
   const int pivA = L - 1, pivB = L - 2;
-  if (NV == 1) {
-    double gv[1] = {0.0};
-    for (int q = tid; q < B.ngp; q += 256) gv[0] += R.GP[2 * q];
-    block_sum_multi<1>(gv, red);
-    const double xL = R.X[L - 1];
-    if (gv[0] > 0.0) { sA = -sign_of(sqrt(gv[0]), xL); betaA = gv[0] - sA * xL; }
-    else { sA = xL; betaA = 0.0; }
-  } else {
-    sA = R.sc[SC_SA];
-    betaA = R.sc[SC_BETA_A];
-    double hv[1] = {0.0};
-    for (int q = tid; q < B.ngp; q += 256) hv[0] += R.GP[R.gp2_off + q];
-    block_sum_multi<1>(hv, red);
-    const double xL = (pivB >= 0) ? R.X[2 * ldp + pivB] : 0.0;
-    if (hv[0] > 0.0) { sB = -sign_of(sqrt(hv[0]), xL); betaB = hv[0] - sB * xL; }
-    else { sB = xL; betaB = 0.0; }
+  {
+    double gv[3] = {0.0, 0.0, 0.0};
+    for (int q0 = tid; q0 < B.ngp; q0 += 2048) {
+      double t[8][3];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int q = (q0 + 256 * j < B.ngp) ? q0 + 256 * j : 0;
+        t[j][0] = R.GP[3 * q];
+        if (NV == 2) { t[j][1] = R.GP[3 * q + 1]; t[j][2] = R.GP[3 * q + 2]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = q0 + 256 * j < B.ngp;
+        gv[0] += ok ? t[j][0] : 0.0;
+        if (NV == 2) { gv[1] += ok ? t[j][1] : 0.0; gv[2] += ok ? t[j][2] : 0.0; }
+      }
+    }
+    const double x0L = R.X[L - 1];
+    const double x1L = (NV == 2) ? R.X[ldp + L - 1] : 0.0;
+    const double x1P = (NV == 2 && pivB >= 0) ? R.X[ldp + pivB] : 0.0;
+    const double x0P = (NV == 2 && pivB >= 0) ? R.X[pivB] : 0.0;
+    block_sum_multi<3>(gv, red);
+    if (gv[0] > 0.0) { sA = -sign_of(sqrt(gv[0]), x0L); betaA = gv[0] - sA * x0L; }
+    else { sA = x0L; betaA = 0.0; }
+    if (NV == 2) {
+      if (betaA != 0.0) gammaB = (gv[1] - sA * x1L) / betaA;
+      eL1 = x1L - gammaB * (x0L - sA);              // x1'(L-1) = T(i-2, i-1)
+      double hB = gv[2] - eL1 * eL1;                // ||x1'(0:L-1)||^2
+      if (!(hB >= 0.25 * gv[2])) {
+        double h[1] = {0.0};
+        for (int j = tid; j < L - 1; j += 256) {
+          const double t = R.X[ldp + j] - gammaB * R.X[j];
+          h[0] += t * t;
+        }
+        block_sum_multi<1>(h, red);
+        hB = h[0];
+      }
+      const double xP = x1P - gammaB * x0P;         // x1'(L-2)
+      if (hB > 0.0 && pivB >= 0) { sB = -sign_of(sqrt(hB), xP); betaB = hB - sB * xP; }
+      else { sB = (pivB >= 0) ? xP : 0.0; betaB = 0.0; }
+    }
   }
   // the store-role panel workgroup of chunk 0 publishes the scalars (it exists on every rank)
   if (panel_role && (int)blockIdx.x == B.ncg && (int)blockIdx.y == B.nt && tid == 0) {
+    R.sc[SC_SA] = sA; R.sc[SC_BETA_A] = betaA;
     if (NV == 1) {
-      R.sc[SC_SA] = sA; R.sc[SC_BETA_A] = betaA;
       R.e[i] = sA;                               // e(i,1) = T(i-1,i)
     } else {
       R.sc[SC_SB] = sB; R.sc[SC_BETA_B] = betaB;
+      R.e[R.lde + i] = sA;                       // e(i,2)   = T(i-2,i)
+      R.e[i - 1] = eL1;                          // e(i-1,1) = T(i-2,i-1)
       if (i - 1 >= 2) R.e[R.lde + i - 1] = sB;   // e(i-1,2) = T(i-3,i-1)
     }
   }
-  // u_a(j) = X_a(j) - [j == piv_a] s_a ;  uB(L-1) = 0 ; zero when the reflector is trivial or j >= L
+  // u_A(j) = x0(j) - [j == pivA] sA ;  u_B(j) = x1'(j) - [j == pivB] sB, u_B(L-1) = 0 ;
+  // zero when the reflector is trivial or j >= L.  raw0/raw1 = x0(j), x1(j).
+  auto ufix2 = [&](int a, int j, double raw0, double raw1) -> double {
+    if (j >= L) return 0.0;
+    if (a == 0) return (betaA != 0.0) ? raw0 - (j == pivA ? sA : 0.0) : 0.0;
+    if (j >= L - 1 || betaB == 0.0) return 0.0;
+    return raw1 - gammaB * raw0 - (j == pivB ? sB : 0.0);
+  };
   auto uval = [&](int a, int j) -> double {
     if (j >= L) return 0.0;
-    if (a == 0) return (betaA != 0.0) ? R.X[j] - (j == pivA ? sA : 0.0) : 0.0;
-    if (j >= L - 1 || betaB == 0.0) return 0.0;
-    return R.X[2 * ldp + j] - (j == pivB ? sB : 0.0);
+    return ufix2(a, j, R.X[j], (NV == 2) ? R.X[ldp + j] : 0.0);
   };
 
   if (panel_role) {
@@ -586,19 +668,12 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   const bool diag = (tx == ty);
   double* yrs = dyn;            // [4 waves][NV][T]
   double* ucs = dyn + DYN;      // [NV][T] : u_a at the tile's columns
-  // u_a(j) from the pre-loaded raw x value: pivot shift, trivial-reflector and range rules of uval()
-  auto ufix = [&](int a, int j, double raw) -> double {
-    if (j >= L) return 0.0;
-    if (a == 0) return (betaA != 0.0) ? raw - (j == pivA ? sA : 0.0) : 0.0;
-    if (j >= L - 1 || betaB == 0.0) return 0.0;
-    return raw - (j == pivB ? sB : 0.0);
-  };
 #pragma unroll
   for (int q = 0; q < (T + 255) / 256; ++q) {
     const int t = tid + 256 * q;
     if (t < T) {
 #pragma unroll
-      for (int a = 0; a < NV; ++a) ucs[a * T + t] = ufix(a, col0 + t, craw[a][q]);
+      for (int a = 0; a < NV; ++a) ucs[a * T + t] = ufix2(a, col0 + t, craw[0][q], craw[NV - 1][q]);
     }
   }
   __syncthreads();
@@ -609,8 +684,8 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
     const int r0 = row0 + rb * 128 + lane * 2;
 #pragma unroll
     for (int a = 0; a < NV; ++a) {
-      ux[a][rb][0] = ufix(a, r0, rraw[a][rb][0]);
-      ux[a][rb][1] = ufix(a, r0 + 1, rraw[a][rb][1]);
+      ux[a][rb][0] = ufix2(a, r0, rraw[0][rb][0], rraw[NV - 1][rb][0]);
+      ux[a][rb][1] = ufix2(a, r0 + 1, rraw[0][rb][1], rraw[NV - 1][rb][1]);
       yr[a][rb][0] = 0.0; yr[a][rb][1] = 0.0;
     }
   }
@@ -770,7 +845,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   }
   block_sum_multi<3>(sp, red);
   if (tid == 0) {
-    const size_t w = (size_t)ty * B.nt + tx;
+    const size_t w = (size_t)ty * R.maxseg + tx;
     R.SP[w * 3 + 0] = sp[0]; R.SP[w * 3 + 1] = sp[1]; R.SP[w * 3 + 2] = sp[2];
   }
 }
@@ -808,13 +883,14 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   R.KD = ctx.pool.get_t<double>("red.KD", (size_t)R.kdab_off + R.maxchunk + 8);
   R.SP = ctx.pool.get_t<double>("red.SP", (size_t)(maxseg * maxseg) * 3 + 8);
   const int maxgp = (n + KA_ROWS - 1) / KA_ROWS + 2;
-  R.gp2_off = maxgp * 2;
+  R.gp2_off = 0;
   R.GP = ctx.pool.get_t<double>("red.GP", (size_t)maxgp * 3 + 8);
   R.sc = ctx.pool.get_t<double>("red.sc", SC_COUNT);
   R.RB = ctx.pool.get_t<double>("red.RB", (size_t)NB * (n + 8) + 16);
   hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, st, R.UW, (size_t)ldp * m * 3, 0.0);
   hipLaunchKernelGGL(fill_kernel, dim3(8), dim3(256), 0, st, e, (size_t)lde * NB, 0.0);
   hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, R.sc, (size_t)SC_COUNT, 0.0);
+  hipLaunchKernelGGL(fill_kernel, dim3(16), dim3(256), 0, st, R.SP, (size_t)(maxseg * maxseg) * 3 + 8, 0.0);
 
   const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   KAArgs S;
@@ -846,13 +922,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     B.toprows = i + 1;
     const int npd = (B.toprows + PD_ROWS - 1) / PD_ROWS;
     const int gx = g.nt > B.ncg + 1 ? g.nt : B.ncg + 1;
-    if (NB == 2) {
-      const int nbm = (L + KM_ROWS - 1) / KM_ROWS;
-      hipLaunchKernelGGL(km_kernel, dim3(nbm), dim3(256), 0, st, R, i, L, nb_ka);
-      B.ngp = nbm;
-    } else {
-      B.ngp = nb_ka;
-    }
+    B.ngp = nb_ka;
     const bool prof = ctx.prof_stride > 0 && (n_symv % ctx.prof_stride) == 0;
     if (prof) ctx.prof_begin(0, 8.0 * ((double)L * (L + 1) / 2) / R.P, st);  // this rank's share of the triangle
     if (g.T == 128) hipLaunchKernelGGL((symv_kernel<NB, 1>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);

@@ -74,6 +74,82 @@ def frank_eigenvalues(n):
     return np.sort(1.0 / (2.0 * (1.0 - np.cos((2 * k - 1) * np.pi / (2 * n + 1)))))
 
 
+def toeplitz(n):
+    """Toeplitz matrix: -7.2 on the diagonal, -3/(i-j)^2 elsewhere (benchmark/mat_set.f:134-152)."""
+    i = np.arange(n, dtype=np.float64)
+    d = i[:, None] - i[None, :]
+    with np.errstate(divide="ignore"):
+        A = -3.0 / (d * d)
+    A[np.diag_indices(n)] = -7.2
+    return A
+
+
+def frank2(n):
+    """'Frank matrix 2': a_ij = n + 1 - max(i, j), 1-based (benchmark/mat_set.f:188-202); same spectrum as
+    the Frank matrix (benchmark/mat_set.f:638-647 lists both under one formula)."""
+    i = np.arange(1, n + 1)
+    return (n + 1 - np.maximum.outer(i, i)).astype(np.float64)
+
+
+def helmert(n):
+    """orthogonal Helmert matrix H (rows): row 1 = 1/sqrt(n); row i >= 2 has i-1 entries 1/sqrt(i(i-1)),
+    then -(i-1)/sqrt(i(i-1)), then zeros (benchmark/mat_set.f:395-423)."""
+    H = np.zeros((n, n))
+    H[0, :] = 1.0 / np.sqrt(n)
+    for i in range(2, n + 1):
+        c = 1.0 / np.sqrt(float(i) * (i - 1))
+        H[i - 1, : i - 1] = c
+        H[i - 1, i - 1] = -(i - 1) * c
+    return H
+
+
+def spectrum(n, mtype, seed=7):
+    """prescribed spectra of the reference's matrix types 4..9 (benchmark/mat_set.f:651-718):
+    4: 0..n-1;  5: sin(5 pi i/(n-1) + eps^(1/4))^3;  6: mod(i,5)+mod(i,2) (heavily degenerate);
+    7: the Frank spectrum;  8: uniform [0,1);  9: normal(0,1).  Types 8/9 use the compiler RNG in the
+    reference (not reproducible elsewhere); here a seeded numpy generator."""
+    i = np.arange(1, n + 1, dtype=np.float64)
+    if mtype == 4:
+        return i - 1.0
+    if mtype == 5:
+        return np.sin(np.pi * 5.0 * i / max(n - 1, 1) + np.finfo(np.float64).eps ** 0.25) ** 3
+    if mtype == 6:
+        return np.mod(i, 5) + np.mod(i, 2)
+    if mtype == 7:
+        return frank_eigenvalues(n)
+    rng = np.random.default_rng(seed)
+    if mtype == 8:
+        return rng.random(n)
+    if mtype == 9:
+        return rng.standard_normal(n)
+    raise ValueError(f"no prescribed spectrum for matrix type {mtype}")
+
+
+def helmert_spectrum_matrix(n, mtype, seed=7):
+    """A = H^T diag(w) H with the spectrum of `mtype` in a seeded random order, w scaled by 1/max(1, max|w|)
+    exactly as helmert_trans does (benchmark/mat_set.f:336-456).  Returns (A, ascending eigenvalues)."""
+    w = spectrum(n, mtype, seed)
+    w = w / max(1.0, np.abs(w).max())
+    wp = np.random.default_rng(seed + 1).permutation(w)
+    H = helmert(n)
+    A = (H.T * wp[None, :]) @ H
+    return 0.5 * (A + A.T), np.sort(w)
+
+
+def reference_matrix(n, mtype, seed=7):
+    """the reference benchmark's matrix families by its type number (benchmark/mat_set.f:566-595);
+    returns (A, known ascending eigenvalues or None)."""
+    if mtype == 0:
+        return frank(n), frank_eigenvalues(n)
+    if mtype == 1:
+        return toeplitz(n), None
+    if mtype == 2:
+        return random_symmetric(n, seed=seed), None
+    if mtype == 3:
+        return frank2(n), frank_eigenvalues(n)
+    return helmert_spectrum_matrix(n, mtype, seed)
+
+
 def _mix64(x):
     x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
     x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)

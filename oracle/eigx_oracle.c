@@ -505,8 +505,10 @@ static void band_dc_rec(int n, double* dd, double* e, int lde, int band, double*
   band_dc_rec(n1, dd, e, lde, band, ev, q, ldq, flops);
   band_dc_rec(n2, dd + n1, e + n1, lde, band, ev + n1, &Q_(n1, n1), ldq, flops);
   double* z = (double*)malloc((size_t)n * sizeof(double));
+  int merged = 0;
   for (int k = 0; k < band; ++k) {
     if (sig[k] == 0.0) continue;
+    merged = 1;
     /* z = Q^T [0..0, y_k, x_k, 0..0] */
     for (int j = 0; j < n; ++j) {
       double acc = 0.0;
@@ -515,6 +517,8 @@ static void band_dc_rec(int n, double* dd, double* e, int lde, int band, double*
     }
     rank_one_merge(n, ev, z, sig[k], q, ldq, n, flops);
   }
+  /* zero coupling (block-diagonal input): nothing to merge, but the two halves still have to be interleaved */
+  if (!merged) { memset(z, 0, (size_t)n * sizeof(double)); rank_one_merge(n, ev, z, 0.0, q, ldq, n, flops); }
   free(z);
 #undef Q_
 }

@@ -376,3 +376,133 @@ def test_rccl_plumbing_single_rank(gpu_lib):
     """RCCL call path of comm.hip with a 1-rank communicator (the N>1 transport cannot be exercised with
     more ranks on a one-GPU box; the algorithm itself is covered by test_multi_rank_solver_on_one_gpu)"""
     assert gpu_lib.eigx_rccl_selftest() == 0
+
+
+# ------------------------------------------------------------------ reference matrix families, special branches
+def _solve_gpu(A, route, nvec=None):
+    import eigenexa_amd as ee
+    from eigenexa_amd import api
+
+    n = A.shape[0]
+    nvec = n if nvec is None else nvec
+    a = np.asfortranarray(np.triu(A))
+    z = np.zeros((n, n), order="F")
+    w = np.zeros(n)
+    (ee.eigen_sx if route == "sx" else ee.eigen_s)(n, nvec, a, n, w, z, n, mode="A")
+    assert api.last_status() == 0
+    return w, z
+
+
+@pytest.mark.parametrize("route", ["sx", "s"])
+@pytest.mark.parametrize("mtype", [1, 3, 4, 5, 6, 7, 8, 9])
+def test_reference_matrix_families(gpu_lib, orc, route, mtype):
+    """matrix types of the reference's benchmark driver (benchmark/mat_set.f:566-595): eigenvalues against the
+    oracle and the prescribed spectrum (benchmark/w_test.f:141-154), eigenvectors through the two gates"""
+    from eigenexa_amd import layout
+
+    n = 333
+    A, lam = layout.reference_matrix(n, mtype)
+    wo, _, _, _ = orc.eigen(A, route)
+    w, z = _solve_gpu(A, route)
+    assert np.abs(w - wo).max() < 1e-12 * max(1.0, np.abs(wo).max())
+    if lam is not None:
+        nz = np.abs(lam) > 1e-6 * np.abs(lam).max()
+        assert np.abs((w[nz] - lam[nz]) / lam[nz]).max() < np.sqrt(EPS)
+        assert np.abs(w - lam).max() < np.sqrt(EPS)
+    res, orth = layout.accuracy_metrics(A, w, z)
+    assert res < GATE_RES and orth < GATE_ORTH
+
+
+@pytest.mark.parametrize("route", ["sx", "s"])
+@pytest.mark.parametrize("kind", ["diag", "identity", "zero", "band1", "band2", "band3", "band5", "wilkinson",
+                                  "clustered", "arrow"])
+@pytest.mark.parametrize("n", [97, 300])
+def test_structured_matrices(gpu_lib, route, kind, n):
+    """trivial reflectors (diagonal / zero input), column pairs whose weight sits in the pivot row (band input:
+    the explicit-norm branch of the two-column reflector step), wholesale deflation, clusters"""
+    from eigenexa_amd import layout
+    from test_oracle import _structured
+
+    A = _structured(kind, n)
+    wr = np.linalg.eigvalsh(A)
+    w, z = _solve_gpu(A, route)
+    assert np.abs(w - wr).max() < 1e-12 * max(1.0, np.abs(wr).max())
+    if np.linalg.norm(A) > 0:
+        res, orth = layout.accuracy_metrics(A, w, z)
+        assert res < GATE_RES
+    else:
+        orth = np.linalg.norm(z.T @ z - np.eye(n)) / (n * EPS)
+    assert orth < GATE_ORTH
+
+
+# ------------------------------------------------------------------ the LDS-DMA ring GEMM on awkward shapes
+@pytest.mark.parametrize("opa,opb", [("N", "N"), ("N", "T"), ("T", "N"), ("T", "T")])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 78), (129, 257, 16), (5, 3, 2), (640, 515, 130), (131, 130, 8)])
+def test_gemm_ring_kernel_vs_torch(gpu_lib, opa, opb, M, N, K):
+    """eigx_tune(0, 3) forces the ring kernel wherever its alignment preconditions hold (even leading
+    dimensions, even K for k-contiguous operands); M/N/K tails, zero-page slabs, 16-byte C accesses"""
+    import torch
+
+    torch.manual_seed(M * 7 + N)
+    A = torch.randn((M, K) if opa == "N" else (K, M), dtype=torch.float64, device=_dev())
+    B = torch.randn((K, N) if opb == "N" else (N, K), dtype=torch.float64, device=_dev())
+    Cm = torch.randn(M, N, dtype=torch.float64, device=_dev())
+    ev = lambda x: x + (x & 1)
+    At, lda = _to_colmajor(A.cpu().numpy(), ev(A.shape[0] + 4))
+    Bt, ldb = _to_colmajor(B.cpu().numpy(), ev(B.shape[0] + 2))
+    Ct, ldc = _to_colmajor(Cm.cpu().numpy(), ev(M + 6))
+    torch.cuda.synchronize()
+    old = gpu_lib.eigx_tune(0, 3)
+    try:
+        rc = gpu_lib.eigx_dgemm_dev(opa.encode(), opb.encode(), M, N, K, -0.5, At.data_ptr(), lda, Bt.data_ptr(),
+                                    ldb, 2.0, Ct.data_ptr(), ldc, 0)
+    finally:
+        gpu_lib.eigx_tune(0, old)
+    assert rc == 0
+    ref = -0.5 * ((A if opa == "N" else A.T) @ (B if opb == "N" else B.T)) + 2.0 * Cm
+    assert (Ct[:, :M].T - ref).abs().max().item() < 1e-12 * K
+    assert torch.equal(Ct[:, M:], torch.zeros_like(Ct[:, M:]))  # padding rows untouched
+
+
+@pytest.mark.parametrize("n,k", [(1000, 96), (1153, 256), (3000, 64), (4224, 256)])
+def test_gemm_ring_kernel_upper_triangle(gpu_lib, n, k):
+    """trailing-update form: only tiles that touch the upper triangle change, in every tile order"""
+    import torch
+
+    torch.manual_seed(n)
+    P = torch.randn(n, k, dtype=torch.float64, device=_dev())
+    Q = torch.randn(n, k, dtype=torch.float64, device=_dev())
+    C0 = torch.randn(n, n, dtype=torch.float64, device=_dev())
+    ld = n + (n & 1) + 2
+    Pt = torch.zeros(k, ld, dtype=torch.float64, device=_dev()); Pt[:, :n] = P.T
+    Qt = torch.zeros(k, ld, dtype=torch.float64, device=_dev()); Qt[:, :n] = Q.T
+    Ct = torch.zeros(n, ld, dtype=torch.float64, device=_dev()); Ct[:, :n] = C0.T
+    torch.cuda.synchronize()
+    assert gpu_lib.eigx_dgemm_dev(b"N", b"T", n, n, k, -1.0, Pt.data_ptr(), ld, Qt.data_ptr(), ld, 1.0,
+                                  Ct.data_ptr(), ld, 1) == 0
+    got = Ct[:, :n].T
+    ref = C0 - P @ Q.T
+    t = torch.arange(n, device=_dev()) // 128
+    mask = t[:, None] <= t[None, :]
+    assert ((got - ref) * mask).abs().max().item() < 1e-12 * k
+    assert torch.equal(got[~mask], C0[~mask])
+
+
+def test_gemm_ring_gather_large(gpu_lib):
+    """gather variant through the ring kernel (large enough to be dispatched to it by default)"""
+    import torch
+
+    torch.manual_seed(5)
+    M, N, K, na, nb = 2050, 1800, 1501, 2100, 1900
+    A = torch.randn(M, na, dtype=torch.float64, device=_dev())
+    B = torch.randn(N, nb, dtype=torch.float64, device=_dev())
+    ma = torch.randperm(na, device=_dev())[:K].to(torch.int32)
+    mb = torch.randperm(nb, device=_dev())[:K].to(torch.int32)
+    At, lda = _to_colmajor(A.cpu().numpy())
+    Bt, ldb = _to_colmajor(B.cpu().numpy())
+    Ct, ldc = _to_colmajor(np.zeros((M, N)))
+    torch.cuda.synchronize()
+    assert gpu_lib.eigx_dgemm_gather_dev(b"N", b"T", M, N, K, 1.0, At.data_ptr(), lda, Bt.data_ptr(), ldb, 0.0,
+                                         Ct.data_ptr(), ldc, ma.data_ptr(), mb.data_ptr()) == 0
+    ref = A[:, ma.long()] @ B[:, mb.long()].T
+    assert (Ct[:, :M].T - ref).abs().max().item() < 1e-12 * K

@@ -100,3 +100,77 @@ def test_nan_input_sets_w_nan(orc):
     A[2, 5] = np.nan
     w, _, _, _ = orc.eigen(A, "sx")
     assert np.isnan(w).all()
+
+
+def _structured(kind, n):
+    """matrices that stress the special branches of the path: trivial reflectors, a column pair whose
+    weight sits in the pivot row (band input), wholesale deflation"""
+    rng = np.random.default_rng(11)
+    if kind == "diag":
+        return np.diag(rng.standard_normal(n))
+    if kind == "identity":
+        return np.eye(n)
+    if kind == "zero":
+        return np.zeros((n, n))
+    if kind.startswith("band"):
+        bw = int(kind[4:])
+        A = np.zeros((n, n))
+        for b in range(bw + 1):
+            v = rng.standard_normal(n - b)
+            A += np.diag(v, b) + (np.diag(v, -b) if b else 0)
+        return A
+    if kind == "wilkinson":
+        m = (n - 1) / 2.0
+        return np.diag(np.abs(np.arange(n) - m)) + np.diag(np.ones(n - 1), 1) + np.diag(np.ones(n - 1), -1)
+    if kind == "clustered":
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        w = np.repeat([1.0, 1.0 + 1e-13, 2.0, 3.0], n // 4 + 1)[:n]
+        A = (Q * w) @ Q.T
+        return 0.5 * (A + A.T)
+    if kind == "arrow":
+        A = np.diag(np.arange(1.0, n + 1))
+        A[-1, :] = A[:, -1] = 1.0
+        A[-1, -1] = n
+        return A
+    raise ValueError(kind)
+
+
+STRUCTURED = ["diag", "identity", "zero", "band1", "band2", "band3", "band5", "wilkinson", "clustered", "arrow"]
+
+
+@pytest.mark.parametrize("route", ["sx", "s"])
+@pytest.mark.parametrize("mtype", [1, 3, 4, 5, 6, 7, 8, 9])
+def test_reference_matrix_families(orc, route, mtype):
+    """the matrix types of the reference's benchmark driver (benchmark/mat_set.f:566-595) with the
+    eigenvalue gate of benchmark/w_test.f:141-151 (relative error < sqrt(eps) where the spectrum is known)
+    and the residual / orthogonality gates of benchmark/ev_test.f:181-204"""
+    n = 120
+    A, lam = layout.reference_matrix(n, mtype)
+    w, Z, _, _ = orc.eigen(A, route)
+    wr = np.linalg.eigvalsh(A)
+    assert np.abs(w - wr).max() <= 1e-12 * max(1.0, np.abs(wr).max())
+    if lam is not None:
+        # relative gate where it is meaningful (the reference prints "|w| is too small, so it is not severe"
+        # for tiny eigenvalues, benchmark/w_test.f:146-149), absolute gate everywhere (:152-154)
+        nz = np.abs(lam) > 1e-6 * np.abs(lam).max()
+        assert np.abs((w[nz] - lam[nz]) / lam[nz]).max() < np.sqrt(np.finfo(float).eps)
+        assert np.abs(w - lam).max() < np.sqrt(np.finfo(float).eps)
+    res, orth = layout.accuracy_metrics(A, w, Z)
+    assert res < GATE_RES and orth < GATE_ORTH
+
+
+@pytest.mark.parametrize("route", ["sx", "s"])
+@pytest.mark.parametrize("kind", STRUCTURED)
+def test_structured_matrices(orc, route, kind):
+    n = 97
+    A = _structured(kind, n)
+    w, Z, _, _ = orc.eigen(A, route)
+    wr = np.linalg.eigvalsh(A)
+    assert np.abs(w - wr).max() <= 1e-12 * max(1.0, np.abs(wr).max())
+    anorm = np.linalg.norm(A)
+    if anorm > 0:
+        res, orth = layout.accuracy_metrics(A, w, Z)
+        assert res < GATE_RES
+    else:
+        orth = np.linalg.norm(Z.T @ Z - np.eye(n)) / (n * np.finfo(float).eps)
+    assert orth < GATE_ORTH
