@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libeigenexa_amd.so")
+# EIGX_LIB: alternative build of the same library (tools/: the diagnostic build with in-kernel stamps)
+LIB_PATH = os.environ.get("EIGX_LIB") or os.path.join(_HERE, "lib", "libeigenexa_amd.so")
 
 _c_double_p = C.POINTER(C.c_double)
 _c_int_p = C.POINTER(C.c_int)

@@ -36,7 +36,16 @@ namespace eigx {
 
 namespace {
 
-constexpr int PD_ROWS = 512;   // rows per panel-dot chunk
+// rows per panel-dot chunk: at most 4 chunks (K_A re-reduces them in one batch of loads), at least 512 rows
+static inline int pd_rows_for(int toprows) { int r = ((toprows + 3) / 4 + 63) / 64 * 64; return r < 512 ? 512 : r; }
+#ifdef EIGX_STAMPS
+#define EIGX_STAMP(slot) do { if (R.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) { \
+  const unsigned long long _t = __builtin_amdgcn_s_memtime(); atomicAdd(&R.dbg[slot], _t - stamp_prev); stamp_prev = _t; } } while (0)
+#define EIGX_STAMP_INIT unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#else
+#define EIGX_STAMP(slot) do {} while (0)
+#define EIGX_STAMP_INIT
+#endif
 constexpr int PD_COLS = 16;    // panel columns per panel-dot workgroup
 constexpr int KA_ROWS = 16;    // rows per K_A workgroup
 constexpr int KA_SL = 256 / KA_ROWS;  // panel slices per row (KA_ROWS x KA_SL = 256 threads)
@@ -60,6 +69,7 @@ struct RedArgs {
   // allreduced over the ranks once per step.
   int P, p;
   double* RB;
+  unsigned long long* dbg;        // EIGX_STAMPS diagnostic build only: accumulated s_memtime stamps
 };
 
 // SYMV tiling: square tiles of T = 128*RB rows/cols (RB = 1,2,4); tile (ty,tx) with tx >= ty is one
@@ -114,21 +124,22 @@ struct KAArgs {
   int L;          // rows above the new block (Gram sums run over r < L)
   int k;          // panel fill to use for the new columns (= kprev+NB if has_prev)
   int rows;       // rows to cover: max(iprev+1, i+1)
+  int nt_prev, lgT_prev;  // SYMV tiling of the previous step: tiles per dimension, log2(tile edge)
 };
 
 template <int NB>
 __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
-  __shared__ double red[48];
+  __shared__ double red[64];
   __shared__ double kd[4][256];        // reduced panel-dot vectors: [UuA, WuA, UuB, WuB][kk]  (m <= 256)
   __shared__ double rowU[2][258], rowW[2][258];  // U(c, kk), W(c, kk) for the new block columns c
-  __shared__ double tm[8];             // T (tAA,tAB,tBB) and M (m11,m12,m21,m22)
-  __shared__ double slice[KA_SL][KA_ROWS][4];
+  __shared__ double slice[4][KA_ROWS][4];        // per-wave slice sums
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int rr = tid & (KA_ROWS - 1), ks = tid / KA_ROWS;
   const int ldp = R.ldp, m = R.m;
   double* Up = R.UW;
   double* Wp = R.UW + (size_t)ldp * m;
-  const SymvGeom g = symv_geom(S.Lprev, R.P);
+  const int nt = S.nt_prev, lgT = S.lgT_prev;      // SYMV tiling of the previous step (T = 1 << lgT)
   const bool mg = R.P > 1;
   const bool hp = S.has_prev != 0;
   const int Lp = (S.Lprev + 7) / 8 * 8;  // RB stride
@@ -137,29 +148,47 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   const int kold = hp ? S.kprev : S.k;  // panel slots that are final in memory
   const int r = blockIdx.x * KA_ROWS + rr;
   const bool rowok = r < S.rows;
+  EIGX_STAMP_INIT
 
   // ============ phase 0: every load that depends on nothing computed in this kernel ==================
-  // The kernel is a latency chain (a few hundred bytes per thread), so ALL loads are issued up front in
-  // straight-line batches with clamped indices (values of out-of-range entries are dropped by a select
-  // afterwards, never by a branch around the load): the chain costs about one memory round trip.
-  // --- the panel rows of phase 3 first: the longest batch, consumed last
-  constexpr int KB = 8;                 // kk per slice and batch (8 * KA_SL = 128 panel columns)
+  // The kernel is a latency chain (a few hundred bytes per thread): ALL loads are issued first, in
+  // straight-line batches whose extent is cut by wave-uniform conditions (no per-thread branches, no integer
+  // divisions, clamped indices; out-of-range entries are dropped by a select afterwards), and nothing is
+  // consumed before the last load is issued: the chain costs about one memory round trip.
+  constexpr int KB = 8;                 // panel columns per slice in the first batch (8 * KA_SL = 128)
+  constexpr int RPB = 10;               // SYMV partials per slice in the first batch (10 * KA_SL = 160)
+  constexpr int CHB = 4;                // K_P row chunks (pd_rows_for() never makes more)
+  constexpr int SPB = 8;                // folded SP rows per wave in the first batch (covers nt <= 64)
   double tu[KB], tw[KB];
+  double ta[RPB], tb[RPB];
+  double kdl[4][CHB];
+  double spl[SPB][3];
+  double abl = 0.0, pcl[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+  double bA = 0.0, bB = 0.0;
+  double ru[2] = {0.0, 0.0}, rw[2] = {0.0, 0.0};
+  double uA_r = 0.0, uB_r = 0.0, a_i = 0.0, a_im = 0.0;
+  const bool rowp = hp && rowok && r < S.Lprev;
+#pragma unroll
+  for (int j = 0; j < KB; ++j) { tu[j] = 0.0; tw[j] = 0.0; }
+#pragma unroll
+  for (int j = 0; j < RPB; ++j) { ta[j] = 0.0; tb[j] = 0.0; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < CHB; ++j) kdl[q][j] = 0.0;
+#pragma unroll
+  for (int j = 0; j < SPB; ++j) { spl[j][0] = 0.0; spl[j][1] = 0.0; spl[j][2] = 0.0; }
   {
     const int rc = rowok ? r : 0;
 #pragma unroll
     for (int j = 0; j < KB; ++j) {
-      const int kk = (ks + j * KA_SL < kloop) ? ks + j * KA_SL : 0;
-      tu[j] = Up[(size_t)kk * ldp + rc];
-      tw[j] = Wp[(size_t)kk * ldp + rc];
+      if (j * KA_SL < kloop) {            // uniform
+        const int kk = (ks + j * KA_SL < kloop) ? ks + j * KA_SL : 0;
+        tu[j] = Up[(size_t)kk * ldp + rc];
+        tw[j] = Wp[(size_t)kk * ldp + rc];
+      }
     }
   }
-  double bA = 0.0, bB = 0.0;
-  double kdv[4] = {0.0, 0.0, 0.0, 0.0};          // my (kind,kk) entries of the reduced panel dots
-  double v[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [0..2] SP, [3..5] corrections, [6] uA.uB, [7..10] P(c,a)
-  double ru[2] = {0.0, 0.0}, rw[2] = {0.0, 0.0};
-  double prA = 0.0, prB = 0.0;                   // my share of this row's SYMV partial sums
-  double uA_r = 0.0, uB_r = 0.0, a_i = 0.0, a_im = 0.0;
   if (S.ncols > 0) {
     for (int cc = 0; cc < S.ncols; ++cc) {
       const int c = S.i - cc;
@@ -180,161 +209,183 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       uA_r = Up[(size_t)kp * ldp + r];
       if (NB == 2) uB_r = Up[(size_t)(kp + 1) * ldp + r];
     }
-    // --- SYMV partial sums of my row: t-th partial, t in [0, nt]: t <= ty -> column result of tile row t
+    // SYMV partial sums of my row: t-th partial, t in [0, nt]: t <= ty -> column result of tile row t
     // (column r of tile (t, ty)); t > ty -> row result of tile column t-1 (row r of tile (ty, t-1))
-    constexpr int RPB = 5;              // partials per slice and batch (5 * KA_SL = 80)
-    double ta[2][RPB], tb[2][RPB];
-    const bool rowp = rowok && r < S.Lprev;
+    if (!mg) {
+      const int rc = rowp ? r : 0;
+      const int ty = rc >> lgT;
+#pragma unroll
+      for (int j = 0; j < RPB; ++j) {
+        if (j * KA_SL < nt + 1) {          // uniform
+          const int tt = ks + j * KA_SL;
+          const int t = (tt < nt + 1) ? tt : 0;
+          const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
+          ta[j] = base[rc];
+          if (NB == 2) tb[j] = base[ldp + rc];
+        }
+      }
+    }
+    // panel dots: thread kk = tid (< kp <= 256) sums entry (kind, kk) over the K_P row chunks
+    {
+      const int kk = (tid < kp) ? tid : 0;
+#pragma unroll
+      for (int j = 0; j < CHB; ++j) {
+        if (j < S.nchunk_prev) {           // uniform
+#pragma unroll
+          for (int q = 0; q < 2 * NB; ++q) kdl[q][j] = R.KD[((size_t)j * 2 * NB + q) * m + kk];
+        }
+      }
+    }
+    // bilinear partials of the SYMV tiles, SP[ty][tx] with the fixed row stride maxseg, tx >= ty only.
+    // Folded rows: row f (nt - f tiles) and row nt-1-f (f + 1 tiles) together fill nt + 1 <= 64 lanes;
+    // wave w takes the folded rows f = w, w + 4, ...
+    if (!mg && nt <= 63) {
+#pragma unroll
+      for (int j = 0; j < SPB; ++j) {
+        const int f = wave + 4 * j;
+        if (2 * f < nt) {                  // uniform per wave
+          const int cnt = nt - f;          // tiles in row f
+          const int f2 = nt - 1 - f;       // partner row (== f for the middle row of an odd nt: skipped)
+          int ty = f, tx = f + lane;
+          bool ok = lane < cnt;
+          if (!ok) { ty = f2; tx = f2 + (lane - cnt); ok = (f2 > f) && tx < nt; }
+          const double* sp = R.SP + ((size_t)(ok ? ty : 0) * R.maxseg + (ok ? tx : 0)) * 3;
+          const double s0 = sp[0];
+          spl[j][0] = ok ? s0 : 0.0;
+          if (NB == 2) { const double s1 = sp[1], s2 = sp[2]; spl[j][1] = ok ? s1 : 0.0; spl[j][2] = ok ? s2 : 0.0; }
+        }
+      }
+    }
+    if (NB == 2) abl = R.KD[R.kdab_off + (tid < S.nchunk_prev ? tid : 0)];
+    // P(c, a): rows c of the previous step's SYMV result for the new block columns
+    if (!mg) {
+      for (int cc = 0; cc < S.ncols; ++cc) {
+        const int c = S.i - cc;
+        const int ty = c >> lgT;
+        const int t = (tid < nt + 1) ? tid : 0;
+        const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
+        pcl[cc][0] = base[c];
+        if (NB == 2) pcl[cc][1] = base[ldp + c];
+      }
+    }
+  }
+  EIGX_STAMP(0);
+  // ---- everything is in flight; now consume -----------------------------------------------------------
+  double v[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [0..2] SP, [3..5] corrections, [6] uA.uB, [7..10] P(c,a)
+  double prA = 0.0, prB = 0.0;                   // my share of this row's SYMV partial sums
+  if (hp) {
     if (mg) {
       if (ks == 0 && rowp) { prA = R.RB[r]; if (NB == 2) prB = R.RB[Lp + r]; }
-    } else {
-      const int rc = rowp ? r : 0;
-      const int ty = rc / g.T;
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int j = 0; j < RPB; ++j) {
-          const int tt = ks + (b * RPB + j) * KA_SL;
-          const int t = (tt < g.nt + 1) ? tt : 0;
-          const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
-          ta[b][j] = base[rc];
-          if (NB == 2) tb[b][j] = base[ldp + rc];
-        }
-    }
-    // --- reduced panel dots: entry (kind, kk) summed over the K_P row chunks
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int idx = tid + 256 * q;
-      if (idx < 2 * NB * kp) {
-        const int kind = idx / kp, kk = idx - kind * kp;
-        double acc = 0.0;
-        for (int c0 = 0; c0 < S.nchunk_prev; c0 += 4) {
-          double t[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int c = (c0 + j < S.nchunk_prev) ? c0 + j : 0;
-            t[j] = R.KD[((size_t)c * 2 * NB + kind) * m + kk];
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc += (c0 + j < S.nchunk_prev) ? t[j] : 0.0;
-        }
-        kdv[q] = acc;
-      }
-    }
-    // --- bilinear partials of the SYMV tiles.  SP is laid out [ty][tx] with the fixed stride maxseg;
-    // entries below the tile diagonal are never written and stay zero, so the sum runs unconditionally
-    // over the nt x nt square, 8 entries per thread and batch
-    if (mg) {
       if (tid == 0) { v[0] = R.RB[NB * Lp + 0]; if (NB == 2) { v[1] = R.RB[NB * Lp + 1]; v[2] = R.RB[NB * Lp + 2]; } }
+      for (int cc = 0; cc < S.ncols; ++cc) {
+        const int c = S.i - cc;
+        if (tid == 0) { v[7 + 2 * cc] += R.RB[c]; if (NB == 2) v[8 + 2 * cc] += R.RB[Lp + c]; }
+      }
     } else {
-      const int tot = g.nt * g.nt;
-      for (int w0 = tid; w0 < tot; w0 += 2048) {
-        double t[8][3];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int w = (w0 + 256 * j < tot) ? w0 + 256 * j : 0;
-          const int ty = w / g.nt, tx = w - ty * g.nt;
-          const double* sp = R.SP + ((size_t)ty * R.maxseg + tx) * 3;
-          t[j][0] = sp[0];
-          if (NB == 2) { t[j][1] = sp[1]; t[j][2] = sp[2]; }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const bool ok = w0 + 256 * j < tot;
-          v[0] += ok ? t[j][0] : 0.0;
-          if (NB == 2) { v[1] += ok ? t[j][1] : 0.0; v[2] += ok ? t[j][2] : 0.0; }
+      for (int j = 0; j < RPB; ++j) {
+        const bool ok = rowp && (ks + j * KA_SL < nt + 1);
+        prA += ok ? ta[j] : 0.0;
+        if (NB == 2) prB += ok ? tb[j] : 0.0;
+      }
+      if (rowp) {   // more than RPB * KA_SL = 160 partials per row: not reached by symv_geom below N ~ 80000
+        const int ty = r >> lgT;
+        for (int t = ks + RPB * KA_SL; t < nt + 1; t += KA_SL) {
+          const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
+          prA += base[r];
+          if (NB == 2) prB += base[ldp + r];
         }
       }
-    }
-    if (NB == 2)
-      for (int c = tid; c < S.nchunk_prev; c += 256) v[6] += R.KD[R.kdab_off + c];
-    // P(c, a) partial sums for the new block columns (rows c of the previous step's SYMV result)
-    for (int cc = 0; cc < S.ncols; ++cc) {
-      const int c = S.i - cc;
-      if (mg) {
-        if (tid == 0) { v[7 + 2 * cc] += R.RB[c]; if (NB == 2) v[8 + 2 * cc] += R.RB[Lp + c]; }
-      } else {
-        const int ty = c / g.T;
-        for (int t = tid; t < g.nt + 1; t += 256) {
+#pragma unroll
+      for (int j = 0; j < SPB; ++j) {
+        v[0] += spl[j][0];
+        if (NB == 2) { v[1] += spl[j][1]; v[2] += spl[j][2]; }
+      }
+      if (nt > 63) {   // more tiles than the folded batch covers: plain sweep of the upper tile triangle
+        for (int ty = wave; ty < nt; ty += 4)
+          for (int tx = ty + lane; tx < nt; tx += 64) {
+            const double* sp = R.SP + ((size_t)ty * R.maxseg + tx) * 3;
+            v[0] += sp[0];
+            if (NB == 2) { v[1] += sp[1]; v[2] += sp[2]; }
+          }
+      }
+      for (int cc = 0; cc < S.ncols; ++cc) {
+        const bool ok = tid < nt + 1;
+        v[7 + 2 * cc] += ok ? pcl[cc][0] : 0.0;
+        if (NB == 2) v[8 + 2 * cc] += ok ? pcl[cc][1] : 0.0;
+        const int c = S.i - cc, ty = c >> lgT;
+        for (int t = tid + 256; t < nt + 1; t += 256) {
           const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
           v[7 + 2 * cc] += base[c];
           if (NB == 2) v[8 + 2 * cc] += base[ldp + c];
         }
       }
     }
-    if (!mg) {
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int j = 0; j < RPB; ++j) {
-          const bool ok = rowp && (ks + (b * RPB + j) * KA_SL < g.nt + 1);
-          prA += ok ? ta[b][j] : 0.0;
-          if (NB == 2) prB += ok ? tb[b][j] : 0.0;
-        }
-      // more than 2*RPB*KA_SL = 160 partials per row (not reached by symv_geom's tile choice below N ~ 80000)
-      if (rowp) {
-        const int ty = r / g.T;
-        for (int t = ks + 2 * RPB * KA_SL; t < g.nt + 1; t += KA_SL) {
-          const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
-          prA += base[r];
-          if (NB == 2) prB += base[ldp + r];
-        }
-      }
+    if (NB == 2) {
+      v[6] = (tid < S.nchunk_prev) ? abl : 0.0;
+      for (int c = tid + 256; c < S.nchunk_prev; c += 256) v[6] += R.KD[R.kdab_off + c];
     }
   }
+  EIGX_STAMP(1);
 
   // ============ phase 1: publish kd / rowU / rowW in LDS ============================================
-  if (hp) {
+  double kdr[4] = {0.0, 0.0, 0.0, 0.0};
+  if (hp && tid < kp) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int idx = tid + 256 * q;
-      if (idx < 2 * NB * kp) { const int kind = idx / kp; kd[kind][idx - kind * kp] = kdv[q]; }
+    for (int q = 0; q < 2 * NB; ++q) {
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < CHB; ++j) acc += kdl[q][j];
+      for (int c = CHB; c < S.nchunk_prev; ++c) acc += R.KD[((size_t)c * 2 * NB + q) * m + tid];
+      kdr[q] = acc;
+      kd[q][tid] = acc;
     }
   }
   if (S.ncols > 0 && tid < S.k) {
     for (int cc = 0; cc < S.ncols; ++cc) { rowU[cc][tid] = ru[cc]; rowW[cc][tid] = rw[cc]; }
   }
-  __syncthreads();
-
   // ============ phase 2: one block reduction for all replicated scalars ================================
+  // thread kk = tid holds kd(:, kk) in registers: the corrections need no LDS round trip
+  double tm[7] = {0, 0, 0, 0, 0, 0, 0};  // T (tAA,tAB,tBB) and M (m11,m12,m21,m22), in every thread
+  double wnew[2][2] = {{0.0, 0.0}, {0.0, 0.0}};  // W(c, kp), W(c, kp+1) of the new block columns
   if (hp) {
-    for (int kk = tid; kk < kp; kk += 256) {
-      v[3] += 2.0 * kd[0][kk] * kd[1][kk];
+    if (tid < kp) {
+      v[3] += 2.0 * kdr[0] * kdr[1];
       if (NB == 2) {
-        v[4] += kd[0][kk] * kd[3][kk] + kd[1][kk] * kd[2][kk];
-        v[5] += 2.0 * kd[2][kk] * kd[3][kk];
+        v[4] += kdr[0] * kdr[3] + kdr[1] * kdr[2];
+        v[5] += 2.0 * kdr[2] * kdr[3];
       }
       for (int cc = 0; cc < S.ncols; ++cc) {
-        const double u = rowU[cc][kk], w = rowW[cc][kk];
-        v[7 + 2 * cc] -= u * kd[1][kk] + w * kd[0][kk];
-        if (NB == 2) v[8 + 2 * cc] -= u * kd[3][kk] + w * kd[2][kk];
+        v[7 + 2 * cc] -= ru[cc] * kdr[1] + rw[cc] * kdr[0];
+        if (NB == 2) v[8 + 2 * cc] -= ru[cc] * kdr[3] + rw[cc] * kdr[2];
       }
     }
-    block_sum_multi<11>(v, red);
-    if (tid == 0) {
-      const double gAA = v[0] - v[3], gAB = v[1] - v[4], gBB = v[2] - v[5], uab = v[6];
-      const double tAA = bA != 0.0 ? 1.0 / bA : 0.0;
-      const double tBB = bB != 0.0 ? 1.0 / bB : 0.0;
-      const double tAB = -uab * tAA * tBB;
-      // GT = G T ; M = T^T GT
-      const double gt11 = gAA * tAA, gt12 = gAA * tAB + gAB * tBB;
-      const double gt21 = gAB * tAA, gt22 = gAB * tAB + gBB * tBB;
-      tm[0] = tAA; tm[1] = tAB; tm[2] = tBB;
-      tm[3] = tAA * gt11;               // m11
-      tm[4] = tAA * gt12;               // m12
-      tm[5] = tAB * gt11 + tBB * gt21;  // m21
-      tm[6] = tAB * gt12 + tBB * gt22;  // m22
-      // W(c, new slots) = row c of the previous step's W (same formula as the row loop below)
-      for (int cc = 0; cc < S.ncols; ++cc) {
-        const double pA = v[7 + 2 * cc], pB = v[8 + 2 * cc];
-        const double uA = rowU[cc][kp], uB = (NB == 2) ? rowU[cc][kp + 1] : 0.0;
-        const double yA = tm[0] * pA, yB = tm[1] * pA + tm[2] * pB;
-        rowW[cc][kp] = yA - 0.5 * (uA * tm[3] + uB * tm[5]);
-        if (NB == 2) rowW[cc][kp + 1] = yB - 0.5 * (uA * tm[4] + uB * tm[6]);
-      }
+    block_sum_multi<11>(v, red);     // (its first barrier also publishes kd / rowU / rowW)
+    // the 2x2 algebra in every thread (no broadcast, no extra barrier)
+    const double gAA = v[0] - v[3], gAB = v[1] - v[4], gBB = v[2] - v[5], uab = v[6];
+    const double tAA = bA != 0.0 ? 1.0 / bA : 0.0;
+    const double tBB = bB != 0.0 ? 1.0 / bB : 0.0;
+    const double tAB = -uab * tAA * tBB;
+    // GT = G T ; M = T^T GT
+    const double gt11 = gAA * tAA, gt12 = gAA * tAB + gAB * tBB;
+    const double gt21 = gAB * tAA, gt22 = gAB * tAB + gBB * tBB;
+    tm[0] = tAA; tm[1] = tAB; tm[2] = tBB;
+    tm[3] = tAA * gt11;               // m11
+    tm[4] = tAA * gt12;               // m12
+    tm[5] = tAB * gt11 + tBB * gt21;  // m21
+    tm[6] = tAB * gt12 + tBB * gt22;  // m22
+    // W(c, new slots) = row c of the previous step's W (same formula as the row loop below)
+    for (int cc = 0; cc < S.ncols; ++cc) {
+      const double pA = v[7 + 2 * cc], pB = v[8 + 2 * cc];
+      const double uA = rowU[cc][kp], uB = (NB == 2) ? rowU[cc][kp + 1] : 0.0;
+      const double yA = tm[0] * pA, yB = tm[1] * pA + tm[2] * pB;
+      wnew[cc][0] = yA - 0.5 * (uA * tm[3] + uB * tm[5]);
+      if (NB == 2) wnew[cc][1] = yB - 0.5 * (uA * tm[4] + uB * tm[6]);
     }
+  } else {
     __syncthreads();
   }
+  EIGX_STAMP(2);
 
   // ============ phase 3: row loop: slice partial sums ================================================
   {
@@ -368,14 +419,25 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
           if (k0 + j * KA_SL < kloop) accum(k0 + j * KA_SL, xu[j], xw[j]);
       }
     }
-    slice[ks][rr][0] = pA; slice[ks][rr][1] = pB; slice[ks][rr][2] = x0; slice[ks][rr][3] = x1;
+    // the wave's 4 slices (lane >> 4) of each row are combined with two shuffles, the 4 waves through LDS
+    double q4[4] = {pA, pB, x0, x1};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      q4[q] += __shfl_xor(q4[q], 16, 64);
+      q4[q] += __shfl_xor(q4[q], 32, 64);
+    }
+    if (lane < KA_ROWS) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) slice[wave][lane][q] = q4[q];
+    }
   }
   __syncthreads();
+  EIGX_STAMP(3);
   double gg[3] = {0.0, 0.0, 0.0};
   if (ks == 0 && rowok) {
     double pA = 0.0, pB = 0.0, x0 = 0.0, x1 = 0.0;
 #pragma unroll
-    for (int q = 0; q < KA_SL; ++q) {
+    for (int q = 0; q < 4; ++q) {
       pA += slice[q][rr][0]; pB += slice[q][rr][1]; x0 += slice[q][rr][2]; x1 += slice[q][rr][3];
     }
     if (hp) {
@@ -387,11 +449,11 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       Wp[(size_t)kp * ldp + r] = wA;
       if (NB == 2) Wp[(size_t)(kp + 1) * ldp + r] = wB;
       if (S.ncols > 0) {
-        x0 += uA * rowW[0][kp] + wA * rowU[0][kp];
-        if (NB == 2) x0 += uB * rowW[0][kp + 1] + wB * rowU[0][kp + 1];
+        x0 += uA * wnew[0][0] + wA * rowU[0][kp];
+        if (NB == 2) x0 += uB * wnew[0][1] + wB * rowU[0][kp + 1];
         if (S.ncols > 1) {
-          x1 += uA * rowW[1][kp] + wA * rowU[1][kp];
-          if (NB == 2) x1 += uB * rowW[1][kp + 1] + wB * rowU[1][kp + 1];
+          x1 += uA * wnew[1][0] + wA * rowU[1][kp];
+          if (NB == 2) x1 += uB * wnew[1][1] + wB * rowU[1][kp + 1];
         }
       }
     }
@@ -408,11 +470,17 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       if (S.ncols > 1 && r == S.i - 1) { R.e[S.i] = xi; R.d[S.i - 1] = xim; }  // e(i,1) = A_eff(i-1,i)
     }
   }
-  if (S.ncols > 0) {
+  if (S.ncols > 0 && wave == 0) {
     // Gram partials of the new columns over the rows above the block: x_i.x_i, x_i.x_{i-1}, x_{i-1}.x_{i-1}
-    block_sum_multi<3>(gg, red);
-    if (tid == 0) { R.GP[blockIdx.x * 3 + 0] = gg[0]; R.GP[blockIdx.x * 3 + 1] = gg[1]; R.GP[blockIdx.x * 3 + 2] = gg[2]; }
+    // (the 16 row threads are lanes 0..15 of wave 0: no block reduction needed)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) gg[q] = wave_sum(gg[q]);
+    if (lane == 0) { R.GP[blockIdx.x * 3 + 0] = gg[0]; R.GP[blockIdx.x * 3 + 1] = gg[1]; R.GP[blockIdx.x * 3 + 2] = gg[2]; }
   }
+  EIGX_STAMP(4);
+#ifdef EIGX_STAMPS
+  if (R.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) atomicAdd(&R.dbg[7], 1ull);
+#endif
 }
 
 // =================================================================================================
@@ -429,7 +497,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
 //                      cg < ncg : panel columns [cg*PD_COLS, +PD_COLS) of U and W against the NV new vectors
 //                      cg == ncg: store the reflectors into the panel (both U copies) and into `a`, uA.uB
 // =================================================================================================
-struct KBArgs { int i, L, nt, ngp, k, ncg, toprows; };
+struct KBArgs { int i, L, nt, ngp, k, ncg, toprows, pdr; };
 
 // K_L (multi-GPU only): reduce this rank's SYMV partials (owned tile columns) into RB before the allreduce
 template <int NB>
@@ -475,8 +543,8 @@ template <int K> struct IC { static constexpr int value = K; };
 template <int NV, int RB>
 __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   constexpr int T = 128 * RB;
-  constexpr int DYN = (4 * NV * T > NV * PD_ROWS + NV * T) ? 4 * NV * T : NV * PD_ROWS + NV * T;
-  __shared__ __attribute__((aligned(16))) double dyn[DYN + NV * T];  // [4][NV][T] row sums | panel us ; then uc[NV][T]
+  constexpr int DYN = 4 * NV * T;
+  __shared__ __attribute__((aligned(16))) double dyn[DYN + NV * T];  // [4 waves][NV][T] row sums ; then uc[NV][T]
   __shared__ double red[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ldp = R.ldp;
@@ -490,6 +558,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   // raw x values of this tile's columns / this lane's rows and the first 8-column unit of A
   const int ty = blockIdx.y, tx = blockIdx.x;
   const int row0 = ty * T, col0 = tx * T;
+  EIGX_STAMP_INIT
   const int wcol0 = wave * (T / 4);       // first tile column of this wave
   double craw[NV][(T + 255) / 256];       // raw x at the tile's columns (thread t -> column t, t+256)
   double rraw[NV][RB][2];                 // raw x at this lane's rows
@@ -525,6 +594,9 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
     }
   }
 
+#ifdef EIGX_STAMPS
+  if (!panel_role) { if (R.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); atomicAdd(&R.dbg[8], _t - stamp_prev); stamp_prev = _t; } }
+#endif
   // ---- reflector scalars (every workgroup, same order) -------------------------------------------
   // NV = 1: s = -sign(||x||, x_piv), beta = ||x||^2 - s x_piv from the Gram partials of K_A.
   // NV = 2: two sequential Householder steps on the column pair (x0 = column i, x1 = column i-1) without a
@@ -537,16 +609,16 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   const int pivA = L - 1, pivB = L - 2;
   {
     double gv[3] = {0.0, 0.0, 0.0};
-    for (int q0 = tid; q0 < B.ngp; q0 += 2048) {
-      double t[8][3];
+    for (int q0 = tid; q0 < B.ngp; q0 += 512) {   // one batch up to 512 K_A workgroups (N <= 8192)
+      double t[2][3];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 2; ++j) {
         const int q = (q0 + 256 * j < B.ngp) ? q0 + 256 * j : 0;
         t[j][0] = R.GP[3 * q];
         if (NV == 2) { t[j][1] = R.GP[3 * q + 1]; t[j][2] = R.GP[3 * q + 2]; }
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 2; ++j) {
         const bool ok = q0 + 256 * j < B.ngp;
         gv[0] += ok ? t[j][0] : 0.0;
         if (NV == 2) { gv[1] += ok ? t[j][1] : 0.0; gv[2] += ok ? t[j][2] : 0.0; }
@@ -597,33 +669,26 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
     if (j >= L - 1 || betaB == 0.0) return 0.0;
     return raw1 - gammaB * raw0 - (j == pivB ? sB : 0.0);
   };
-  auto uval = [&](int a, int j) -> double {
-    if (j >= L) return 0.0;
-    return ufix2(a, j, R.X[j], (NV == 2) ? R.X[ldp + j] : 0.0);
-  };
-
   if (panel_role) {
     // ================================================================ K_P
+    // No LDS staging: u_A, u_B are recomputed from the x vectors (L2-hot) next to every U/W load, so the
+    // chunk length is free and there are never more than 4 row chunks to re-reduce in K_A.
     const int m = R.m, k = B.k;
     const int chunk = blockIdx.y - B.nt, cg = blockIdx.x;
-    const int rbase = chunk * PD_ROWS;
-    double* us = dyn;  // [NV][PD_ROWS]
-    for (int t = tid; t < PD_ROWS; t += 256) {
-      const int r = rbase + t;
-#pragma unroll
-      for (int a = 0; a < NV; ++a) us[a * PD_ROWS + t] = uval(a, r);
-    }
-    __syncthreads();
+    const int pdr = B.pdr;
+    const int rbase = chunk * pdr;
     double* Up = R.UW;
     double* Wp = R.UW + (size_t)ldp * m;
     double* U2 = R.UW + (size_t)2 * ldp * m;
     if (cg == B.ncg) {
+      // reflector store: panel slots (both U copies), column(s) of `a`, partial uA.uB
       double ab[1] = {0.0};
-      for (int t = tid; t < PD_ROWS; t += 256) {
-        const int r = rbase + t;
-        if (r >= B.toprows) continue;
-        const double uA = us[t];
-        const double uB = (NV == 2) ? us[(NV - 1) * PD_ROWS + t] : 0.0;
+      const int rend = (rbase + pdr < B.toprows) ? rbase + pdr : B.toprows;
+      for (int r = rbase + tid; r < rend; r += 256) {
+        const double x0 = R.X[r];
+        const double x1 = (NV == 2) ? R.X[ldp + r] : 0.0;
+        const double uA = ufix2(0, r, x0, x1);
+        const double uB = (NV == 2) ? ufix2(NV - 1, r, x0, x1) : 0.0;
         Up[(size_t)k * ldp + r] = uA;
         U2[(size_t)k * ldp + r] = uA;
         if (NV == 2) { Up[(size_t)(k + 1) * ldp + r] = uB; U2[(size_t)(k + 1) * ldp + r] = uB; }
@@ -639,32 +704,63 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
       }
       return;
     }
-    // wave per panel column: lanes stride the chunk's rows
-    const int rows_here = (L - rbase < PD_ROWS) ? L - rbase : PD_ROWS;
-    for (int cc = wave; cc < PD_COLS; cc += 4) {
-      const int kk = cg * PD_COLS + cc;
-      if (kk >= k) break;
-      const double* ucol = Up + (size_t)kk * ldp + rbase;
-      const double* wcol = Wp + (size_t)kk * ldp + rbase;
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      for (int t = lane; t < rows_here; t += 64) {
-        const double u = ucol[t], w = wcol[t];
-        const double a = us[t];
-        s0 += u * a; s1 += w * a;
-        if (NV == 2) { const double b = us[(NV - 1) * PD_ROWS + t]; s2 += u * b; s3 += w * b; }
+    // panel dots: wave w owns panel columns kk0 .. kk0+3; lanes stride the chunk's rows, two row groups
+    // (20 loads) per batch
+    const int kk0 = cg * PD_COLS + wave * 4;
+    if (kk0 >= k) return;
+    const int rend = (rbase + pdr < L) ? rbase + pdr : L;
+    double su[4][2], sw[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { su[c][0] = su[c][1] = sw[c][0] = sw[c][1] = 0.0; }
+    for (int r0 = rbase + lane; r0 < rend; r0 += 128) {
+      double x0[2], x1[2], tu[2][4], tw[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = (r0 + 64 * j < rend) ? r0 + 64 * j : rbase;
+        x0[j] = R.X[r];
+        x1[j] = (NV == 2) ? R.X[ldp + r] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int kk = (kk0 + c < k) ? kk0 + c : kk0;
+          tu[j][c] = Up[(size_t)kk * ldp + r];
+          tw[j][c] = Wp[(size_t)kk * ldp + r];
+        }
       }
-      s0 = wave_sum(s0); s1 = wave_sum(s1);
-      if (NV == 2) { s2 = wave_sum(s2); s3 = wave_sum(s3); }
-      if (lane == 0) {
-        double* kdp = R.KD + (size_t)chunk * 2 * NV * m;
-        kdp[0 * m + kk] = s0; kdp[1 * m + kk] = s1;
-        if (NV == 2) { kdp[2 * m + kk] = s2; kdp[3 * m + kk] = s3; }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = r0 + 64 * j;
+        if (r < rend) {
+          const double a = ufix2(0, r, x0[j], x1[j]);
+          const double b = (NV == 2) ? ufix2(NV - 1, r, x0[j], x1[j]) : 0.0;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            su[c][0] += tu[j][c] * a; sw[c][0] += tw[j][c] * a;
+            if (NV == 2) { su[c][1] += tu[j][c] * b; sw[c][1] += tw[j][c] * b; }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      su[c][0] = wave_sum(su[c][0]); sw[c][0] = wave_sum(sw[c][0]);
+      if (NV == 2) { su[c][1] = wave_sum(su[c][1]); sw[c][1] = wave_sum(sw[c][1]); }
+    }
+    if (lane == 0) {
+      double* kdp = R.KD + (size_t)chunk * 2 * NV * m;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int kk = kk0 + c;
+        if (kk < k) {
+          kdp[0 * m + kk] = su[c][0]; kdp[1 * m + kk] = sw[c][0];
+          if (NV == 2) { kdp[2 * m + kk] = su[c][1]; kdp[3 * m + kk] = sw[c][1]; }
+        }
       }
     }
     return;
   }
 
   // ================================================================== K_B (SYMV tile)
+  EIGX_STAMP(9);
   const bool diag = (tx == ty);
   double* yrs = dyn;            // [4 waves][NV][T]
   double* ucs = dyn + DYN;      // [NV][T] : u_a at the tile's columns
@@ -816,6 +912,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
     }
   }
 
+  EIGX_STAMP(10);
   // ---- row sums: combine the 4 waves through LDS; bilinear row part ----------------------------------
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
@@ -848,6 +945,8 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
     const size_t w = (size_t)ty * R.maxseg + tx;
     R.SP[w * 3 + 0] = sp[0]; R.SP[w * 3 + 1] = sp[1]; R.SP[w * 3 + 2] = sp[2];
   }
+  EIGX_STAMP(11);
+  if (R.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) atomicAdd(&R.dbg[15], 1ull);
 }
 
 // zero-fill helper
@@ -874,7 +973,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   maxseg += 1;
   R.maxseg = maxseg;
   R.maxrs = maxseg;
-  R.maxchunk = (n + PD_ROWS - 1) / PD_ROWS + 1;
+  R.maxchunk = 4 + 1;
   R.UW = ctx.pool.get_t<double>("red.UW", (size_t)ldp * m * 3);
   R.X = ctx.pool.get_t<double>("red.X", (size_t)ldp * 3);
   R.YR = ctx.pool.get_t<double>("red.YR", (size_t)maxseg * NB * ldp);
@@ -887,6 +986,11 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   R.GP = ctx.pool.get_t<double>("red.GP", (size_t)maxgp * 3 + 8);
   R.sc = ctx.pool.get_t<double>("red.sc", SC_COUNT);
   R.RB = ctx.pool.get_t<double>("red.RB", (size_t)NB * (n + 8) + 16);
+  R.dbg = nullptr;
+#ifdef EIGX_STAMPS
+  R.dbg = ctx.pool.get_t<unsigned long long>("red.dbg", 32);
+  EIGX_HIP_CHECK(hipMemsetAsync(R.dbg, 0, 32 * sizeof(unsigned long long), st));
+#endif
   hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, st, R.UW, (size_t)ldp * m * 3, 0.0);
   hipLaunchKernelGGL(fill_kernel, dim3(8), dim3(256), 0, st, e, (size_t)lde * NB, 0.0);
   hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, R.sc, (size_t)SC_COUNT, 0.0);
@@ -894,7 +998,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
 
   const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   KAArgs S;
-  S.has_prev = 0; S.iprev = 0; S.Lprev = 0; S.kprev = 0; S.nchunk_prev = 0;
+  S.has_prev = 0; S.iprev = 0; S.Lprev = 0; S.kprev = 0; S.nchunk_prev = 0; S.nt_prev = 0; S.lgT_prev = 7;
   int k = 0;        // panel fill
   int i = n - 1;    // top column of the current block
   double t_symv_bytes = 0.0;
@@ -920,7 +1024,8 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     B.i = i; B.L = L; B.nt = g.nt; B.k = k;
     B.ncg = (k + PD_COLS - 1) / PD_COLS;
     B.toprows = i + 1;
-    const int npd = (B.toprows + PD_ROWS - 1) / PD_ROWS;
+    B.pdr = pd_rows_for(B.toprows);
+    const int npd = (B.toprows + B.pdr - 1) / B.pdr;
     const int gx = g.nt > B.ncg + 1 ? g.nt : B.ncg + 1;
     B.ngp = nb_ka;
     const bool prof = ctx.prof_stride > 0 && (n_symv % ctx.prof_stride) == 0;
@@ -939,6 +1044,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     // bookkeeping for the next K_A
     S.has_prev = 1; S.iprev = i; S.Lprev = L; S.kprev = k;
     S.nchunk_prev = npd;
+    S.nt_prev = g.nt; S.lgT_prev = (g.T == 128) ? 7 : (g.T == 256 ? 8 : 9);
     k += NB;
     i -= NB;
     if (k >= m && i - NB + 1 >= 1) {
@@ -974,6 +1080,17 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     const double ts = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     fprintf(stderr, "[eigx] reduction: enqueue loop %.1f ms, then %.1f ms until the stream drained\n", (te - t_begin) * 1e3, (ts - te) * 1e3);
   }
+#ifdef EIGX_STAMPS
+  {
+    unsigned long long h[32];
+    EIGX_HIP_CHECK(hipStreamSynchronize(st));
+    EIGX_HIP_CHECK(hipMemcpy(h, R.dbg, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[eigx stamps] NB=%d n=%d K_A launches %llu: avg cycles issue %.0f consume %.0f reduce %.0f rows %.0f tail %.0f | SYMV %llu: "
+            "entry %.0f scalars %.0f stream %.0f tail %.0f\n", NB, n, h[7], (double)h[0] / h[7], (double)h[1] / h[7], (double)h[2] / h[7],
+            (double)h[3] / h[7], (double)h[4] / h[7], h[15], (double)h[8] / (h[15] ? h[15] : 1), (double)h[9] / (h[15] ? h[15] : 1),
+            (double)h[10] / (h[15] ? h[15] : 1), (double)h[11] / (h[15] ? h[15] : 1));
+  }
+#endif
   EIGX_HIP_CHECK(hipGetLastError());
   ctx.timers[6] = (double)n_k1;
   ctx.timers[7] = k1_flops;
