@@ -85,6 +85,15 @@ __host__ __device__ inline SymvGeom symv_geom(int L, int P = 1) {
   return g;
 }
 
+typedef double d2v_t __attribute__((ext_vector_type(2)));
+// 16-byte load of two consecutive doubles; NT = streaming (non-temporal) hint for the once-per-step sweep of a
+// triangle that is far larger than L2 + Infinity Cache (A/B on one MI355X, N=32768 reduction: 6.06 -> 5.72 s)
+template <bool NT>
+__device__ __forceinline__ double2 ld2(const double* p) {
+  const d2v_t v = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2v_t*>(p)) : *reinterpret_cast<const d2v_t*>(p);
+  return make_double2(v.x, v.y);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -543,6 +552,7 @@ template <int K> struct IC { static constexpr int value = K; };
 template <int NV, int RB>
 __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   constexpr int T = 128 * RB;
+  constexpr bool NTL = (RB == 4);   // non-temporal A loads for the 512 tile (L > 14000: triangles > 0.8 GB)
   constexpr int DYN = 4 * NV * T;
   __shared__ __attribute__((aligned(16))) double dyn[DYN + NV * T];  // [4 waves][NV][T] row sums ; then uc[NV][T]
   __shared__ double red[16];
@@ -588,7 +598,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = col0 + wcol0 + j;
-        if (rok && c < L) av0[j] = *reinterpret_cast<const double2*>(Ap + (size_t)c * R.lda);
+        if (rok && c < L) av0[j] = ld2<NTL>(Ap + (size_t)c * R.lda);
         else av0[j] = make_double2(0.0, 0.0);
       }
     }
@@ -796,7 +806,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = col0 + wcol0 + g * 8 + j;
-      if (rok && c < L) av[j] = *reinterpret_cast<const double2*>(Ap + (size_t)c * R.lda);
+      if (rok && c < L) av[j] = ld2<NTL>(Ap + (size_t)c * R.lda);
       else av[j] = make_double2(0.0, 0.0);
     }
   };
