@@ -84,6 +84,9 @@ void band_reduce_dev(Context& ctx, int n, double* A, int lda, double* d, double*
 void band_dc_dev(Context& ctx, int n, int nvec, const double* d, const double* e, int lde, int band, double* w,
                  double* z, int ldz);
 
+// bisect.hip: eigenvalues only of the band matrix by Sturm counts (multi-section); w ascending
+void band_bisect_dev(Context& ctx, int n, const double* d, const double* e, int lde, int band, double* w);
+
 // solver.hip
 int64_t solver_workspace_bytes(const Context& ctx, int n, int lda, int ldz, int mf, int mb);
 

@@ -292,9 +292,11 @@ __device__ double g_zero_page[128];        // 1 KiB of zeros: source of every k 
 // Written as inline asm on purpose: for the builtin form hipcc (ROCm 7.2) makes every later ds_read wait
 // vmcnt(0) for ALL outstanding LDS-DMA (no alias information), which drains the ring once per slab; with asm
 // the compiler sees no LDS-DMA and the ring is ordered by the counted s_waitcnt vmcnt + s_barrier below.
+// M0 is a reserved register (hipcc sets it immediately before each of its own uses and keeps no value in it
+// across statements), so writing it here needs -- and accepts -- no clobber entry.
 __device__ __forceinline__ void glds16(const double* gp, double* lp) {
   const unsigned lds_off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lp;
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lds_off) : "m0", "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lds_off) : "memory");
 }
 
 // Issue this wave's share (2 wave-instructions) of one operand slab [k0, k0+8).

@@ -93,6 +93,13 @@ double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// z(:, j) = e_j for the first gridDim.y columns (modes 'S', 'C': eigen_identity, src/eigen_sx.F:214)
+__global__ void identity_kernel(double* __restrict__ z, int ldz, int n) {
+  const int j = blockIdx.y;
+  double* col = z + (size_t)j * ldz;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) col[r] = (r == j) ? 1.0 : 0.0;
+}
+
 int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb,
               char mode, int band) {
   if (!ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
@@ -188,7 +195,15 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   const double t2 = now_s();
 
   // ---- divide and conquer --------------------------------------------------------------------------
-  band_dc_dev(ctx, n, want_vec ? nvec : 0, d, e, lde, band, w, want_vec ? z : nullptr, ldz);
+  // modes (src/eigen_sx.F:200-222): A/X/T/R divide and conquer (X: eigenvalues then re-done by bisection),
+  // S/C identity eigenvector matrix + bisection, N bisection only
+  if (mode == 'N' || mode == 'S' || mode == 'C') {
+    if (want_vec) hipLaunchKernelGGL(identity_kernel, dim3(8, nvec), dim3(256), 0, st, z, ldz, n);
+    band_bisect_dev(ctx, n, d, e, lde, band, w);
+  } else {
+    band_dc_dev(ctx, n, nvec, d, e, lde, band, w, z, ldz);
+    if (mode == 'X') band_bisect_dev(ctx, n, d, e, lde, band, w);
+  }
   const double t3 = now_s();
 
   // ---- back-transformation ---------------------------------------------------------------------------
@@ -310,6 +325,13 @@ int eigx_band_dc_dev(int n, int nvec, const double* d, const double* e, int lde,
     return EIGX_ERR_BAD_ARG;
   if (g_ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;
   band_dc_dev(g_ctx, n, nvec, d, e, lde, band, w, z, ldz);
+  return EIGX_OK;
+}
+
+int eigx_band_bisect_dev(int n, const double* d, const double* e, int lde, int band, double* w) {
+  if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  if (n <= 0 || lde < n || (band != 1 && band != 2) || !d || !e || !w) return EIGX_ERR_BAD_ARG;
+  band_bisect_dev(g_ctx, n, d, e, lde, band, w);
   return EIGX_OK;
 }
 

@@ -128,6 +128,11 @@ int eigx_band_reduce_dev(int n, double* a_dev, int lda, double* d_dev, double* e
 int eigx_band_dc_dev(int n, int nvec, const double* d_dev, const double* e_dev, int lde, int band,
                      double* w_dev, double* z_dev, int ldz);
 
+/* replaces eigen_bisect(d,e,w,n,mode) src/bisect.F:67-397 (band=1) / eigen_bisect2(d,e,f,w,n,mode)
+ * src/bisect2.F:71-718 (band=2): all eigenvalues of the band matrix by Sturm counts, w_dev ascending.
+ * Used by modes 'N', 'S', 'C' (alone) and 'X' (after the divide and conquer), src/eigen_sx.F:200-222. */
+int eigx_band_bisect_dev(int n, const double* d_dev, const double* e_dev, int lde, int band, double* w_dev);
+
 /* replaces eigen_common_trbakwy(n,nvec,a,lda,z,ldz,e,m,nb) src/trbakwy4.F:77-222 */
 int eigx_trbak_dev(int n, int nvec, const double* a_dev, int lda, double* z_dev, int ldz,
                    const double* e_dev, int lde, int m_backward, int band);
@@ -161,7 +166,8 @@ int eigx_profile(int stride);
 int eigx_profile_read(double* out6);
 
 /* Tuning hook for A/B measurements (tools/, tests/): key 0 = GEMM kernel (2 = LDS-DMA ring kernel where it
- * applies [default], 1 = register-staged kernel everywhere).  Returns the previous value, or -1 for an
+ * applies [default], 1 = register-staged kernel everywhere); key 1 = target number of concurrent Sturm
+ * sweeps of the bisection (default 65536).  Returns the previous value, or -1 for an
  * unknown key.  Not part of the reference's interface. */
 int eigx_tune(int key, int value);
 

@@ -568,6 +568,139 @@ int orc_trbak(int n, int nvec, const double* a, int lda, double* z, int ldz, con
  * drivers (src/eigen_sx.F:30-308, src/eigen_s.F:30-307).  mode 'A' (all) or 'N' (values only).
  * On return a(0,0)=flops, a(1,0)=seconds, a(2,0)=-1 as in src/eigen_sx.F:285-296.
  * ------------------------------------------------------------------------------------------------ */
+/* ------------------------------------------------------------------------------------------------
+ * Eigenvalues only by Sturm counts: eigen_bisect (src/bisect.F:67-397, tridiagonal) and eigen_bisect2
+ * (src/bisect2.F:71-718, pentadiagonal).  count(x) = number of negative pivots of an LDL^T factorisation
+ * of T - xI.  Tridiagonal: three-term recurrence with a pivmin guard.  Pentadiagonal: 4 x 4 window of the
+ * running Schur complement, the larger of the two leading diagonal entries is the pivot (symmetric
+ * interchange inside the window), 2 x 2 block pivot when both vanish -- the "diagonal-neighbour pivoting" of
+ * sturm2_LDLT (src/bisect2.F:398-676).  Plain bisection per eigenvalue until the midpoint stops moving
+ * (src/bisect2.F:329-345), Gershgorin start interval (:147-185), final sort (:682-712).
+ * ------------------------------------------------------------------------------------------------ */
+static int sturm_tri(int n, const double* d, const double* e, int lde, double x, double pivmin) {
+  int cnt = 0;
+  double q = 1.0;
+  for (int i = 0; i < n; ++i) {
+    const double b = (i >= 1) ? E_(i, 1) : 0.0;
+    q = (d[i] - x) - b * b / q;
+    if (fabs(q) <= pivmin) q = -pivmin;
+    cnt += (q < 0.0);
+  }
+  return cnt;
+}
+
+/* inertia of a dense symmetric m x m block (lower triangle in W[4][4]) with the same pivot rule */
+static int dense_negcount(double W[4][4], int m, double pivmin) {
+  int cnt = 0;
+  while (m > 0) {
+    if (m >= 2 && fabs(W[0][0]) < fabs(W[1][1])) {
+      double t = W[0][0]; W[0][0] = W[1][1]; W[1][1] = t;
+      for (int r = 2; r < m; ++r) { t = W[r][0]; W[r][0] = W[r][1]; W[r][1] = t; }
+    }
+    if (W[0][0] == 0.0 && m >= 2) {
+      double e0 = W[1][0];
+      const int tiny = fabs(e0) <= pivmin;
+      if (tiny) e0 = pivmin;
+      cnt += tiny ? 2 : 1;
+      double N[2][2] = {{0, 0}, {0, 0}};
+      for (int i = 2; i < m; ++i)
+        for (int j = 2; j <= i; ++j) N[i - 2][j - 2] = W[i][j] - (W[i][0] * W[j][1] + W[i][1] * W[j][0]) / e0;
+      for (int i = 2; i < m; ++i)
+        for (int j = 2; j <= i; ++j) W[i - 2][j - 2] = N[i - 2][j - 2];
+      m -= 2;
+    } else {
+      double d0 = W[0][0];
+      if (fabs(d0) < pivmin) d0 = -pivmin;
+      cnt += (d0 < 0.0);
+      double N[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      for (int i = 1; i < m; ++i)
+        for (int j = 1; j <= i; ++j) N[i - 1][j - 1] = W[i][j] - W[i][0] * W[j][0] / d0;
+      for (int i = 1; i < m; ++i)
+        for (int j = 1; j <= i; ++j) W[i - 1][j - 1] = N[i - 1][j - 1];
+      m -= 1;
+    }
+  }
+  return cnt;
+}
+
+static int sturm_pen(int n, const double* d, const double* e, int lde, double x, double pivmin) {
+  /* window W (lower triangle) starts as the identity: its rows are decoupled positive pivots */
+  double W[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  int cnt = 0, trail = 0;
+  double pa = 1.0, pb = 0.0, pc = 0.0;
+  for (int i = 0; i <= n; ++i) {
+    /* row entering after this step: matrix row i, or (only to release a pending 2 x 2 block) a decoupled one */
+    double a = 1.0, b = 0.0, c = 0.0;
+    if (i < n) { a = d[i] - x; b = (i >= 1) ? E_(i, 1) : 0.0; c = (i >= 2) ? E_(i, 2) : 0.0; }
+    else if (!trail) break;
+    if (trail) {
+      double e0 = W[1][0];
+      const int tiny = fabs(e0) <= pivmin;
+      if (tiny) e0 = pivmin;
+      const double f0 = W[2][0], g0 = W[3][0], f1 = W[2][1], g1 = W[3][1];
+      const double n11 = W[2][2] - 2.0 * f0 * f1 / e0;
+      const double n21 = W[3][2] - (g0 * f1 + g1 * f0) / e0;
+      const double n22 = W[3][3] - 2.0 * g0 * g1 / e0;
+      cnt += tiny ? 2 : 1;
+      W[0][0] = n11; W[1][0] = n21; W[1][1] = n22;
+      W[2][0] = pc; W[2][1] = pb; W[2][2] = pa;
+      W[3][0] = 0.0; W[3][1] = c; W[3][2] = b; W[3][3] = a;
+      trail = 0;
+      continue;
+    }
+    if (fabs(W[0][0]) < fabs(W[1][1])) {
+      double t = W[0][0]; W[0][0] = W[1][1]; W[1][1] = t;
+      t = W[2][0]; W[2][0] = W[2][1]; W[2][1] = t;
+      t = W[3][0]; W[3][0] = W[3][1]; W[3][1] = t;
+    }
+    if (W[0][0] == 0.0) { trail = 1; pa = a; pb = b; pc = c; continue; }
+    double d0 = W[0][0];
+    if (fabs(d0) < pivmin) d0 = -pivmin;
+    cnt += (d0 < 0.0);
+    const double e0 = W[1][0], f0 = W[2][0], g0 = W[3][0];
+    const double n11 = W[1][1] - e0 * e0 / d0, n21 = W[2][1] - e0 * f0 / d0, n22 = W[2][2] - f0 * f0 / d0;
+    const double n31 = W[3][1] - e0 * g0 / d0, n32 = W[3][2] - f0 * g0 / d0, n33 = W[3][3] - g0 * g0 / d0;
+    W[0][0] = n11; W[1][0] = n21; W[1][1] = n22; W[2][0] = n31; W[2][1] = n32; W[2][2] = n33;
+    W[3][0] = 0.0; W[3][1] = c; W[3][2] = b; W[3][3] = a;
+  }
+  return cnt + dense_negcount(W, 4, pivmin);
+}
+
+static int dbl_cmp(const void* x, const void* y) {
+  const double a = *(const double*)x, b = *(const double*)y;
+  return (a > b) - (a < b);
+}
+
+int orc_band_bisect(int n, const double* d, const double* e, int lde, int band, double* w) {
+  if (n <= 0 || (band != 1 && band != 2) || lde < n) return -1;
+  double lo = DBL_MAX, hi = -DBL_MAX, em = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double r = 0.0;
+    for (int b = 1; b <= band; ++b) {
+      if (i - b >= 0) { r += fabs(E_(i, b)); em = fmax(em, fabs(E_(i, b))); }
+      if (i + b < n) r += fabs(E_(i + b, b));
+    }
+    lo = fmin(lo, d[i] - r);
+    hi = fmax(hi, d[i] + r);
+  }
+  const double x0 = (fabs(lo) + fabs(hi)) * DBL_EPSILON;
+  const double lb_ = (lo - x0) - DBL_EPSILON * em - DBL_MIN, ub_ = (hi + x0) + DBL_EPSILON * em + DBL_MIN;
+  const double pivmin = fmax(DBL_MIN * fmax(1.0, em * em), DBL_MIN);
+  for (int k = 0; k < n; ++k) {
+    double lb = lb_, ub = ub_, x = lb;
+    for (int it = 0; it < 128; ++it) {   /* ITRMAX of src/bisect2.F:128 */
+      const double t = x;
+      x = 0.5 * (lb + ub);
+      if (x == t) break;
+      const int c = (band == 1) ? sturm_tri(n, d, e, lde, x, pivmin) : sturm_pen(n, d, e, lde, x, pivmin);
+      if (c >= k + 1) ub = x; else lb = x;
+    }
+    w[k] = 0.5 * (lb + ub);
+  }
+  qsort(w, (size_t)n, sizeof(double), dbl_cmp);
+  return 0;
+}
+
 static double now_s(void) {
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -598,14 +731,20 @@ static int orc_eigen(int n, int nvec, double* a, int lda, double* wout, double* 
   orc_band_reduce(n, a, lda, d, e, lde, band);
   const double t2 = now_s();
   double fl_dc = 0.0;
-  const int want_vec = !(mode == 'N' || mode == 'n' || nvec == 0);
-  double* ztmp = z;
-  int ldzt = ldz;
-  if (!want_vec) { ztmp = (double*)malloc((size_t)n * n * sizeof(double)); ldzt = n; }
-  orc_band_dc(n, d, e, lde, band, wout, ztmp, ldzt, &fl_dc);
+  if (mode >= 'a' && mode <= 'z') mode = (char)(mode - 'a' + 'A');
+  if (nvec == 0) mode = 'N';
+  const int want_vec = (mode != 'N');
+  /* modes (src/eigen_sx.F:200-222): A/X/T/R divide and conquer (X: eigenvalues then by bisection),
+   * S/C identity eigenvector matrix + bisection, N bisection only */
+  if (mode == 'N' || mode == 'S' || mode == 'C') {
+    if (want_vec) for (int j = 0; j < nvec; ++j) for (int i = 0; i < n; ++i) z[(size_t)i + (size_t)j * ldz] = (i == j) ? 1.0 : 0.0;
+    orc_band_bisect(n, d, e, lde, band, wout);
+  } else {
+    orc_band_dc(n, d, e, lde, band, wout, z, ldz, &fl_dc);
+    if (mode == 'X') orc_band_bisect(n, d, e, lde, band, wout);
+  }
   const double t3 = now_s();
-  if (want_vec) orc_trbak(n, nvec, a, lda, z, ldz, e, lde, band);
-  else free(ztmp);
+  if (want_vec && mode != 'T' && mode != 'C' && mode != 'R') orc_trbak(n, nvec, a, lda, z, ldz, e, lde, band);
   const double t4 = now_s();
   if (sigma != 1.0) for (int i = 0; i < n; ++i) wout[i] /= sigma;
   const double fl = 4.0 / 3.0 * (double)n * n * n + fl_dc + (want_vec ? 2.0 * (double)nvec * n * n : 0.0);

@@ -27,6 +27,7 @@ def load():
                                                                 C.c_char, _dp]
         lib.orc_band_reduce.argtypes = [C.c_int, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int]
         lib.orc_band_dc.argtypes = [C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]
+        lib.orc_band_bisect.argtypes = [C.c_int, _dp, _dp, C.c_int, C.c_int, _dp]
         lib.orc_trbak.argtypes = [C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int]
         _lib = lib
     return _lib
@@ -75,3 +76,15 @@ def band_dc(d, e, band):
     if rc != 0:
         raise RuntimeError(f"oracle band_dc rc={rc}")
     return w, z
+
+
+def band_bisect(d, e, band):
+    """eigenvalues only of the band matrix (d, e) by Sturm counts (eigen_bisect / eigen_bisect2)."""
+    lib = load()
+    n = len(d)
+    w = np.zeros(n)
+    ee = np.ascontiguousarray(e, dtype=np.float64)
+    rc = lib.orc_band_bisect(n, _p(np.ascontiguousarray(d, dtype=np.float64)), _p(ee), ee.shape[1], band, _p(w))
+    if rc != 0:
+        raise RuntimeError(f"oracle band_bisect rc={rc}")
+    return w

@@ -506,3 +506,57 @@ def test_gemm_ring_gather_large(gpu_lib):
                                          Ct.data_ptr(), ldc, ma.data_ptr(), mb.data_ptr()) == 0
     ref = A[:, ma.long()] @ B[:, mb.long()].T
     assert (Ct[:, :M].T - ref).abs().max().item() < 1e-12 * K
+
+
+# ------------------------------------------------------------------ bisection (modes N / X / S / C) 
+@pytest.mark.parametrize("band", [1, 2])
+@pytest.mark.parametrize("kind", ["rand", "zero_diag", "sparse", "blocks", "graded"])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 33, 257, 1100])
+def test_band_bisect_matches_oracle(gpu_lib, orc, band, kind, n):
+    """eigx_band_bisect_dev (multi-section Sturm counts) against the oracle's plain bisection and LAPACK"""
+    import torch
+    from test_oracle import _rand_band
+
+    d, e, T = _rand_band(n, band, seed=n + 7 * band, kind=kind)
+    wo = orc.band_bisect(d, e, band) if n <= 300 else np.linalg.eigvalsh(T)
+    dt = torch.from_numpy(d).to(_dev())
+    et = torch.from_numpy(np.ascontiguousarray(e).reshape(-1)).to(_dev())
+    w = torch.zeros(n, dtype=torch.float64, device=_dev())
+    torch.cuda.synchronize()
+    assert gpu_lib.eigx_band_bisect_dev(n, dt.data_ptr(), et.data_ptr(), n, band, w.data_ptr()) == 0
+    wg = w.cpu().numpy()
+    assert (np.diff(wg) >= 0).all()
+    assert np.abs(wg - wo).max() < 1e-13 * max(1.0, np.abs(wo).max())
+
+
+@pytest.mark.parametrize("route", ["sx", "s"])
+def test_all_modes(gpu_lib, orc, route):
+    """modes of eigen_sx / eigen_s (src/eigen_sx.F:200-240) against the oracle run in the same mode"""
+    import eigenexa_amd as ee
+    from eigenexa_amd import api, layout
+
+    n = 230
+    band = 2 if route == "sx" else 1
+    A = layout.random_symmetric(n, seed=21)
+    wr = np.linalg.eigvalsh(A)
+    for mode in "NXSCTR":
+        wo, _, _, _ = orc.eigen(A, route, mode)
+        a = np.asfortranarray(np.triu(A))
+        z = np.full((n, n), 7.0, order="F")
+        w = np.zeros(n)
+        (ee.eigen_sx if route == "sx" else ee.eigen_s)(n, n, a, n, w, z, n, mode=mode)
+        assert api.last_status() == 0
+        assert np.abs(w - wo).max() < 1e-12 * np.abs(wr).max(), mode
+        if mode == "N":
+            assert (z == 7.0).all()
+        if mode == "X":
+            res, orth = layout.accuracy_metrics(A, w, z)
+            assert res < GATE_RES and orth < GATE_ORTH
+        if mode == "S":
+            B = z.T @ A @ z
+            assert np.abs(z.T @ z - np.eye(n)).max() < 1e-13
+            assert np.abs(np.triu(B, band + 1)).max() < 1e-12 * np.abs(A).max() * n
+        if mode == "C":
+            assert np.array_equal(z, np.eye(n))
+        if mode in "TR":
+            assert np.abs(z.T @ z - np.eye(n)).max() < 1e-12

@@ -174,3 +174,66 @@ def test_structured_matrices(orc, route, kind):
     else:
         orth = np.linalg.norm(Z.T @ Z - np.eye(n)) / (n * np.finfo(float).eps)
     assert orth < GATE_ORTH
+
+
+def _rand_band(n, band, seed, kind="rand"):
+    rng = np.random.default_rng(seed)
+    d = rng.standard_normal(n)
+    e = np.zeros((band, n))
+    for b in range(1, band + 1):
+        e[b - 1, b:] = rng.standard_normal(max(n - b, 0))
+    if kind == "zero_diag":
+        d[:] = 0.0
+    elif kind == "sparse":          # exact zeros on and off the diagonal: 2 x 2 block pivots of the window
+        e[:, ::3] = 0.0
+        d[::2] = 0.0
+    elif kind == "blocks":          # decoupled halves
+        e[:, n // 2] = 0.0
+        if band == 2 and n // 2 + 1 < n:
+            e[1, n // 2 + 1] = 0.0
+    elif kind == "graded":
+        s = 10.0 ** np.linspace(0, -12, n)
+        d *= s
+        e *= s[None, :]
+    T = np.diag(d)
+    for b in range(1, min(band, n - 1) + 1):
+        T += np.diag(e[b - 1, b:n], b) + np.diag(e[b - 1, b:n], -b)
+    return d, e, T
+
+
+@pytest.mark.parametrize("band", [1, 2])
+@pytest.mark.parametrize("kind", ["rand", "zero_diag", "sparse", "blocks", "graded"])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 33, 200])
+def test_band_bisect_vs_lapack(orc, band, kind, n):
+    """eigen_bisect / eigen_bisect2 restatement: Sturm counts + bisection give the band matrix's spectrum"""
+    d, e, T = _rand_band(n, band, seed=n + 7 * band, kind=kind)
+    w = orc.band_bisect(d, e, band)
+    wr = np.linalg.eigvalsh(T)
+    assert (np.diff(w) >= 0).all()
+    assert np.abs(w - wr).max() < 1e-13 * max(1.0, np.abs(wr).max())
+
+
+@pytest.mark.parametrize("route", ["sx", "s"])
+def test_modes(orc, route):
+    """modes of eigen_sx / eigen_s (src/eigen_sx.F:200-240): N eigenvalues only (bisection), X = A with the
+    eigenvalues re-done by bisection, S = Householder basis Q (identity back-transformed) + bisection,
+    C = identity + bisection, T / R = band eigenvectors without back-transformation"""
+    n = 90
+    band = 2 if route == "sx" else 1
+    A = layout.random_symmetric(n, seed=21)
+    wr = np.linalg.eigvalsh(A)
+    for mode in "NXSCTR":
+        w, Z, _, _ = orc.eigen(A, route, mode)
+        assert np.abs(w - wr).max() < 1e-12 * np.abs(wr).max(), mode
+        if mode == "X":
+            res, orth = layout.accuracy_metrics(A, w, Z)
+            assert res < GATE_RES and orth < GATE_ORTH
+        if mode == "S":
+            B = Z.T @ A @ Z   # similarity to the band matrix
+            assert np.abs(Z.T @ Z - np.eye(n)).max() < 1e-13
+            off = np.abs(np.triu(B, band + 1)).max()
+            assert off < 1e-12 * np.abs(A).max() * n
+        if mode == "C":
+            assert np.array_equal(Z, np.eye(n))
+        if mode in "TR":
+            assert np.abs(Z.T @ Z - np.eye(n)).max() < 1e-12
