@@ -230,6 +230,7 @@ int eigx_memcpy_d2h(void* dst, const void* src, int64_t bytes) {
 int eigx_tune(int key, int value) {
   if (key == 0) return set_gemm_variant(value);
   if (key == 1) return set_bisect_threads(value);
+  if (key == 2) return set_bt_q(value);
   return -1;
 }
 

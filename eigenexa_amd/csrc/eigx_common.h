@@ -61,5 +61,7 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
 int set_gemm_variant(int v);
 // tuning hook (eigx_tune key 1): target number of concurrent Sturm sweeps of the bisection
 int set_bisect_threads(int v);
+// tuning hook (eigx_tune key 2): super-block factor of the back-transformation (0 = automatic, 1, 2, 4)
+int set_bt_q(int v);
 
 }  // namespace eigx

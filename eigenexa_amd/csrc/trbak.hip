@@ -23,6 +23,7 @@ namespace eigx {
 namespace {
 
 constexpr int GCH = 512;  // rows per Gram chunk
+int g_bt_q = 0;           // tuning hook (eigx_tune key 2): force the super-block factor (0 = automatic)
 
 // After the reduction the part of column j below its reflector (rows > j-band) holds stale matrix / band
 // entries that nobody reads again (d, e were extracted; `a` is destroyed by contract, src/eigen_sx.F:30-308).
@@ -38,18 +39,22 @@ __global__ void zero_below_kernel(double* __restrict__ A, int lda, int n, int ba
 
 __device__ __forceinline__ int tri_idx(int r, int c) { return r * (r + 1) / 2 + c; }  // c <= r
 
-// T = S^{-1}, S = strict_lower(G) + diag(beta); Gpart: [nchunks][mb x mb] column-major partial Grams
-__global__ __launch_bounds__(256) void tbuild_kernel(const double* __restrict__ Gall, int maxchunks, int mb, int n,
-                                                     const double* __restrict__ A, int lda,
+// T = S^{-1}, S = strict_lower(G) + diag(beta), for one 128-column sub-block of a super-block of mbe columns.
+// Gall: [super-block][chunk][mbe x mbe] column-major partial Grams; the sub-block's diagonal block sits at
+// (sub*mb, sub*mb) of every partial.  Tall: [super-block][mbe x mbe]; only the sub-block's diagonal block is
+// written here (the blocks below the diagonal follow from two small GEMMs per level, see trbak_dev).
+__global__ __launch_bounds__(256) void tbuild_kernel(const double* __restrict__ Gall, int maxchunks, int gch, int mb,
+                                                     int mbe, int nsub, int n, const double* __restrict__ A, int lda,
                                                      const double* __restrict__ e, int lde, int band,
-                                                     double* __restrict__ Tall) {
-  // block b = blockIdx.x: reflectors j0 .. j0+mbk-1
-  const int j0 = band + blockIdx.x * mb;
+                                                     double* __restrict__ Tall, int jstart) {
+  const int sb = blockIdx.x / nsub, sub = blockIdx.x % nsub;
+  const int j0 = jstart + sb * mbe + sub * mb;    // first reflector of this sub-block
+  if (j0 >= n) return;
   const int mbk = (n - j0 < mb) ? n - j0 : mb;
   const int rows = j0 + mbk - band;
-  const int nchunks = (rows + GCH - 1) / GCH;
-  const double* Gpart = Gall + (size_t)blockIdx.x * maxchunks * mb * mb;
-  double* T = Tall + (size_t)blockIdx.x * mb * mb;
+  const int nchunks = (rows + gch - 1) / gch;
+  const double* Gpart = Gall + (size_t)sb * maxchunks * mbe * mbe + (size_t)(sub * mb) * mbe + sub * mb;
+  double* T = Tall + (size_t)sb * mbe * mbe + (size_t)(sub * mb) * mbe + sub * mb;
   extern __shared__ double sm[];  // Gl[mb(mb+1)/2] | Tl[mb(mb+1)/2] | binv[mb]
   const int tri = mb * (mb + 1) / 2;
   double* Gl = sm;
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(256) void tbuild_kernel(const double* __restrict__ 
     const int r = idx % mbk, c = idx / mbk;
     if (c < r) {
       double v = 0.0;
-      for (int q = 0; q < nchunks; ++q) v += Gpart[(size_t)q * mb * mb + (size_t)c * mb + r];
+      for (int q = 0; q < nchunks; ++q) v += Gpart[(size_t)q * mbe * mbe + (size_t)c * mbe + r];
       Gl[tri_idx(r, c)] = v;
     }
   }
@@ -82,22 +87,119 @@ __global__ __launch_bounds__(256) void tbuild_kernel(const double* __restrict__ 
   }
   for (int idx = tid; idx < mb * mb; idx += 256) {
     const int r = idx % mb, c = idx / mb;
-    T[idx] = (r < mbk && c <= r) ? Tl[tri_idx(r, c)] : 0.0;
+    T[(size_t)c * mbe + r] = (r < mbk && c <= r) ? Tl[tri_idx(r, c)] : 0.0;
+  }
+}
+
+// Gs[super-block] = sum over the row chunks of the partial Grams (dense mbe x mbe, for the off-diagonal T blocks)
+__global__ void gsum_kernel(const double* __restrict__ Gall, int maxchunks, int mbe, double* __restrict__ Gs) {
+  const int sb = blockIdx.y;
+  const size_t sz = (size_t)mbe * mbe;
+  const double* src = Gall + (size_t)sb * maxchunks * sz;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < sz; i += (size_t)gridDim.x * blockDim.x) {
+    double v = 0.0;
+    for (int q = 0; q < maxchunks; ++q) v += src[(size_t)q * sz + i];
+    Gs[(size_t)sb * sz + i] = v;
   }
 }
 
 }  // namespace
+
+// reflectors [jstart, jend) in blocks of mbe = q * mb columns (q = 1: any range, the last block may be short;
+// q > 1: jend - jstart must be a multiple of mbe).  T of a super-block is assembled from the 128-column
+// diagonal blocks: S = [[S11, 0], [S21, S22]]  =>  S^-1 = [[T11, 0], [-T22 S21 T11, T22]], S21 = V2^T V1.
+static void bt_range(Context& ctx, int n, int nvec, double* V, int ldv, double* Z, int ldz, const double* e, int lde,
+                     int band, int jstart, int jend, int mb, int q) {
+  if (jend <= jstart) return;
+  hipStream_t st = ctx.stream;
+  const int mbe = mb * q;
+  const int nblk = (jend - jstart + mbe - 1) / mbe;
+  const int rows_all = jend - band;                    // longest reflector of the range
+  // Gram row chunks: 512 rows for plain blocks; ~4096 rows (even, as few padding rows as possible) for
+  // super-blocks, whose partial Grams are mbe x mbe each
+  int gch = GCH, maxchunks = (rows_all + GCH - 1) / GCH;
+  if (q > 1) {
+    maxchunks = (rows_all + 4095) / 4096;
+    gch = ((rows_all + maxchunks - 1) / maxchunks + 1) & ~1;
+  }
+  const size_t msz = (size_t)mbe * mbe;
+  double* Gall = ctx.pool.get_t<double>(q > 1 ? "bt.Gq" : "bt.G", (size_t)nblk * maxchunks * msz);
+  double* Tall = ctx.pool.get_t<double>(q > 1 ? "bt.Tq" : "bt.T", (size_t)nblk * msz);
+  double* W = ctx.pool.get_t<double>("bt.W", (size_t)512 * nvec);
+  double* X = ctx.pool.get_t<double>("bt.X", (size_t)512 * nvec);
+  const size_t tshm = ((size_t)mb * (mb + 1) + mb) * sizeof(double);
+  static bool attr = false;
+  if (!attr) {
+    EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)tbuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(((size_t)128 * 129 + 128) * sizeof(double))));
+    attr = true;
+  }
+  // Gram partials of every block in one launch: batch = chunk (stride gch rows), batch2 = block (stride mbe
+  // columns); chunks beyond a block's reflector length multiply zeros.
+  const int nfull = (jend - jstart) / mbe;  // full blocks; a trailing partial block (q = 1 only) gets its own launch
+  double* Vr = V + (size_t)jstart * ldv;
+  if (nfull > 0)
+    dgemm_dev(st, 'T', 'N', mbe, mbe, gch, 1.0, Vr, ldv, Vr, ldv, 0.0, Gall, mbe, 0, nullptr, nullptr, nullptr,
+              maxchunks, gch, gch, (long)msz, nfull, (long)mbe * ldv, (long)mbe * ldv, (long)maxchunks * msz);
+  if (nfull < nblk) {
+    const int j0 = jstart + nfull * mbe, mbk = jend - j0;
+    dgemm_dev(st, 'T', 'N', mbk, mbk, gch, 1.0, V + (size_t)j0 * ldv, ldv, V + (size_t)j0 * ldv, ldv, 0.0,
+              Gall + (size_t)nfull * maxchunks * msz, mbe, 0, nullptr, nullptr, nullptr, maxchunks, gch, gch,
+              (long)msz);
+  }
+  if (q > 1) EIGX_HIP_CHECK(hipMemsetAsync(Tall, 0, (size_t)nblk * msz * sizeof(double), st));
+  // tbuild addresses reflector j0 = band + sb*mbe + sub*mb: shift the matrix view so that "band" means jstart
+  hipLaunchKernelGGL(tbuild_kernel, dim3(nblk * q), dim3(256), tshm, st, Gall, maxchunks, gch, mb, mbe, q, n, V, ldv, e,
+                     lde, band, Tall, jstart);
+  if (q > 1) {
+    double* Gs = ctx.pool.get_t<double>("bt.Gs", (size_t)nblk * msz);
+    double* Y = ctx.pool.get_t<double>("bt.Y", (size_t)nblk * msz);
+    hipLaunchKernelGGL(gsum_kernel, dim3(64, nblk), dim3(256), 0, st, Gall, maxchunks, mbe, Gs);
+    // level by level: diagonal blocks of size h are done; the block below-left of each pair follows
+    for (int h = mb; h < mbe; h *= 2) {
+      const int np = mbe / (2 * h);                 // pairs per super-block
+      const long dstep = (long)2 * h * (mbe + 1);   // from one pair to the next along the diagonal
+      // Y = G21 * T11   ;   T21 = -T22 * Y
+      dgemm_dev(st, 'N', 'N', h, h, h, 1.0, Gs + h, mbe, Tall, mbe, 0.0, Y, h, 0, nullptr, nullptr, nullptr, np, dstep,
+                dstep, (long)h * h, nblk, (long)msz, (long)msz, (long)np * h * h);
+      dgemm_dev(st, 'N', 'N', h, h, h, -1.0, Tall + (size_t)h * (mbe + 1), mbe, Y, h, 0.0, Tall + h, mbe, 0, nullptr,
+                nullptr, nullptr, np, dstep, (long)h * h, dstep, nblk, (long)msz, (long)np * h * h, (long)msz);
+    }
+  }
+  for (int b = 0; b < nblk; ++b) {
+    const int j0 = jstart + b * mbe;
+    const int mbk = (jend - j0 < mbe) ? jend - j0 : mbe;
+    const int rows = j0 + mbk - band;  // length of the longest reflector of the block
+    const double* Vb = V + (size_t)j0 * ldv;
+    const double* T = Tall + (size_t)b * msz;
+    dgemm_dev(st, 'T', 'N', mbk, nvec, rows, 1.0, Vb, ldv, Z, ldz, 0.0, W, mbe);
+    dgemm_dev(st, 'N', 'N', mbk, nvec, mbk, 1.0, T, mbe, W, mbe, 0.0, X, mbe);
+    dgemm_dev(st, 'N', 'N', rows, nvec, mbk, -1.0, Vb, ldv, X, mbe, 1.0, Z, ldz);
+  }
+}
 
 void trbak_dev(Context& ctx, int n, int nvec, double* A, int lda, double* Z, int ldz, const double* e,
                int lde, int mb, int band) {
   if (nvec <= 0 || n <= band) return;
   hipStream_t st = ctx.stream;
   if (mb < 8) mb = 8;
-  if (mb > 128) mb = 128;  // T-builder keeps two packed mb x mb triangles in LDS
-  const int nblk = (n - band + mb - 1) / mb;
+  if (mb > 128) mb = 128;  // T-builder keeps two packed mb x mb triangles in LDS; wider blocks are assembled
+  // Super-blocks: every block costs three passes over Z (read for W = V^T Z, read + write for Z -= V X), and at
+  // 128 columns those passes, not the MFMA work, bound the back-transformation (AI = mb/6 flop/B).
+  int q = 1;
+  if (mb == 128 && n >= 2048) q = (n >= 6144) ? 4 : 2;   // measured: N=8192 31.4 -> 26.2 (q=2) -> 23.9 ms (q=4)
+  if (g_bt_q > 0 && mb == 128) q = g_bt_q;
+  const int mbe = mb * q;
   const int rows_all = n - band;                       // longest reflector
-  int rows_pad = (rows_all + GCH - 1) / GCH * GCH;     // Gram chunks read up to here: must stay inside lda
-  const int maxchunks = (rows_all + GCH - 1) / GCH;
+  // Gram chunks read whole chunks of rows: the zero padding below the reflectors must stay inside lda
+  int rows_pad = (rows_all + GCH - 1) / GCH * GCH;
+  const int nsup = (q > 1) ? (n - band) / mbe : 0;
+  if (nsup > 0) {   // the super-block range [band, band + nsup*mbe) uses its own (larger) chunks: see bt_range
+    const int rs = nsup * mbe;
+    const int mc = (rs + 4095) / 4096;
+    const int g = ((rs + mc - 1) / mc + 1) & ~1;
+    if (mc * g > rows_pad) rows_pad = mc * g;
+  }
   const bool inplace = rows_pad <= lda;
   double* V = A;
   int ldv = lda;
@@ -109,43 +211,12 @@ void trbak_dev(Context& ctx, int n, int nvec, double* A, int lda, double* Z, int
                                     hipMemcpyDeviceToDevice, st));
   }
   hipLaunchKernelGGL(zero_below_kernel, dim3(8, n), dim3(256), 0, st, V, ldv, n, band, rows_pad);
-  double* Gall = ctx.pool.get_t<double>("bt.G", (size_t)nblk * maxchunks * mb * mb);
-  double* Tall = ctx.pool.get_t<double>("bt.T", (size_t)nblk * mb * mb);
-  double* W = ctx.pool.get_t<double>("bt.W", (size_t)mb * nvec);
-  double* X = ctx.pool.get_t<double>("bt.X", (size_t)mb * nvec);
-  const size_t tshm = ((size_t)mb * (mb + 1) + mb) * sizeof(double);
-  static bool attr = false;
-  if (!attr) {
-    EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)tbuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(((size_t)128 * 129 + 128) * sizeof(double))));
-    attr = true;
-  }
-  // Gram partials of every block in one launch: batch = chunk (stride GCH rows), batch2 = block
-  // (stride mb columns); chunks beyond a block's reflector length multiply zeros.
-  const int nfull = (n - band) / mb;  // full blocks; a trailing partial block gets its own launch
-  if (nfull > 0)
-    dgemm_dev(st, 'T', 'N', mb, mb, GCH, 1.0, V + (size_t)band * ldv, ldv, V + (size_t)band * ldv, ldv, 0.0, Gall, mb,
-              0, nullptr, nullptr, nullptr, maxchunks, GCH, GCH, (long)mb * mb, nfull, (long)mb * ldv, (long)mb * ldv,
-              (long)maxchunks * mb * mb);
-  if (nfull < nblk) {
-    const int j0 = band + nfull * mb, mbk = n - j0;
-    dgemm_dev(st, 'T', 'N', mbk, mbk, GCH, 1.0, V + (size_t)j0 * ldv, ldv, V + (size_t)j0 * ldv, ldv, 0.0,
-              Gall + (size_t)nfull * maxchunks * mb * mb, mb, 0, nullptr, nullptr, nullptr, maxchunks, GCH, GCH,
-              (long)mb * mb);
-  }
-  hipLaunchKernelGGL(tbuild_kernel, dim3(nblk), dim3(256), tshm, st, Gall, maxchunks, mb, n, V, ldv, e, lde, band,
-                     Tall);
-  for (int b = 0; b < nblk; ++b) {
-    const int j0 = band + b * mb;
-    const int mbk = (n - j0 < mb) ? n - j0 : mb;
-    const int rows = j0 + mbk - band;  // length of the longest reflector of the block
-    const double* Vb = V + (size_t)j0 * ldv;
-    const double* T = Tall + (size_t)b * mb * mb;
-    dgemm_dev(st, 'T', 'N', mbk, nvec, rows, 1.0, Vb, ldv, Z, ldz, 0.0, W, mb);
-    dgemm_dev(st, 'N', 'N', mbk, nvec, mbk, 1.0, T, mb, W, mb, 0.0, X, mb);
-    dgemm_dev(st, 'N', 'N', rows, nvec, mbk, -1.0, Vb, ldv, X, mb, 1.0, Z, ldz);
-  }
+  const int jr = band + nsup * mbe;
+  if (nsup > 0) bt_range(ctx, n, nvec, V, ldv, Z, ldz, e, lde, band, band, jr, mb, q);
+  bt_range(ctx, n, nvec, V, ldv, Z, ldz, e, lde, band, jr, n, mb, 1);
   EIGX_HIP_CHECK(hipGetLastError());
 }
+
+int set_bt_q(int v) { const int old = g_bt_q; g_bt_q = v; return old; }
 
 }  // namespace eigx

@@ -152,9 +152,12 @@ def test_band_dc_matches_oracle(gpu_lib, orc, band, n):
 
 # ------------------------------------------------------------------------------------ back-transform
 @pytest.mark.parametrize("band", [1, 2])
-@pytest.mark.parametrize("n,nvec,mb", [(5, 5, 8), (130, 130, 16), (300, 77, 128), (517, 517, 48)])
-def test_trbak_matches_oracle_elementwise(gpu_lib, orc, band, n, nvec, mb):
-    """same reflectors, same Z in -> same Z out (blocked WY on the GPU vs reflector-by-reflector oracle)"""
+@pytest.mark.parametrize("n,nvec,mb,q", [(5, 5, 8, 0), (130, 130, 16, 0), (300, 77, 128, 0), (517, 517, 48, 0),
+                                         (517, 200, 128, 2), (700, 700, 128, 4), (1026, 300, 128, 4),
+                                         (1100, 64, 128, 2)])
+def test_trbak_matches_oracle_elementwise(gpu_lib, orc, band, n, nvec, mb, q):
+    """same reflectors, same Z in -> same Z out (blocked WY on the GPU vs reflector-by-reflector oracle);
+    q > 0 forces super-blocks of q*128 reflectors (T assembled from the 128-column diagonal blocks)"""
     import torch
     from eigenexa_amd import layout
 
@@ -170,7 +173,11 @@ def test_trbak_matches_oracle_elementwise(gpu_lib, orc, band, n, nvec, mb):
     a, lda = _to_colmajor(refl)
     zt, ldz = _to_colmajor(Z0)
     et = torch.from_numpy(ee.reshape(-1).copy()).to(_dev())
-    assert gpu_lib.eigx_trbak_dev(n, nvec, a.data_ptr(), lda, zt.data_ptr(), ldz, et.data_ptr(), n, mb, band) == 0
+    oldq = gpu_lib.eigx_tune(2, q)
+    try:
+        assert gpu_lib.eigx_trbak_dev(n, nvec, a.data_ptr(), lda, zt.data_ptr(), ldz, et.data_ptr(), n, mb, band) == 0
+    finally:
+        gpu_lib.eigx_tune(2, oldq)
     got = zt[:, :n].T.cpu().numpy()
     assert np.abs(got - Zo).max() < 1e-11
 
