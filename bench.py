@@ -238,20 +238,32 @@ def main():
                 "launches_sampled": int(prof[0]), "avg_launch_us": round(prof[2] / prof[0] * 1e6, 2),
                 "algorithmic_bytes_per_launch": round(prof[1] / prof[0], 1),
             }
+            # HBM-side traffic of the same kernel from the committed PMC passes (profiles/r01_symv_traffic.json:
+            # separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+            # 16-byte-per-lane reads on gfx950), expressed like `achieved`: PMC bytes per launch / launch duration
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_symv_traffic.json")))
+                ratio = float(tj["traffic_over_algorithmic"])
+                out["roofline"]["traffic"] = round(ach * ratio, 1)
+                out["roofline"]["traffic_over_algorithmic"] = round(ratio, 3)
+                out["roofline"]["traffic_measured_at_n"] = tj["n"]
+            except Exception:
+                pass
         if prof[3] > 0 and prof[5] > 0:
             ach = prof[4] / prof[5] / 1e12
             out["roofline_trailing_update"] = {
-                "kernel": "gemm_f64_kernel<N,T> tri (rank-2k trailing update)",
+                "kernel": "gemm2_kernel<N,T> tri (rank-2k trailing update, LDS-DMA ring)",
                 "bound": "mfma", "achieved": round(ach, 2), "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(ach / FP64_MFMA_PEAK_TF, 4), "traffic": None,
                 "launches": int(prof[3]), "avg_launch_us": round(prof[5] / prof[3] * 1e6, 2),
             }
-            # HBM traffic of this kernel from the committed PMC passes (profiles/r01_trailing_update_traffic.json:
-            # separate --pmc FETCH_SIZE / WRITE_SIZE runs); reported as measured/algorithmic bytes at the nearest size
+            # HBM-side traffic from the committed PMC passes (profiles/r01_trailing_update_traffic.json), at the
+            # nearest measured size: fetch (doubled, see above) + write bytes over the algorithmic bytes
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r01_trailing_update_traffic.json")))
                 row = min((r for r in tj["rows"] if r["K"] == 256), key=lambda r: abs(r["n"] - n))
                 out["roofline_trailing_update"]["traffic"] = {
+                    "traffic_over_algorithmic": row["traffic_over_algorithmic"],
                     "fetch_over_algorithmic": row["fetch_over_algorithmic"],
                     "write_over_algorithmic": row["write_over_algorithmic"], "measured_at_n": row["n"]}
             except Exception:
