@@ -231,6 +231,9 @@ int eigx_tune(int key, int value) {
   if (key == 0) return set_gemm_variant(value);
   if (key == 1) return set_bisect_threads(value);
   if (key == 2) return set_bt_q(value);
+  if (key == 3) return set_symv_threshold(0, value);
+  if (key == 4) return set_symv_threshold(1, value);
+  if (key == 5) return set_symv_threshold(2, value);
   return -1;
 }
 

@@ -73,14 +73,21 @@ struct RedArgs {
 };
 
 // SYMV tiling: square tiles of T = 128*RB rows/cols (RB = 1,2,4); tile (ty,tx) with tx >= ty is one
-// workgroup.  Small triangles get small tiles so that >= ~400 workgroups exist; large ones get big tiles
-// so that the number of partial sums per row (nt+1) stays ~100.
+// workgroup.  Small triangles get small tiles so that >= ~400 workgroups exist; the 512 tile only bounds the
+// number of partial sums per row (nt+1 <= 160) beyond L = 40000.
 struct SymvGeom { int L, T, nt; };
 
-__host__ __device__ inline SymvGeom symv_geom(int L, int P = 1) {
+// Tile-size thresholds and the active size above which the matrix is streamed with non-temporal loads
+// (eigx_tune keys 3, 4, 5).  A/B on one MI355X (tools/gpu_reduce_time.py): N=16384 972 -> 833 ms and N=32768
+// 6008 -> 5347 ms with the 256 tile + non-temporal loads instead of the 512 tile; N=8192 loses 1 % with
+// non-temporal loads (its 512 MB matrix still profits from the 256 MB Infinity Cache).
+int g_symv_t128 = 4500, g_symv_t256 = 40000;
+int g_symv_nt = 9000;
+
+inline SymvGeom symv_geom(int L, int P = 1) {
   SymvGeom g;
   g.L = L;
-  g.T = (L <= 6000 || P > 1) ? 128 : (L <= 14000 ? 256 : 512);  // P > 1: ownership granularity = 128 columns
+  g.T = (L <= g_symv_t128 || P > 1) ? 128 : (L <= g_symv_t256 ? 256 : 512);  // P > 1: ownership granularity = 128 columns
   g.nt = (L + g.T - 1) / g.T;
   return g;
 }
@@ -549,10 +556,10 @@ __global__ __launch_bounds__(256) void kl_kernel(RedArgs R, int L, int nt) {
 
 template <int K> struct IC { static constexpr int value = K; };
 
-template <int NV, int RB>
+template <int NV, int RB, bool NTL>
 __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   constexpr int T = 128 * RB;
-  constexpr bool NTL = (RB == 4);   // non-temporal A loads for the 512 tile (L > 14000: triangles > 0.8 GB)
+  // NTL: non-temporal A loads, chosen by the launch for triangles far beyond L2 + Infinity Cache (g_symv_nt)
   constexpr int DYN = 4 * NV * T;
   __shared__ __attribute__((aligned(16))) double dyn[DYN + NV * T];  // [4 waves][NV][T] row sums ; then uc[NV][T]
   __shared__ double red[16];
@@ -1040,9 +1047,12 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     B.ngp = nb_ka;
     const bool prof = ctx.prof_stride > 0 && (n_symv % ctx.prof_stride) == 0;
     if (prof) ctx.prof_begin(0, 8.0 * ((double)L * (L + 1) / 2) / R.P, st);  // this rank's share of the triangle
-    if (g.T == 128) hipLaunchKernelGGL((symv_kernel<NB, 1>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
-    else if (g.T == 256) hipLaunchKernelGGL((symv_kernel<NB, 2>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
-    else hipLaunchKernelGGL((symv_kernel<NB, 4>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
+    const bool nt_loads = L > g_symv_nt;
+    if (g.T == 128) hipLaunchKernelGGL((symv_kernel<NB, 1, false>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
+    else if (g.T == 256 && !nt_loads) hipLaunchKernelGGL((symv_kernel<NB, 2, false>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
+    else if (g.T == 256) hipLaunchKernelGGL((symv_kernel<NB, 2, true>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
+    else if (!nt_loads) hipLaunchKernelGGL((symv_kernel<NB, 4, false>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
+    else hipLaunchKernelGGL((symv_kernel<NB, 4, true>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
     if (prof) ctx.prof_end(st);
     if (R.P > 1) {
       const int Lp = (L + 7) / 8 * 8;
@@ -1109,6 +1119,11 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
 }
 
 }  // namespace
+
+int set_symv_threshold(int which, int v) {
+  int& t = (which == 2) ? g_symv_nt : (which ? g_symv_t256 : g_symv_t128);
+  const int old = t; t = v; return old;
+}
 
 void band_reduce_dev(Context& ctx, int n, double* A, int lda, double* d, double* e, int lde, int m, int band) {
   if (band == 1) band_reduce_impl<1>(ctx, n, A, lda, d, e, lde, m);

@@ -63,5 +63,7 @@ int set_gemm_variant(int v);
 int set_bisect_threads(int v);
 // tuning hook (eigx_tune key 2): super-block factor of the back-transformation (0 = automatic, 1, 2, 4)
 int set_bt_q(int v);
+// tuning hook (eigx_tune keys 3, 4): largest L that uses the 128 / 256 SYMV tile
+int set_symv_threshold(int which, int v);
 
 }  // namespace eigx

@@ -167,7 +167,9 @@ int eigx_profile_read(double* out6);
 
 /* Tuning hook for A/B measurements (tools/, tests/): key 0 = GEMM kernel (2 = LDS-DMA ring kernel where it
  * applies [default], 1 = register-staged kernel everywhere); key 1 = target number of concurrent Sturm
- * sweeps of the bisection (default 65536); key 2 = super-block factor of the back-transformation (0 = automatic).
+ * sweeps of the bisection (default 65536); key 2 = super-block factor of the back-transformation (0 = automatic);
+ * keys 3 / 4 = largest active size L that uses the 128 / 256 tile of the fused symmetric mat-vec, key 5 = active
+ * size above which it streams the matrix with non-temporal loads.
  * Returns the previous value, or -1 for an
  * unknown key.  Not part of the reference's interface. */
 int eigx_tune(int key, int value);

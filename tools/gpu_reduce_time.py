@@ -8,6 +8,9 @@ from eigenexa_amd import _lib
 n = int(sys.argv[1]); band = int(sys.argv[2]) if len(sys.argv) > 2 else 2; reps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 lib = _lib.load()
 _lib.check(lib.eigx_init(0), "eigx_init")
+if os.environ.get("EIGX_T128"): lib.eigx_tune(3, int(os.environ["EIGX_T128"]))
+if os.environ.get("EIGX_T256"): lib.eigx_tune(4, int(os.environ["EIGX_T256"]))
+if os.environ.get("EIGX_NT"): lib.eigx_tune(5, int(os.environ["EIGX_NT"]))
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 lda = n + (n & 1) + 2 + 30   # even, not a multiple of a large power of two
@@ -21,5 +24,5 @@ for rep in range(reps + 1):
     t0 = time.perf_counter()
     _lib.check(lib.eigx_band_reduce_dev(n, a.data_ptr(), lda, d.data_ptr(), e.data_ptr(), n, 128, band), "reduce")
     dt = time.perf_counter() - t0
-    print(f"{os.environ.get('EIGX_LIB', 'default')[-24:]} n={n} band={band} rep {rep}: {dt*1e3:.1f} ms  "
+    print(f"{os.environ.get('EIGX_LIB', 'default')[-24:]} t128={os.environ.get('EIGX_T128','-')} t256={os.environ.get('EIGX_T256','-')} nt={os.environ.get('EIGX_NT','-')} n={n} band={band} rep {rep}: {dt*1e3:.1f} ms  "
           f"({4.0/3.0*n**3/dt/1e12:.2f} TFLOP/s of 4/3 n^3; d[0]={d[0].item():.6f})", flush=True)
