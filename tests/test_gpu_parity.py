@@ -567,3 +567,29 @@ def test_all_modes(gpu_lib, orc, route):
             assert np.array_equal(z, np.eye(n))
         if mode in "TR":
             assert np.abs(z.T @ z - np.eye(n)).max() < 1e-12
+
+
+# ------------------------------------------------------------------ the reference's benchmark driver inputs
+def test_benchmark_driver_check_sweep(gpu_lib, tmp_path):
+    """benchmark/check.sh: every N (here a subset of 3..256 plus 511..1025) x {Frank, random} x {eigen_sx, eigen_s}
+    with the accuracy check on, through the input-file driver (python -m eigenexa_amd.benchmark)"""
+    from eigenexa_amd import benchmark
+
+    sizes = list(range(3, 41)) + [63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025]
+    lines = ["!   N  nvec bx  by m t s e"]
+    for n in sizes:
+        for t in (0, 2):
+            for s in (0, 1):
+                lines.append(f"{n} {n} 48 128 1 {t} {s} 1")
+    lines += ["300 300 48 128 0 0 0 1", "300 300 48 128 2 3 1 1", "200 50 48 128 1 4 0 1", "257 257 48 128 1 6 1 1",
+              "-1 0 0 0 0 0 0 0"]
+    p = tmp_path / "IN-check"
+    p.write_text("\n".join(lines) + "\n")
+    log = []
+    bad = []
+    for case in benchmark.parse_input(str(p)):
+        r = benchmark.run_case(case, out=log.append)
+        if not r["ok"]:
+            bad.append((case, r))
+    assert not bad, (bad[:3], log[-30:])
+    assert sum("Residual Error Test ***   : PASSED" in m for m in log) >= 4 * len(sizes)

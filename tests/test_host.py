@@ -173,3 +173,22 @@ def test_gloo_world_size_2(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"OK {r}" in o, o
+
+
+def test_benchmark_driver_input_format(tmp_path):
+    """the reference driver's input-file format (benchmark/main2.f:262-300, benchmark/IN): comments, 8 integers
+    per case, a non-positive N ends the run"""
+    from eigenexa_amd import benchmark
+
+    p = tmp_path / "IN"
+    p.write_text("! N nvec bx by m t s e\n 1000     0 48 128 1 0 1 0\n!comment\n 64 64 48 128 2 2 0 1\n-1 0 0 0 0 0 0 0\n"
+                 " 5 5 48 128 1 0 0 1\n")
+    cases = list(benchmark.parse_input(str(p)))
+    assert cases == [(1000, 0, 48, 128, 1, 0, 1, 0), (64, 64, 48, 128, 2, 2, 0, 1)]
+    assert benchmark.MODES[0] == "N" and benchmark.MODES[2] == "X" and benchmark.MODES[5] == "C"
+    assert benchmark._verdict(1e-9) == "PASSED" and benchmark._verdict(1e-5) == "CAUTION"
+    assert benchmark._verdict(1e-3) == "FAILED"
+    msgs = []
+    lam = np.array([1.0, 2.0, 3.0])
+    assert benchmark.w_test(lam * (1 + 1e-12), lam, msgs.append)
+    assert any("Relative Error *** : PASSED" in m for m in msgs)
