@@ -526,32 +526,43 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   double* S = ctx.pool.get_t<double>("dc.S", (size_t)ldq * n);
   double* dd = ctx.pool.get_t<double>("dc.d", (size_t)n);
   double* de = ctx.pool.get_t<double>("dc.e", (size_t)lde * band);
-  double* Dcur = ctx.pool.get_t<double>("dc.D", (size_t)n);
-  double* zbuf = ctx.pool.get_t<double>("dc.z", (size_t)n);
-  double* dlam = ctx.pool.get_t<double>("dc.dlam", (size_t)n);
-  double* wz = ctx.pool.get_t<double>("dc.wz", (size_t)n);
   double* zh = ctx.pool.get_t<double>("dc.zh", (size_t)n);
-  int* ibuf = ctx.pool.get_t<int>("dc.ibuf", (size_t)13 * n + 64);
-  double* rbuf = ctx.pool.get_t<double>("dc.rbuf", (size_t)2 * n + 64);
   const int maxmerge = n / (LEAF / 2) + 8;
-  MergeDev* md_dev = ctx.pool.get_t<MergeDev>("dc.md", (size_t)maxmerge);
   int* leafinfo = ctx.pool.get_t<int>("dc.leaf", (size_t)2 * maxmerge);
-  // int sub-buffers
-  int* nd_dev = ibuf;               // [n] non-deflated column (global) per merge range, dlam order
-  int* rpj_dev = ibuf + n;          // [n]
-  int* rjj_dev = ibuf + 2 * n;      // [n]
-  int* cps_dev = ibuf + 3 * n;      // [n] copy src
-  int* cpd_dev = ibuf + 4 * n;      // [n] copy dst
-  int* cpr_dev = ibuf + 5 * n;      // [n] copy row0
-  int* cpn_dev = ibuf + 6 * n;      // [n] copy nrows
-  int* perm_dev = ibuf + 7 * n;     // [n]
-  int* topA_dev = ibuf + 8 * n;     // [n] first update: columns with a non-zero top part (global index)
-  int* topB_dev = ibuf + 9 * n;     // [n]   ... and their pole indices
-  int* botA_dev = ibuf + 10 * n;    // [n] same for the bottom part
-  int* botB_dev = ibuf + 11 * n;    // [n]
-  int* iota_dev = ibuf + 12 * n;    // [n] 0,1,2,...: identity map for the pole index of dense updates
-  double* rc_dev = rbuf;            // [n]
-  double* rs_dev = rbuf + n;        // [n]
+  int* perm_dev = ctx.pool.get_t<int>("dc.perm", (size_t)n);
+  int* iota_dev = ctx.pool.get_t<int>("dc.iota", (size_t)n);  // 0,1,2,...: identity map for the pole index of dense updates
+  // One arena holds everything the host exchanges with the device per merge step, mirrored in pinned host
+  // memory: a step is one D2H copy (Dcur | z), the host deflation, and one H2D copy (everything up to Dcur).
+  //   doubles: dlam | wz | rc | rs | Dcur | zbuf        ints: nd rpj rjj cps cpd cpr cpn topA topB botA botB
+  const size_t npad = ((size_t)n + 7) / 8 * 8;
+  const size_t md_bytes = ((size_t)maxmerge * sizeof(MergeDev) + 63) / 64 * 64;
+  const size_t up_bytes = md_bytes + 11 * npad * sizeof(int) + 5 * npad * sizeof(double);   // H2D part
+  const size_t arena_bytes = up_bytes + npad * sizeof(double);                              // + zbuf
+  char* arena = (char*)ctx.pool.get("dc.arena", arena_bytes);
+  char* harena = (char*)ctx.pool.get_host("dc.arena", arena_bytes);
+  auto carve = [&](char* base, size_t& pos, size_t bytes) { char* p_ = base + pos; pos += bytes; return p_; };
+  size_t pos = 0, hpos = 0;
+  MergeDev* md_dev = (MergeDev*)carve(arena, pos, md_bytes);
+  MergeDev* md_h = (MergeDev*)carve(harena, hpos, md_bytes);
+#define EIGX_ARENA_INT(name) int* name##_dev = (int*)carve(arena, pos, npad * sizeof(int)); \
+                             int* name##_h = (int*)carve(harena, hpos, npad * sizeof(int));
+  EIGX_ARENA_INT(nd)     // [n] non-deflated column (global) per merge range, dlam order
+  EIGX_ARENA_INT(rpj) EIGX_ARENA_INT(rjj)
+  EIGX_ARENA_INT(cps) EIGX_ARENA_INT(cpd) EIGX_ARENA_INT(cpr) EIGX_ARENA_INT(cpn)   // copy src / dst / row0 / nrows
+  EIGX_ARENA_INT(topA) EIGX_ARENA_INT(topB)   // first update: columns with a non-zero top part (global index), their pole indices
+  EIGX_ARENA_INT(botA) EIGX_ARENA_INT(botB)   // same for the bottom part
+#undef EIGX_ARENA_INT
+  double* dlam = (double*)carve(arena, pos, npad * 8);  double* dl_h = (double*)carve(harena, hpos, npad * 8);
+  double* wz = (double*)carve(arena, pos, npad * 8);    double* wz_h = (double*)carve(harena, hpos, npad * 8);
+  double* rc_dev = (double*)carve(arena, pos, npad * 8); double* rc_h = (double*)carve(harena, hpos, npad * 8);
+  double* rs_dev = (double*)carve(arena, pos, npad * 8); double* rs_h = (double*)carve(harena, hpos, npad * 8);
+  double* Dcur = (double*)carve(arena, pos, npad * 8);   double* Dh = (double*)carve(harena, hpos, npad * 8);
+  double* zbuf = (double*)carve(arena, pos, npad * 8);   double* zhost = (double*)carve(harena, hpos, npad * 8);
+  const size_t down_off = up_bytes - npad * 8;   // byte offset of Dcur: the D2H copy takes [Dcur | zbuf]
+  // the merge descriptors also go up once BEFORE the deflation (zgather needs offsets): own staging buffer, because
+  // the previous step's arena upload may still be in flight when the host prepares them
+  MergeDev* md_h2 = (MergeDev*)ctx.pool.get_host("dc.md2", md_bytes);
+  memset(harena, 0, arena_bytes);
 
   EIGX_HIP_CHECK(hipMemcpyAsync(dd, H.d.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
   EIGX_HIP_CHECK(hipMemcpyAsync(de, H.e.data(), (size_t)lde * band * 8, hipMemcpyHostToDevice, st));
@@ -578,9 +589,8 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   }
 
   // ---- merges, height by height ---------------------------------------------------------------------
-  std::vector<double> Dh(n), zhost(n), Dnew(n), dl_h(n), wz_h(n), rc_h(n), rs_h(n);
-  std::vector<int> nd_h(n), rpj_h(n), rjj_h(n), cps_h(n), cpd_h(n), cpr_h(n), cpn_h(n);
-  std::vector<int> topA_h(n), topB_h(n), botA_h(n), botB_h(n), ctype(n), ktop(n / 2 + 8), kbot(n / 2 + 8);
+  std::vector<double> Dold(n);
+  std::vector<int> ctype(n), ktop(n / 2 + 8), kbot(n / 2 + 8);
   std::vector<MergeDev> mds;
   std::vector<std::pair<double, int>> ord;
   double gemm_flops = 0.0;
@@ -600,20 +610,20 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
         for (int t = 0; t < 4; ++t) M.wv[t] = nd.wv[k][t];
         maxnm = std::max(maxnm, nd.n);
       }
-      EIGX_HIP_CHECK(hipMemcpyAsync(md_dev, mds.data(), mds.size() * sizeof(MergeDev), hipMemcpyHostToDevice, st));
+      memcpy(md_h2, mds.data(), mds.size() * sizeof(MergeDev));
+      EIGX_HIP_CHECK(hipMemcpyAsync(md_dev, md_h2, mds.size() * sizeof(MergeDev), hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(zgather_kernel, dim3((maxnm + 255) / 256, (unsigned)ids.size()), dim3(256), 0, st, md_dev,
                          band, Qa, ldq, zbuf, r0, r1);
       if (P > 1) comm_allreduce_sum(ctx, COMM_WORLD, zbuf, (size_t)n, st);
-      EIGX_HIP_CHECK(hipMemcpyAsync(zhost.data(), zbuf, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-      EIGX_HIP_CHECK(hipMemcpyAsync(Dh.data(), Dcur, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+      EIGX_HIP_CHECK(hipMemcpyAsync(harena + down_off, arena + down_off, 2 * npad * 8, hipMemcpyDeviceToHost, st));  // Dcur | z
       EIGX_HIP_CHECK(hipStreamSynchronize(st));
       // -- host deflation -------------------------------------------------------------------------------
       int nrot = 0, ncopy = 0;
-      Dnew = Dh;
+      std::copy(Dh, Dh + n, Dold.begin());   // Dh (pinned) becomes the new D in place
       for (size_t q = 0; q < ids.size(); ++q) {
         MergeDev& M = mds[q];
         const int off = M.off, nm = M.nm;
-        double* dloc = &Dh[off];
+        double* dloc = &Dold[off];
         double* zloc = &zhost[off];
         double zn = 0.0;
         for (int i = 0; i < nm; ++i) zn += zloc[i] * zloc[i];
@@ -701,36 +711,16 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
             cps_h[ncopy] = src; cpd_h[ncopy] = dst; cpr_h[ncopy] = ca; cpn_h[ncopy] = cb - ca;
             ++ncopy;
           }
-          Dnew[dst] = dloc[defl[t]];
+          Dh[dst] = dloc[defl[t]];
         }
-        for (int t = 0; t < K; ++t) Dnew[off + t] = 0.0;  // overwritten by the secular kernel
+        for (int t = 0; t < K; ++t) Dh[off + t] = 0.0;  // overwritten by the secular kernel
       }
       // -- upload and run the GPU part ---------------------------------------------------------------------
-      EIGX_HIP_CHECK(hipMemcpyAsync(md_dev, mds.data(), mds.size() * sizeof(MergeDev), hipMemcpyHostToDevice, st));
-      EIGX_HIP_CHECK(hipMemcpyAsync(nd_dev, nd_h.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-      if (k == 0) {
-        EIGX_HIP_CHECK(hipMemcpyAsync(topA_dev, topA_h.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-        EIGX_HIP_CHECK(hipMemcpyAsync(topB_dev, topB_h.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-        EIGX_HIP_CHECK(hipMemcpyAsync(botA_dev, botA_h.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-        EIGX_HIP_CHECK(hipMemcpyAsync(botB_dev, botB_h.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-      }
-      EIGX_HIP_CHECK(hipMemcpyAsync(dlam, dl_h.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-      EIGX_HIP_CHECK(hipMemcpyAsync(wz, wz_h.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-      EIGX_HIP_CHECK(hipMemcpyAsync(Dcur, Dnew.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-      if (nrot > 0) {
-        EIGX_HIP_CHECK(hipMemcpyAsync(rpj_dev, rpj_h.data(), (size_t)nrot * 4, hipMemcpyHostToDevice, st));
-        EIGX_HIP_CHECK(hipMemcpyAsync(rjj_dev, rjj_h.data(), (size_t)nrot * 4, hipMemcpyHostToDevice, st));
-        EIGX_HIP_CHECK(hipMemcpyAsync(rc_dev, rc_h.data(), (size_t)nrot * 8, hipMemcpyHostToDevice, st));
-        EIGX_HIP_CHECK(hipMemcpyAsync(rs_dev, rs_h.data(), (size_t)nrot * 8, hipMemcpyHostToDevice, st));
+      memcpy(md_h, mds.data(), mds.size() * sizeof(MergeDev));
+      EIGX_HIP_CHECK(hipMemcpyAsync(arena, harena, up_bytes, hipMemcpyHostToDevice, st));   // everything at once
+      if (nrot > 0)
         hipLaunchKernelGGL(rotate_kernel, dim3((maxnm + 255) / 256, (unsigned)ids.size()), dim3(256), 0, st, md_dev,
                            rpj_dev, rjj_dev, rc_dev, rs_dev, Qa, ldq, r0, r1);
-      }
-      if (ncopy > 0) {
-        EIGX_HIP_CHECK(hipMemcpyAsync(cps_dev, cps_h.data(), (size_t)ncopy * 4, hipMemcpyHostToDevice, st));
-        EIGX_HIP_CHECK(hipMemcpyAsync(cpd_dev, cpd_h.data(), (size_t)ncopy * 4, hipMemcpyHostToDevice, st));
-        EIGX_HIP_CHECK(hipMemcpyAsync(cpr_dev, cpr_h.data(), (size_t)ncopy * 4, hipMemcpyHostToDevice, st));
-        EIGX_HIP_CHECK(hipMemcpyAsync(cpn_dev, cpn_h.data(), (size_t)ncopy * 4, hipMemcpyHostToDevice, st));
-      }
       int maxK = 0;
       for (const MergeDev& M : mds) maxK = std::max(maxK, M.K);
       if (maxK > 0) {
@@ -816,7 +806,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   }
 
   // ---- final sort + copy-out ----------------------------------------------------------------------------
-  EIGX_HIP_CHECK(hipMemcpyAsync(Dh.data(), Dcur, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  EIGX_HIP_CHECK(hipMemcpyAsync(Dh, Dcur, (size_t)n * 8, hipMemcpyDeviceToHost, st));
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
   ord.resize(n);
   for (int i = 0; i < n; ++i) ord[i] = std::make_pair(Dh[i], i);

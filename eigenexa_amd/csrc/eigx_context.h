@@ -27,10 +27,26 @@ struct Pool {
   template <typename T> T* get_t(const std::string& name, size_t count) {
     return (T*)get(name, count * sizeof(T));
   }
+  // pinned host staging buffers (one D2H / H2D copy per D&C merge step instead of sixteen pageable ones)
+  std::map<std::string, Buf> hbufs;
+  void* get_host(const std::string& name, size_t bytes) {
+    Buf& b = hbufs[name];
+    if (b.bytes < bytes) {
+      if (b.p) EIGX_HIP_CHECK(hipHostFree(b.p));
+      b.p = nullptr;
+      size_t want = bytes + bytes / 16 + 256;
+      EIGX_HIP_CHECK(hipHostMalloc(&b.p, want, hipHostMallocDefault));
+      b.bytes = want;
+    }
+    return b.p;
+  }
   void release() {
     for (auto& kv : bufs)
       if (kv.second.p) EIGX_HIP_CHECK(hipFree(kv.second.p));
     bufs.clear();
+    for (auto& kv : hbufs)
+      if (kv.second.p) EIGX_HIP_CHECK(hipHostFree(kv.second.p));
+    hbufs.clear();
   }
 };
 
