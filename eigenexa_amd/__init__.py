@@ -21,6 +21,7 @@ from .api import (  # noqa: F401
     eigen_owner_index,
     eigen_sx,
     eigen_s,
+    KMATH_EIGEN_GEV,
     eigen_NB_f,
     eigen_NB_b,
 )

@@ -261,3 +261,24 @@ def eigen_sx(n, nvec, a, lda, w, z, ldz, m_forward=None, m_backward=None, mode="
 def eigen_s(n, nvec, a, lda, w, z, ldz, m_forward=None, m_backward=None, mode="A"):
     """Tridiagonal route (eigen_trd -> dc2 -> trbakwy, src/eigen_libs.F:150-202)."""
     _solve("s", n, nvec, a, lda, w, z, ldz, m_forward, m_backward, mode)
+
+
+def KMATH_EIGEN_GEV(n, a, lda, b, ldb, w, z, ldz):
+    """Generalised symmetric-definite problem A x = lambda B x (src/KMATH_EIGEN_GEV.F:1-64): two eigen_s solves and
+    three GEMMs.  Upper triangles of ``a``, ``b`` significant; ``w`` ascending, ``z`` B-orthonormal; ``a`` and ``b``
+    are destroyed.  If B is not positive definite a message is printed and the call returns (status -7)."""
+    lib = _lib.load()
+    if not _state["initialized"]:
+        _state["last_status"] = -1
+        return
+    dev = _is_torch(a)
+    if dev:
+        import torch
+
+        torch.cuda.current_stream().synchronize()
+    pa, pb, pw, pz = _ptr(a, "a", dev), _ptr(b, "b", dev), _ptr(w, "w", dev), _ptr(z, "z", dev)
+    fn = lib.eigx_gev_dev if dev else lib.eigx_gev
+    rc = fn(int(n), pa, int(lda), pb, int(ldb), pw, pz, int(ldz))
+    _state["last_status"] = rc
+    if rc not in (0, -7):
+        print(f"Warning: KMATH_EIGEN_GEV returned without computing (status {rc})", file=sys.stderr)

@@ -278,6 +278,82 @@ int solve_host(Context& ctx, int n, int nvec, double* a, int lda, double* w, dou
   return EIGX_OK;
 }
 
+// ---- KMATH_EIGEN_GEV: generalised symmetric-definite problem A x = lambda B x -----------------------------
+// lower triangle := upper triangle (the GEMMs below need the full symmetric A; trpos_utol of the reference,
+// src/KMATH_EIGEN_GEV_misc.F:140-173)
+__global__ void symmetrize_kernel(double* __restrict__ a, int lda, int n) {
+  const int j = blockIdx.y;
+  for (int i = j + 1 + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    a[(size_t)j * lda + i] = a[(size_t)i * lda + j];
+}
+
+// b(:, j) = z(:, j) * w(j)^(-1/2)   (diag_mult, src/KMATH_EIGEN_GEV_misc.F:49-104)
+__global__ void scale_cols_rsqrt_kernel(const double* __restrict__ z, int ldz, const double* __restrict__ w,
+                                        double* __restrict__ b, int ldb, int n) {
+  const int j = blockIdx.y;
+  const double s = 1.0 / sqrt(w[j]);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    b[(size_t)j * ldb + i] = z[(size_t)j * ldz + i] * s;
+}
+
+// Same sequence as KMATH_EIGEN_GEV_1 (src/KMATH_EIGEN_GEV_1.F:57-139): eigen_s(B, 'X') -> B^(-1/2) := Z_B W_B^(-1/2);
+// A' = B^(-1/2)^T A B^(-1/2) by two GEMMs; eigen_s(A', 'X') -> w, Y; Z = B^(-1/2) Y (B-orthonormal).  On entry only
+// the upper triangles of a and b are significant; a, b are destroyed (a holds Y, b holds B^(-1/2) on exit, as in
+// the reference).  One GPU; all three products run on the fp64 MFMA GEMM.
+int gev_dev(Context& ctx, int n, double* a, int lda, double* b, int ldb, double* w, double* z, int ldz) {
+  if (!ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  if (ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;
+  if (n <= 0 || !a || !b || !w || !z || lda < n || ldb < n || ldz < n || ((lda | ldb | ldz) & 1)) return EIGX_ERR_BAD_ARG;
+  EIGX_HIP_CHECK(hipSetDevice(ctx.device));
+  hipStream_t st = ctx.stream;
+  const double t0 = now_s();
+  hipLaunchKernelGGL(symmetrize_kernel, dim3(8, n), dim3(256), 0, st, a, lda, n);
+  int rc = solve_dev(ctx, n, n, b, ldb, w, z, ldz, 128, 128, 'X', 1);      // B = Z_B W_B Z_B^T
+  if (rc != EIGX_OK) return rc;
+  const double t1 = now_s();
+  double wmin = 0.0;
+  EIGX_HIP_CHECK(hipMemcpy(&wmin, w, 8, hipMemcpyDeviceToHost));
+  if (!(wmin > 0.0)) {
+    fprintf(stderr, "[eigx] Matrix B is not positive definite!\n");            // src/KMATH_EIGEN_GEV_1.F:75-80
+    return EIGX_ERR_NOT_SPD;
+  }
+  hipLaunchKernelGGL(scale_cols_rsqrt_kernel, dim3(8, n), dim3(256), 0, st, z, ldz, w, b, ldb, n);
+  const int ldc = pad_ld(n);
+  double* c = ctx.pool.get_t<double>("gev.c", (size_t)ldc * n);
+  dgemm_dev(st, 'N', 'N', n, n, n, 1.0, a, lda, b, ldb, 0.0, c, ldc);          // C  = A B^(-1/2)
+  dgemm_dev(st, 'T', 'N', n, n, n, 1.0, b, ldb, c, ldc, 0.0, z, ldz);          // A' = B^(-1/2)^T C
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  const double t2 = now_s();
+  rc = solve_dev(ctx, n, n, z, ldz, w, a, lda, 128, 128, 'X', 1);            // A' = Y W Y^T, Y in a
+  if (rc != EIGX_OK) return rc;
+  const double t3 = now_s();
+  dgemm_dev(st, 'N', 'N', n, n, n, 1.0, b, ldb, a, lda, 0.0, z, ldz);          // Z = B^(-1/2) Y
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  const double t4 = now_s();
+  ctx.timers[0] = t4 - t0; ctx.timers[1] = t1 - t0; ctx.timers[2] = t2 - t1; ctx.timers[3] = t3 - t2; ctx.timers[4] = t4 - t3;
+  return EIGX_OK;
+}
+
+int gev_host(Context& ctx, int n, double* a, int lda, double* b, int ldb, double* w, double* z, int ldz) {
+  if (!ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  if (n <= 0 || !a || !b || !w || !z || lda < n || ldb < n || ldz < n) return EIGX_ERR_BAD_ARG;
+  EIGX_HIP_CHECK(hipSetDevice(ctx.device));
+  const int ldd = pad_ld(n + 2);
+  double* ad = ctx.pool.get_t<double>("host.a", (size_t)ldd * n);
+  double* zd = ctx.pool.get_t<double>("host.z", (size_t)ldd * n);
+  double* bd = ctx.pool.get_t<double>("host.b", (size_t)ldd * n);
+  double* wd = ctx.pool.get_t<double>("host.w", (size_t)n);
+  EIGX_HIP_CHECK(hipMemcpy2D(ad, (size_t)ldd * 8, a, (size_t)lda * 8, (size_t)n * 8, (size_t)n, hipMemcpyHostToDevice));
+  EIGX_HIP_CHECK(hipMemcpy2D(bd, (size_t)ldd * 8, b, (size_t)ldb * 8, (size_t)n * 8, (size_t)n, hipMemcpyHostToDevice));
+  const int rc = gev_dev(ctx, n, ad, ldd, bd, ldd, wd, zd, ldd);
+  if (rc != EIGX_OK) return rc;
+  EIGX_HIP_CHECK(hipMemcpy(w, wd, (size_t)n * 8, hipMemcpyDeviceToHost));
+  EIGX_HIP_CHECK(hipMemcpy2D(z, (size_t)ldz * 8, zd, (size_t)ldd * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToHost));
+  EIGX_HIP_CHECK(hipMemcpy2D(a, (size_t)lda * 8, ad, (size_t)ldd * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToHost));
+  EIGX_HIP_CHECK(hipMemcpy2D(b, (size_t)ldb * 8, bd, (size_t)ldd * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToHost));
+  return EIGX_OK;
+}
+
 }  // namespace
 
 int64_t solver_workspace_bytes(const Context&, int n, int lda, int ldz, int mf, int mb) {
@@ -326,6 +402,13 @@ int eigx_band_dc_dev(int n, int nvec, const double* d, const double* e, int lde,
   if (g_ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;
   band_dc_dev(g_ctx, n, nvec, d, e, lde, band, w, z, ldz);
   return EIGX_OK;
+}
+
+int eigx_gev(int n, double* a, int lda, double* b, int ldb, double* w, double* z, int ldz) {
+  return gev_host(g_ctx, n, a, lda, b, ldb, w, z, ldz);
+}
+int eigx_gev_dev(int n, double* a, int lda, double* b, int ldb, double* w, double* z, int ldz) {
+  return gev_dev(g_ctx, n, a, lda, b, ldb, w, z, ldz);
 }
 
 int eigx_band_bisect_dev(int n, const double* d, const double* e, int lde, int band, double* w) {

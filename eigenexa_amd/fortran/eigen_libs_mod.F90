@@ -299,3 +299,23 @@ contains
   end subroutine eigen_s
 
 end module eigen_libs_mod
+
+
+! KMATH_EIGEN_GEV is an external subroutine in the reference (src/KMATH_EIGEN_GEV.F:1-64, not a module procedure):
+! generalised symmetric-definite problem A x = lambda B x.  Same argument list; one GPU.
+subroutine KMATH_EIGEN_GEV(n, a, lda, b, ldb, w, z, ldz)
+  use, intrinsic :: iso_c_binding
+  implicit none
+  integer, intent(inout) :: n, lda, ldb, ldz
+  real(8), intent(inout) :: a(lda, *), b(ldb, *)
+  real(8), intent(inout) :: w(*), z(ldz, *)
+  interface
+    integer(c_int) function eigx_gev(n, a, lda, b, ldb, w, z, ldz) bind(C, name="eigx_gev")
+      import :: c_int, c_double
+      integer(c_int), value :: n, lda, ldb, ldz
+      real(c_double), intent(inout) :: a(lda, *), b(ldb, *), w(*), z(ldz, *)
+    end function
+  end interface
+  integer(c_int) :: rc
+  rc = eigx_gev(int(n, c_int), a, int(lda, c_int), b, int(ldb, c_int), w, z, int(ldz, c_int))
+end subroutine KMATH_EIGEN_GEV

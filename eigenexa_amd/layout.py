@@ -106,7 +106,7 @@ def helmert(n):
 def spectrum(n, mtype, seed=7):
     """prescribed spectra of the reference's matrix types 4..9 (benchmark/mat_set.f:651-718):
     4: 0..n-1;  5: sin(5 pi i/(n-1) + eps^(1/4))^3;  6: mod(i,5)+mod(i,2) (heavily degenerate);
-    7: the Frank spectrum;  8: uniform [0,1);  9: normal(0,1).  Types 8/9 use the compiler RNG in the
+    7: the Frank spectrum;  8: uniform [0,1);  9: normal(0,1);  10: the file W.dat.  Types 8/9 use the compiler RNG in the
     reference (not reproducible elsewhere); here a seeded numpy generator."""
     i = np.arange(1, n + 1, dtype=np.float64)
     if mtype == 4:
@@ -117,6 +117,11 @@ def spectrum(n, mtype, seed=7):
         return np.mod(i, 5) + np.mod(i, 2)
     if mtype == 7:
         return frank_eigenvalues(n)
+    if mtype == 10:
+        # benchmark/W.dat (the spectrum file of the KMATH_EIGEN_GEV driver, benchmark/KMATH_EIGEN_GEV_main.f:57-58):
+        # its k-th entry is 10 + sin(k-1) printed with six significant digits (checked against all 100000 entries)
+        v = 10.0 + np.sin(i - 1.0)
+        return np.where(v >= 10.0, np.round(v, 4), np.round(v, 5))
     rng = np.random.default_rng(seed)
     if mtype == 8:
         return rng.random(n)

@@ -38,6 +38,7 @@ extern "C" {
 #define EIGX_ERR_NO_DEVICE (-4)
 #define EIGX_ERR_NONFINITE (-5)
 #define EIGX_ERR_INTERNAL (-6)
+#define EIGX_ERR_NOT_SPD (-7)
 
 /* ---- life cycle -------------------------------------------------------------------------- */
 
@@ -127,6 +128,14 @@ int eigx_band_reduce_dev(int n, double* a_dev, int lda, double* d_dev, double* e
  * the symmetric band matrix (d,e); w_dev ascending, z_dev(ldz, n) eigenvectors. */
 int eigx_band_dc_dev(int n, int nvec, const double* d_dev, const double* e_dev, int lde, int band,
                      double* w_dev, double* z_dev, int ldz);
+
+/* replaces KMATH_EIGEN_GEV(n,a,lda,b,ldb,w,z,ldz) src/KMATH_EIGEN_GEV.F:1-64 (-> KMATH_EIGEN_GEV_1.F:1-159): generalised
+ * symmetric-definite problem A x = lambda B x through two eigen_s solves and three GEMMs.  Upper triangles of a, b
+ * significant; w ascending; z B-orthonormal (z^T B z = I); a, b destroyed.  EIGX_ERR_NOT_SPD if B is not positive
+ * definite (the reference prints "Matrix B is not positive definite!" and returns).  Host / device-resident arrays;
+ * leading dimensions of the device form must be even.  One GPU. */
+int eigx_gev(int n, double* a, int lda, double* b, int ldb, double* w, double* z, int ldz);
+int eigx_gev_dev(int n, double* a_dev, int lda, double* b_dev, int ldb, double* w_dev, double* z_dev, int ldz);
 
 /* replaces eigen_bisect(d,e,w,n,mode) src/bisect.F:67-397 (band=1) / eigen_bisect2(d,e,f,w,n,mode)
  * src/bisect2.F:71-718 (band=2): all eigenvalues of the band matrix by Sturm counts, w_dev ascending.

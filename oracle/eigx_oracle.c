@@ -762,3 +762,44 @@ int orc_eigen_sx(int n, int nvec, double* a, int lda, double* w, double* z, int 
 int orc_eigen_s(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, char mode, double* times3) {
   return orc_eigen(n, nvec, a, lda, w, z, ldz, mode, 1, times3);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * KMATH_EIGEN_GEV (src/KMATH_EIGEN_GEV.F:1-64 -> src/KMATH_EIGEN_GEV_1.F:57-139): A x = lambda B x, B positive
+ * definite.  eigen_s(B,'X') -> B^(-1/2) := Z_B W_B^(-1/2) ; A' = B^(-1/2)^T A B^(-1/2) ; eigen_s(A','X') -> w, Y ;
+ * Z = B^(-1/2) Y.  Upper triangles of a, b significant; a (-> Y) and b (-> B^(-1/2)) are destroyed.  Returns 2 if B
+ * is not positive definite.  Plain triple loops for the products.
+ * ------------------------------------------------------------------------------------------------ */
+int orc_gev(int n, double* a, int lda, double* b, int ldb, double* w, double* z, int ldz) {
+  if (n <= 0 || lda < n || ldb < n || ldz < n) return -1;
+#define M_(p, ld, i, j) (p)[(size_t)(i) + (size_t)(j) * (ld)]
+  for (int j = 0; j < n; ++j) for (int i = j + 1; i < n; ++i) M_(a, lda, i, j) = M_(a, lda, j, i);
+  double* keep = (double*)malloc((size_t)n * n * sizeof(double));   /* A survives eigen_s(B) untouched; B is destroyed */
+  int rc = orc_eigen(n, n, b, ldb, w, z, ldz, 'X', 1, NULL);
+  if (rc != 0) { free(keep); return rc; }
+  if (!(w[0] > 0.0)) { free(keep); return 2; }
+  for (int j = 0; j < n; ++j) { const double sc = 1.0 / sqrt(w[j]); for (int i = 0; i < n; ++i) M_(b, ldb, i, j) = M_(z, ldz, i, j) * sc; }
+  /* C = A Bh (keep) ; A' = Bh^T C (z) */
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) {
+      double acc = 0.0;
+      for (int k = 0; k < n; ++k) acc += M_(a, lda, i, k) * M_(b, ldb, k, j);
+      keep[(size_t)i + (size_t)j * n] = acc;
+    }
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) {
+      double acc = 0.0;
+      for (int k = 0; k < n; ++k) acc += M_(b, ldb, k, i) * keep[(size_t)k + (size_t)j * n];
+      M_(z, ldz, i, j) = acc;
+    }
+  rc = orc_eigen(n, n, z, ldz, w, a, lda, 'X', 1, NULL);
+  if (rc != 0) { free(keep); return rc; }
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) {
+      double acc = 0.0;
+      for (int k = 0; k < n; ++k) acc += M_(b, ldb, i, k) * M_(a, lda, k, j);
+      M_(z, ldz, i, j) = acc;
+    }
+  free(keep);
+#undef M_
+  return 0;
+}

@@ -28,6 +28,7 @@ def load():
         lib.orc_band_reduce.argtypes = [C.c_int, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int]
         lib.orc_band_dc.argtypes = [C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]
         lib.orc_band_bisect.argtypes = [C.c_int, _dp, _dp, C.c_int, C.c_int, _dp]
+        lib.orc_gev.argtypes = [C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, _dp, C.c_int]
         lib.orc_trbak.argtypes = [C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int]
         _lib = lib
     return _lib
@@ -88,3 +89,19 @@ def band_bisect(d, e, band):
     if rc != 0:
         raise RuntimeError(f"oracle band_bisect rc={rc}")
     return w
+
+
+def gev(A, B):
+    """KMATH_EIGEN_GEV restatement: returns (w, Z) of A x = lambda B x (Z is B-orthonormal); raises if B is not SPD."""
+    lib = load()
+    n = A.shape[0]
+    a = np.asfortranarray(A, dtype=np.float64).copy(order="F")
+    b = np.asfortranarray(B, dtype=np.float64).copy(order="F")
+    w = np.zeros(n)
+    z = np.zeros((n, n), order="F")
+    rc = lib.orc_gev(n, _p(a), n, _p(b), n, _p(w), _p(z), n)
+    if rc == 2:
+        raise ValueError("Matrix B is not positive definite!")
+    if rc != 0:
+        raise RuntimeError(f"oracle gev rc={rc}")
+    return w, z

@@ -593,3 +593,55 @@ def test_benchmark_driver_check_sweep(gpu_lib, tmp_path):
             bad.append((case, r))
     assert not bad, (bad[:3], log[-30:])
     assert sum("Residual Error Test ***   : PASSED" in m for m in log) >= 4 * len(sizes)
+
+
+# ------------------------------------------------------------------ KMATH_EIGEN_GEV
+@pytest.mark.parametrize("n", [1, 2, 5, 130, 517])
+def test_gev_matches_oracle(gpu_lib, orc, n):
+    """A x = lambda B x on the reference GEV driver's matrices (A random, B Helmert/W.dat), host API like the
+    Fortran subroutine; eigenvalues against the oracle, |AX-BXW|_F and |X^T B X - I|_F as in
+    benchmark/KMATH_EIGEN_GEV_check.f"""
+    import eigenexa_amd as ee
+    from eigenexa_amd import api, layout
+
+    A = layout.random_symmetric(n, seed=3)
+    B = layout.helmert_spectrum_matrix(n, 10)[0] if n > 1 else np.array([[10.0]])
+    wo, _ = orc.gev(A, B)
+    a = np.asfortranarray(np.triu(A))
+    b = np.asfortranarray(np.triu(B))
+    z = np.zeros((n, n), order="F")
+    w = np.zeros(n)
+    ee.KMATH_EIGEN_GEV(n, a, n, b, n, w, z, n)
+    assert api.last_status() == 0
+    scale = max(1.0, np.abs(wo).max())
+    assert np.abs(w - wo).max() < 1e-12 * scale
+    assert np.linalg.norm(A @ z - B @ z * w) < 1e-12 * scale * n
+    assert np.linalg.norm(z.T @ B @ z - np.eye(n)) < 1e-12 * n
+
+
+def test_gev_device_api_and_indefinite_b(gpu_lib):
+    import torch
+    import eigenexa_amd as ee
+    from eigenexa_amd import api, layout
+
+    n = 1200
+    A = layout.random_symmetric(n, seed=5)
+    B = layout.helmert_spectrum_matrix(n, 10)[0]
+    ld = n + 2
+    dev = _dev()
+    a = torch.zeros(n, ld, dtype=torch.float64, device=dev); a[:, :n] = torch.from_numpy(np.triu(A).T.copy()).to(dev)
+    b = torch.zeros(n, ld, dtype=torch.float64, device=dev); b[:, :n] = torch.from_numpy(np.triu(B).T.copy()).to(dev)
+    z = torch.zeros(n, ld, dtype=torch.float64, device=dev)
+    w = torch.zeros(n, dtype=torch.float64, device=dev)
+    ee.KMATH_EIGEN_GEV(n, a, ld, b, ld, w, z, ld)
+    assert api.last_status() == 0
+    Z = z[:, :n].T.cpu().numpy()
+    wg = w.cpu().numpy()
+    scale = np.abs(wg).max()
+    assert np.linalg.norm(A @ Z - B @ Z * wg) < 1e-12 * scale * n
+    assert np.linalg.norm(Z.T @ B @ Z - np.eye(n)) < 1e-12 * n
+    # B indefinite: message + status, no result
+    Bi = layout.random_symmetric(50, seed=4) - 1.0
+    a2 = np.asfortranarray(layout.random_symmetric(50, seed=3)); b2 = np.asfortranarray(Bi)
+    ee.KMATH_EIGEN_GEV(50, a2, 50, b2, 50, np.zeros(50), np.zeros((50, 50), order="F"), 50)
+    assert api.last_status() == -7

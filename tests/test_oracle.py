@@ -237,3 +237,35 @@ def test_modes(orc, route):
             assert np.array_equal(Z, np.eye(n))
         if mode in "TR":
             assert np.abs(Z.T @ Z - np.eye(n)).max() < 1e-12
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 40, 150])
+def test_gev_vs_scipy(orc, n):
+    """KMATH_EIGEN_GEV restatement (two eigen_s solves + three products) against LAPACK's generalised solver, on the
+    matrices of the reference's GEV driver: A random (type 2), B = Helmert matrix with the W.dat spectrum (type 10),
+    benchmark/KMATH_EIGEN_GEV_main.f:57-58; checks of benchmark/KMATH_EIGEN_GEV_check.f: |AX-BXW|_F, |X^T B X - I|_F"""
+    import scipy.linalg as sl
+
+    A = layout.random_symmetric(n, seed=3)
+    B = layout.helmert_spectrum_matrix(n, 10)[0] if n > 1 else np.array([[10.0]])
+    w, Z = orc.gev(A, B)
+    wr = sl.eigh(A, B, eigvals_only=True)
+    scale = max(1.0, np.abs(wr).max())
+    assert np.abs(w - wr).max() < 1e-12 * scale
+    assert np.linalg.norm(A @ Z - B @ Z * w) < 1e-12 * scale * n
+    assert np.linalg.norm(Z.T @ B @ Z - np.eye(n)) < 1e-12 * n
+
+
+def test_gev_rejects_indefinite_b(orc):
+    """src/KMATH_EIGEN_GEV_1.F:75-80: 'Matrix B is not positive definite!'"""
+    n = 20
+    A = layout.random_symmetric(n, seed=3)
+    B = layout.random_symmetric(n, seed=4) - 1.0   # indefinite
+    with pytest.raises(ValueError):
+        orc.gev(A, B)
+
+
+def test_w_dat_formula():
+    """spectrum type 10 = the reference's benchmark/W.dat, reproduced by formula (first entries of the file)"""
+    w = layout.spectrum(8, 10)
+    assert np.array_equal(w, np.array([10.0, 10.8415, 10.9093, 10.1411, 9.2432, 9.04108, 9.72058, 10.657]))
