@@ -39,10 +39,12 @@ namespace {
 // rows per panel-dot chunk: at most 4 chunks (K_A re-reduces them in one batch of loads), at least 512 rows
 static inline int pd_rows_for(int toprows) { int r = ((toprows + 3) / 4 + 63) / 64 * 64; return r < 512 ? 512 : r; }
 #ifdef EIGX_STAMPS
+#define EIGX_ABL(bit) (R.abl & (bit))
 #define EIGX_STAMP(slot) do { if (R.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) { \
   const unsigned long long _t = __builtin_amdgcn_s_memtime(); atomicAdd(&R.dbg[slot], _t - stamp_prev); stamp_prev = _t; } } while (0)
 #define EIGX_STAMP_INIT unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
 #else
+#define EIGX_ABL(bit) false
 #define EIGX_STAMP(slot) do {} while (0)
 #define EIGX_STAMP_INIT
 #endif
@@ -69,6 +71,7 @@ struct RedArgs {
   // allreduced over the ranks once per step.
   int P, p;
   double* RB;
+  int abl;                        // EIGX_STAMPS diagnostic build only: ablation mask (timing experiments)
   unsigned long long* dbg;        // EIGX_STAMPS diagnostic build only: accumulated s_memtime stamps
 };
 
@@ -101,9 +104,25 @@ __device__ __forceinline__ double2 ld2(const double* p) {
   return make_double2(v.x, v.y);
 }
 
+// v + (v of the lane selected by a DPP control): a VALU data-parallel-primitive move, no LDS crossbar round trip
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return v + __hiloint2double(hi2, lo2);
+}
+
+// sum over the 64 lanes, result in every lane, fixed order.  Within a row of 16 lanes by DPP (quad_perm [1,0,3,2],
+// quad_perm [2,3,0,1], row_half_mirror, row_mirror: ~4 x 2 VALU moves), across the four rows by two shuffles --
+// 2 instead of 6 dependent ds_bpermute round trips per value on these latency-bound kernels.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  v = dpp_add<0x140>(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 
@@ -198,7 +217,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
     const int rc = rowok ? r : 0;
 #pragma unroll
     for (int j = 0; j < KB; ++j) {
-      if (j * KA_SL < kloop) {            // uniform
+      if (j * KA_SL < kloop && !(EIGX_ABL(8))) {            // uniform
         const int kk = (ks + j * KA_SL < kloop) ? ks + j * KA_SL : 0;
         tu[j] = Up[(size_t)kk * ldp + rc];
         tw[j] = Wp[(size_t)kk * ldp + rc];
@@ -232,7 +251,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       const int ty = rc >> lgT;
 #pragma unroll
       for (int j = 0; j < RPB; ++j) {
-        if (j * KA_SL < nt + 1) {          // uniform
+        if (j * KA_SL < nt + 1 && !(EIGX_ABL(4))) {          // uniform
           const int tt = ks + j * KA_SL;
           const int t = (tt < nt + 1) ? tt : 0;
           const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
@@ -246,7 +265,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       const int kk = (tid < kp) ? tid : 0;
 #pragma unroll
       for (int j = 0; j < CHB; ++j) {
-        if (j < S.nchunk_prev) {           // uniform
+        if (j < S.nchunk_prev && !(EIGX_ABL(2))) {           // uniform
 #pragma unroll
           for (int q = 0; q < 2 * NB; ++q) kdl[q][j] = R.KD[((size_t)j * 2 * NB + q) * m + kk];
         }
@@ -259,7 +278,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
 #pragma unroll
       for (int j = 0; j < SPB; ++j) {
         const int f = wave + 4 * j;
-        if (2 * f < nt) {                  // uniform per wave
+        if (2 * f < nt && !(EIGX_ABL(1))) {                  // uniform per wave
           const int cnt = nt - f;          // tiles in row f
           const int f2 = nt - 1 - f;       // partner row (== f for the middle row of an odd nt: skipped)
           int ty = f, tx = f + lane;
@@ -289,6 +308,9 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   // ---- everything is in flight; now consume -----------------------------------------------------------
   double v[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [0..2] SP, [3..5] corrections, [6] uA.uB, [7..10] P(c,a)
   double prA = 0.0, prB = 0.0;                   // my share of this row's SYMV partial sums
+  // the two reciprocals of the 2x2 algebra only need the betas: start them here, off the post-reduction chain
+  const double tAA = (hp && bA != 0.0) ? 1.0 / bA : 0.0;
+  const double tBB = (hp && bB != 0.0) ? 1.0 / bB : 0.0;
   if (hp) {
     if (mg) {
       if (ks == 0 && rowp) { prA = R.RB[r]; if (NB == 2) prB = R.RB[Lp + r]; }
@@ -376,11 +398,12 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
         if (NB == 2) v[8 + 2 * cc] -= ru[cc] * kdr[3] + rw[cc] * kdr[2];
       }
     }
-    block_sum_multi<11>(v, red);     // (its first barrier also publishes kd / rowU / rowW)
+    // G = (bilinear partials) - (panel corrections) needs only the differences: 8 values to reduce, not 11
+    double rv[8] = {v[0] - v[3], v[1] - v[4], v[2] - v[5], v[6], v[7], v[8], v[9], v[10]};
+    block_sum_multi<8>(rv, red);     // (its first barrier also publishes kd / rowU / rowW)
+    v[7] = rv[4]; v[8] = rv[5]; v[9] = rv[6]; v[10] = rv[7];
     // the 2x2 algebra in every thread (no broadcast, no extra barrier)
-    const double gAA = v[0] - v[3], gAB = v[1] - v[4], gBB = v[2] - v[5], uab = v[6];
-    const double tAA = bA != 0.0 ? 1.0 / bA : 0.0;
-    const double tBB = bB != 0.0 ? 1.0 / bB : 0.0;
+    const double gAA = rv[0], gAB = rv[1], gBB = rv[2], uab = rv[3];
     const double tAB = -uab * tAA * tBB;
     // GT = G T ; M = T^T GT
     const double gt11 = gAA * tAA, gt12 = gAA * tAB + gAB * tBB;
@@ -626,7 +649,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   const int pivA = L - 1, pivB = L - 2;
   {
     double gv[3] = {0.0, 0.0, 0.0};
-    for (int q0 = tid; q0 < B.ngp; q0 += 512) {   // one batch up to 512 K_A workgroups (N <= 8192)
+    for (int q0 = tid; q0 < (EIGX_ABL(16) ? 1 : B.ngp); q0 += 512) {   // one batch up to 512 K_A workgroups (N <= 8192)
       double t[2][3];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -1004,6 +1027,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   R.sc = ctx.pool.get_t<double>("red.sc", SC_COUNT);
   R.RB = ctx.pool.get_t<double>("red.RB", (size_t)NB * (n + 8) + 16);
   R.dbg = nullptr;
+  R.abl = getenv("EIGX_ABL") ? atoi(getenv("EIGX_ABL")) : 0;
 #ifdef EIGX_STAMPS
   R.dbg = ctx.pool.get_t<unsigned long long>("red.dbg", 32);
   EIGX_HIP_CHECK(hipMemsetAsync(R.dbg, 0, 32 * sizeof(unsigned long long), st));
