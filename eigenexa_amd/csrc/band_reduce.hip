@@ -113,6 +113,13 @@ __device__ __forceinline__ double dpp_add(double v) {
   return v + __hiloint2double(hi2, lo2);
 }
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo2 = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi2, lo2);
+}
+
 // sum over the 64 lanes, result in every lane, fixed order.  Within a row of 16 lanes by DPP (quad_perm [1,0,3,2],
 // quad_perm [2,3,0,1], row_half_mirror, row_mirror: ~4 x 2 VALU moves), across the four rows by two shuffles --
 // 2 instead of 6 dependent ds_bpermute round trips per value on these latency-bound kernels.
@@ -899,11 +906,12 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
         {
           const double keep = hi8 ? v2[1] : v2[0];
           const double send = hi8 ? v2[0] : v2[1];
-          v1 = keep + __shfl_xor(send, 8, 64);
+          v1 = keep + dpp_mov<0x128>(send);     // row_ror:8 = lane ^ 8 within the row of 16
         }
-        v1 += __shfl_xor(v1, 4, 64);
-        v1 += __shfl_xor(v1, 2, 64);
-        v1 += __shfl_xor(v1, 1, 64);
+        // the 8 lanes of a group all end up with the group's total (quad_perm x2, row_half_mirror): VALU only
+        v1 = dpp_add<0xB1>(v1);
+        v1 = dpp_add<0x4E>(v1);
+        v1 = dpp_add<0x141>(v1);
         fin[a] = v1;
       }
       // lane with (lane&7)==0 holds column j = 4*bit5 + 2*bit4 + bit3 : complete over the tile's rows
