@@ -120,16 +120,31 @@ __device__ __forceinline__ double dpp_mov(double v) {
   return __hiloint2double(hi2, lo2);
 }
 
+// gfx950 lane-swap adds (v_permlane32_swap / v_permlane16_swap, VALU): with a' / b' the two registers after the swap,
+//   swapadd32(a, b): lanes  0..31 get a[i] + a[i+32],  lanes 32..63 get b[i-32] + b[i]
+//   swapadd16(a, b): even rows of 16 lanes get a[row] + a[row+1], odd rows get b[row-1] + b[row]
+// i.e. one stage of a halving butterfly on two values, or with a == b the xor-32 / xor-16 stage of an all-reduce.
+__device__ __forceinline__ double swapadd32(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double swapadd16(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
 // sum over the 64 lanes, result in every lane, fixed order.  Within a row of 16 lanes by DPP (quad_perm [1,0,3,2],
-// quad_perm [2,3,0,1], row_half_mirror, row_mirror: ~4 x 2 VALU moves), across the four rows by two shuffles --
-// 2 instead of 6 dependent ds_bpermute round trips per value on these latency-bound kernels.
+// quad_perm [2,3,0,1], row_half_mirror, row_mirror), across the four rows by the gfx950 lane swaps: VALU only,
+// instead of 6 dependent ds_bpermute (LDS crossbar) round trips per value on these latency-bound kernels.
 __device__ __forceinline__ double wave_sum(double v) {
   v = dpp_add<0xB1>(v);
   v = dpp_add<0x4E>(v);
   v = dpp_add<0x141>(v);
   v = dpp_add<0x140>(v);
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
+  v = swapadd16(v, v);
+  v = swapadd32(v, v);
   return v;
 }
 
@@ -890,19 +905,11 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
 #pragma unroll
       for (int a = 0; a < NV; ++a) {
         double v4[4], v2[2], v1;
-        const bool hi32 = lane & 32, hi16 = lane & 16, hi8 = lane & 8;
+        const bool hi8 = lane & 8;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const double keep = hi32 ? yc[a][j + 4] : yc[a][j];
-          const double send = hi32 ? yc[a][j] : yc[a][j + 4];
-          v4[j] = keep + __shfl_xor(send, 32, 64);
-        }
+        for (int j = 0; j < 4; ++j) v4[j] = swapadd32(yc[a][j], yc[a][j + 4]);   // lanes < 32 keep column j, the others j+4
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const double keep = hi16 ? v4[j + 2] : v4[j];
-          const double send = hi16 ? v4[j] : v4[j + 2];
-          v2[j] = keep + __shfl_xor(send, 16, 64);
-        }
+        for (int j = 0; j < 2; ++j) v2[j] = swapadd16(v4[j], v4[j + 2]);         // even rows keep j, odd rows j+2
         {
           const double keep = hi8 ? v2[1] : v2[0];
           const double send = hi8 ? v2[0] : v2[1];
