@@ -622,6 +622,21 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   const int row0 = ty * T, col0 = tx * T;
   EIGX_STAMP_INIT
   const int wcol0 = wave * (T / 4);       // first tile column of this wave
+  // Loads that feed the reflector scalars go FIRST (vmcnt retires in order: behind the A-tile loads below they
+  // would make the scalar phase wait for HBM); the empty asm keeps the compiler from sinking them.
+  const int pivA = L - 1, pivB = L - 2;
+  double gpt[2][3];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = (tid + 256 * j < B.ngp) ? tid + 256 * j : 0;
+    gpt[j][0] = R.GP[3 * q];
+    if (NV == 2) { gpt[j][1] = R.GP[3 * q + 1]; gpt[j][2] = R.GP[3 * q + 2]; }
+  }
+  const double x0L = R.X[L - 1];
+  const double x1L = (NV == 2) ? R.X[ldp + L - 1] : 0.0;
+  const double x1P = (NV == 2 && pivB >= 0) ? R.X[ldp + pivB] : 0.0;
+  const double x0P = (NV == 2 && pivB >= 0) ? R.X[pivB] : 0.0;
+  asm volatile("" ::: "memory");
   double craw[NV][(T + 255) / 256];       // raw x at the tile's columns (thread t -> column t, t+256)
   double rraw[NV][RB][2];                 // raw x at this lane's rows
   double2 av0[8], av1[8];
@@ -668,28 +683,18 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   // (more than 3/4 of the column's weight in the pivot row) the sum is taken explicitly instead -- same
   // order in every workgroup, so the replicas stay bit-identical either way.
   double sA, sB = 0.0, betaA, betaB = 0.0, gammaB = 0.0, eL1 = 0.0;
-  const int pivA = L - 1, pivB = L - 2;
   {
     double gv[3] = {0.0, 0.0, 0.0};
-    for (int q0 = tid; q0 < (EIGX_ABL(16) ? 1 : B.ngp); q0 += 512) {   // one batch up to 512 K_A workgroups (N <= 8192)
-      double t[2][3];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int q = (q0 + 256 * j < B.ngp) ? q0 + 256 * j : 0;
-        t[j][0] = R.GP[3 * q];
-        if (NV == 2) { t[j][1] = R.GP[3 * q + 1]; t[j][2] = R.GP[3 * q + 2]; }
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const bool ok = q0 + 256 * j < B.ngp;
-        gv[0] += ok ? t[j][0] : 0.0;
-        if (NV == 2) { gv[1] += ok ? t[j][1] : 0.0; gv[2] += ok ? t[j][2] : 0.0; }
-      }
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = tid + 256 * j < B.ngp;
+      gv[0] += ok ? gpt[j][0] : 0.0;
+      if (NV == 2) { gv[1] += ok ? gpt[j][1] : 0.0; gv[2] += ok ? gpt[j][2] : 0.0; }
     }
-    const double x0L = R.X[L - 1];
-    const double x1L = (NV == 2) ? R.X[ldp + L - 1] : 0.0;
-    const double x1P = (NV == 2 && pivB >= 0) ? R.X[ldp + pivB] : 0.0;
-    const double x0P = (NV == 2 && pivB >= 0) ? R.X[pivB] : 0.0;
+    for (int q = tid + 512; q < B.ngp; q += 256) {   // more than 512 K_A workgroups (N > 8192)
+      gv[0] += R.GP[3 * q];
+      if (NV == 2) { gv[1] += R.GP[3 * q + 1]; gv[2] += R.GP[3 * q + 2]; }
+    }
     block_sum_multi<3>(gv, red);
     if (gv[0] > 0.0) { sA = -sign_of(sqrt(gv[0]), x0L); betaA = gv[0] - sA * x0L; }
     else { sA = x0L; betaA = 0.0; }
