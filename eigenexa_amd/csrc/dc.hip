@@ -226,10 +226,19 @@ __global__ void unpack_rows_kernel(const double* __restrict__ in, int n, int rp,
 // combined with an xor butterfly (bit-identical in all 8 lanes, so the group branches uniformly).
 // Writes lambda_j to Dn[off+j] and S'(j,i) = d_i - lambda_j (root index contiguous).
 // ================================================================================================
+template <int CTRL>
+__device__ __forceinline__ double dc_dpp_add(double v) {
+  const int lo2 = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return v + __hiloint2double(hi2, lo2);
+}
+
 __device__ __forceinline__ double group8_sum(double v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
+  // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror: the 8 lanes of a group by VALU DPP moves instead of
+  // three dependent LDS-crossbar shuffles (this kernel is a latency chain: five such sums per secular iteration)
+  v = dc_dpp_add<0xB1>(v);
+  v = dc_dpp_add<0x4E>(v);
+  v = dc_dpp_add<0x141>(v);
   return v;
 }
 
