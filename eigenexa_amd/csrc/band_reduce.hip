@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   if (S.ncols > 0) {
     for (int cc = 0; cc < S.ncols; ++cc) {
       const int c = S.i - cc;
-      if (tid < S.k) {
+      if (tid < S.k && !(EIGX_ABL(32))) {
         ru[cc] = Up[(size_t)tid * ldp + c];
         rw[cc] = (tid < kold) ? Wp[(size_t)tid * ldp + c] : 0.0;
       }
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
     }
     if (NB == 2) abl = R.KD[R.kdab_off + (tid < S.nchunk_prev ? tid : 0)];
     // P(c, a): rows c of the previous step's SYMV result for the new block columns
-    if (!mg) {
+    if (!mg && !(EIGX_ABL(64))) {
       for (int cc = 0; cc < S.ncols; ++cc) {
         const int c = S.i - cc;
         const int ty = c >> lgT;
