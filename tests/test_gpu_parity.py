@@ -645,3 +645,34 @@ def test_gev_device_api_and_indefinite_b(gpu_lib):
     a2 = np.asfortranarray(layout.random_symmetric(50, seed=3)); b2 = np.asfortranarray(Bi)
     ee.KMATH_EIGEN_GEV(50, a2, 50, b2, 50, np.zeros(50), np.zeros((50, 50), order="F"), 50)
     assert api.last_status() == -7
+
+
+def test_large_n_eigenvalues_only_invariants(gpu_lib):
+    """mode 'N' (reduction + bisection, no eigenvectors) at N = 16384 -- the single-GPU stand-in for BASELINE.json
+    configs[4] (N = 65536 runs the same code in 43 s, tools/gpu_big_n.py): size-independent invariants
+    sum(w) = trace(A), ||w||_2 = ||A||_F, sortedness"""
+    import torch
+    from eigenexa_amd import layout
+
+    n = 16384
+    dev = _dev()
+    lda = n + 34
+    a = torch.empty(n, lda, dtype=torch.float64, device=dev)
+    a[:, n:] = 0.0
+    tr = 0.0
+    fro2 = 0.0
+    for c0 in range(0, n, 4096):
+        cols = np.arange(c0, c0 + 4096)
+        blk = layout.random_symmetric_torch(n, dev, rows=np.arange(n), cols=cols)
+        a[c0:c0 + 4096, :n] = blk.T
+        fro2 += float((blk * blk).sum().item())
+        tr += float(torch.diagonal(blk[c0:c0 + 4096, :]).sum().item())
+        del blk
+    w = torch.zeros(n, dtype=torch.float64, device=dev)
+    z = torch.zeros(8, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    assert gpu_lib.eigx_sx_dev(n, 0, a.data_ptr(), lda, w.data_ptr(), z.data_ptr(), lda, 128, 128, b"N") == 0
+    wh = w.cpu().numpy()
+    assert (np.diff(wh) >= 0).all()
+    assert abs(wh.sum() - tr) / np.sqrt(fro2) < 1e-12 * np.sqrt(n)
+    assert abs(np.sqrt((wh * wh).sum()) - np.sqrt(fro2)) / np.sqrt(fro2) < 1e-12
