@@ -87,7 +87,17 @@ def main():
     mg_note = ""
     if not replicas:
         try:
-            ee.eigen_init(comm=True, device=dev.index)   # RCCL world communicator from a broadcast unique id
+            init_ok = 1.0
+            try:
+                ee.eigen_init(comm=True, device=dev.index)   # RCCL world communicator from a broadcast unique id
+            except Exception as exc_init:
+                print(f"[bench] rank {rank}: eigen_init failed: {exc_init}", file=sys.stderr, flush=True)
+                init_ok = 0.0
+            # every rank must take the same branch: agree on the outcome before any library collective runs
+            flag = torch.tensor([init_ok], dtype=torch.float64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if flag.item() != 1.0:
+                raise RuntimeError("eigen_init failed on at least one rank")
             procs, Px, Py = ee.eigen_get_procs()
             _, xi, yi = ee.eigen_get_id()
             px, py = xi - 1, yi - 1

@@ -92,7 +92,8 @@ bool comm_uses_callbacks(const Context& ctx) { return ctx.comm && ctx.comm->call
 int comm_get_unique_id(void* out128) {
   if (!out128) return EIGX_ERR_BAD_ARG;
   if (!load_rccl()) return EIGX_ERR_INTERNAL;
-  EIGX_NCCL_CHECK(api.GetUniqueId(out128));
+  const int rc_id = api.GetUniqueId(out128);
+  if (rc_id != 0) { fprintf(stderr, "[eigx] ncclGetUniqueId failed: %d\n", rc_id); return EIGX_ERR_INTERNAL; }
   return EIGX_OK;
 }
 
@@ -109,7 +110,13 @@ int comm_init(Context& ctx, const void* uid) {
   ncclUniqueIdBlob id;
   memcpy(id.internal, uid, 128);
   const Grid& g = ctx.grid;
-  EIGX_NCCL_CHECK(api.CommInitRank(&cs->world, g.nranks, id, g.rank));
+  // a failed communicator is reported, not fatal: bench.py then falls back to independent replicas
+  const int rc_init = api.CommInitRank(&cs->world, g.nranks, id, g.rank);
+  if (rc_init != 0) {
+    fprintf(stderr, "[eigx] ncclCommInitRank failed: %d (%s)\n", rc_init, api.GetErrorString ? api.GetErrorString(rc_init) : "?");
+    delete cs;
+    return EIGX_ERR_INTERNAL;
+  }
   // round 1 uses the world communicator only; X / Y groups are split on demand
   ctx.comm = cs;
   return EIGX_OK;
