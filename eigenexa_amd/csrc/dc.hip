@@ -233,6 +233,12 @@ __device__ __forceinline__ double dc_dpp_add(double v) {
   return v + __hiloint2double(hi2, lo2);
 }
 
+__device__ __forceinline__ double dc_swapadd16(double v) {   // v[row] + v[row ^ 1] over rows of 16 lanes (v_permlane16_swap)
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
 __device__ __forceinline__ double group8_sum(double v) {
   // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror: the 8 lanes of a group by VALU DPP moves instead of
   // three dependent LDS-crossbar shuffles (this kernel is a latency chain: five such sums per secular iteration)
@@ -242,15 +248,27 @@ __device__ __forceinline__ double group8_sum(double v) {
   return v;
 }
 
+// LPR lanes per root: 8 (32 roots per workgroup) for the small merges, 32 (8 roots per workgroup) for K >= 2048, where
+// 8 lanes per root leave the chip at under one wave per SIMD (top merge of N=8192: 1.9 ms of dependent fp64 divisions)
+template <int LPR>
+__device__ __forceinline__ double group_sum(double v) {
+  v = group8_sum(v);
+  if (LPR == 32) { v = dc_dpp_add<0x140>(v); v = dc_swapadd16(v); }   // row_mirror: 16 lanes; lane swap: the row pair
+  return v;
+}
+
+template <int LPR>
 __global__ __launch_bounds__(256) void secular_kernel(const MergeDev* __restrict__ md,
                                                       const double* __restrict__ dlam,
                                                       const double* __restrict__ wz, double* __restrict__ Dn,
                                                       double* __restrict__ S, int lds) {
   const MergeDev M = md[blockIdx.y];
   const int K = M.K;
-  if ((int)(blockIdx.x * 32) >= K) return;
-  const int sub = threadIdx.x & 7;
-  const int jraw = blockIdx.x * 32 + (threadIdx.x >> 3);
+  constexpr int RPW = 256 / LPR;   // roots per workgroup
+  __shared__ double so[RPW], stau[RPW];
+  if ((int)(blockIdx.x * RPW) >= K) return;
+  const int sub = threadIdx.x & (LPR - 1);
+  const int jraw = blockIdx.x * RPW + threadIdx.x / LPR;
   const bool act = jraw < K;
   const int j = act ? jraw : K - 1;  // idle groups recompute the last root (keeps every lane in the shuffles)
   const double* __restrict__ d = dlam + M.off;
@@ -273,9 +291,9 @@ __global__ __launch_bounds__(256) void secular_kernel(const MergeDev* __restrict
     const double gap = last ? rho : d[j + 1] - d[j];
     const double mid = last ? d[K - 1] + 0.5 * rho : 0.5 * (d[j] + d[j + 1]);
     double c = 0.0;
-    for (int i = sub; i < K; i += 8)
+    for (int i = sub; i < K; i += LPR)
       if (i != jl && i != jr) c += z[i] * z[i] / (d[i] - mid);
-    c = group8_sum(c) + rhoinv;
+    c = group_sum<LPR>(c) + rhoinv;
     const double zl2 = z[jl] * z[jl], zr2 = z[jr] * z[jr];
     const double fmid = c + zl2 / (d[jl] - mid) + zr2 / (d[jr] - mid);
     int org;
@@ -297,15 +315,15 @@ __global__ __launch_bounds__(256) void secular_kernel(const MergeDev* __restrict
   }
   for (int iter = 0; iter < 100; ++iter) {
     double psi = 0.0, dpsi = 0.0, phi = 0.0, dphi = 0.0, err = 0.0;
-    for (int i = sub; i < K; i += 8) {
+    for (int i = sub; i < K; i += LPR) {
       const double t = z[i] / ((d[i] - origin) - tau);
       const double zt = z[i] * t, tt = t * t;
       if (i <= jl) { psi += zt; dpsi += tt; err += fabs(psi); }
       else { phi += zt; dphi += tt; err += fabs(phi); }
     }
-    psi = group8_sum(psi); dpsi = group8_sum(dpsi);
-    phi = group8_sum(phi); dphi = group8_sum(dphi);
-    err = group8_sum(err);
+    psi = group_sum<LPR>(psi); dpsi = group_sum<LPR>(dpsi);
+    phi = group_sum<LPR>(phi); dphi = group_sum<LPR>(dphi);
+    err = group_sum<LPR>(err);
     const double wv = rhoinv + phi + psi;
     err = 8.0 * (fabs(phi) + fabs(psi)) + err + 2.0 * rhoinv + fabs(tau) * (dpsi + dphi);
     if (fabs(wv) <= eps * err) break;
@@ -329,9 +347,17 @@ __global__ __launch_bounds__(256) void secular_kernel(const MergeDev* __restrict
     if (tnew == tau) break;
     tau = tnew;
   }
-  if (act) {
-    if (sub == 0) Dn[M.off + j] = origin + tau;
-    for (int i = sub; i < K; i += 8) Sp[j + (size_t)i * lds] = (d[i] - origin) - tau;
+  // S'(j, i) = (d_i - origin_j) - tau_j: the workgroup's RPW roots are consecutive j, so the store is re-mapped to
+  // lanes = (root, pole) pairs with the root index fastest: RPW * 8-byte segments instead of one element per line
+  if (sub == 0) { so[threadIdx.x / LPR] = origin; stau[threadIdx.x / LPR] = tau; if (act) Dn[M.off + j] = origin + tau; }
+  __syncthreads();
+  {
+    const int r = threadIdx.x % RPW, ii = threadIdx.x / RPW;
+    const int jr = blockIdx.x * RPW + r;
+    if (jr < K) {
+      const double o_ = so[r], t_ = stau[r];
+      for (int i = ii; i < K; i += 256 / RPW) Sp[jr + (size_t)i * lds] = (d[i] - o_) - t_;
+    }
   }
 }
 
@@ -362,33 +388,56 @@ __global__ __launch_bounds__(256) void loewner_kernel(const MergeDev* __restrict
 
 // eigenvectors of the rank-one problem: S'(j,i) <- zhat_i / (d_i - lam_j), normalised over i.
 // workgroup = 64 roots (lanes) x 4 waves (wave w owns the poles i = w mod 4): coalesced along j.
-__global__ __launch_bounds__(256) void vectors_kernel(const MergeDev* __restrict__ md, const double* __restrict__ zh,
-                                                      double* __restrict__ S, int lds) {
+// eigenvectors of the rank-one update: S'(j,i) <- zh_i / S'(j,i), then every root's row j normalised.
+// Two launches over a 2-D grid (64 roots x VEC_IC poles per workgroup) so that the K x K matrix is streamed by the
+// whole chip: pass 1 writes the quotients and per-chunk partial norms (deterministic two-phase reduction), pass 2
+// re-reduces the partials and scales.  (One workgroup per 64 roots looping over all K poles reached 0.9 TB/s on
+// the top merges.)
+constexpr int VEC_IC = 256;
+__global__ __launch_bounds__(256) void vectors1_kernel(const MergeDev* __restrict__ md, const double* __restrict__ zh,
+                                                       double* __restrict__ S, int lds, double* __restrict__ vnp,
+                                                       int ldn) {
   __shared__ double part[4][64];
-  const MergeDev M = md[blockIdx.y];
+  const MergeDev M = md[blockIdx.z];
   const int K = M.K;
-  if ((int)(blockIdx.x * 64) >= K) return;
+  if ((int)(blockIdx.x * 64) >= K || (int)(blockIdx.y * VEC_IC) >= K) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + lane;
   const bool act = j < K;
   double* Sp = S + (size_t)M.off * lds + M.off + j;
   const double* zz = zh + M.off;
+  const int i0 = blockIdx.y * VEC_IC;
+  const int i1 = (i0 + VEC_IC < K) ? i0 + VEC_IC : K;
   double nrm = 0.0;
   if (act)
-    for (int i = wave; i < K; i += 4) {
+    for (int i = i0 + wave; i < i1; i += 4) {
       const double v = zz[i] / Sp[(size_t)i * lds];
       Sp[(size_t)i * lds] = v;
       nrm += v * v;
     }
   part[wave][lane] = nrm;
   __syncthreads();
-  if (act) {
-    const double sc = 1.0 / sqrt((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
-    for (int i = wave; i < K; i += 4) Sp[(size_t)i * lds] *= sc;
-  }
+  if (wave == 0 && act)
+    vnp[(size_t)blockIdx.y * ldn + M.off + j] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+__global__ __launch_bounds__(256) void vectors2_kernel(const MergeDev* __restrict__ md, double* __restrict__ S, int lds,
+                                                       const double* __restrict__ vnp, int ldn) {
+  const MergeDev M = md[blockIdx.z];
+  const int K = M.K;
+  if ((int)(blockIdx.x * 64) >= K || (int)(blockIdx.y * VEC_IC) >= K) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  if (j >= K) return;
+  const int nch = (K + VEC_IC - 1) / VEC_IC;
+  double nrm = 0.0;
+  for (int c = 0; c < nch; ++c) nrm += vnp[(size_t)c * ldn + M.off + j];
+  const double sc = 1.0 / sqrt(nrm);
+  double* Sp = S + (size_t)M.off * lds + M.off + j;
+  const int i0 = blockIdx.y * VEC_IC;
+  const int i1 = (i0 + VEC_IC < K) ? i0 + VEC_IC : K;
+  for (int i = i0 + wave; i < i1; i += 4) Sp[(size_t)i * lds] *= sc;
 }
 
-// copy deflated columns Qa(:, src) -> Qb(:, dst) on the merge's row range
 __global__ void copycols_kernel(const int* __restrict__ src, const int* __restrict__ dst,
                                 const int* __restrict__ row0, const int* __restrict__ nrows,
                                 const double* __restrict__ Qa, double* __restrict__ Qb, int ldq) {
@@ -536,6 +585,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   double* dd = ctx.pool.get_t<double>("dc.d", (size_t)n);
   double* de = ctx.pool.get_t<double>("dc.e", (size_t)lde * band);
   double* zh = ctx.pool.get_t<double>("dc.zh", (size_t)n);
+  double* vnp = ctx.pool.get_t<double>("dc.vnp", (size_t)n * ((n + VEC_IC - 1) / VEC_IC + 1));  // partial column norms
   const int maxmerge = n / (LEAF / 2) + 8;
   int* leafinfo = ctx.pool.get_t<int>("dc.leaf", (size_t)2 * maxmerge);
   int* perm_dev = ctx.pool.get_t<int>("dc.perm", (size_t)n);
@@ -734,10 +784,16 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
       for (const MergeDev& M : mds) maxK = std::max(maxK, M.K);
       if (maxK > 0) {
         const unsigned nmg = (unsigned)ids.size();
-        hipLaunchKernelGGL(secular_kernel, dim3((maxK + 31) / 32, nmg), dim3(256), 0, st, md_dev, dlam, wz, Dcur, S,
-                           ldq);
+        if (maxK >= 2048)
+          hipLaunchKernelGGL(secular_kernel<32>, dim3((maxK + 7) / 8, nmg), dim3(256), 0, st, md_dev, dlam, wz, Dcur, S, ldq);
+        else
+          hipLaunchKernelGGL(secular_kernel<8>, dim3((maxK + 31) / 32, nmg), dim3(256), 0, st, md_dev, dlam, wz, Dcur, S, ldq);
         hipLaunchKernelGGL(loewner_kernel, dim3((maxK + 3) / 4, nmg), dim3(256), 0, st, md_dev, dlam, wz, S, ldq, zh);
-        hipLaunchKernelGGL(vectors_kernel, dim3((maxK + 63) / 64, nmg), dim3(256), 0, st, md_dev, zh, S, ldq);
+        {
+          const dim3 vg((maxK + 63) / 64, (maxK + VEC_IC - 1) / VEC_IC, nmg);
+          hipLaunchKernelGGL(vectors1_kernel, vg, dim3(256), 0, st, md_dev, zh, S, ldq, vnp, n);
+          hipLaunchKernelGGL(vectors2_kernel, vg, dim3(256), 0, st, md_dev, S, ldq, vnp, n);
+        }
         // the merges of one height are independent: when there are several, spread their GEMMs over the aux
         // streams so that small products run side by side instead of one after another
         const bool fan = mds.size() > 1;
