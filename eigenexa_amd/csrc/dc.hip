@@ -248,7 +248,7 @@ __device__ __forceinline__ double group8_sum(double v) {
   return v;
 }
 
-// LPR lanes per root: 8 (32 roots per workgroup) for the small merges, 32 (8 roots per workgroup) for K >= 2048, where
+// LPR lanes per root: 8 (32 roots per workgroup) for the small merges, 32 (8 roots per workgroup) for K >= 512, where
 // 8 lanes per root leave the chip at under one wave per SIMD (top merge of N=8192: 1.9 ms of dependent fp64 divisions)
 template <int LPR>
 __device__ __forceinline__ double group_sum(double v) {
@@ -784,7 +784,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
       for (const MergeDev& M : mds) maxK = std::max(maxK, M.K);
       if (maxK > 0) {
         const unsigned nmg = (unsigned)ids.size();
-        if (maxK >= 2048)
+        if (maxK >= 512)
           hipLaunchKernelGGL(secular_kernel<32>, dim3((maxK + 7) / 8, nmg), dim3(256), 0, st, md_dev, dlam, wz, Dcur, S, ldq);
         else
           hipLaunchKernelGGL(secular_kernel<8>, dim3((maxK + 31) / 32, nmg), dim3(256), 0, st, md_dev, dlam, wz, Dcur, S, ldq);
