@@ -1118,17 +1118,29 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       hipLaunchKernelGGL((ka_kernel<NB>), dim3((F.rows + KA_ROWS - 1) / KA_ROWS), dim3(256), 0, st, R, F);
       const int nr = i + 1;
       if (ctx.prof_stride > 0) ctx.prof_begin(1, 2.0 * (double)nr * nr * m / R.P, st);
-      dgemm_dev(st, 'N', 'T', nr, nr, 2 * m, -1.0, R.UW, ldp, R.UW + (size_t)ldp * m, ldp, 1.0, A, lda, 1,
-                nullptr, nullptr, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, R.P, R.p);
-      if (R.P > 1) {
-        // next panel = columns (i-m, i]: fetch each 128-column block from its owner (the reference's
-        // panel-load allgather, src/eigen_prd_t7.F:74-250); whole blocks, so already-reduced columns that
-        // share a block are simply re-sent unchanged
+      if (R.P == 1) {
+        dgemm_dev(st, 'N', 'T', nr, nr, 2 * m, -1.0, R.UW, ldp, R.UW + (size_t)ldp * m, ldp, 1.0, A, lda, 1);
+      } else {
+        // Look-ahead: the tile columns that hold the next panel, columns (i-m, i], are updated first; their
+        // owners then broadcast them on the side stream (the reference's panel-load allgather,
+        // src/eigen_prd_t7.F:74-250) while the compute stream updates the rest of the trailing matrix.  Whole
+        // 128-column blocks travel, so already-reduced columns that share a block are re-sent unchanged.
         const int clo = (i - m + 1 > 0) ? i - m + 1 : 0;
-        for (int b = clo / 128; b <= i / 128; ++b) {
+        const int tb0 = clo / 128;
+        dgemm_dev(st, 'N', 'T', nr, nr, 2 * m, -1.0, R.UW, ldp, R.UW + (size_t)ldp * m, ldp, 1.0, A, lda, 1,
+                  nullptr, nullptr, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, R.P, R.p, nullptr, tb0, 0x7fffffff);
+        EIGX_HIP_CHECK(hipEventRecord(ctx.aux_ev[0], st));
+        if (tb0 > 0)
+          dgemm_dev(st, 'N', 'T', nr, nr, 2 * m, -1.0, R.UW, ldp, R.UW + (size_t)ldp * m, ldp, 1.0, A, lda, 1,
+                    nullptr, nullptr, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, R.P, R.p, nullptr, 0, tb0);
+        hipStream_t sd = ctx.side_stream;
+        EIGX_HIP_CHECK(hipStreamWaitEvent(sd, ctx.aux_ev[0], 0));
+        for (int b = tb0; b <= i / 128; ++b) {
           const int c0 = b * 128, c1 = (c0 + 128 < n) ? c0 + 128 : n;
-          comm_bcast(ctx, COMM_WORLD, A + (size_t)c0 * lda, (size_t)(c1 - c0) * lda, b % R.P, st);
+          comm_bcast(ctx, COMM_WORLD, A + (size_t)c0 * lda, (size_t)(c1 - c0) * lda, b % R.P, sd);
         }
+        EIGX_HIP_CHECK(hipEventRecord(ctx.aux_ev[1], sd));
+        EIGX_HIP_CHECK(hipStreamWaitEvent(st, ctx.aux_ev[1], 0));
       }
       if (ctx.prof_stride > 0) ctx.prof_end(st);
       k1_flops += 2.0 * (double)nr * nr * m;  // 2*nr*nr*(2m)/2 : upper triangle only

@@ -50,12 +50,14 @@ static inline int local_count(int n, int P, int p) { return n > p ? (n - p + P -
 // of a matrix whose local element (i,j) is global (i*Px+px, j*Py+py).
 // batch > 1: `batch` independent products, operand b at A + b*strideA etc. (elements).
 // kmapA (device, optional, opA='N'): A's column for k-index k; cmapC (device, optional): C's column for n.
+// tri mode: ownP/ownp = multi-GPU ownership of 128-column tile columns; [tn_lo, tn_hi) restricts the launch to a
+// window of tile columns (the look-ahead split of the trailing update).
 void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, double alpha,
                const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc,
                int tri_mode = 0, const Grid* g = nullptr, const int* kmapA = nullptr,
                const int* cmapC = nullptr, int batch = 1, long strideA = 0, long strideB = 0, long strideC = 0,
                int batch2 = 1, long strideA2 = 0, long strideB2 = 0, long strideC2 = 0, int ownP = 1,
-               int ownp = 0, const int* kmapB = nullptr);
+               int ownp = 0, const int* kmapB = nullptr, int tn_lo = 0, int tn_hi = 0x7fffffff);
 
 // tuning hook (eigx_tune key 0): 2 = LDS-DMA ring GEMM where supported, 1 = register-staged GEMM only
 int set_gemm_variant(int v);

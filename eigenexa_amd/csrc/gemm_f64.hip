@@ -53,6 +53,7 @@ struct GemmArgs {
   long sA2, sB2, sC2;  // second-level batch strides (blockIdx.z)
   int ownP, ownp;      // tri mode, multi-GPU: this rank updates tile columns tn with tn % ownP == ownp
   int tri_gb;          // gemm2 tri mode: tile-block edge of the XCD-aware order
+  int tn_lo, tn_hi;    // tri mode: only tile columns tn_lo <= tn < tn_hi are updated (look-ahead split of the trailing update)
 };
 
 // column indices (gather map) of the slab starting at k0 for this thread's NL elements
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 
   if (g.tri_mode == 1) {
     if (g.ownP > 1 && (tn % g.ownP) != g.ownp) return;
+    if (tn < g.tn_lo || tn >= g.tn_hi) return;
     // skip tiles strictly below the diagonal: min global row > max global col
     const long grow_min = (long)m0 * g.Px + g.px;
     const int jmax = (n0 + BN - 1 < g.N - 1) ? n0 + BN - 1 : g.N - 1;
@@ -403,6 +405,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmArgs g) {
   const int m0 = tm * 128, n0 = tn * 128;
   if (g.tri_mode == 1) {
     if (g.ownP > 1 && (tn % g.ownP) != g.ownp) return;
+    if (tn < g.tn_lo || tn >= g.tn_hi) return;
     const long grow_min = (long)m0 * g.Px + g.px;
     const int jmax = (n0 + 127 < g.N - 1) ? n0 + 127 : g.N - 1;
     const long gcol_max = (long)jmax * g.Py + g.py;
@@ -577,7 +580,7 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
                int lda, const double* B, int ldb, double beta, double* C, int ldc, int tri_mode,
                const Grid* grid, const int* kmapA, const int* cmapC, int batch, long strideA, long strideB,
                long strideC, int batch2, long strideA2, long strideB2, long strideC2, int ownP, int ownp,
-               const int* kmapB) {
+               const int* kmapB, int tn_lo, int tn_hi) {
   if (M <= 0 || N <= 0 || batch <= 0 || batch2 <= 0) return;
   GemmArgs g;
   g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
@@ -589,6 +592,7 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
   g.sA2 = strideA2; g.sB2 = strideB2; g.sC2 = strideC2;
   g.ownP = ownP; g.ownp = ownp; g.tri_gb = 1;
+  g.tn_lo = tn_lo; g.tn_hi = tn_hi;
   g.Px = grid ? grid->Px : 1; g.px = grid ? grid->px : 0;
   g.Py = grid ? grid->Py : 1; g.py = grid ? grid->py : 0;
   const bool a_kc = (opA == 'T' || opA == 't');   // op(A)(m,k) = A[k + m*lda]
