@@ -30,6 +30,7 @@
 #include "eigx_comm.h"
 #include "../../include/eigenexa_amd.h"
 #include <algorithm>
+#include <chrono>
 #include <cfloat>
 #include <cstring>
 
@@ -626,6 +627,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   EIGX_HIP_CHECK(hipMemcpyAsync(dd, H.d.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
   EIGX_HIP_CHECK(hipMemcpyAsync(de, H.e.data(), (size_t)lde * band * 8, hipMemcpyHostToDevice, st));
   EIGX_HIP_CHECK(hipMemsetAsync(Qa, 0, (size_t)ldq * n * 8, st));
+  EIGX_HIP_CHECK(hipMemsetAsync(Qb, 0, (size_t)ldq * n * 8, st));
   {
     std::vector<int> iota(n);
     for (int q = 0; q < n; ++q) iota[q] = q;
@@ -653,6 +655,8 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   std::vector<MergeDev> mds;
   std::vector<std::pair<double, int>> ord;
   double gemm_flops = 0.0;
+  const bool trace = getenv("EIGX_TRACE_DC") != nullptr;
+  auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (int h = 1; h <= maxh; ++h) {
     std::vector<int> ids;
     for (int id = 0; id < (int)H.nodes.size(); ++id)
@@ -674,8 +678,10 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
       hipLaunchKernelGGL(zgather_kernel, dim3((maxnm + 255) / 256, (unsigned)ids.size()), dim3(256), 0, st, md_dev,
                          band, Qa, ldq, zbuf, r0, r1);
       if (P > 1) comm_allreduce_sum(ctx, COMM_WORLD, zbuf, (size_t)n, st);
+      const double tt0 = trace ? now_s() : 0.0;
       EIGX_HIP_CHECK(hipMemcpyAsync(harena + down_off, arena + down_off, 2 * npad * 8, hipMemcpyDeviceToHost, st));  // Dcur | z
       EIGX_HIP_CHECK(hipStreamSynchronize(st));
+      const double tt1 = trace ? now_s() : 0.0;
       // -- host deflation -------------------------------------------------------------------------------
       int nrot = 0, ncopy = 0;
       std::copy(Dh, Dh + n, Dold.begin());   // Dh (pinned) becomes the new D in place
@@ -775,6 +781,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
         for (int t = 0; t < K; ++t) Dh[off + t] = 0.0;  // overwritten by the secular kernel
       }
       // -- upload and run the GPU part ---------------------------------------------------------------------
+      const double tt2 = trace ? now_s() : 0.0;
       memcpy(md_h, mds.data(), mds.size() * sizeof(MergeDev));
       EIGX_HIP_CHECK(hipMemcpyAsync(arena, harena, up_bytes, hipMemcpyHostToDevice, st));   // everything at once
       if (nrot > 0)
@@ -849,14 +856,26 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
                            ldq);
       // the host vectors are reused next round: wait for the uploads (tiny) before touching them
       // merged blocks go back into Qa (blocks that do not merge at this height stay where they are)
-      for (const MergeDev& M : mds) {
-        int ca, cb;
-        if (!clip(M.off, M.off + M.nm, ca, cb)) continue;
-        EIGX_HIP_CHECK(hipMemcpy2DAsync(Qa + (size_t)M.off * ldq + ca, (size_t)ldq * 8,
-                                        Qb + (size_t)M.off * ldq + ca, (size_t)ldq * 8, (size_t)(cb - ca) * 8,
-                                        (size_t)M.nm, hipMemcpyDeviceToDevice, st));
+      // When the merges of this height cover every column (balanced tree: always), Qb now IS the new Q: swap the
+      // buffers instead of copying n^2 doubles back.  Both buffers are zero outside the diagonal blocks (memset at
+      // the start; GEMMs and column copies only ever write rows inside their own block).
+      size_t covered = 0;
+      for (const MergeDev& M : mds) covered += (size_t)M.nm;
+      if (covered == (size_t)n) {
+        std::swap(Qa, Qb);
+      } else {
+        for (const MergeDev& M : mds) {
+          int ca, cb;
+          if (!clip(M.off, M.off + M.nm, ca, cb)) continue;
+          EIGX_HIP_CHECK(hipMemcpy2DAsync(Qa + (size_t)M.off * ldq + ca, (size_t)ldq * 8,
+                                          Qb + (size_t)M.off * ldq + ca, (size_t)ldq * 8, (size_t)(cb - ca) * 8,
+                                          (size_t)M.nm, hipMemcpyDeviceToDevice, st));
+        }
       }
       EIGX_HIP_CHECK(hipStreamSynchronize(st));
+      if (trace)
+        fprintf(stderr, "[eigx dc] height %d pass %d: %zu merges, z gather + D2H %.3f ms, host deflation %.3f ms, device part %.3f ms\n",
+                h, k, ids.size(), (tt1 - tt0) * 1e3, (tt2 - tt1) * 1e3, (now_s() - tt2) * 1e3);
     }
   }
 
