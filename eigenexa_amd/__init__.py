@@ -21,6 +21,9 @@ from .api import (  # noqa: F401
     eigen_owner_index,
     eigen_sx,
     eigen_s,
+    eigen_sx_bc,
+    eigen_s_bc,
+    numroc,
     KMATH_EIGEN_GEV,
     eigen_NB_f,
     eigen_NB_b,

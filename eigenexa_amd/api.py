@@ -232,7 +232,7 @@ def _ptr(x, name, want_device):
     return x.ctypes.data
 
 
-def _solve(which, n, nvec, a, lda, w, z, ldz, m_forward, m_backward, mode):
+def _solve(which, n, nvec, a, lda, w, z, ldz, m_forward, m_backward, mode, nb=None):
     lib = _lib.load()
     if not _state["initialized"]:
         # reference: silent return when eigen_init has not been called (src/eigen_sx.F:82-86)
@@ -246,8 +246,13 @@ def _solve(which, n, nvec, a, lda, w, z, ldz, m_forward, m_backward, mode):
     pa, pw, pz = _ptr(a, "a", dev), _ptr(w, "w", dev), _ptr(z, "z", dev)
     mf = eigen_NB_f if m_forward is None else int(m_forward)
     mb = eigen_NB_b if m_backward is None else int(m_backward)
-    fn = getattr(lib, ("eigx_sx" if which == "sx" else "eigx_s") + ("_dev" if dev else ""))
-    rc = fn(int(n), int(nvec), pa, int(lda), pw, pz, int(ldz), mf, mb, _char(mode, "A"))
+    if nb is None:
+        fn = getattr(lib, ("eigx_sx" if which == "sx" else "eigx_s") + ("_dev" if dev else ""))
+        rc = fn(int(n), int(nvec), pa, int(lda), pw, pz, int(ldz), mf, mb, _char(mode, "A"))
+    else:
+        fn = lib.eigx_solve_bc_dev if dev else lib.eigx_solve_bc
+        rc = fn(2 if which == "sx" else 1, int(n), int(nvec), pa, int(lda), pw, pz, int(ldz), int(nb), mf, mb,
+                _char(mode, "A"))
     _state["last_status"] = rc
     if rc not in (0, -5):
         print(f"Warning: eigen_{which} returned without computing (status {rc})", file=sys.stderr)
@@ -261,6 +266,22 @@ def eigen_sx(n, nvec, a, lda, w, z, ldz, m_forward=None, m_backward=None, mode="
 def eigen_s(n, nvec, a, lda, w, z, ldz, m_forward=None, m_backward=None, mode="A"):
     """Tridiagonal route (eigen_trd -> dc2 -> trbakwy, src/eigen_libs.F:150-202)."""
     _solve("s", n, nvec, a, lda, w, z, ldz, m_forward, m_backward, mode)
+
+
+def eigen_sx_bc(n, nvec, a, lda, w, z, ldz, nb, m_forward=None, m_backward=None, mode="A"):
+    """eigen_sx on the local blocks of a 2-D block-cyclic (ScaLAPACK, MB = NB = nb) distribution over the process grid:
+    no pdgemr2d redistribution into the cyclic layout is needed (manual 3.4).  ``z`` returns in the same distribution."""
+    _solve("sx", n, nvec, a, lda, w, z, ldz, m_forward, m_backward, mode, nb=nb)
+
+
+def eigen_s_bc(n, nvec, a, lda, w, z, ldz, nb, m_forward=None, m_backward=None, mode="A"):
+    """eigen_s on block-cyclic local blocks (see eigen_sx_bc)."""
+    _solve("s", n, nvec, a, lda, w, z, ldz, m_forward, m_backward, mode, nb=nb)
+
+
+def numroc(n, nb, iproc, nprocs):
+    """ScaLAPACK NUMROC with source process 0: local extent of n indices in blocks of nb on process iproc of nprocs"""
+    return _lib.load().eigx_numroc(int(n), int(nb), int(iproc), int(nprocs))
 
 
 def KMATH_EIGEN_GEV(n, a, lda, b, ldb, w, z, ldz):

@@ -42,6 +42,16 @@ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b;
 
 // number of local indices l with global index l*P+p < n
 static inline int local_count(int n, int P, int p) { return n > p ? (n - p + P - 1) / P : 0; }
+// ScaLAPACK NUMROC with source process 0: local extent of n indices dealt in blocks of nb to process p of P
+// (nb = 1 is the cyclic layout of the EigenExa API: numroc(n, 1, p, P) == local_count(n, P, p))
+static inline int numroc(int n, int nb, int p, int P) {
+  const int nblocks = n / nb;
+  int cnt = (nblocks / P) * nb;
+  const int extra = nblocks % P;
+  if (p < extra) cnt += nb;
+  else if (p == extra) cnt += n % nb;
+  return cnt;
+}
 
 // ---- kernels / launchers (device pointers, column-major, all on `stream`) -------------------
 

@@ -57,29 +57,32 @@ __global__ void fill_vec_kernel(double* __restrict__ w, int n, double v) {
   if (i < n) w[i] = v;
 }
 
-// recv = [rank q][li + lj*bx] : local cyclic blocks of all ranks -> full matrix F(gi, gj), gi = li*Px+qx, ...
+// local index l of process p (of P) -> global index, blocks of nb (nb = 1: cyclic, l*P + p)
+__device__ __forceinline__ int bc_l2g(int l, int nb, int P, int p) { return ((l / nb) * P + p) * nb + l % nb; }
+
+// recv = [rank q][li + lj*bx] : local (block-)cyclic blocks of all ranks -> full matrix F(gi, gj)
 __global__ void cyclic_to_full_kernel(const double* __restrict__ recv, int bx, int by, int Px, int Py, int order_r,
-                                      int n, double* __restrict__ F, int ldf) {
+                                      int n, int nb, double* __restrict__ F, int ldf) {
   const int q = blockIdx.z;
   const int qx = order_r ? q / Py : q % Px, qy = order_r ? q % Py : q / Px;
   const int lj = blockIdx.y;
-  const int gj = lj * Py + qy;
+  const int gj = bc_l2g(lj, nb, Py, qy);
   if (gj >= n) return;
   const double* src = recv + (size_t)q * bx * by + (size_t)lj * bx;
   for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < bx; li += gridDim.x * blockDim.x) {
-    const int gi = li * Px + qx;
+    const int gi = bc_l2g(li, nb, Px, qx);
     if (gi < n) F[(size_t)gj * ldf + gi] = src[li];
   }
 }
 
-// local (nloc_r x nloc_c) cyclic block of the full matrix: dst(li, lj) = F(li*Px+px, lj*Py+py)
-__global__ void full_to_cyclic_kernel(const double* __restrict__ F, int ldf, int nrows, int ncols, int Px, int px,
-                                      int Py, int py, double* __restrict__ dst, int ldd) {
+// local (nloc_r x nloc_c) block of the full matrix: dst(li, lj) = F(l2g(li), l2g(lj))
+__global__ void full_to_cyclic_kernel(const double* __restrict__ F, int ldf, int nloc_r, int ncols, int nb, int Px,
+                                      int px, int Py, int py, double* __restrict__ dst, int ldd) {
   const int lj = blockIdx.y;
-  const int gj = lj * Py + py;
+  const int gj = bc_l2g(lj, nb, Py, py);
   if (gj >= ncols) return;
-  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li * Px + px < nrows; li += gridDim.x * blockDim.x)
-    dst[(size_t)lj * ldd + li] = F[(size_t)gj * ldf + li * Px + px];
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < nloc_r; li += gridDim.x * blockDim.x)
+    dst[(size_t)lj * ldd + li] = F[(size_t)gj * ldf + bc_l2g(li, nb, Px, px)];
 }
 
 __global__ void pack_block_kernel(const double* __restrict__ a, int lda, int nr, int nc, double* __restrict__ out,
@@ -100,8 +103,10 @@ __global__ void identity_kernel(double* __restrict__ z, int ldz, int n) {
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) col[r] = (r == j) ? 1.0 : 0.0;
 }
 
+// nb = block size of the 2-D block-cyclic layout of a and z over the process grid (1 = the cyclic layout of the
+// EigenExa API; a ScaLAPACK caller passes its descriptor's MB = NB and needs no pdgemr2d redistribution, manual 3.4)
 int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb,
-              char mode, int band) {
+              char mode, int band, int nb) {
   if (!ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
   if (n <= 0) {
     fprintf(stderr, "[eigx] warning: non-positive dimension is invalid\n");  // src/eigen_sx.F:95-98
@@ -109,7 +114,8 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   }
   const Grid& G = ctx.grid;
   const int P = G.nranks;
-  const int nloc_r = local_count(n, G.Px, G.px), nloc_c = local_count(n, G.Py, G.py);
+  if (nb < 1) return EIGX_ERR_BAD_ARG;
+  const int nloc_r = numroc(n, nb, G.px, G.Px), nloc_c = numroc(n, nb, G.py, G.Py);
   if (P == 1) {
     if (lda < n || (lda & 1) || !a || !w) return EIGX_ERR_BAD_ARG;
   } else {
@@ -136,7 +142,7 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   const int lda_user = lda, ldz_user = ldz;
   int zcols_per_rank = 0;
   if (P > 1) {
-    const int bx = ceil_div(n, G.Px), by = ceil_div(n, G.Py);
+    const int bx = numroc(n, nb, 0, G.Px), by = numroc(n, nb, 0, G.Py);   // process 0 holds the largest block
     const int ldf = pad_ld(n);
     double* sendb = ctx.pool.get_t<double>("mg.send", (size_t)bx * by);
     double* recvb = ctx.pool.get_t<double>("mg.recv", (size_t)bx * by * P);
@@ -145,7 +151,7 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
     comm_allgather(ctx, COMM_WORLD, sendb, recvb, (size_t)bx * by, st);
     const int order_r = G.row_major;
     hipLaunchKernelGGL(cyclic_to_full_kernel, dim3(8, by, P), dim3(256), 0, st, recvb, bx, by, G.Px, G.Py, order_r, n,
-                       Afull, ldf);
+                       nb, Afull, ldf);
     a = Afull;
     lda = ldf;
     zcols_per_rank = ceil_div(nvec > 0 ? nvec : 1, P);
@@ -220,10 +226,10 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
     }
   }
   if (P > 1 && want_vec) {
-    const int nzc = local_count(nvec, G.Py, G.py);
+    const int nzc = numroc(nvec, nb, G.py, G.Py);
     if (nzc > 0 && nloc_r > 0)
-      hipLaunchKernelGGL(full_to_cyclic_kernel, dim3(8, nzc), dim3(256), 0, st, z, ldz, n, nvec, G.Px, G.px, G.Py,
-                         G.py, z_user, ldz_user);
+      hipLaunchKernelGGL(full_to_cyclic_kernel, dim3(8, nzc), dim3(256), 0, st, z, ldz, nloc_r, nvec, nb, G.Px, G.px,
+                         G.Py, G.py, z_user, ldz_user);
   }
   if (sigma != 1.0 && sigma != 0.0)
     hipLaunchKernelGGL(scale_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, n, 1.0 / sigma);
@@ -248,9 +254,10 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
 }
 
 int solve_host(Context& ctx, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb,
-               char mode, int band) {
+               char mode, int band, int nb) {
   if (!ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
-  const int nr = local_count(n, ctx.grid.Px, ctx.grid.px), nc = local_count(n, ctx.grid.Py, ctx.grid.py);
+  if (nb < 1) return EIGX_ERR_BAD_ARG;
+  const int nr = numroc(n, nb, ctx.grid.px, ctx.grid.Px), nc = numroc(n, nb, ctx.grid.py, ctx.grid.Py);
   if (n <= 0 || !a || !w || lda < nr) return EIGX_ERR_BAD_ARG;
   EIGX_HIP_CHECK(hipSetDevice(ctx.device));
   const int ldd = pad_ld(nr + 2);  // device leading dimension: even (16-byte column loads), odd multiple of 32
@@ -261,14 +268,14 @@ int solve_host(Context& ctx, int n, int nvec, double* a, int lda, double* w, dou
   if (nr > 0 && nc > 0)
     EIGX_HIP_CHECK(hipMemcpy2D(ad, (size_t)ldd * 8, a, (size_t)lda * 8, (size_t)nr * 8, (size_t)nc,
                                hipMemcpyHostToDevice));
-  const int rc = solve_dev(ctx, n, nvec, ad, ldd, wd, zd, ldd, mf, mb, mode, band);
+  const int rc = solve_dev(ctx, n, nvec, ad, ldd, wd, zd, ldd, mf, mb, mode, band, nb);
   EIGX_HIP_CHECK(hipMemcpy(w, wd, (size_t)n * 8, hipMemcpyDeviceToHost));
   if (rc != EIGX_OK) return rc;
   char md = mode;
   if (md >= 'a' && md <= 'z') md = (char)(md - 'a' + 'A');
   int nv = nvec < 0 ? -nvec : nvec;
   if (nv > n) nv = n;
-  const int nzc = local_count(nv, ctx.grid.Py, ctx.grid.py);
+  const int nzc = numroc(nv, nb, ctx.grid.py, ctx.grid.Py);
   if (z && nzc > 0 && nr > 0 && md != 'N')
     EIGX_HIP_CHECK(hipMemcpy2D(z, (size_t)ldz * 8, zd, (size_t)ldd * 8, (size_t)nr * 8, (size_t)nzc,
                                hipMemcpyDeviceToHost));
@@ -308,7 +315,7 @@ int gev_dev(Context& ctx, int n, double* a, int lda, double* b, int ldb, double*
   hipStream_t st = ctx.stream;
   const double t0 = now_s();
   hipLaunchKernelGGL(symmetrize_kernel, dim3(8, n), dim3(256), 0, st, a, lda, n);
-  int rc = solve_dev(ctx, n, n, b, ldb, w, z, ldz, 128, 128, 'X', 1);      // B = Z_B W_B Z_B^T
+  int rc = solve_dev(ctx, n, n, b, ldb, w, z, ldz, 128, 128, 'X', 1, 1);      // B = Z_B W_B Z_B^T
   if (rc != EIGX_OK) return rc;
   const double t1 = now_s();
   double wmin = 0.0;
@@ -324,7 +331,7 @@ int gev_dev(Context& ctx, int n, double* a, int lda, double* b, int ldb, double*
   dgemm_dev(st, 'T', 'N', n, n, n, 1.0, b, ldb, c, ldc, 0.0, z, ldz);          // A' = B^(-1/2)^T C
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
   const double t2 = now_s();
-  rc = solve_dev(ctx, n, n, z, ldz, w, a, lda, 128, 128, 'X', 1);            // A' = Y W Y^T, Y in a
+  rc = solve_dev(ctx, n, n, z, ldz, w, a, lda, 128, 128, 'X', 1, 1);            // A' = Y W Y^T, Y in a
   if (rc != EIGX_OK) return rc;
   const double t3 = now_s();
   dgemm_dev(st, 'N', 'N', n, n, n, 1.0, b, ldb, a, lda, 0.0, z, ldz);          // Z = B^(-1/2) Y
@@ -373,16 +380,31 @@ using namespace eigx;
 extern "C" {
 
 int eigx_sx(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb, char mode) {
-  return solve_host(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 2);
+  return solve_host(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 2, 1);
 }
 int eigx_s(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb, char mode) {
-  return solve_host(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 1);
+  return solve_host(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 1, 1);
 }
 int eigx_sx_dev(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb, char mode) {
-  return solve_dev(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 2);
+  return solve_dev(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 2, 1);
 }
 int eigx_s_dev(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb, char mode) {
-  return solve_dev(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 1);
+  return solve_dev(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 1, 1);
+}
+// block-cyclic (ScaLAPACK descriptor MB = NB = nb) local blocks in and out; route 2 = eigen_sx, 1 = eigen_s
+int eigx_solve_bc(int route, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int nb, int mf, int mb,
+                  char mode) {
+  if (route != 1 && route != 2) return EIGX_ERR_BAD_ARG;
+  return solve_host(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, route, nb);
+}
+int eigx_solve_bc_dev(int route, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int nb, int mf,
+                      int mb, char mode) {
+  if (route != 1 && route != 2) return EIGX_ERR_BAD_ARG;
+  return solve_dev(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, route, nb);
+}
+int eigx_numroc(int n, int nb, int iproc, int nprocs) {
+  if (n < 0 || nb < 1 || nprocs < 1 || iproc < 0 || iproc >= nprocs) return -1;
+  return numroc(n, nb, iproc, nprocs);
 }
 
 int eigx_band_reduce_dev(int n, double* a, int lda, double* d, double* e, int lde, int mf, int band) {

@@ -21,6 +21,7 @@ module eigen_libs_mod
   public :: eigen_loop_start, eigen_loop_end, eigen_translate_l2g, eigen_translate_g2l
   public :: eigen_owner_node, eigen_owner_index
   public :: eigen_sx, eigen_s
+  public :: eigen_sx_bc, eigen_s_bc   ! ScaLAPACK block-cyclic local blocks in and out (no pdgemr2d step)
 
   interface
     integer(c_int) function eigx_init(device) bind(C, name="eigx_init")
@@ -103,6 +104,13 @@ module eigen_libs_mod
       integer(c_int), value :: n, nvec, lda, ldz, mf, mb
       real(c_double), intent(inout) :: a(lda, *)
       real(c_double), intent(out) :: w(*), z(ldz, *)
+      character(kind=c_char), value :: mode
+    end function
+    integer(c_int) function eigx_solve_bc(route, n, nvec, a, lda, w, z, ldz, nb, mf, mb, mode) &
+        bind(C, name="eigx_solve_bc")
+      import :: c_int, c_double, c_char
+      integer(c_int), value :: route, n, nvec, lda, ldz, nb, mf, mb
+      real(c_double) :: a(*), w(*), z(*)
       character(kind=c_char), value :: mode
     end function
   end interface
@@ -297,6 +305,40 @@ contains
     if (present(mode)) md = mode(1:1)
     rc = eigx_s(n, nvec, a, lda, w, z, ldz, mf, mb, md)
   end subroutine eigen_s
+
+  !> eigen_sx on the local blocks of a ScaLAPACK descriptor with MB = NB = nb, RSRC = CSRC = 0 on the eigen process
+  !> grid: a is numroc(n,nb,x_id-1,0,x_procs) x numroc(n,nb,y_id-1,0,y_procs); z returns in the same distribution.
+  !> Replaces the pdgemr2d round trip of the reference manual 3.4 (the layout is an index map at the solver's entry).
+  subroutine eigen_sx_bc(n, nvec, a, lda, w, z, ldz, nb, m_forward, m_backward, mode)
+    integer, intent(in) :: n, nvec, lda, ldz, nb
+    real(8), intent(inout) :: a(lda, *)
+    real(8), intent(out) :: w(*), z(ldz, *)
+    integer, intent(in), optional :: m_forward, m_backward
+    character(*), intent(in), optional :: mode
+    integer :: mf, mb, rc
+    character(kind=c_char) :: md
+    mf = eigen_NB_f; mb = eigen_NB_b; md = 'A'
+    if (present(m_forward)) mf = m_forward
+    if (present(m_backward)) mb = m_backward
+    if (present(mode)) md = mode(1:1)
+    rc = eigx_solve_bc(2, n, nvec, a, lda, w, z, ldz, nb, mf, mb, md)
+  end subroutine eigen_sx_bc
+
+  !> eigen_s on block-cyclic local blocks (see eigen_sx_bc)
+  subroutine eigen_s_bc(n, nvec, a, lda, w, z, ldz, nb, m_forward, m_backward, mode)
+    integer, intent(in) :: n, nvec, lda, ldz, nb
+    real(8), intent(inout) :: a(lda, *)
+    real(8), intent(out) :: w(*), z(ldz, *)
+    integer, intent(in), optional :: m_forward, m_backward
+    character(*), intent(in), optional :: mode
+    integer :: mf, mb, rc
+    character(kind=c_char) :: md
+    mf = eigen_NB_f; mb = eigen_NB_b; md = 'A'
+    if (present(m_forward)) mf = m_forward
+    if (present(m_backward)) mb = m_backward
+    if (present(mode)) md = mode(1:1)
+    rc = eigx_solve_bc(1, n, nvec, a, lda, w, z, ldz, nb, mf, mb, md)
+  end subroutine eigen_s_bc
 
 end module eigen_libs_mod
 

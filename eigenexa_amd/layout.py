@@ -59,6 +59,46 @@ def gather_cyclic(blocks, n0, n1, order="C"):
     return out
 
 
+def numroc(n, nb, p, nprocs):
+    """ScaLAPACK NUMROC (source process 0): local extent of n indices dealt in blocks of nb to process p"""
+    nblocks = n // nb
+    cnt = (nblocks // nprocs) * nb
+    extra = nblocks % nprocs
+    if p < extra:
+        cnt += nb
+    elif p == extra:
+        cnt += n % nb
+    return cnt
+
+
+def block_cyclic_indices(n, nb, p, nprocs):
+    """global indices (ascending) owned by process p of a 1-D block-cyclic distribution; nb = 1 is cyclic"""
+    g = np.arange(n)
+    return g[(g // nb) % nprocs == p]
+
+
+def scatter_block_cyclic(a_global, nb, nranks, rank, order="C"):
+    """local block (Fortran order) of `rank` for the 2-D block-cyclic (nb x nb) distribution of a global matrix"""
+    Px, Py = grid_shape(nranks)
+    px, py = rank_coords(rank, nranks, order)
+    rows = block_cyclic_indices(a_global.shape[0], nb, px, Px)
+    cols = block_cyclic_indices(a_global.shape[1], nb, py, Py)
+    return np.asfortranarray(a_global[np.ix_(rows, cols)])
+
+
+def gather_block_cyclic(blocks, n0, n1, nb, order="C"):
+    """inverse of scatter_block_cyclic: blocks[rank] -> global (n0, n1) matrix"""
+    nranks = len(blocks)
+    Px, Py = grid_shape(nranks)
+    out = np.zeros((n0, n1), dtype=blocks[0].dtype)
+    for rank, b in enumerate(blocks):
+        px, py = rank_coords(rank, nranks, order)
+        rows = block_cyclic_indices(n0, nb, px, Px)
+        cols = block_cyclic_indices(n1, nb, py, Py)
+        out[np.ix_(rows, cols)] = b[: len(rows), : len(cols)]
+    return out
+
+
 # ---- synthetic matrices -------------------------------------------------------------------------
 
 def frank(n, rows=None, cols=None):

@@ -115,6 +115,20 @@ int eigx_sx_dev(int n, int nvec, double* a_dev, int lda, double* w_dev, double* 
 int eigx_s_dev(int n, int nvec, double* a_dev, int lda, double* w_dev, double* z_dev, int ldz,
                int m_forward, int m_backward, char mode);
 
+/* ScaLAPACK interop without a redistribution step.  The reference asks block-cyclic callers to
+ * convert with pdgemr2d into its cyclic layout first (manual 3.4; benchmark/ev_test.f:68-84 does the reverse for the
+ * check).  Here the layout is only an index map at the entry and exit of the solver, so the local blocks of a
+ * descriptor with MB = NB = nb, RSRC = CSRC = 0 on the eigx process grid (eigx_get_procs / eigx_get_id, same grid
+ * as a BLACS grid of that shape and order) are accepted as they are: a is the local numroc(n,nb,px,Px) x
+ * numroc(n,nb,py,Py) block, z comes back as the local block of the n x nvec eigenvector matrix in the same
+ * distribution, w replicated.  route: 2 = eigen_sx, 1 = eigen_s.  nb = 1 is the cyclic layout of eigx_sx / eigx_s. */
+int eigx_solve_bc(int route, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int nb,
+                  int m_forward, int m_backward, char mode);
+int eigx_solve_bc_dev(int route, int n, int nvec, double* a_dev, int lda, double* w_dev, double* z_dev, int ldz,
+                      int nb, int m_forward, int m_backward, char mode);
+/* NUMROC(n, nb, iproc, 0, nprocs) of ScaLAPACK (TOOLS/numroc.f): local extent; -1 for invalid arguments */
+int eigx_numroc(int n, int nb, int iproc, int nprocs);
+
 /* ---- stage entry points (device arrays; used by the parity tests and the profiler) ---------- */
 
 /* replaces eigen_trd(n,a,lda,d,e,m) src/eigen_trd.F:82-113 (band=1) and

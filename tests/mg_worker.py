@@ -1,5 +1,6 @@
 """Worker of the multi-rank GPU test: `world` processes share GPU 0, collectives go through the host-staged
-gloo transport (RCCL refuses duplicate devices).  argv: rank world port n route"""
+gloo transport (RCCL refuses duplicate devices).  argv: rank world port n route [nb]
+nb > 0: the local blocks are those of a 2-D block-cyclic (nb x nb) distribution and go through eigen_sx_bc / eigen_s_bc"""
 import os
 import sys
 
@@ -10,6 +11,7 @@ import torch
 import torch.distributed as dist
 
 rank, world, port, n, route = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+nb = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
 import eigenexa_amd as ee
 from eigenexa_amd import api, layout
@@ -20,22 +22,41 @@ idn, xi, yi = ee.eigen_get_id()
 assert (xp, yp) == layout.grid_shape(world) and idn == rank + 1
 px, py = xi - 1, yi - 1
 A = layout.random_symmetric(n)
-nx, ny = ee.eigen_get_matdims(n)
-# fill the local cyclic block with the reference's index helpers (benchmark/main2.f style)
-a = np.zeros((nx, ny), order="F")
-rows = np.arange(px, n, xp)
-cols = np.arange(py, n, yp)
-a[: len(rows), : len(cols)] = layout.random_symmetric(n, rows=rows, cols=cols)
-z = np.zeros((nx, ny), order="F")
-w = np.zeros(n)
-(ee.eigen_sx if route == "sx" else ee.eigen_s)(n, n, a, nx, w, z, nx, m_forward=32, mode="A")
-assert api.last_status() == 0, api.last_status()
-# gather the cyclic eigenvector blocks
-zl = np.zeros(((n + xp - 1) // xp, (n + yp - 1) // yp))
-zl[: len(rows), : len(cols)] = z[: len(rows), : len(cols)]
-blocks = [torch.zeros(zl.shape, dtype=torch.float64) for _ in range(world)]
-dist.all_gather(blocks, torch.from_numpy(np.ascontiguousarray(zl)))
-Z = layout.gather_cyclic([b.numpy() for b in blocks], n, n)
+if nb == 0:
+    nx, ny = ee.eigen_get_matdims(n)
+    # fill the local cyclic block with the reference's index helpers (benchmark/main2.f style)
+    a = np.zeros((nx, ny), order="F")
+    rows = np.arange(px, n, xp)
+    cols = np.arange(py, n, yp)
+    a[: len(rows), : len(cols)] = layout.random_symmetric(n, rows=rows, cols=cols)
+    z = np.zeros((nx, ny), order="F")
+    w = np.zeros(n)
+    (ee.eigen_sx if route == "sx" else ee.eigen_s)(n, n, a, nx, w, z, nx, m_forward=32, mode="A")
+    assert api.last_status() == 0, api.last_status()
+    # gather the cyclic eigenvector blocks
+    zl = np.zeros(((n + xp - 1) // xp, (n + yp - 1) // yp))
+    zl[: len(rows), : len(cols)] = z[: len(rows), : len(cols)]
+    blocks = [torch.zeros(zl.shape, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(blocks, torch.from_numpy(np.ascontiguousarray(zl)))
+    Z = layout.gather_cyclic([b.numpy() for b in blocks], n, n)
+else:
+    # ScaLAPACK-style caller: descriptor MB = NB = nb on the same process grid, local extents from NUMROC
+    rows = layout.block_cyclic_indices(n, nb, px, xp)
+    cols = layout.block_cyclic_indices(n, nb, py, yp)
+    assert len(rows) == ee.numroc(n, nb, px, xp) == layout.numroc(n, nb, px, xp)
+    assert len(cols) == ee.numroc(n, nb, py, yp) == layout.numroc(n, nb, py, yp)
+    lld = max(1, len(rows)) + 3
+    a = np.zeros((lld, max(1, len(cols))), order="F")
+    a[: len(rows), : len(cols)] = layout.random_symmetric(n, rows=rows, cols=cols)
+    z = np.zeros((lld, max(1, len(cols))), order="F")
+    w = np.zeros(n)
+    (ee.eigen_sx_bc if route == "sx" else ee.eigen_s_bc)(n, n, a, lld, w, z, lld, nb, m_forward=32, mode="A")
+    assert api.last_status() == 0, api.last_status()
+    zl = np.zeros((layout.numroc(n, nb, 0, xp), layout.numroc(n, nb, 0, yp)))
+    zl[: len(rows), : len(cols)] = z[: len(rows), : len(cols)]
+    blocks = [torch.zeros(zl.shape, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(blocks, torch.from_numpy(np.ascontiguousarray(zl)))
+    Z = layout.gather_block_cyclic([b.numpy() for b in blocks], n, n, nb)
 wr = np.linalg.eigvalsh(A)
 werr = np.abs(w - wr).max() / np.abs(wr).max()
 res, orth = layout.accuracy_metrics(A, w, Z)
@@ -47,4 +68,4 @@ assert abs(a[0, 0]) > 0 if (px == 0 and py == 0) else True
 ee.eigen_free()
 dist.barrier()
 dist.destroy_process_group()
-print(f"OK rank {rank}/{world} n={n} {route}: werr {werr:.2e} res {res:.3e} orth {orth:.3e}", flush=True)
+print(f"OK rank {rank}/{world} n={n} {route} nb={nb}: werr {werr:.2e} res {res:.3e} orth {orth:.3e}", flush=True)

@@ -333,10 +333,12 @@ def test_baseline_size_properties(gpu_lib, route):
     assert (w[1:] >= w[:-1]).all()                                             # ascending
 
 
-@pytest.mark.parametrize("world,n,route", [(2, 300, "sx"), (4, 517, "sx"), (4, 300, "s"), (3, 260, "sx")])
-def test_multi_rank_solver_on_one_gpu(world, n, route):
+@pytest.mark.parametrize("world,n,route,nb", [(2, 300, "sx", 0), (4, 517, "sx", 0), (4, 300, "s", 0), (3, 260, "sx", 0),
+                                              (4, 517, "sx", 32), (4, 301, "s", 7), (2, 260, "sx", 64)])
+def test_multi_rank_solver_on_one_gpu(world, n, route, nb):
     """the N>1 path (tile-column sharded reduction, replicated D&C, column-parallel back-transform, 2-D cyclic
-    API layout) with `world` ranks sharing the GPU over the host-staged gloo transport"""
+    API layout) with `world` ranks sharing the GPU over the host-staged gloo transport; nb > 0: ScaLAPACK-style
+    block-cyclic local blocks through eigen_sx_bc / eigen_s_bc (ragged last blocks, ranks without a last block)"""
     import socket
     import subprocess
     import sys
@@ -346,7 +348,7 @@ def test_multi_rank_solver_on_one_gpu(world, n, route):
     port = s.getsockname()[1]
     s.close()
     script = os.path.join(os.path.dirname(__file__), "mg_worker.py")
-    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port), str(n), route],
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port), str(n), route, str(nb)],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:

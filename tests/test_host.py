@@ -192,3 +192,30 @@ def test_benchmark_driver_input_format(tmp_path):
     lam = np.array([1.0, 2.0, 3.0])
     assert benchmark.w_test(lam * (1 + 1e-12), lam, msgs.append)
     assert any("Relative Error *** : PASSED" in m for m in msgs)
+
+
+def test_numroc_and_block_cyclic_layout():
+    """NUMROC of the C-ABI against the python restatement and a brute-force count; block-cyclic scatter/gather round
+    trip (the layout eigx_solve_bc accepts); nb = 1 reduces to the cyclic layout of the EigenExa API"""
+    from eigenexa_amd import _lib, layout
+
+    lib = _lib.load()
+    for n in (1, 5, 64, 100, 301):
+        for nb in (1, 2, 7, 32, 64):
+            for P in (1, 2, 3, 4):
+                tot = 0
+                for p in range(P):
+                    c = layout.numroc(n, nb, p, P)
+                    assert c == lib.eigx_numroc(n, nb, p, P) == len(layout.block_cyclic_indices(n, nb, p, P))
+                    if nb == 1:
+                        assert c == layout.local_count(n, p, P)
+                    tot += c
+                assert tot == n
+    assert lib.eigx_numroc(10, 0, 0, 2) == -1 and lib.eigx_numroc(10, 2, 2, 2) == -1
+    A = np.arange(35 * 29.0).reshape(35, 29)
+    for nb in (1, 4, 16):
+        blocks = [layout.scatter_block_cyclic(A, nb, 4, r) for r in range(4)]
+        assert (layout.gather_block_cyclic(blocks, 35, 29, nb) == A).all()
+    # nb = 1 block-cyclic == cyclic
+    for r in range(4):
+        assert (layout.scatter_block_cyclic(A, 1, 4, r) == layout.scatter_cyclic(A, 4, r)).all()
