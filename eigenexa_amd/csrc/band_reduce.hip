@@ -547,14 +547,14 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
 // =================================================================================================
 // K_B : fused symmetric mat-vec on the upper triangle, NV vectors, plus (same launch, extra workgroup
 // rows) K_P : panel dot products and reflector store.
-// grid (gx, nt + npd):
-//   blockIdx.y <  nt : SYMV workgroup, tile (ty = blockIdx.y, tx = blockIdx.x), tx >= ty, T = 128*RB:
+// grid: 1-D, nt(nt+1)/2 tile workgroups (row-major upper block triangle) followed by npd*(ncg+1) panel workgroups
+//   tile (ty, tx), tx >= ty, T = 128*RB:
 //                      rows [ty*T, +T) x columns [tx*T, +T) of [0,L).  Wave w owns the tile columns
 //                      [w*T/4, +T/4) in groups of 8; a lane owns rows 2*lane, 2*lane+1 of each of the RB
 //                      128-row blocks (16-byte loads, 1 KiB per wave-instruction, down the columns).
 //                      Column sums: halving butterfly of wave shuffles once per column group.
 //                      Row sums: per-wave registers, combined over the 4 waves through LDS.
-//   blockIdx.y >= nt : panel workgroup, row chunk = blockIdx.y - nt, column group cg = blockIdx.x:
+//   panel workgroup (row chunk, column group cg):
 //                      cg < ncg : panel columns [cg*PD_COLS, +PD_COLS) of U and W against the NV new vectors
 //                      cg == ncg: store the reflectors into the panel (both U copies) and into `a`, uA.uB
 // =================================================================================================
@@ -611,14 +611,32 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ldp = R.ldp;
   const int L = B.L, i = B.i;
-  const bool panel_role = (int)blockIdx.y >= B.nt;
-  if (!panel_role && ((int)blockIdx.x >= B.nt || blockIdx.x < blockIdx.y)) return;
-  if (!panel_role && R.P > 1 && ((int)blockIdx.x % R.P) != R.p) return;  // not my tile column
-  if (panel_role && (int)blockIdx.x > B.ncg) return;
+  // 1-D grid: the nt(nt+1)/2 tiles of the upper block triangle (row-major), then the K_P workgroups
+  // [chunk][column group 0..ncg]: no empty workgroups for the lower triangle
+  const int bid = blockIdx.x;
+  const int ntri = B.nt * (B.nt + 1) / 2;
+  const bool panel_role = bid >= ntri;
+  int tyv = 0, txv = 0;
+  if (!panel_role) {
+    // row ty starts at ty*nt - ty(ty-1)/2: invert with a float sqrt and fix up by at most one step each way
+    const float fn = 2.0f * (float)B.nt + 1.0f;
+    int ty = (int)((fn - sqrtf(fn * fn - 8.0f * (float)bid)) * 0.5f);
+    if (ty < 0) ty = 0;
+    if (ty > B.nt - 1) ty = B.nt - 1;
+    while (ty > 0 && ty * B.nt - ty * (ty - 1) / 2 > bid) --ty;
+    while ((ty + 1) * B.nt - (ty + 1) * ty / 2 <= bid) ++ty;
+    tyv = ty;
+    txv = ty + (bid - (ty * B.nt - ty * (ty - 1) / 2));
+    if (R.P > 1 && (txv % R.P) != R.p) return;  // not my tile column
+  } else {
+    const int q = bid - ntri;
+    tyv = B.nt + q / (B.ncg + 1);   // nt + row chunk
+    txv = q - (q / (B.ncg + 1)) * (B.ncg + 1);   // column group
+  }
 
   // ---- SYMV role: issue everything that needs no scalar before the (latency-bound) scalar reduction:
   // raw x values of this tile's columns / this lane's rows and the first 8-column unit of A
-  const int ty = blockIdx.y, tx = blockIdx.x;
+  const int ty = tyv, tx = txv;
   const int row0 = ty * T, col0 = tx * T;
   EIGX_STAMP_INIT
   const int wcol0 = wave * (T / 4);       // first tile column of this wave
@@ -717,7 +735,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
     }
   }
   // the store-role panel workgroup of chunk 0 publishes the scalars (it exists on every rank)
-  if (panel_role && (int)blockIdx.x == B.ncg && (int)blockIdx.y == B.nt && tid == 0) {
+  if (panel_role && tx == B.ncg && ty == B.nt && tid == 0) {
     R.sc[SC_SA] = sA; R.sc[SC_BETA_A] = betaA;
     if (NV == 1) {
       R.e[i] = sA;                               // e(i,1) = T(i-1,i)
@@ -741,7 +759,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
     // No LDS staging: u_A, u_B are recomputed from the x vectors (L2-hot) next to every U/W load, so the
     // chunk length is free and there are never more than 4 row chunks to re-reduce in K_A.
     const int m = R.m, k = B.k;
-    const int chunk = blockIdx.y - B.nt, cg = blockIdx.x;
+    const int chunk = ty - B.nt, cg = tx;
     const int pdr = B.pdr;
     const int rbase = chunk * pdr;
     double* Up = R.UW;
@@ -1087,16 +1105,16 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     B.toprows = i + 1;
     B.pdr = pd_rows_for(B.toprows);
     const int npd = (B.toprows + B.pdr - 1) / B.pdr;
-    const int gx = g.nt > B.ncg + 1 ? g.nt : B.ncg + 1;
+    const int gx = g.nt * (g.nt + 1) / 2 + npd * (B.ncg + 1);   // tiles of the upper block triangle + K_P workgroups
     B.ngp = nb_ka;
     const bool prof = ctx.prof_stride > 0 && (n_symv % ctx.prof_stride) == 0;
     if (prof) ctx.prof_begin(0, 8.0 * ((double)L * (L + 1) / 2) / R.P, st);  // this rank's share of the triangle
     const bool nt_loads = L > g_symv_nt;
-    if (g.T == 128) hipLaunchKernelGGL((symv_kernel<NB, 1, false>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
-    else if (g.T == 256 && !nt_loads) hipLaunchKernelGGL((symv_kernel<NB, 2, false>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
-    else if (g.T == 256) hipLaunchKernelGGL((symv_kernel<NB, 2, true>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
-    else if (!nt_loads) hipLaunchKernelGGL((symv_kernel<NB, 4, false>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
-    else hipLaunchKernelGGL((symv_kernel<NB, 4, true>), dim3(gx, g.nt + npd), dim3(256), 0, st, R, B);
+    if (g.T == 128) hipLaunchKernelGGL((symv_kernel<NB, 1, false>), dim3(gx), dim3(256), 0, st, R, B);
+    else if (g.T == 256 && !nt_loads) hipLaunchKernelGGL((symv_kernel<NB, 2, false>), dim3(gx), dim3(256), 0, st, R, B);
+    else if (g.T == 256) hipLaunchKernelGGL((symv_kernel<NB, 2, true>), dim3(gx), dim3(256), 0, st, R, B);
+    else if (!nt_loads) hipLaunchKernelGGL((symv_kernel<NB, 4, false>), dim3(gx), dim3(256), 0, st, R, B);
+    else hipLaunchKernelGGL((symv_kernel<NB, 4, true>), dim3(gx), dim3(256), 0, st, R, B);
     if (prof) ctx.prof_end(st);
     if (R.P > 1) {
       const int Lp = (L + 7) / 8 * 8;
