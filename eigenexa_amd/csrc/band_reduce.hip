@@ -76,15 +76,17 @@ struct RedArgs {
 };
 
 // SYMV tiling: square tiles of T = 128*RB rows/cols (RB = 1,2,4); tile (ty,tx) with tx >= ty is one
-// workgroup.  Small triangles get small tiles so that >= ~400 workgroups exist; the 512 tile only bounds the
-// number of partial sums per row (nt+1 <= 160) beyond L = 40000.
+// workgroup.  Small triangles get small tiles so that >= ~400 workgroups exist; the 512 tile takes over beyond
+// L = 20000 (fewer partial sums per row, 2.5 % faster there).
 struct SymvGeom { int L, T, nt; };
 
 // Tile-size thresholds and the active size above which the matrix is streamed with non-temporal loads
 // (eigx_tune keys 3, 4, 5).  A/B on one MI355X (tools/gpu_reduce_time.py): N=16384 972 -> 833 ms and N=32768
 // 6008 -> 5347 ms with the 256 tile + non-temporal loads instead of the 512 tile; N=8192 loses 1 % with
-// non-temporal loads (its 512 MB matrix still profits from the 256 MB Infinity Cache).
-int g_symv_t128 = 4500, g_symv_t256 = 40000;
+// non-temporal loads (its 512 MB matrix still profits from the 256 MB Infinity Cache).  Re-swept after the 1-D
+// triangular grid: N=32768 5131 ms (256 tile throughout) -> 5005 ms with the 512 tile for L > 20000; N=16384 prefers
+// the 256 tile everywhere (797 vs 818 ms with a threshold of 12000).
+int g_symv_t128 = 4500, g_symv_t256 = 20000;
 int g_symv_nt = 9000;
 
 inline SymvGeom symv_geom(int L, int P = 1) {
