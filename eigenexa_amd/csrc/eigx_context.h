@@ -61,6 +61,11 @@ struct Context {
   static constexpr int kAux = 6;
   hipStream_t aux[kAux] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // concurrent small GEMMs (D&C levels)
   hipEvent_t aux_ev[kAux + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // back-transformation plan prepared ahead (trbak_prepare_dev on the side stream during the D&C): event + key
+  hipEvent_t bt_ev = nullptr;
+  bool bt_ready = false;
+  const double* bt_a = nullptr; double* bt_V = nullptr;
+  int bt_n = 0, bt_mb = 0, bt_band = 0, bt_ldv = 0;
   Pool pool;
   CommState* comm = nullptr;
   int64_t errinfo = 0;

@@ -13,6 +13,8 @@
 
 namespace eigx {
 
+void trbak_prepare_dev(Context& ctx, int n, double* A, int lda, const double* e, int lde, int mb, int band,
+                       hipStream_t s);
 void trbak_dev(Context& ctx, int n, int nvec, double* A, int lda, double* Z, int ldz, const double* e,
                int lde, int mb, int band);
 
@@ -203,6 +205,11 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   // ---- divide and conquer --------------------------------------------------------------------------
   // modes (src/eigen_sx.F:200-222): A/X/T/R divide and conquer (X: eigenvalues then re-done by bisection),
   // S/C identity eigenvector matrix + bisection, N bisection only
+  const bool do_bt = want_vec && mode != 'T' && mode != 'C' && mode != 'R';  // src/eigen_sx.F:240
+  // The T factors of the back-transformation depend on the reflectors only: build them on the side stream while the
+  // divide and conquer (launch-bound at its low levels) has the compute stream.  The reduction is complete here
+  // (the host synchronised the compute stream above).
+  if (do_bt && nvec > 0) trbak_prepare_dev(ctx, n, a, lda, e, lde, mb, band, ctx.side_stream);
   if (mode == 'N' || mode == 'S' || mode == 'C') {
     if (want_vec) hipLaunchKernelGGL(identity_kernel, dim3(8, nvec), dim3(256), 0, st, z, ldz, n);
     band_bisect_dev(ctx, n, d, e, lde, band, w);
@@ -213,7 +220,6 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   const double t3 = now_s();
 
   // ---- back-transformation ---------------------------------------------------------------------------
-  const bool do_bt = want_vec && mode != 'T' && mode != 'C' && mode != 'R';  // src/eigen_sx.F:240
   if (do_bt) {
     if (P == 1) {
       trbak_dev(ctx, n, nvec, a, lda, z, ldz, e, lde, mb, band);

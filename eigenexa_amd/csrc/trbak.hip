@@ -108,25 +108,35 @@ __global__ void gsum_kernel(const double* __restrict__ Gall, int maxchunks, int 
 // reflectors [jstart, jend) in blocks of mbe = q * mb columns (q = 1: any range, the last block may be short;
 // q > 1: jend - jstart must be a multiple of mbe).  T of a super-block is assembled from the 128-column
 // diagonal blocks: S = [[S11, 0], [S21, S22]]  =>  S^-1 = [[T11, 0], [-T22 S21 T11, T22]], S21 = V2^T V1.
-static void bt_range(Context& ctx, int n, int nvec, double* V, int ldv, double* Z, int ldz, const double* e, int lde,
-                     int band, int jstart, int jend, int mb, int q) {
-  if (jend <= jstart) return;
-  hipStream_t st = ctx.stream;
-  const int mbe = mb * q;
-  const int nblk = (jend - jstart + mbe - 1) / mbe;
+// bt_prepare_range builds the T factors (they depend on the reflectors only, so trbak_prepare_dev runs this on the
+// side stream while the divide and conquer occupies the compute stream); bt_apply_range applies them to Z.
+struct BtRange { int mbe, nblk, gch, maxchunks; size_t msz; double* Tall; };
+
+static BtRange bt_range_geom(Context& ctx, int band, int jstart, int jend, int mb, int q) {
+  BtRange g;
+  g.mbe = mb * q;
+  g.nblk = (jend - jstart + g.mbe - 1) / g.mbe;
   const int rows_all = jend - band;                    // longest reflector of the range
   // Gram row chunks: 512 rows for plain blocks; ~4096 rows (even, as few padding rows as possible) for
   // super-blocks, whose partial Grams are mbe x mbe each
-  int gch = GCH, maxchunks = (rows_all + GCH - 1) / GCH;
+  g.gch = GCH; g.maxchunks = (rows_all + GCH - 1) / GCH;
   if (q > 1) {
-    maxchunks = (rows_all + 4095) / 4096;
-    gch = ((rows_all + maxchunks - 1) / maxchunks + 1) & ~1;
+    g.maxchunks = (rows_all + 4095) / 4096;
+    g.gch = ((rows_all + g.maxchunks - 1) / g.maxchunks + 1) & ~1;
   }
-  const size_t msz = (size_t)mbe * mbe;
+  g.msz = (size_t)g.mbe * g.mbe;
+  g.Tall = ctx.pool.get_t<double>(q > 1 ? "bt.Tq" : "bt.T", (size_t)g.nblk * g.msz);
+  return g;
+}
+
+static void bt_prepare_range(Context& ctx, hipStream_t st, int n, double* V, int ldv, const double* e, int lde, int band,
+                             int jstart, int jend, int mb, int q) {
+  if (jend <= jstart) return;
+  const BtRange g = bt_range_geom(ctx, band, jstart, jend, mb, q);
+  const int mbe = g.mbe, nblk = g.nblk, gch = g.gch, maxchunks = g.maxchunks;
+  const size_t msz = g.msz;
+  double* Tall = g.Tall;
   double* Gall = ctx.pool.get_t<double>(q > 1 ? "bt.Gq" : "bt.G", (size_t)nblk * maxchunks * msz);
-  double* Tall = ctx.pool.get_t<double>(q > 1 ? "bt.Tq" : "bt.T", (size_t)nblk * msz);
-  double* W = ctx.pool.get_t<double>("bt.W", (size_t)512 * nvec);
-  double* X = ctx.pool.get_t<double>("bt.X", (size_t)512 * nvec);
   const size_t tshm = ((size_t)mb * (mb + 1) + mb) * sizeof(double);
   static bool attr = false;
   if (!attr) {
@@ -166,22 +176,34 @@ static void bt_range(Context& ctx, int n, int nvec, double* V, int ldv, double* 
                 nullptr, nullptr, np, dstep, (long)h * h, dstep, nblk, (long)msz, (long)np * h * h, (long)msz);
     }
   }
-  for (int b = 0; b < nblk; ++b) {
+}
+
+static void bt_apply_range(Context& ctx, int nvec, const double* V, int ldv, double* Z, int ldz, int band, int jstart,
+                           int jend, int mb, int q) {
+  if (jend <= jstart) return;
+  hipStream_t st = ctx.stream;
+  const BtRange g = bt_range_geom(ctx, band, jstart, jend, mb, q);
+  const int mbe = g.mbe;
+  double* W = ctx.pool.get_t<double>("bt.W", (size_t)512 * nvec);
+  double* X = ctx.pool.get_t<double>("bt.X", (size_t)512 * nvec);
+  for (int b = 0; b < g.nblk; ++b) {
     const int j0 = jstart + b * mbe;
     const int mbk = (jend - j0 < mbe) ? jend - j0 : mbe;
     const int rows = j0 + mbk - band;  // length of the longest reflector of the block
     const double* Vb = V + (size_t)j0 * ldv;
-    const double* T = Tall + (size_t)b * msz;
+    const double* T = g.Tall + (size_t)b * g.msz;
     dgemm_dev(st, 'T', 'N', mbk, nvec, rows, 1.0, Vb, ldv, Z, ldz, 0.0, W, mbe);
     dgemm_dev(st, 'N', 'N', mbk, nvec, mbk, 1.0, T, mbe, W, mbe, 0.0, X, mbe);
     dgemm_dev(st, 'N', 'N', rows, nvec, mbk, -1.0, Vb, ldv, X, mbe, 1.0, Z, ldz);
   }
 }
 
-void trbak_dev(Context& ctx, int n, int nvec, double* A, int lda, double* Z, int ldz, const double* e,
-               int lde, int mb, int band) {
-  if (nvec <= 0 || n <= band) return;
-  hipStream_t st = ctx.stream;
+// Block plan of the whole back-transformation: a head range of (n - band) mod mbe short reflectors in plain
+// 128-column blocks, then super-blocks up to column n -- the long reflectors, where a block costs three passes over
+// all of Z, are always inside super-blocks (the remainder used to sit at the long end: 3.5 of 21.4 ms at N=8192).
+struct BtPlan { int mb, q, mbe, js, rows_pad; };
+static BtPlan bt_plan(int n, int mb, int band) {
+  BtPlan p;
   if (mb < 8) mb = 8;
   if (mb > 128) mb = 128;  // T-builder keeps two packed mb x mb triangles in LDS; wider blocks are assembled
   // Super-blocks: every block costs three passes over Z (read for W = V^T Z, read + write for Z -= V X), and at
@@ -189,31 +211,56 @@ void trbak_dev(Context& ctx, int n, int nvec, double* A, int lda, double* Z, int
   int q = 1;
   if (mb == 128 && n >= 2048) q = (n >= 6144) ? 4 : 2;   // measured: N=8192 31.4 -> 26.2 (q=2) -> 23.9 ms (q=4)
   if (g_bt_q > 0 && mb == 128) q = g_bt_q;
-  const int mbe = mb * q;
-  const int rows_all = n - band;                       // longest reflector
-  // Gram chunks read whole chunks of rows: the zero padding below the reflectors must stay inside lda
-  int rows_pad = (rows_all + GCH - 1) / GCH * GCH;
-  const int nsup = (q > 1) ? (n - band) / mbe : 0;
-  if (nsup > 0) {   // the super-block range [band, band + nsup*mbe) uses its own (larger) chunks: see bt_range
-    const int rs = nsup * mbe;
-    const int mc = (rs + 4095) / 4096;
-    const int g = ((rs + mc - 1) / mc + 1) & ~1;
-    if (mc * g > rows_pad) rows_pad = mc * g;
+  p.mb = mb; p.q = q; p.mbe = mb * q;
+  const int total = n - band;                          // number of reflectors = longest reflector
+  const int nsup = (q > 1) ? total / p.mbe : 0;
+  p.js = (nsup > 0) ? n - nsup * p.mbe : n;            // super-block range [js, n); plain blocks [band, js)
+  if (nsup == 0) p.q = 1;
+  // Gram chunks read whole chunks of rows: the zero padding below the reflectors must stay inside the leading dimension
+  p.rows_pad = (total + GCH - 1) / GCH * GCH;
+  if (nsup > 0) {
+    const int mc = (total + 4095) / 4096;
+    const int gg = ((total + mc - 1) / mc + 1) & ~1;
+    if (mc * gg > p.rows_pad) p.rows_pad = mc * gg;
   }
-  const bool inplace = rows_pad <= lda;
+  return p;
+}
+
+// T factors of all blocks, on stream s (any stream: the caller orders it after the reduction).  Records ctx.bt_ev.
+void trbak_prepare_dev(Context& ctx, int n, double* A, int lda, const double* e, int lde, int mb, int band,
+                       hipStream_t s) {
+  ctx.bt_ready = false;
+  if (n <= band) return;
+  const BtPlan p = bt_plan(n, mb, band);
+  const bool inplace = p.rows_pad <= lda;
   double* V = A;
   int ldv = lda;
   if (!inplace) {
     // lda too small for the zero padding of the last Gram chunk: work on a padded copy of the reflectors
-    ldv = pad_ld(rows_pad);
+    ldv = pad_ld(p.rows_pad);
     V = ctx.pool.get_t<double>("bt.Vall", (size_t)ldv * n);
     EIGX_HIP_CHECK(hipMemcpy2DAsync(V, (size_t)ldv * 8, A, (size_t)lda * 8, (size_t)n * 8, (size_t)n,
-                                    hipMemcpyDeviceToDevice, st));
+                                    hipMemcpyDeviceToDevice, s));
   }
-  hipLaunchKernelGGL(zero_below_kernel, dim3(8, n), dim3(256), 0, st, V, ldv, n, band, rows_pad);
-  const int jr = band + nsup * mbe;
-  if (nsup > 0) bt_range(ctx, n, nvec, V, ldv, Z, ldz, e, lde, band, band, jr, mb, q);
-  bt_range(ctx, n, nvec, V, ldv, Z, ldz, e, lde, band, jr, n, mb, 1);
+  hipLaunchKernelGGL(zero_below_kernel, dim3(8, n), dim3(256), 0, s, V, ldv, n, band, p.rows_pad);
+  bt_prepare_range(ctx, s, n, V, ldv, e, lde, band, band, p.js, p.mb, 1);
+  if (p.js < n) bt_prepare_range(ctx, s, n, V, ldv, e, lde, band, p.js, n, p.mb, p.q);
+  EIGX_HIP_CHECK(hipEventRecord(ctx.bt_ev, s));
+  ctx.bt_ready = true;
+  ctx.bt_a = A; ctx.bt_n = n; ctx.bt_mb = mb; ctx.bt_band = band; ctx.bt_V = V; ctx.bt_ldv = ldv;
+}
+
+void trbak_dev(Context& ctx, int n, int nvec, double* A, int lda, double* Z, int ldz, const double* e,
+               int lde, int mb, int band) {
+  if (nvec <= 0 || n <= band) { ctx.bt_ready = false; return; }
+  hipStream_t st = ctx.stream;
+  if (!(ctx.bt_ready && ctx.bt_a == A && ctx.bt_n == n && ctx.bt_mb == mb && ctx.bt_band == band))
+    trbak_prepare_dev(ctx, n, A, lda, e, lde, mb, band, st);
+  EIGX_HIP_CHECK(hipStreamWaitEvent(st, ctx.bt_ev, 0));
+  ctx.bt_ready = false;   // the plan belongs to this reduction's reflectors only
+  const BtPlan p = bt_plan(n, mb, band);
+  bt_apply_range(ctx, nvec, ctx.bt_V, ctx.bt_ldv, Z, ldz, band, band, p.js, p.mb, 1);
+  if (p.js < n) bt_apply_range(ctx, nvec, ctx.bt_V, ctx.bt_ldv, Z, ldz, band, p.js, n, p.mb, p.q);
   EIGX_HIP_CHECK(hipGetLastError());
 }
 
