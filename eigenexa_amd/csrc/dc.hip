@@ -873,9 +873,12 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
         }
       }
       EIGX_HIP_CHECK(hipStreamSynchronize(st));
-      if (trace)
-        fprintf(stderr, "[eigx dc] height %d pass %d: %zu merges, z gather + D2H %.3f ms, host deflation %.3f ms, device part %.3f ms\n",
-                h, k, ids.size(), (tt1 - tt0) * 1e3, (tt2 - tt1) * 1e3, (now_s() - tt2) * 1e3);
+      if (trace) {
+        long sumK = 0, sumN = 0;
+        for (const MergeDev& M : mds) { sumK += M.K; sumN += M.nm; }
+        fprintf(stderr, "[eigx dc] height %d pass %d: %zu merges (non-deflated %ld of %ld), z gather + D2H %.3f ms, host deflation %.3f ms, "
+                "device part %.3f ms\n", h, k, ids.size(), sumK, sumN, (tt1 - tt0) * 1e3, (tt2 - tt1) * 1e3, (now_s() - tt2) * 1e3);
+      }
     }
   }
 

@@ -184,8 +184,8 @@ static void bt_apply_range(Context& ctx, int nvec, const double* V, int ldv, dou
   hipStream_t st = ctx.stream;
   const BtRange g = bt_range_geom(ctx, band, jstart, jend, mb, q);
   const int mbe = g.mbe;
-  double* W = ctx.pool.get_t<double>("bt.W", (size_t)512 * nvec);
-  double* X = ctx.pool.get_t<double>("bt.X", (size_t)512 * nvec);
+  double* W = ctx.pool.get_t<double>("bt.W", (size_t)(mbe > 512 ? mbe : 512) * nvec);
+  double* X = ctx.pool.get_t<double>("bt.X", (size_t)(mbe > 512 ? mbe : 512) * nvec);
   for (int b = 0; b < g.nblk; ++b) {
     const int j0 = jstart + b * mbe;
     const int mbk = (jend - j0 < mbe) ? jend - j0 : mbe;
