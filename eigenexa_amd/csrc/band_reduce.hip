@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
 // =================================================================================================
 // K_B : fused symmetric mat-vec on the upper triangle, NV vectors, plus (same launch, extra workgroup
 // rows) K_P : panel dot products and reflector store.
-// grid: 1-D, nt(nt+1)/2 tile workgroups (row-major upper block triangle) followed by npd*(ncg+1) panel workgroups
+// grid: 1-D, npd*(ncg+1) panel workgroups followed by the nt(nt+1)/2 tile workgroups (row-major upper block triangle)
 //   tile (ty, tx), tx >= ty, T = 128*RB:
 //                      rows [ty*T, +T) x columns [tx*T, +T) of [0,L).  Wave w owns the tile columns
 //                      [w*T/4, +T/4) in groups of 8; a lane owns rows 2*lane, 2*lane+1 of each of the RB
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
 //                      cg < ncg : panel columns [cg*PD_COLS, +PD_COLS) of U and W against the NV new vectors
 //                      cg == ncg: store the reflectors into the panel (both U copies) and into `a`, uA.uB
 // =================================================================================================
-struct KBArgs { int i, L, nt, ngp, k, ncg, toprows, pdr; };
+struct KBArgs { int i, L, nt, ngp, k, ncg, toprows, pdr, npd; };
 
 // K_L (multi-GPU only): reduce this rank's SYMV partials (owned tile columns) into RB before the allreduce
 template <int NB>
@@ -613,11 +613,11 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ldp = R.ldp;
   const int L = B.L, i = B.i;
-  // 1-D grid: the nt(nt+1)/2 tiles of the upper block triangle (row-major), then the K_P workgroups
-  // [chunk][column group 0..ncg]: no empty workgroups for the lower triangle
-  const int bid = blockIdx.x;
-  const int ntri = B.nt * (B.nt + 1) / 2;
-  const bool panel_role = bid >= ntri;
+  // 1-D grid: the K_P workgroups [chunk][column group 0..ncg], then the nt(nt+1)/2 tiles of the upper block triangle
+  // (row-major): no empty workgroups for the lower triangle
+  const int nkp = B.npd * (B.ncg + 1);
+  const bool panel_role = (int)blockIdx.x < nkp;     // K_P first: its workgroups are the long ones at small L
+  const int bid = (int)blockIdx.x - nkp;
   int tyv = 0, txv = 0;
   if (!panel_role) {
     // row ty starts at ty*nt - ty(ty-1)/2: invert with a float sqrt and fix up by at most one step each way
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
     txv = ty + (bid - (ty * B.nt - ty * (ty - 1) / 2));
     if (R.P > 1 && (txv % R.P) != R.p) return;  // not my tile column
   } else {
-    const int q = bid - ntri;
+    const int q = blockIdx.x;
     tyv = B.nt + q / (B.ncg + 1);   // nt + row chunk
     txv = q - (q / (B.ncg + 1)) * (B.ncg + 1);   // column group
   }
@@ -1107,6 +1107,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     B.toprows = i + 1;
     B.pdr = pd_rows_for(B.toprows);
     const int npd = (B.toprows + B.pdr - 1) / B.pdr;
+    B.npd = npd;
     const int gx = g.nt * (g.nt + 1) / 2 + npd * (B.ncg + 1);   // tiles of the upper block triangle + K_P workgroups
     B.ngp = nb_ka;
     const bool prof = ctx.prof_stride > 0 && (n_symv % ctx.prof_stride) == 0;
