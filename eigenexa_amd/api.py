@@ -39,11 +39,15 @@ def _char(c, default):
     return str(c)[:1].encode()
 
 
-def eigen_init(comm=None, order="C", device=None):
+def eigen_init(comm=None, order="C", device=None, dims=None):
     """eigen_init(comm, order): ``comm`` is None (single GPU) or an initialised ``torch.distributed``
     process group / True for the default group (one process per GPU; RCCL communicators are built from
-    a unique id broadcast over it).  ``order`` 'R' or 'C' as in the reference (src/eigen_libs.F:88-97)."""
+    a unique id broadcast over it).  ``order`` 'R' or 'C' as in the reference (src/eigen_libs.F:88-97).
+    ``dims`` = (Px, Py): explicit process grid, the counterpart of passing a 2-D cartesian communicator
+    (src/eigen_libs0.F:579-715)."""
     lib = _lib.load()
+    if dims is not None:
+        _lib.check(lib.eigx_set_grid_dims(int(dims[0]), int(dims[1])), "eigx_set_grid_dims")
     rank, nranks = 0, 1
     dist = None
     if comm is not None and comm is not False:

@@ -1,6 +1,7 @@
 """eigenexa_benchmark for the MI355X build: runs the reference's benchmark input files against libeigenexa_amd.
 
-    python -m eigenexa_amd.benchmark [-f IN] [-c | -n] [-L]
+    python -m eigenexa_amd.benchmark [-f IN] [-c | -n] [-L] [-g R|C|A|<k>] [-x Px Py]
+    python -m torch.distributed.run --nproc-per-node P -m eigenexa_amd.benchmark ...      (one process per GPU)
 
 Same input-file format as the reference driver (benchmark/IN, benchmark/main2.f:262-300): one case per line,
 ``N nvec bx by mode matrix solver check``; lines starting with ``!`` are comments; a non-positive N ends the run.
@@ -14,8 +15,14 @@ Same input-file format as the reference driver (benchmark/IN, benchmark/main2.f:
            sets, residual / orthogonality test (benchmark/ev_test.f:181-204)
 
 The matrix stays in HBM (device API of the C-ABI); the report lines follow the reference's (elapsed time, FLOP,
-GFLOPS, the PASSED / CAUTION / FAILED verdicts with the same thresholds).  Options -g / -x (process-grid shapes of
-the MPI build) do not apply to the one-GPU driver.
+GFLOPS, the PASSED / CAUTION / FAILED verdicts with the same thresholds).
+
+Multi-rank runs (one process per GPU, launched by torch.distributed.run) take the reference's process-grid options
+(benchmark/main2.f:139-216): ``-g R`` / ``-g C`` row- / column-major rank order, ``-g A`` every rank solves alone on
+its own 1x1 grid (the MPI_COMM_SELF case), ``-g <k>`` split the ranks into k groups of which group 0 solves and the
+others do not participate (the MPI_COMM_NULL case), ``-x Px Py`` an explicit Px x Py grid (Px <= Py).  The local
+2-D cyclic blocks are filled from the same matrix generators; the checks gather the eigenvector blocks onto rank 0.
+``EIGX_BENCH_BACKEND=gloo`` runs all ranks on GPU 0 over the host-staged transport (functional rehearsal only).
 """
 import argparse
 import sys
@@ -100,8 +107,9 @@ def ev_test(A_dev, w_dev, z_dev, n, out):
     return r < 768 and o < 8
 
 
-def run_case(case, check_default=None, out=print):
-    """one input line; returns a dict with the timings and verdicts"""
+def run_case(case, check_default=None, out=print, mr=None):
+    """one input line; returns a dict with the timings and verdicts.  ``mr`` (multi-rank runs) = dict with the
+    torch.distributed module, the solver group, this rank's index in it and its size"""
     import torch
 
     n, nvec, bx, by, imode, mtype, solver, merror = case
@@ -110,25 +118,32 @@ def run_case(case, check_default=None, out=print):
     check = (merror == 1) if check_default is None else check_default
     if mtype not in MATRIX_TEXT:
         raise ValueError(f"matrix type {mtype} is not supported by this driver")
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda", torch.cuda.current_device())
     A, lam = layout.reference_matrix(n, mtype)
     nx, ny = api.eigen_get_matdims(n)
-    A_dev = torch.from_numpy(A).to(dev)
+    procs, Px, Py = api.eigen_get_procs()
+    _, xi, yi = api.eigen_get_id()
+    px, py = xi - 1, yi - 1
+    rows = np.arange(px, n, Px)      # global indices of this rank's cyclic block (src/eigen_libs0.F:1825-2258)
+    cols = np.arange(py, n, Py)
     a = torch.zeros(ny, nx, dtype=torch.float64, device=dev)   # column-major (nx, ny)
-    a[:n, :n] = A_dev.T
+    a[: len(cols), : len(rows)] = torch.from_numpy(np.ascontiguousarray(A[np.ix_(rows, cols)].T)).to(dev)
     z = torch.zeros(ny, nx, dtype=torch.float64, device=dev)
     w = torch.zeros(n, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
+    if mr is not None:
+        mr["dist"].barrier(group=mr["group"])
     t0 = time.perf_counter()
     (api.eigen_sx if solver == 0 else api.eigen_s)(n, nvec, a, nx, w, z, nx, m_forward=bx, m_backward=by, mode=mode)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     status = api.last_status()
-    flops = float(a[0, 0].item()) if n >= 1 else 0.0
+    lead = mr is None or mr["rank"] == 0   # rank 0 of the solver group runs the checks
+    flops = float(a[0, 0].item()) if (n >= 1 and px == 0 and py == 0) else 0.0
     out("======================================================")
     out("Solver = eigen_sx / via penta-diagonal format" if solver == 0 else "Solver = eigen_s  / via tri-diagonal format")
     out(f"Block width = {bx} / {by}")
-    out("NUM.OF.PROCESS= 1 ( 1 1 )   [1x MI355X]")
+    out(f"NUM.OF.PROCESS= {procs} ( {Px} {Py} )   [{procs}x MI355X]")
     out(f"Matrix dimension = {n}")
     out(f"Matrix type = {mtype} {MATRIX_TEXT[mtype]}")
     out(f"The number of eigenvectors computed = {nvec}")
@@ -138,40 +153,128 @@ def run_case(case, check_default=None, out=print):
     out(f"Performance  = {abs(flops) / elapsed * 1e-9:.3f} [GFLOPS]")
     res = {"n": n, "mode": mode, "solver": solver, "mtype": mtype, "elapsed": elapsed, "status": status, "ok": status == 0}
     if check and status == 0:
-        wh = w.cpu().numpy()
-        res["w_ok"] = w_test(wh, lam, out)
-        res["ok"] = res["ok"] and res["w_ok"]
-        if mode in ("A", "X") and nvec == n:
-            res["ev_ok"] = ev_test(A_dev, w, z[:n, :n].T, n, out)
-            res["ok"] = res["ok"] and res["ev_ok"]
+        want_ev = mode in ("A", "X") and nvec == n
+        Zfull = None
+        if want_ev and mr is not None:
+            # gather the cyclic eigenvector blocks onto every rank of the solver group (driver sizes only)
+            bxm, bym = (n + Px - 1) // Px, (n + Py - 1) // Py
+            zl = torch.zeros(bym, bxm, dtype=torch.float64, device=dev)
+            zl[: len(cols), : len(rows)] = z[: len(cols), : len(rows)]
+            zl = zl.cpu() if mr["host_gather"] else zl
+            blocks = [torch.zeros_like(zl) for _ in range(mr["size"])]
+            mr["dist"].all_gather(blocks, zl, group=mr["group"])
+            ids = torch.tensor([px, py], dtype=torch.int64)
+            ids = ids if mr["host_gather"] else ids.to(dev)
+            idl = [torch.zeros_like(ids) for _ in range(mr["size"])]
+            mr["dist"].all_gather(idl, ids, group=mr["group"])
+            if lead:
+                Zfull = torch.zeros(n, n, dtype=torch.float64, device=dev)   # Zfull[j, i] = Z(i, j)
+                for b, idv in zip(blocks, idl):
+                    qx, qy = int(idv[0]), int(idv[1])
+                    r_q, c_q = np.arange(qx, n, Px), np.arange(qy, n, Py)
+                    Zfull[torch.as_tensor(c_q, device=dev)[:, None], torch.as_tensor(r_q, device=dev)[None, :]] = \
+                        b[: len(c_q), : len(r_q)].to(dev)
+        elif want_ev:
+            Zfull = z[:n, :n]
+        if lead:
+            wh = w.cpu().numpy()
+            res["w_ok"] = w_test(wh, lam, out)
+            res["ok"] = res["ok"] and res["w_ok"]
+            if want_ev:
+                res["ev_ok"] = ev_test(torch.from_numpy(A).to(dev), w, Zfull.T, n, out)
+                res["ok"] = res["ok"] and res["ev_ok"]
     out("======================================================")
     out("")
     return res
 
 
 def main(argv=None):
+    import os
+
     ap = argparse.ArgumentParser(prog="eigenexa_benchmark", description=__doc__.split("\n\n")[0])
     ap.add_argument("-f", dest="input_file", default="IN", help="input file (default ./IN)")
     ap.add_argument("-c", dest="check", action="store_true", default=None, help="check accuracy for every case")
     ap.add_argument("-n", dest="nocheck", action="store_true", help="never check accuracy")
     ap.add_argument("-L", dest="list", action="store_true", help="list the test matrices and exit")
+    ap.add_argument("-g", dest="grid", default=None, help="R | C rank order, A every rank alone, <k> k groups (group 0 solves)")
+    ap.add_argument("-x", dest="dims", nargs=2, type=int, default=None, metavar=("PX", "PY"), help="explicit process grid")
     args = ap.parse_args(argv)
     if args.list:
         for k in sorted(MATRIX_TEXT):
             print(f" Matrix type = {k:3d} {MATRIX_TEXT[k]}")
         return 0
     check_default = True if args.check else (False if args.nocheck else None)
-    lib = _lib.load()
-    api.eigen_init()
-    ver = np.zeros(1, dtype=np.int32)
-    print(f" INPUT FILE='{args.input_file}'")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    mr = None
+    participant = True
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("EIGX_BENCH_BACKEND", "nccl")
+        local_rank = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0
+        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
+        grid = (args.grid or "C")[:1]
+        if args.dims is not None:
+            pxd, pyd = args.dims
+            if pxd * pyd != world:
+                if rank == 0:
+                    print("Illegal dimensions are specified.")
+                dist.destroy_process_group()
+                return 1
+            if pxd > pyd:
+                if rank == 0:
+                    print("This process map is not supported.\nPx should be smaller than Py")
+                dist.destroy_process_group()
+                return 1
+            api.eigen_init(comm=True, device=local_rank, dims=(pxd, pyd))
+            mr = {"dist": dist, "group": None, "rank": rank, "size": world}
+        elif grid in "Aa":
+            api.eigen_init(device=local_rank)       # MPI_COMM_SELF: every rank owns a 1x1 grid
+        elif grid.isdigit() and int(grid) >= 1:
+            k = int(grid)
+            members = [r for r in range(world) if r % k == 0]
+            group = dist.new_group(ranks=members)   # collective over all ranks
+            participant = rank % k == 0             # the others hold MPI_COMM_NULL: every call returns at once
+            if participant and len(members) > 1:
+                api.eigen_init(comm=group, device=local_rank)
+                mr = {"dist": dist, "group": group, "rank": members.index(rank), "size": len(members)}
+            elif participant:
+                api.eigen_init(device=local_rank)
+        else:
+            api.eigen_init(comm=True, order="R" if grid in "Rr" else "C", device=local_rank)
+            mr = {"dist": dist, "group": None, "rank": rank, "size": world}
+        if mr is not None:
+            mr["host_gather"] = backend != "nccl"
+    else:
+        _lib.load()
+        api.eigen_init()
+    # world rank 0 reports (it is rank 0 of every solver group that exists here)
+    out = print if rank == 0 else (lambda *a_, **k_: None)
+    out(f" INPUT FILE='{args.input_file}'")
     bad = 0
-    for case in parse_input(args.input_file):
-        r = run_case(case, check_default)
-        bad += 0 if r["ok"] else 1
-    api.eigen_free()
-    print(" Benchmark completed" + (f" ({bad} case(s) did not pass)" if bad else ""))
-    del lib, ver
+    if participant:
+        for case in parse_input(args.input_file):
+            r = run_case(case, check_default, out=out, mr=mr)
+            bad += 0 if r["ok"] else 1
+        api.eigen_free()
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        t = torch.tensor([float(bad)], dtype=torch.float64)
+        t = t if os.environ.get("EIGX_BENCH_BACKEND", "nccl") != "nccl" else t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        bad = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    out(" Benchmark completed" + (f" ({bad} case(s) did not pass)" if bad else ""))
     return 1 if bad else 0
 
 

@@ -20,6 +20,15 @@ int eigx_get_rccl_unique_id(void* out128) {
   return comm_get_unique_id(out128);
 }
 
+// one-shot grid shape for the next eigx_init_multi (the 2-D cartesian communicator path of eigen_init,
+// eigen_init_cartesian_check src/eigen_libs0.F:579-715; benchmark/main2.f:193-211 builds it for its -x option)
+static int g_next_px = 0, g_next_py = 0;
+int eigx_set_grid_dims(int px, int py) {
+  if (px < 0 || py < 0 || (px == 0) != (py == 0)) return EIGX_ERR_BAD_ARG;
+  g_next_px = px; g_next_py = py;
+  return EIGX_OK;
+}
+
 int eigx_init_multi(int device, int rank, int nranks, const void* uid, char order) {
   if (g_ctx.initialized) {
     // reference behaviour: a second eigen_init self-frees first (src/eigen_libs0.F:329-339)
@@ -39,6 +48,15 @@ int eigx_init_multi(int device, int rank, int nranks, const void* uid, char orde
   int Px = 1;
   for (int x = 1; x * x <= nranks; ++x)
     if (nranks % x == 0) Px = x;
+  if (g_next_px > 0) {   // explicit (cartesian) shape requested
+    const int rx = g_next_px, ry = g_next_py;
+    g_next_px = g_next_py = 0;
+    if (rx * ry != nranks) {
+      fprintf(stderr, "[eigx] illegal grid dimensions %d x %d for %d ranks\n", rx, ry, nranks);
+      return EIGX_ERR_BAD_ARG;
+    }
+    Px = rx;
+  }
   Grid& g = g_ctx.grid;
   g.Px = Px;
   g.Py = nranks / Px;

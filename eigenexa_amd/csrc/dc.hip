@@ -782,6 +782,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
       }
       // -- upload and run the GPU part ---------------------------------------------------------------------
       const double tt2 = trace ? now_s() : 0.0;
+      double t_gemm_enq = 0.0;
       memcpy(md_h, mds.data(), mds.size() * sizeof(MergeDev));
       EIGX_HIP_CHECK(hipMemcpyAsync(arena, harena, up_bytes, hipMemcpyHostToDevice, st));   // everything at once
       if (nrot > 0)
@@ -809,6 +810,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
           for (int q = 0; q < Context::kAux; ++q) EIGX_HIP_CHECK(hipStreamWaitEvent(ctx.aux[q], ctx.aux_ev[Context::kAux], 0));
         }
         int rr = 0;
+        const double tg0 = trace ? now_s() : 0.0;
         for (size_t q = 0; q < mds.size(); ++q) {
           const MergeDev& M = mds[q];
           if (M.K <= 0) continue;
@@ -850,6 +852,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
             EIGX_HIP_CHECK(hipEventRecord(ctx.aux_ev[q], ctx.aux[q]));
             EIGX_HIP_CHECK(hipStreamWaitEvent(st, ctx.aux_ev[q], 0));
           }
+        if (trace) t_gemm_enq = now_s() - tg0;
       }
       if (ncopy > 0)
         hipLaunchKernelGGL(copycols_kernel, dim3(ncopy), dim3(256), 0, st, cps_dev, cpd_dev, cpr_dev, cpn_dev, Qa, Qb,
@@ -877,7 +880,8 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
         long sumK = 0, sumN = 0;
         for (const MergeDev& M : mds) { sumK += M.K; sumN += M.nm; }
         fprintf(stderr, "[eigx dc] height %d pass %d: %zu merges (non-deflated %ld of %ld), z gather + D2H %.3f ms, host deflation %.3f ms, "
-                "device part %.3f ms\n", h, k, ids.size(), sumK, sumN, (tt1 - tt0) * 1e3, (tt2 - tt1) * 1e3, (now_s() - tt2) * 1e3);
+                "device part %.3f ms (GEMM enqueue %.3f ms)\n", h, k, ids.size(), sumK, sumN, (tt1 - tt0) * 1e3, (tt2 - tt1) * 1e3,
+                (now_s() - tt2) * 1e3, t_gemm_enq * 1e3);
       }
     }
   }

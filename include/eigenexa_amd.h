@@ -54,6 +54,10 @@ int eigx_init(int device);
  * eigen_init_comm_setup/eigen_init_cartesian_check, src/eigen_libs0.F:382-428, :579-715. */
 int eigx_init_multi(int device, int rank, int nranks, const void* rccl_unique_id, char order);
 int eigx_get_rccl_unique_id(void* out128);
+/* Explicit Px x Py process grid for the NEXT eigx_init_multi call (one-shot; 0, 0 clears): the 2-D cartesian
+ * communicator form of eigen_init (eigen_init_cartesian_check, src/eigen_libs0.F:579-715), which the reference's
+ * benchmark driver builds for its -x option (benchmark/main2.f:193-211). */
+int eigx_set_grid_dims(int px, int py);
 
 /* Test transport for the N>1 path on machines where RCCL cannot be used (several ranks sharing one GPU):
  * the collectives of the multi-rank solvers are delegated to host callbacks (buffers are host pointers;

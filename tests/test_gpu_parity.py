@@ -597,6 +597,52 @@ def test_benchmark_driver_check_sweep(gpu_lib, tmp_path):
     assert sum("Residual Error Test ***   : PASSED" in m for m in log) >= 4 * len(sizes)
 
 
+@pytest.mark.parametrize("world,opts", [(4, ["-g", "R"]), (4, ["-x", "1", "4"]), (3, ["-g", "A"]), (4, ["-g", "2"]),
+                                        (2, [])])
+def test_benchmark_driver_multi_rank_grid_options(gpu_lib, tmp_path, world, opts):
+    """the reference driver's process-grid options (benchmark/main2.f:139-216) with `world` ranks on one GPU over the
+    host-staged gloo transport: -g R/C rank order, -x Px Py explicit grid, -g A every rank alone (MPI_COMM_SELF),
+    -g k split with non-participating ranks (MPI_COMM_NULL)"""
+    import socket
+    import subprocess
+    import sys
+
+    p = tmp_path / "IN-mr"
+    p.write_text("! N nvec bx by m t s e\n200 200 48 128 1 0 0 1\n131 131 32 64 1 2 1 1\n97 97 48 128 0 0 0 1\n-1 0 0 0 0 0 0 0\n")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), EIGX_BENCH_BACKEND="gloo", PYTHONPATH=root)
+        procs.append(subprocess.Popen([sys.executable, "-m", "eigenexa_amd.benchmark", "-f", str(p)] + opts, env=env,
+                                      cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for q in procs:
+        try:
+            outs.append(q.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            for q2 in procs:
+                q2.kill()
+            raise
+    for r, (q, o) in enumerate(zip(procs, outs)):
+        assert q.returncode == 0, (r, o[-3000:])
+    o0 = outs[0]
+    assert "Benchmark completed" in o0 and "did not pass" not in o0, o0[-3000:]
+    assert o0.count("*** Residual Error Test ***   : PASSED") == 2 and "FAILED" not in o0, o0[-3000:]
+    if opts == ["-x", "1", "4"]:
+        assert "NUM.OF.PROCESS= 4 ( 1 4 )" in o0
+    if opts == ["-g", "R"]:
+        assert "NUM.OF.PROCESS= 4 ( 2 2 )" in o0
+    if opts == ["-g", "A"]:
+        assert "NUM.OF.PROCESS= 1 ( 1 1 )" in o0
+    if opts == ["-g", "2"]:
+        assert "NUM.OF.PROCESS= 2 ( 1 2 )" in o0
+
+
 # ------------------------------------------------------------------ KMATH_EIGEN_GEV (SURVEY 8f-2)
 @pytest.mark.parametrize("n", [1, 2, 5, 130, 517])
 def test_gev_matches_oracle(gpu_lib, orc, n):
