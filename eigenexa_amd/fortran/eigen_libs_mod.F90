@@ -106,6 +106,10 @@ module eigen_libs_mod
       real(c_double), intent(out) :: w(*), z(ldz, *)
       character(kind=c_char), value :: mode
     end function
+    integer(c_int) function eigx_set_grid_dims(px, py) bind(C, name="eigx_set_grid_dims")
+      import :: c_int
+      integer(c_int), value :: px, py
+    end function
     integer(c_int) function eigx_solve_bc(route, n, nvec, a, lda, w, z, ldz, nb, mf, mb, mode) &
         bind(C, name="eigx_solve_bc")
       import :: c_int, c_double, c_char
@@ -125,7 +129,8 @@ contains
     integer, intent(in), optional :: comm
     character(*), intent(in), optional :: order
     character(kind=c_char) :: ord, uid(128)
-    integer :: rc, rank, nranks, ierr, dev, lcomm
+    integer :: rc, rank, nranks, ierr, dev, lcomm, topo, ndims, dims(2), coords(2)
+    logical :: periods(2)
     ord = 'C'
     if (present(order)) ord = order(1:1)
     rank = 0; nranks = 1
@@ -141,6 +146,17 @@ contains
       rc = eigx_init(0)
     else
 #ifdef EIGX_WITH_MPI
+      ! a 2-D cartesian communicator fixes the process grid (eigen_init_cartesian_check, src/eigen_libs0.F:579-715);
+      ! MPI numbers cartesian ranks row-major
+      call MPI_Topo_test(lcomm, topo, ierr)
+      if (topo == MPI_CART) then
+        call MPI_Cartdim_get(lcomm, ndims, ierr)
+        if (ndims == 2) then
+          call MPI_Cart_get(lcomm, 2, dims, periods, coords, ierr)
+          rc = eigx_set_grid_dims(dims(1), dims(2))
+          ord = 'R'
+        end if
+      end if
       if (rank == 0) rc = eigx_get_rccl_unique_id(uid)
       call MPI_Bcast(uid, 128, MPI_CHARACTER, 0, lcomm, ierr)
       rc = eigx_init_multi(dev, rank, nranks, uid, ord)
