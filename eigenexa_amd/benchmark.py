@@ -233,7 +233,8 @@ def main(argv=None):
                     print("This process map is not supported.\nPx should be smaller than Py")
                 dist.destroy_process_group()
                 return 1
-            api.eigen_init(comm=True, device=local_rank, dims=(pxd, pyd))
+            # MPI_Cart_create numbers the ranks of a cartesian communicator row-major
+            api.eigen_init(comm=True, order="R", device=local_rank, dims=(pxd, pyd))
             mr = {"dist": dist, "group": None, "rank": rank, "size": world}
         elif grid in "Aa":
             api.eigen_init(device=local_rank)       # MPI_COMM_SELF: every rank owns a 1x1 grid
