@@ -1,5 +1,5 @@
 """Timing only: band reduction (eigx_band_reduce_dev) of a random symmetric matrix generated on the GPU.
-usage: gpu_reduce_time.py N [band=2] [reps=1]   (library selectable with EIGX_LIB for A/B runs)"""
+usage: gpu_reduce_time.py N [band=2] [reps=1]   (library selectable with EIGX_LIB for A/B runs; EIGX_MF = panel width)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,7 +22,7 @@ for rep in range(reps + 1):
     a[:, :n] = a[:, :n] + a[:, :n].T
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    _lib.check(lib.eigx_band_reduce_dev(n, a.data_ptr(), lda, d.data_ptr(), e.data_ptr(), n, 128, band), "reduce")
+    _lib.check(lib.eigx_band_reduce_dev(n, a.data_ptr(), lda, d.data_ptr(), e.data_ptr(), n, int(os.environ.get('EIGX_MF', '128')), band), "reduce")
     dt = time.perf_counter() - t0
-    print(f"{os.environ.get('EIGX_LIB', 'default')[-24:]} t128={os.environ.get('EIGX_T128','-')} t256={os.environ.get('EIGX_T256','-')} nt={os.environ.get('EIGX_NT','-')} n={n} band={band} rep {rep}: {dt*1e3:.1f} ms  "
+    print(f"{os.environ.get('EIGX_LIB', 'default')[-24:]} t128={os.environ.get('EIGX_T128','-')} t256={os.environ.get('EIGX_T256','-')} nt={os.environ.get('EIGX_NT','-')} mf={os.environ.get('EIGX_MF','128')} n={n} band={band} rep {rep}: {dt*1e3:.1f} ms  "
           f"({4.0/3.0*n**3/dt/1e12:.2f} TFLOP/s of 4/3 n^3; d[0]={d[0].item():.6f})", flush=True)
