@@ -803,3 +803,109 @@ int orc_gev(int n, double* a, int lda, double* b, int ldb, double* w, double* z,
 #undef M_
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * eigen_h (src/eigen_h.F:30-322): complex Hermitian A -> real tridiagonal (eigen_hrd) -> real D&C (dc2) -> complex
+ * back-transformation (eigen_hrbakwyx).  PARITY UNPINNED: the reference tree holds no test driver, golden vector or
+ * known-answer test for eigen_h (benchmark/ only exercises eigen_sx / eigen_s / KMATH_EIGEN_GEV); this restatement is
+ * checked against analytic spectra (D F D^H with the Frank matrix F) and LAPACK's zheevd in tests/, not against
+ * reference outputs.
+ *
+ * a, z: interleaved complex(8) (re, im), column-major, leading dimensions in complex elements; upper triangle of a
+ * significant; a is destroyed (column i keeps its reflector u_i in rows 0..i-1, as the reference leaves it).
+ * Unblocked statement of the reference's step (one column i = n-1 .. 1, L = i rows above it):
+ *   x = A(0:L, i); g = -sign(||x||, Re x_{L-1}); u = x, u_{L-1} -= g; beta = -u_{L-1} g   (src/eigen_hrd_t4.F:76-84)
+ *   q = A u; s = u^H q; alpha = s / (2 beta); v = (q - alpha u) / conj(beta)           (src/eigen_hrd_t6_3.F:256-272)
+ *   A <- A - u v^H - v u^H                                                            (src/eigen_hrd_t1.F:2-110)
+ *   e_i = g (real), d_i = Re A(i,i)
+ * Back-transformation: z = H_{n-1}^H ... H_1^H y with H_j = I - u_j u_j^H / beta_j (src/hrbakwy4.F:157-555).
+ * ------------------------------------------------------------------------------------------------ */
+#include <complex.h>
+typedef double _Complex zc;
+int orc_eigen_h(int n, int nvec, double* a_ri, int lda, double* wout, double* z_ri, int ldz, char mode) {
+  if (n <= 0 || lda < n) return -1;
+  if (mode >= 'a' && mode <= 'z') mode = (char)(mode - 'a' + 'A');
+  if (nvec == 0) mode = 'N';
+  if (nvec < 0) nvec = -nvec;
+  if (nvec > n) nvec = n;
+  zc* a = (zc*)a_ri;
+  zc* z = (zc*)z_ri;
+#define A_(i, j) a[(size_t)(i) + (size_t)(j) * lda]
+  /* full Hermitian matrix from the upper triangle; diagonal made real */
+  for (int j = 0; j < n; ++j) {
+    A_(j, j) = creal(A_(j, j));
+    for (int i = j + 1; i < n; ++i) A_(i, j) = conj(A_(j, i));
+  }
+  /* eigen_scaling_h (src/eigen_scaling_h.F): same rule as the real solver of this oracle */
+  double anrm = 0.0;
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i <= j; ++i) {
+      const double re = fabs(creal(A_(i, j))), im = fabs(cimag(A_(i, j)));
+      if (!(re <= DBL_MAX) || !(im <= DBL_MAX)) { for (int k = 0; k < n; ++k) wout[k] = NAN; return 1; }
+      anrm = fmax(anrm, fmax(re, im));
+    }
+  double sigma = 1.0;
+  if (anrm > 0.0 && (anrm < 1e-90 || anrm > 1e90)) { int ex; (void)frexp(anrm, &ex); sigma = ldexp(1.0, -ex); }
+  if (sigma != 1.0) for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) A_(i, j) *= sigma;
+  double* d = (double*)calloc((size_t)n, sizeof(double));
+  double* e = (double*)calloc((size_t)n, sizeof(double));
+  zc* beta = (zc*)calloc((size_t)n, sizeof(zc));
+  zc* u = (zc*)calloc((size_t)n, sizeof(zc));
+  zc* q = (zc*)calloc((size_t)n, sizeof(zc));
+  for (int i = n - 1; i >= 1; --i) {
+    const int L = i;
+    double nrm2 = 0.0;
+    for (int r = 0; r < L; ++r) { u[r] = A_(r, i); nrm2 += creal(u[r]) * creal(u[r]) + cimag(u[r]) * cimag(u[r]); }
+    d[i] = creal(A_(i, i));
+    if (nrm2 != 0.0) {
+      const zc an = u[L - 1];
+      const double g = -sign_of(sqrt(nrm2), creal(an));
+      u[L - 1] = an - g;
+      beta[i] = -u[L - 1] * g;
+      e[i] = g;
+      for (int r = 0; r < L; ++r) {
+        zc acc = 0.0;
+        for (int c = 0; c < L; ++c) acc += A_(r, c) * u[c];
+        q[r] = acc;
+      }
+      zc s = 0.0;
+      for (int r = 0; r < L; ++r) s += q[r] * conj(u[r]);
+      const zc alpha = s / (2.0 * beta[i]);
+      for (int r = 0; r < L; ++r) q[r] = (q[r] - alpha * u[r]) / conj(beta[i]);   /* q := v */
+      for (int c = 0; c < L; ++c)
+        for (int r = 0; r < L; ++r) A_(r, c) -= u[r] * conj(q[c]) + q[r] * conj(u[c]);
+    } else {
+      beta[i] = 1.0; e[i] = 0.0;
+      for (int r = 0; r < L; ++r) u[r] = 0.0;
+    }
+    for (int r = 0; r < L; ++r) A_(r, i) = u[r];   /* reflector stays in column i */
+  }
+  d[0] = creal(A_(0, 0));
+  e[0] = 0.0;
+  int rc = 0;
+  if (mode == 'N') {
+    rc = orc_band_bisect(n, d, e, n, 1, wout);
+  } else {
+    double* y = (double*)calloc((size_t)n * n, sizeof(double));
+    rc = orc_band_dc(n, d, e, n, 1, wout, y, n, NULL);
+    if (mode == 'X' && rc == 0) rc = orc_band_bisect(n, d, e, n, 1, wout);
+    if (rc == 0) {
+      for (int k = 0; k < nvec; ++k) {
+        zc* col = z + (size_t)k * ldz;
+        for (int r = 0; r < n; ++r) col[r] = y[(size_t)r + (size_t)k * n];
+        for (int j = 1; j < n; ++j) {          /* H_1^H first, H_{n-1}^H last */
+          if (e[j] == 0.0 && creal(beta[j]) == 1.0 && cimag(beta[j]) == 0.0) continue;   /* trivial reflector */
+          zc dot = 0.0;
+          for (int r = 0; r < j; ++r) dot += conj(A_(r, j)) * col[r];
+          dot /= conj(beta[j]);
+          for (int r = 0; r < j; ++r) col[r] -= A_(r, j) * dot;
+        }
+      }
+    }
+    free(y);
+  }
+  if (sigma != 1.0) for (int k = 0; k < n; ++k) wout[k] /= sigma;
+  free(d); free(e); free(beta); free(u); free(q);
+#undef A_
+  return rc;
+}

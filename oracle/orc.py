@@ -29,6 +29,7 @@ def load():
         lib.orc_band_dc.argtypes = [C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]
         lib.orc_band_bisect.argtypes = [C.c_int, _dp, _dp, C.c_int, C.c_int, _dp]
         lib.orc_gev.argtypes = [C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, _dp, C.c_int]
+        lib.orc_eigen_h.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, _dp, C.c_void_p, C.c_int, C.c_char]
         lib.orc_trbak.argtypes = [C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int]
         _lib = lib
     return _lib
@@ -104,4 +105,17 @@ def gev(A, B):
         raise ValueError("Matrix B is not positive definite!")
     if rc != 0:
         raise RuntimeError(f"oracle gev rc={rc}")
+    return w, z
+
+
+def eigen_h(A, mode="A"):
+    """eigen_h restatement (PARITY UNPINNED, see eigx_oracle.c): Hermitian A (complex128) -> (w, Z complex)."""
+    lib = load()
+    n = A.shape[0]
+    a = np.asfortranarray(A, dtype=np.complex128).copy(order="F")
+    w = np.zeros(n)
+    z = np.zeros((n, n), dtype=np.complex128, order="F")
+    rc = lib.orc_eigen_h(n, n, a.ctypes.data, n, _p(w), z.ctypes.data, n, mode.encode()[:1])
+    if rc != 0:
+        raise RuntimeError(f"oracle eigen_h rc={rc}")
     return w, z
