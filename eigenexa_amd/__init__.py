@@ -21,6 +21,7 @@ from .api import (  # noqa: F401
     eigen_owner_index,
     eigen_sx,
     eigen_s,
+    eigen_h,
     eigen_sx_bc,
     eigen_s_bc,
     numroc,

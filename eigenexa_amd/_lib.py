@@ -45,6 +45,10 @@ SIGNATURES = {
     "eigx_solve_bc_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_char]),
     "eigx_numroc": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "eigx_h": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                         C.c_int, C.c_int, C.c_char]),
+    "eigx_h_dev": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                             C.c_int, C.c_int, C.c_char]),
     "eigx_set_grid_dims": (C.c_int, [C.c_int, C.c_int]),
     "eigx_band_reduce_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_int, C.c_int]),

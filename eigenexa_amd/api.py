@@ -272,6 +272,49 @@ def eigen_s(n, nvec, a, lda, w, z, ldz, m_forward=None, m_backward=None, mode="A
     _solve("s", n, nvec, a, lda, w, z, ldz, m_forward, m_backward, mode)
 
 
+def eigen_h(n, nvec, a, lda, w, z, ldz, m_forward=None, m_backward=None, mode="A"):
+    """Complex Hermitian solver (src/eigen_h.F:30-322: eigen_hrd -> dc2 -> eigen_hrbakwyx).  ``a``, ``z``: complex128,
+    column-major (numpy, Fortran order) or GPU tensors holding the column-major image (``a[j, i] = A(i, j)``); upper
+    triangle of ``a`` significant, ``a`` destroyed; ``w`` float64 ascending.  modes 'A', 'N', 'X'.  One GPU."""
+    lib = _lib.load()
+    if not _state["initialized"]:
+        _state["last_status"] = -1
+        return
+    dev = _is_torch(a)
+
+    def cptr(x, name, real=False):
+        if x is None:
+            return None
+        if dev:
+            import torch
+
+            if not (_is_torch(x) and x.is_cuda):
+                raise ValueError("a, w, z must all be host arrays or all be device tensors")
+            if x.dtype != (torch.float64 if real else torch.complex128):
+                raise ValueError(f"{name}: {'float64' if real else 'complex128'} required")
+            return x.data_ptr()
+        if _is_torch(x):
+            raise ValueError("a, w, z must all be host arrays or all be device tensors")
+        if x.dtype != (np.float64 if real else np.complex128):
+            raise ValueError(f"{name}: {'float64' if real else 'complex128'} required")
+        if x.ndim == 2 and not x.flags.f_contiguous:
+            raise ValueError(f"{name}: Fortran (column-major) order required, as in the reference")
+        return x.ctypes.data
+
+    if dev:
+        import torch
+
+        torch.cuda.current_stream().synchronize()
+    mf = eigen_NB_f if m_forward is None else int(m_forward)
+    mb = eigen_NB_b if m_backward is None else int(m_backward)
+    fn = lib.eigx_h_dev if dev else lib.eigx_h
+    rc = fn(int(n), int(nvec), cptr(a, "a"), int(lda), cptr(w, "w", real=True), cptr(z, "z"), int(ldz), mf, mb,
+            _char(mode, "A"))
+    _state["last_status"] = rc
+    if rc not in (0, -5):
+        print(f"Warning: eigen_h returned without computing (status {rc})", file=sys.stderr)
+
+
 def eigen_sx_bc(n, nvec, a, lda, w, z, ldz, nb, m_forward=None, m_backward=None, mode="A"):
     """eigen_sx on the local blocks of a 2-D block-cyclic (ScaLAPACK, MB = NB = nb) distribution over the process grid:
     no pdgemr2d redistribution into the cyclic layout is needed (manual 3.4).  ``z`` returns in the same distribution."""

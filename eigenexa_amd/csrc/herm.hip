@@ -1,0 +1,562 @@
+// herm.hip -- eigen_h: complex Hermitian eigensolver, first version, one GPU.
+//
+// Replaces eigen_h (src/eigen_h.F:30-322): eigen_scaling_h -> eigen_hrd (Hermitian -> REAL symmetric tridiagonal,
+// src/eigen_hrd.F:1-448) -> dc2 (the real tridiagonal D&C of dc.hip, unchanged) -> eigen_hrbakwyx (complex WY
+// back-transformation, src/hrbakwy4.F:1-720, src/hrbakwy4_body.F:1-553).
+//
+// MI355X design: complex data lives in SPLIT PLANES (re, im) in HBM, so every O(n^3) contraction is a handful of real
+// fp64 MFMA GEMMs of gemm_f64.hip instead of a ZGEMM port:
+//   trailing update  A -= U W^H + W U^H :  Ar -= [Ur Ui Wr Wi][Wr Wi Ur Ui]^T ,  Ai -= [Ui -Ur Wi -Wr][Wr Wi Ur Ui]^T  (K = 4m)
+//   back-transform   Z -= V (S^-H (V^H Z))  : 4 real GEMMs each for V^H Z and V X, 4 small ones for the block Gram matrix
+// The reduction keeps BOTH triangles of A (the Hermitian mat-vec is then a plain coalesced streaming GEMV over the planes)
+// and forms each column lazily from the panel (dlatrd style), one column per step as the reference does:
+//   x = A_eff(0:L, i);  g = -sign(||x||, Re x_{L-1});  u = x, u_{L-1} -= g;  beta = -u_{L-1} g       (src/eigen_hrd_t4.F:40-95)
+//   q = A_eff u;  s = u^H q;  alpha = s / (2 beta);  v = (q - alpha u) / conj(beta)                 (src/eigen_hrd_t6_3.F:256-272)
+//   A_eff = A - U W^H - W U^H  (panel of m columns, applied every m steps)                          (src/eigen_hrd_t1.F:2-110)
+// Five small kernels per column (form x | reflector | panel dots | GEMV partials | combine | v): this version is
+// latency-bound per step like the first real-symmetric version was; the fused / tiled structure of band_reduce.hip is the
+// template for the next one.  All cross-workgroup reductions are two-phase and deterministic (no atomics).
+#include "eigx_context.h"
+#include "eigx_common.h"
+#include "../../include/eigenexa_amd.h"
+#include <cfloat>
+#include <chrono>
+#include <limits>
+#include <vector>
+
+namespace eigx {
+
+namespace {
+
+constexpr int HT = 256;      // threads per workgroup
+constexpr int HM = 128;      // max panel width (LDS arrays)
+constexpr int GC = 256;      // GEMV column chunk
+constexpr int PDR = 1024;    // rows per panel-dot chunk
+constexpr int HMB = 64;      // reflectors per back-transformation block (S^H of a block lives in LDS)
+
+struct HArgs {
+  double *Ar, *Ai; int ld; int n;
+  double *Ur, *Ui, *Wr, *Wi; int ldp;
+  double *xr, *xi, *pr, *pi;
+  double *beta, *d, *e;
+  double *pn;      // norm partials [workgroup]
+  double *pd;      // panel-dot partials [chunk][HM][4]
+  double *qr, *qi; // GEMV partials [column chunk][ldp]
+  double *ps;      // s partials [workgroup][2]
+};
+
+__device__ __forceinline__ double hwave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// deterministic block sum of K values (256 threads); result in every thread
+template <int K>
+__device__ __forceinline__ void hblock_sum(double (&v)[K], double* red /* 4*K */) {
+#pragma unroll
+  for (int q = 0; q < K; ++q) v[q] = hwave_sum(v[q]);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) red[(threadIdx.x >> 6) * K + q] = v[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < K; ++q) v[q] = (red[q] + red[K + q]) + (red[2 * K + q] + red[3 * K + q]);
+}
+
+// interleaved complex(8) upper triangle -> split planes of the FULL Hermitian matrix (lower := conj(upper), real diagonal)
+__global__ void h_split_kernel(const double* __restrict__ a, int lda, int n, double* __restrict__ Ar,
+                               double* __restrict__ Ai, int ld) {
+  const int j = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= j; i += gridDim.x * blockDim.x) {
+    const double re = a[2 * ((size_t)i + (size_t)j * lda)];
+    const double im = (i == j) ? 0.0 : a[2 * ((size_t)i + (size_t)j * lda) + 1];
+    Ar[(size_t)i + (size_t)j * ld] = re; Ai[(size_t)i + (size_t)j * ld] = im;
+    if (i < j) { Ar[(size_t)j + (size_t)i * ld] = re; Ai[(size_t)j + (size_t)i * ld] = -im; }
+  }
+}
+
+// max |re|, |im| over the upper triangle and a non-finite flag (eigen_scaling_h, src/eigen_scaling_h.F)
+__global__ __launch_bounds__(HT) void h_absmax_kernel(const double* __restrict__ a, int lda, int n, double* __restrict__ out) {
+  __shared__ double red[8];
+  double v[2] = {0.0, 0.0};
+  for (int j = blockIdx.x; j < n; j += gridDim.x)
+    for (int i = threadIdx.x; i <= j; i += HT) {
+      const double re = fabs(a[2 * ((size_t)i + (size_t)j * lda)]);
+      const double im = (i == j) ? 0.0 : fabs(a[2 * ((size_t)i + (size_t)j * lda) + 1]);
+      if (!(re <= DBL_MAX) || !(im <= DBL_MAX)) v[1] = 1.0;
+      else v[0] = fmax(v[0], fmax(re, im));
+    }
+  for (int o = 32; o > 0; o >>= 1) { v[0] = fmax(v[0], __shfl_xor(v[0], o, 64)); v[1] = fmax(v[1], __shfl_xor(v[1], o, 64)); }
+  if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = v[0]; red[(threadIdx.x >> 6) * 2 + 1] = v[1]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = fmax(fmax(red[0], red[2]), fmax(red[4], red[6]));
+    out[2 * blockIdx.x + 1] = fmax(fmax(red[1], red[3]), fmax(red[5], red[7]));
+  }
+}
+
+__global__ void h_scale_kernel(double* __restrict__ a, int lda, int n, double s) {   // interleaved, upper triangle
+  const int j = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= j; i += gridDim.x * blockDim.x) {
+    a[2 * ((size_t)i + (size_t)j * lda)] *= s;
+    a[2 * ((size_t)i + (size_t)j * lda) + 1] *= s;
+  }
+}
+
+__global__ void h_fill_kernel(double* p, size_t n, double v) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// K1: x = A_eff(0:i, i) (rows 0..i-1), d_i = Re A_eff(i,i); partial ||x||^2 per workgroup
+__global__ __launch_bounds__(HT) void h_form_x_kernel(HArgs H, int i, int k) {
+  __shared__ double cwr[HM], cwi[HM], cur[HM], cui[HM];
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  if (tid < k) {   // conj of row i of the panel
+    cwr[tid] = H.Wr[(size_t)i + (size_t)tid * H.ldp]; cwi[tid] = -H.Wi[(size_t)i + (size_t)tid * H.ldp];
+    cur[tid] = H.Ur[(size_t)i + (size_t)tid * H.ldp]; cui[tid] = -H.Ui[(size_t)i + (size_t)tid * H.ldp];
+  }
+  __syncthreads();
+  const int r = blockIdx.x * HT + tid;
+  double nrm[1] = {0.0};
+  if (r <= i) {
+    double xr = H.Ar[(size_t)r + (size_t)i * H.ld], xi = H.Ai[(size_t)r + (size_t)i * H.ld];
+    for (int j = 0; j < k; ++j) {
+      const double ur = H.Ur[(size_t)r + (size_t)j * H.ldp], ui = H.Ui[(size_t)r + (size_t)j * H.ldp];
+      const double wr = H.Wr[(size_t)r + (size_t)j * H.ldp], wi = H.Wi[(size_t)r + (size_t)j * H.ldp];
+      xr -= (ur * cwr[j] - ui * cwi[j]) + (wr * cur[j] - wi * cui[j]);
+      xi -= (ur * cwi[j] + ui * cwr[j]) + (wr * cui[j] + wi * cur[j]);
+    }
+    if (r < i) { H.xr[r] = xr; H.xi[r] = xi; nrm[0] = xr * xr + xi * xi; }
+    else H.d[i] = xr;
+  }
+  hblock_sum<1>(nrm, red);
+  if (tid == 0) H.pn[blockIdx.x] = nrm[0];
+}
+
+// K2: reflector of column i (L = i rows): every workgroup reduces the norm partials in the same order
+__global__ __launch_bounds__(HT) void h_reflector_kernel(HArgs H, int i, int k, int nparts) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x, L = i;
+  double nr[1] = {0.0};
+  for (int q = tid; q < nparts; q += HT) nr[0] += H.pn[q];
+  hblock_sum<1>(nr, red);
+  const double nrm2 = nr[0];
+  const double anr = H.xr[L - 1], ani = H.xi[L - 1];
+  double g = 0.0, unr = 0.0, uni = 0.0, br = 1.0, bi = 0.0;
+  if (nrm2 != 0.0) {
+    const double mag = sqrt(nrm2);
+    g = (anr >= 0.0) ? -mag : mag;
+    unr = anr - g; uni = ani;
+    br = -unr * g; bi = -uni * g;
+  }
+  const int r = blockIdx.x * HT + tid;
+  if (r < L) {
+    double ur = 0.0, ui = 0.0;
+    if (nrm2 != 0.0) { ur = (r == L - 1) ? unr : H.xr[r]; ui = (r == L - 1) ? uni : H.xi[r]; }
+    H.Ur[(size_t)r + (size_t)k * H.ldp] = ur; H.Ui[(size_t)r + (size_t)k * H.ldp] = ui;
+    H.Ar[(size_t)r + (size_t)i * H.ld] = ur; H.Ai[(size_t)r + (size_t)i * H.ld] = ui;   // reflector stays in column i
+  }
+  if (blockIdx.x == 0 && tid == 0) { H.beta[2 * i] = br; H.beta[2 * i + 1] = bi; H.e[i] = g; }
+}
+
+// K2b: panel dots dw_j = W(:,j)^H u, du_j = U(:,j)^H u over a chunk of rows; grid (k, row chunks)
+__global__ __launch_bounds__(HT) void h_paneldot_kernel(HArgs H, int L, int k) {
+  __shared__ double red[16];
+  const int j = blockIdx.x, c = blockIdx.y;
+  const int r1 = (c * PDR + PDR < L) ? c * PDR + PDR : L;
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int r = c * PDR + threadIdx.x; r < r1; r += HT) {
+    const double ur = H.Ur[(size_t)r + (size_t)k * H.ldp], ui = H.Ui[(size_t)r + (size_t)k * H.ldp];
+    const double wr = H.Wr[(size_t)r + (size_t)j * H.ldp], wi = H.Wi[(size_t)r + (size_t)j * H.ldp];
+    const double pr = H.Ur[(size_t)r + (size_t)j * H.ldp], pi = H.Ui[(size_t)r + (size_t)j * H.ldp];
+    v[0] += wr * ur + wi * ui; v[1] += wr * ui - wi * ur;   // conj(w) u
+    v[2] += pr * ur + pi * ui; v[3] += pr * ui - pi * ur;   // conj(U_j) u
+  }
+  hblock_sum<4>(v, red);
+  if (threadIdx.x == 0) {
+    double* o = H.pd + ((size_t)c * HM + j) * 4;
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  }
+}
+
+// K3: q = A(0:L, 0:L) u, partial sums over a chunk of GC columns; grid (row blocks, column chunks)
+__global__ __launch_bounds__(HT) void h_gemv_kernel(HArgs H, int L, int k) {
+  __shared__ double sur[GC], sui[GC];
+  const int c0 = blockIdx.y * GC;
+  const int nc = (c0 + GC < L) ? GC : L - c0;
+  for (int t = threadIdx.x; t < nc; t += HT) {
+    sur[t] = H.Ur[(size_t)(c0 + t) + (size_t)k * H.ldp]; sui[t] = H.Ui[(size_t)(c0 + t) + (size_t)k * H.ldp];
+  }
+  __syncthreads();
+  const int r = blockIdx.x * HT + threadIdx.x;
+  if (r >= L) return;
+  const double* ar = H.Ar + (size_t)r + (size_t)c0 * H.ld;
+  const double* ai = H.Ai + (size_t)r + (size_t)c0 * H.ld;
+  double qr = 0.0, qi = 0.0;
+#pragma unroll 4
+  for (int t = 0; t < nc; ++t) {
+    const double xr = ar[(size_t)t * H.ld], xi = ai[(size_t)t * H.ld];
+    qr += xr * sur[t] - xi * sui[t];
+    qi += xr * sui[t] + xi * sur[t];
+  }
+  H.qr[(size_t)blockIdx.y * H.ldp + r] = qr; H.qi[(size_t)blockIdx.y * H.ldp + r] = qi;
+}
+
+// K4: p = q - U (W^H u) - W (U^H u); partial s = sum p conj(u)
+__global__ __launch_bounds__(HT) void h_combine_kernel(HArgs H, int L, int k, int nqc, int npdc) {
+  __shared__ double dwr[HM], dwi[HM], dur[HM], dui[HM];
+  __shared__ double red[8];
+  const int tid = threadIdx.x;
+  if (tid < k) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int c = 0; c < npdc; ++c) {
+      const double* o = H.pd + ((size_t)c * HM + tid) * 4;
+      a0 += o[0]; a1 += o[1]; a2 += o[2]; a3 += o[3];
+    }
+    dwr[tid] = a0; dwi[tid] = a1; dur[tid] = a2; dui[tid] = a3;
+  }
+  __syncthreads();
+  const int r = blockIdx.x * HT + tid;
+  double s[2] = {0.0, 0.0};
+  if (r < L) {
+    double pr = 0.0, pi = 0.0;
+    for (int c = 0; c < nqc; ++c) { pr += H.qr[(size_t)c * H.ldp + r]; pi += H.qi[(size_t)c * H.ldp + r]; }
+    for (int j = 0; j < k; ++j) {
+      const double ur = H.Ur[(size_t)r + (size_t)j * H.ldp], ui = H.Ui[(size_t)r + (size_t)j * H.ldp];
+      const double wr = H.Wr[(size_t)r + (size_t)j * H.ldp], wi = H.Wi[(size_t)r + (size_t)j * H.ldp];
+      pr -= (ur * dwr[j] - ui * dwi[j]) + (wr * dur[j] - wi * dui[j]);
+      pi -= (ur * dwi[j] + ui * dwr[j]) + (wr * dui[j] + wi * dur[j]);
+    }
+    H.pr[r] = pr; H.pi[r] = pi;
+    const double ur = H.Ur[(size_t)r + (size_t)k * H.ldp], ui = H.Ui[(size_t)r + (size_t)k * H.ldp];
+    s[0] = pr * ur + pi * ui;    // p conj(u)
+    s[1] = pi * ur - pr * ui;
+  }
+  hblock_sum<2>(s, red);
+  if (tid == 0) { H.ps[2 * blockIdx.x] = s[0]; H.ps[2 * blockIdx.x + 1] = s[1]; }
+}
+
+// K5: v = (p - alpha u) / conj(beta), alpha = s / (2 beta)
+__global__ __launch_bounds__(HT) void h_make_v_kernel(HArgs H, int i, int k, int nparts) {
+  __shared__ double red[8];
+  const int tid = threadIdx.x, L = i;
+  double s[2] = {0.0, 0.0};
+  for (int q = tid; q < nparts; q += HT) { s[0] += H.ps[2 * q]; s[1] += H.ps[2 * q + 1]; }
+  hblock_sum<2>(s, red);
+  const double br = H.beta[2 * i], bi = H.beta[2 * i + 1];
+  const double b2 = br * br + bi * bi;
+  // alpha = s / (2 beta) = s conj(beta) / (2 |beta|^2)
+  const double alr = (s[0] * br + s[1] * bi) / (2.0 * b2), ali = (s[1] * br - s[0] * bi) / (2.0 * b2);
+  const int r = blockIdx.x * HT + tid;
+  if (r < L) {
+    const double ur = H.Ur[(size_t)r + (size_t)k * H.ldp], ui = H.Ui[(size_t)r + (size_t)k * H.ldp];
+    const double tr = H.pr[r] - (alr * ur - ali * ui), ti = H.pi[r] - (alr * ui + ali * ur);
+    // t / conj(beta) = t beta / |beta|^2
+    H.Wr[(size_t)r + (size_t)k * H.ldp] = (tr * br - ti * bi) / b2;
+    H.Wi[(size_t)r + (size_t)k * H.ldp] = (tr * bi + ti * br) / b2;
+  }
+}
+
+// panel end: P1 = [Ur Ui Wr Wi], P2 = [Ui -Ur Wi -Wr], P3 = [Wr Wi Ur Ui]  (rows < nr, k columns each part)
+__global__ void h_pack_kernel(HArgs H, int nr, int k, double* __restrict__ P1, double* __restrict__ P2,
+                              double* __restrict__ P3) {
+  const int j = blockIdx.y;   // 0..k-1
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
+    const double ur = H.Ur[(size_t)r + (size_t)j * H.ldp], ui = H.Ui[(size_t)r + (size_t)j * H.ldp];
+    const double wr = H.Wr[(size_t)r + (size_t)j * H.ldp], wi = H.Wi[(size_t)r + (size_t)j * H.ldp];
+    const size_t c0 = (size_t)j * H.ldp + r, st = (size_t)k * H.ldp;
+    P1[c0] = ur; P1[c0 + st] = ui; P1[c0 + 2 * st] = wr; P1[c0 + 3 * st] = wi;
+    P2[c0] = ui; P2[c0 + st] = -ur; P2[c0 + 2 * st] = wi; P2[c0 + 3 * st] = -wr;
+    P3[c0] = wr; P3[c0 + st] = wi; P3[c0 + 2 * st] = ur; P3[c0 + 3 * st] = ui;
+  }
+}
+
+// back-transformation helpers -----------------------------------------------------------------------------------
+// zero rows >= j of reflector column j (what is left there is the old lower triangle); column 0 holds no reflector
+__global__ void h_zero_below_kernel(double* __restrict__ Vr, double* __restrict__ Vi, int ld, int n, int rows_pad) {
+  const int j = blockIdx.y;
+  for (int r = j + blockIdx.x * blockDim.x + threadIdx.x; r < rows_pad; r += gridDim.x * blockDim.x) {
+    Vr[(size_t)r + (size_t)j * ld] = 0.0; Vi[(size_t)r + (size_t)j * ld] = 0.0;
+  }
+}
+
+// X = S^-H Y for one block: S^H lower triangular, S^H(a,b) = G(a,b) = v_a^H v_b (a > b), S^H(a,a) = conj(beta_a).
+// One thread per right-hand side, S^H in LDS, X overwrites Y (mb x nvec, column-major, ld = HMB).
+__global__ __launch_bounds__(HT) void h_trsolve_kernel(const double* __restrict__ Gr, const double* __restrict__ Gi,
+                                                        const double* __restrict__ beta, int j0, int nb, int nvec,
+                                                        double* __restrict__ Yr, double* __restrict__ Yi) {
+  extern __shared__ double sm[];   // [2][HMB*HMB]
+  double* sr = sm; double* si = sm + HMB * HMB;
+  for (int t = threadIdx.x; t < nb * nb; t += HT) {
+    const int a = t % nb, b = t / nb;
+    sr[a + b * HMB] = Gr[a + b * HMB]; si[a + b * HMB] = Gi[a + b * HMB];
+  }
+  __syncthreads();
+  const int c = blockIdx.x * HT + threadIdx.x;
+  if (c >= nvec) return;
+  double* yr = Yr + (size_t)c * HMB; double* yi = Yi + (size_t)c * HMB;
+  for (int a = 0; a < nb; ++a) {
+    double tr = yr[a], ti = yi[a];
+    for (int b = 0; b < a; ++b) {
+      const double gr = sr[a + b * HMB], gi = si[a + b * HMB];
+      tr -= gr * yr[b] - gi * yi[b];
+      ti -= gr * yi[b] + gi * yr[b];
+    }
+    // divide by conj(beta_a): t * beta / |beta|^2
+    const double br = beta[2 * (j0 + a)], bi = beta[2 * (j0 + a) + 1];
+    const double b2 = br * br + bi * bi;
+    yr[a] = (tr * br - ti * bi) / b2;
+    yi[a] = (tr * bi + ti * br) / b2;
+  }
+}
+
+__global__ void h_join_kernel(const double* __restrict__ Zr, const double* __restrict__ Zi, int ldzp, int n, int nvec,
+                              double* __restrict__ z, int ldz) {
+  const int c = blockIdx.y;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    z[2 * ((size_t)r + (size_t)c * ldz)] = Zr[(size_t)r + (size_t)c * ldzp];
+    z[2 * ((size_t)r + (size_t)c * ldz) + 1] = Zi[(size_t)r + (size_t)c * ldzp];
+  }
+}
+
+__global__ void h_scale_vec_kernel(double* __restrict__ w, int n, double s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w[i] *= s;
+}
+__global__ void h_fill_vec_kernel(double* __restrict__ w, int n, double v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w[i] = v;
+}
+
+double hnow() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+// a, z: device, interleaved complex(8), leading dimensions in complex elements
+int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb,
+                   char mode) {
+  if (!ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  if (ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;   // one GPU in this version
+  if (n <= 0) {
+    fprintf(stderr, "[eigx] warning: non-positive dimension is invalid\n");   // src/eigen_h.F:91-94
+    return EIGX_ERR_BAD_ARG;
+  }
+  if (!a || !w || lda < n) return EIGX_ERR_BAD_ARG;
+  if (mode >= 'a' && mode <= 'z') mode = (char)(mode - 'a' + 'A');
+  if (nvec == 0) mode = 'N';                      // src/eigen_h.F:104-106
+  if (nvec < 0) nvec = -nvec;
+  if (nvec > n) nvec = n;
+  if (mode != 'N' && mode != 'A' && mode != 'X') mode = 'A';
+  const bool want_vec = mode != 'N';
+  if (want_vec && (!z || ldz < n)) return EIGX_ERR_BAD_ARG;
+  int m = mf <= 0 ? 48 : mf;
+  if (m > HM) m = HM;
+  if (m > n) m = n;
+  EIGX_HIP_CHECK(hipSetDevice(ctx.device));
+  hipStream_t st = ctx.stream;
+  ctx.errinfo = 0;
+  for (int q = 0; q < 16; ++q) ctx.timers[q] = 0.0;
+  const double t0 = hnow();
+
+  // ---- eigen_scaling_h -------------------------------------------------------------------------------------------
+  double sigma = 1.0;
+  {
+    const int nbk = 256;
+    double* part = ctx.pool.get_t<double>("h.absmax", (size_t)2 * nbk);
+    hipLaunchKernelGGL(h_absmax_kernel, dim3(nbk), dim3(HT), 0, st, a, lda, n, part);
+    std::vector<double> hp(2 * nbk);
+    EIGX_HIP_CHECK(hipMemcpyAsync(hp.data(), part, hp.size() * 8, hipMemcpyDeviceToHost, st));
+    EIGX_HIP_CHECK(hipStreamSynchronize(st));
+    double anrm = 0.0, bad = 0.0;
+    for (int q = 0; q < nbk; ++q) { anrm = std::max(anrm, hp[2 * q]); bad = std::max(bad, hp[2 * q + 1]); }
+    if (bad != 0.0) {   // NaN / Inf in the input: w(:) = NaN (src/eigen_h.F:147-150)
+      hipLaunchKernelGGL(h_fill_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, n,
+                         std::numeric_limits<double>::quiet_NaN());
+      EIGX_HIP_CHECK(hipStreamSynchronize(st));
+      ctx.errinfo = -1;
+      return EIGX_ERR_NONFINITE;
+    }
+    if (anrm > 0.0 && (anrm < 1e-90 || anrm > 1e90)) { int ex = 0; (void)frexp(anrm, &ex); sigma = ldexp(1.0, -ex); }
+    if (sigma != 1.0) hipLaunchKernelGGL(h_scale_kernel, dim3(8, n), dim3(256), 0, st, a, lda, n, sigma);
+  }
+
+  // ---- workspace -----------------------------------------------------------------------------------------------------
+  const int ld = pad_ld(n + 2);
+  const int ldp = ld;
+  HArgs H;
+  H.n = n; H.ld = ld; H.ldp = ldp;
+  H.Ar = ctx.pool.get_t<double>("h.Ar", (size_t)ld * n);
+  H.Ai = ctx.pool.get_t<double>("h.Ai", (size_t)ld * n);
+  H.Ur = ctx.pool.get_t<double>("h.Ur", (size_t)ldp * m);
+  H.Ui = ctx.pool.get_t<double>("h.Ui", (size_t)ldp * m);
+  H.Wr = ctx.pool.get_t<double>("h.Wr", (size_t)ldp * m);
+  H.Wi = ctx.pool.get_t<double>("h.Wi", (size_t)ldp * m);
+  double* P1 = ctx.pool.get_t<double>("h.P1", (size_t)ldp * 4 * m);
+  double* P2 = ctx.pool.get_t<double>("h.P2", (size_t)ldp * 4 * m);
+  double* P3 = ctx.pool.get_t<double>("h.P3", (size_t)ldp * 4 * m);
+  H.xr = ctx.pool.get_t<double>("h.xr", (size_t)ldp); H.xi = ctx.pool.get_t<double>("h.xi", (size_t)ldp);
+  H.pr = ctx.pool.get_t<double>("h.pr", (size_t)ldp); H.pi = ctx.pool.get_t<double>("h.pi", (size_t)ldp);
+  H.beta = ctx.pool.get_t<double>("h.beta", (size_t)2 * n + 2);
+  const int lde = (n + 3) / 4 * 4;
+  H.d = ctx.pool.get_t<double>("h.d", (size_t)n);
+  H.e = ctx.pool.get_t<double>("h.e", (size_t)lde);
+  const int nwg = ceil_div(n, HT) + 1;
+  const int nqc_max = ceil_div(n, GC) + 1;
+  const int npdc_max = ceil_div(n, PDR) + 1;
+  H.pn = ctx.pool.get_t<double>("h.pn", (size_t)nwg);
+  H.ps = ctx.pool.get_t<double>("h.ps", (size_t)2 * nwg);
+  H.pd = ctx.pool.get_t<double>("h.pd", (size_t)npdc_max * HM * 4);
+  H.qr = ctx.pool.get_t<double>("h.qr", (size_t)nqc_max * ldp);
+  H.qi = ctx.pool.get_t<double>("h.qi", (size_t)nqc_max * ldp);
+
+  hipLaunchKernelGGL(h_split_kernel, dim3(8, n), dim3(256), 0, st, a, lda, n, H.Ar, H.Ai, ld);
+  hipLaunchKernelGGL(h_fill_kernel, dim3(64), dim3(256), 0, st, H.e, (size_t)lde, 0.0);
+  hipLaunchKernelGGL(h_fill_kernel, dim3(64), dim3(256), 0, st, H.beta, (size_t)2 * n + 2, 0.0);
+  auto zero_panel = [&]() {
+    hipLaunchKernelGGL(h_fill_kernel, dim3(256), dim3(256), 0, st, H.Ur, (size_t)ldp * m, 0.0);
+    hipLaunchKernelGGL(h_fill_kernel, dim3(256), dim3(256), 0, st, H.Ui, (size_t)ldp * m, 0.0);
+    hipLaunchKernelGGL(h_fill_kernel, dim3(256), dim3(256), 0, st, H.Wr, (size_t)ldp * m, 0.0);
+    hipLaunchKernelGGL(h_fill_kernel, dim3(256), dim3(256), 0, st, H.Wi, (size_t)ldp * m, 0.0);
+  };
+  zero_panel();
+
+  // ---- eigen_hrd: Hermitian -> real tridiagonal ---------------------------------------------------------------------
+  const double t1 = hnow();
+  int k = 0;
+  for (int i = n - 1; i >= 1; --i) {
+    const int L = i;
+    const int nb1 = ceil_div(i + 1, HT), nbl = ceil_div(L, HT);
+    hipLaunchKernelGGL(h_form_x_kernel, dim3(nb1), dim3(HT), 0, st, H, i, k);
+    hipLaunchKernelGGL(h_reflector_kernel, dim3(nbl), dim3(HT), 0, st, H, i, k, nb1);
+    const int npdc = ceil_div(L, PDR);
+    if (k > 0) hipLaunchKernelGGL(h_paneldot_kernel, dim3(k, npdc), dim3(HT), 0, st, H, L, k);
+    const int nqc = ceil_div(L, GC);
+    hipLaunchKernelGGL(h_gemv_kernel, dim3(nbl, nqc), dim3(HT), 0, st, H, L, k);
+    hipLaunchKernelGGL(h_combine_kernel, dim3(nbl), dim3(HT), 0, st, H, L, k, nqc, npdc);
+    hipLaunchKernelGGL(h_make_v_kernel, dim3(nbl), dim3(HT), 0, st, H, i, k, nbl);
+    ++k;
+    if (k == m || i == 1) {
+      // trailing update of the remaining i x i block (both triangles), two real GEMMs with K = 4k
+      const int nr = i;
+      hipLaunchKernelGGL(h_pack_kernel, dim3(ceil_div(nr, 256), k), dim3(256), 0, st, H, nr, k, P1, P2, P3);
+      dgemm_dev(st, 'N', 'T', nr, nr, 4 * k, -1.0, P1, ldp, P3, ldp, 1.0, H.Ar, ld);
+      dgemm_dev(st, 'N', 'T', nr, nr, 4 * k, -1.0, P2, ldp, P3, ldp, 1.0, H.Ai, ld);
+      zero_panel();
+      k = 0;
+    }
+  }
+  hipLaunchKernelGGL(h_form_x_kernel, dim3(1), dim3(HT), 0, st, H, 0, 0);   // d_0 = Re A(0,0)
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  const double t2 = hnow();
+
+  // ---- real tridiagonal eigenproblem (dc2 / bisect) --------------------------------------------------------------------
+  double* Zr = nullptr;
+  double* Zi = nullptr;
+  const int ldzp = pad_ld(n + 2);
+  if (!want_vec) {
+    band_bisect_dev(ctx, n, H.d, H.e, lde, 1, w);
+  } else {
+    Zr = ctx.pool.get_t<double>("h.Zr", (size_t)ldzp * n);
+    Zi = ctx.pool.get_t<double>("h.Zi", (size_t)ldzp * n);
+    band_dc_dev(ctx, n, nvec, H.d, H.e, lde, 1, w, Zr, ldzp);
+    if (mode == 'X') band_bisect_dev(ctx, n, H.d, H.e, lde, 1, w);
+    hipLaunchKernelGGL(h_fill_kernel, dim3(1024), dim3(256), 0, st, Zi, (size_t)ldzp * nvec, 0.0);
+  }
+  const double t3 = hnow();
+
+  // ---- eigen_hrbakwyx: z = H_{n-1}^H ... H_1^H y in blocks of HMB reflectors -------------------------------------------
+  if (want_vec && n > 1) {
+    int bw = mb <= 0 ? HMB : mb;
+    if (bw > HMB) bw = HMB;
+    hipLaunchKernelGGL(h_zero_below_kernel, dim3(8, n), dim3(256), 0, st, H.Ar, H.Ai, ld, n, n);
+    double* Gr = ctx.pool.get_t<double>("h.Gr", (size_t)HMB * HMB);
+    double* Gi = ctx.pool.get_t<double>("h.Gi", (size_t)HMB * HMB);
+    double* Yr = ctx.pool.get_t<double>("h.Yr", (size_t)HMB * nvec);
+    double* Yi = ctx.pool.get_t<double>("h.Yi", (size_t)HMB * nvec);
+    const size_t shm = (size_t)2 * HMB * HMB * sizeof(double);
+    static bool attr = false;
+    if (!attr) {
+      EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)h_trsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      attr = true;
+    }
+    for (int j0 = 1; j0 < n; j0 += bw) {
+      const int nb = (j0 + bw <= n) ? bw : n - j0;
+      const int rows = j0 + nb - 1;               // longest reflector of the block (column j has rows 0..j-1)
+      const double* Vr = H.Ar + (size_t)j0 * ld;
+      const double* Vi = H.Ai + (size_t)j0 * ld;
+      // G = V^H V : Gr = Vr^T Vr + Vi^T Vi ; Gi = Vr^T Vi - Vi^T Vr
+      dgemm_dev(st, 'T', 'N', nb, nb, rows, 1.0, Vr, ld, Vr, ld, 0.0, Gr, HMB);
+      dgemm_dev(st, 'T', 'N', nb, nb, rows, 1.0, Vi, ld, Vi, ld, 1.0, Gr, HMB);
+      dgemm_dev(st, 'T', 'N', nb, nb, rows, 1.0, Vr, ld, Vi, ld, 0.0, Gi, HMB);
+      dgemm_dev(st, 'T', 'N', nb, nb, rows, -1.0, Vi, ld, Vr, ld, 1.0, Gi, HMB);
+      // Y = V^H Z : Yr = Vr^T Zr + Vi^T Zi ; Yi = Vr^T Zi - Vi^T Zr
+      dgemm_dev(st, 'T', 'N', nb, nvec, rows, 1.0, Vr, ld, Zr, ldzp, 0.0, Yr, HMB);
+      dgemm_dev(st, 'T', 'N', nb, nvec, rows, 1.0, Vi, ld, Zi, ldzp, 1.0, Yr, HMB);
+      dgemm_dev(st, 'T', 'N', nb, nvec, rows, 1.0, Vr, ld, Zi, ldzp, 0.0, Yi, HMB);
+      dgemm_dev(st, 'T', 'N', nb, nvec, rows, -1.0, Vi, ld, Zr, ldzp, 1.0, Yi, HMB);
+      hipLaunchKernelGGL(h_trsolve_kernel, dim3(ceil_div(nvec, HT)), dim3(HT), shm, st, Gr, Gi, H.beta, j0, nb, nvec, Yr, Yi);
+      // Z -= V X : Zr -= Vr Xr - Vi Xi ; Zi -= Vr Xi + Vi Xr
+      dgemm_dev(st, 'N', 'N', rows, nvec, nb, -1.0, Vr, ld, Yr, HMB, 1.0, Zr, ldzp);
+      dgemm_dev(st, 'N', 'N', rows, nvec, nb, 1.0, Vi, ld, Yi, HMB, 1.0, Zr, ldzp);
+      dgemm_dev(st, 'N', 'N', rows, nvec, nb, -1.0, Vr, ld, Yi, HMB, 1.0, Zi, ldzp);
+      dgemm_dev(st, 'N', 'N', rows, nvec, nb, -1.0, Vi, ld, Yr, HMB, 1.0, Zi, ldzp);
+    }
+  }
+  if (want_vec) hipLaunchKernelGGL(h_join_kernel, dim3(8, nvec), dim3(256), 0, st, Zr, Zi, ldzp, n, nvec, z, ldz);
+  if (sigma != 1.0 && sigma != 0.0)
+    hipLaunchKernelGGL(h_scale_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, n, 1.0 / sigma);
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  EIGX_HIP_CHECK(hipGetLastError());
+  const double t4 = hnow();
+
+  // ---- statistics (src/eigen_h.F:284-288): a(1,1) = flops, a(2,1) = seconds (real parts) ------------------------------
+  const double f_red = 4.0 / 3.0 * (double)n * n * n;
+  const double f_dc = ctx.timers[11];
+  const double f_bt = want_vec ? 2.0 * (double)nvec * n * n : 0.0;
+  const double ret = f_red + f_dc + f_bt;
+  ctx.timers[0] = t4 - t0; ctx.timers[1] = t2 - t1; ctx.timers[2] = t3 - t2; ctx.timers[3] = t4 - t3; ctx.timers[12] = ret;
+  const double stats[4] = {ret, 0.0, t4 - t0, 0.0};
+  EIGX_HIP_CHECK(hipMemcpyAsync(a, stats, (size_t)(n >= 2 ? 4 : 2) * 8, hipMemcpyHostToDevice, st));
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  return EIGX_OK;
+}
+
+int herm_solve_host(Context& ctx, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb,
+                    char mode) {
+  if (!ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  if (n <= 0 || !a || !w || lda < n) return EIGX_ERR_BAD_ARG;
+  EIGX_HIP_CHECK(hipSetDevice(ctx.device));
+  const int ldd = n + 2;
+  double* ad = ctx.pool.get_t<double>("hh.a", (size_t)2 * ldd * n);
+  double* zd = ctx.pool.get_t<double>("hh.z", (size_t)2 * ldd * n);
+  double* wd = ctx.pool.get_t<double>("hh.w", (size_t)n);
+  EIGX_HIP_CHECK(hipMemcpy2D(ad, (size_t)ldd * 16, a, (size_t)lda * 16, (size_t)n * 16, (size_t)n, hipMemcpyHostToDevice));
+  const int rc = herm_solve_dev(ctx, n, nvec, ad, ldd, wd, zd, ldd, mf, mb, mode);
+  EIGX_HIP_CHECK(hipMemcpy(w, wd, (size_t)n * 8, hipMemcpyDeviceToHost));
+  if (rc != EIGX_OK) return rc;
+  char md = mode;
+  if (md >= 'a' && md <= 'z') md = (char)(md - 'a' + 'A');
+  int nv = nvec < 0 ? -nvec : nvec;
+  if (nv > n) nv = n;
+  if (z && nv > 0 && md != 'N')
+    EIGX_HIP_CHECK(hipMemcpy2D(z, (size_t)ldz * 16, zd, (size_t)ldd * 16, (size_t)n * 16, (size_t)nv, hipMemcpyDeviceToHost));
+  EIGX_HIP_CHECK(hipMemcpy(a, ad, (size_t)(n >= 2 ? 4 : 2) * 8, hipMemcpyDeviceToHost));   // statistics only: a is destroyed
+  return EIGX_OK;
+}
+
+}  // namespace eigx
+
+using namespace eigx;
+
+extern "C" {
+
+int eigx_h(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb, char mode) {
+  return herm_solve_host(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode);
+}
+int eigx_h_dev(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb, char mode) {
+  return herm_solve_dev(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode);
+}
+
+}

@@ -724,3 +724,105 @@ def test_large_n_eigenvalues_only_invariants(gpu_lib):
     assert (np.diff(wh) >= 0).all()
     assert abs(wh.sum() - tr) / np.sqrt(fro2) < 1e-12 * np.sqrt(n)
     assert abs(np.sqrt((wh * wh).sum()) - np.sqrt(fro2)) / np.sqrt(fro2) < 1e-12
+
+
+# ------------------------------------------------------------------ eigen_h: complex Hermitian route
+def _herm_random(n, seed=11):
+    rng = np.random.default_rng(seed)
+    B = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    return (B + B.conj().T) / 2
+
+
+def _herm_check(A, w, Z):
+    n = A.shape[0]
+    anorm = np.linalg.norm(A)
+    res = np.linalg.norm(A @ Z - Z * w[None, :]) / (n * EPS * anorm) if anorm > 0 else 0.0
+    orth = np.linalg.norm(Z.conj().T @ Z - np.eye(n)) / (n * EPS)
+    return res, orth
+
+
+@pytest.mark.parametrize("n,m", [(1, 8), (2, 8), (3, 8), (5, 4), (17, 4), (64, 16), (130, 48), (300, 48), (517, 128)])
+def test_eigen_h_matches_oracle(gpu_lib, orc, n, m):
+    """complex Hermitian solver, host API: eigenvalues against the oracle restatement (oracle/eigx_oracle.c orc_eigen_h,
+    parity unpinned: the reference holds no eigen_h fixtures) and against LAPACK; residual and unitarity with the
+    reference's thresholds for the real solvers (benchmark/ev_test.f:181-204).  The strict lower triangle is poisoned."""
+    import eigenexa_amd as ee
+
+    A = _herm_random(n)
+    a = np.asfortranarray(np.triu(A))
+    a[np.tril_indices(n, -1)] = np.nan + 1j * np.nan
+    z = np.zeros((n, n), dtype=np.complex128, order="F")
+    w = np.zeros(n)
+    ee.eigen_init()
+    ee.eigen_h(n, n, a, n, w, z, n, m_forward=m, m_backward=64, mode="A")
+    assert ee.api.last_status() == 0
+    wo, _ = orc.eigen_h(A)
+    wl = np.linalg.eigvalsh(A)
+    scale = max(1.0, np.abs(wl).max())
+    assert np.abs(w - wo).max() < 1e-12 * scale and np.abs(w - wl).max() < 1e-12 * scale
+    res, orth = _herm_check(A, w, z)
+    assert res < GATE_RES and orth < GATE_ORTH, (res, orth)
+    assert a[0, 0].real > 0 and (n < 2 or a[1, 0].real >= 0)      # a(1,1) = flops, a(2,1) = seconds
+
+
+def test_eigen_h_known_spectrum_and_modes(gpu_lib, orc):
+    """A = D F D^H with the Frank matrix F and a unitary diagonal D has Frank's analytic spectrum
+    (benchmark/mat_set.f:638-647); modes 'N' and 'X'; partial eigenvector sets; a real symmetric matrix passed as
+    complex gives eigen_s's eigenvalues; device API"""
+    import torch
+
+    import eigenexa_amd as ee
+    from eigenexa_amd import layout
+
+    ee.eigen_init()
+    n = 257
+    rng = np.random.default_rng(5)
+    ph = np.exp(1j * rng.uniform(0, 2 * np.pi, n))
+    A = (ph[:, None] * layout.frank(n)) * ph.conj()[None, :]
+    lam = np.sort(layout.frank_eigenvalues(n))
+    for mode in ("A", "N", "X"):
+        a = np.asfortranarray(np.triu(A))
+        z = np.zeros((n, n), dtype=np.complex128, order="F")
+        w = np.zeros(n)
+        ee.eigen_h(n, n, a, n, w, z, n, mode=mode)
+        assert ee.api.last_status() == 0
+        assert (np.abs(w - lam) / lam).max() < 1e-9, mode                # cond(Frank) ~ n^2
+        if mode != "N":
+            res, orth = _herm_check(A, w, z)
+            assert res < GATE_RES and orth < GATE_ORTH, (mode, res, orth)
+    # partial set, device API (column-major image: at[j, i] = A(i, j))
+    nvec = 40
+    at = torch.from_numpy(np.ascontiguousarray(np.triu(A).T)).cuda()
+    zt = torch.zeros(n, n, dtype=torch.complex128, device="cuda")
+    wt = torch.zeros(n, dtype=torch.float64, device="cuda")
+    ee.eigen_h(n, nvec, at, n, wt, zt, n)
+    assert ee.api.last_status() == 0
+    Zp = zt.cpu().numpy()[:nvec, :].T
+    wp = wt.cpu().numpy()
+    assert np.linalg.norm(A @ Zp - Zp * wp[None, :nvec]) / (n * EPS * np.linalg.norm(A)) < GATE_RES
+    # real symmetric input
+    S = layout.random_symmetric(200)
+    a = np.asfortranarray(np.triu(S).astype(np.complex128))
+    z = np.zeros((200, 200), dtype=np.complex128, order="F")
+    w = np.zeros(200)
+    ee.eigen_h(200, 200, a, 200, w, z, 200)
+    assert np.abs(w - np.linalg.eigvalsh(S)).max() < 1e-12 * np.abs(S).sum(axis=1).max()
+    # structured: diagonal, zero, and a matrix whose columns vanish above the diagonal early (trivial reflectors)
+    for M in (np.diag(np.arange(1.0, 41.0)).astype(np.complex128), np.zeros((33, 33), dtype=np.complex128),
+              np.diag(np.arange(1.0, 31.0)).astype(np.complex128) + np.diag(1j * np.ones(29), 1) + np.diag(-1j * np.ones(29), -1)):
+        k = M.shape[0]
+        a = np.asfortranarray(np.triu(M))
+        z = np.zeros((k, k), dtype=np.complex128, order="F")
+        w = np.zeros(k)
+        ee.eigen_h(k, k, a, k, w, z, k)
+        assert ee.api.last_status() == 0
+        assert np.abs(w - np.linalg.eigvalsh(M)).max() < 1e-12 * max(1.0, np.abs(M).max())
+        res, orth = _herm_check(M, w, z)
+        assert res < GATE_RES and orth < GATE_ORTH
+    # NaN input: w = NaN (src/eigen_h.F:147-150)
+    a = np.asfortranarray(np.triu(_herm_random(20)))
+    a[3, 7] = np.nan
+    w = np.zeros(20)
+    z = np.zeros((20, 20), dtype=np.complex128, order="F")
+    ee.eigen_h(20, 20, a, 20, w, z, 20)
+    assert np.isnan(w).all()
