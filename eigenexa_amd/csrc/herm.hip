@@ -8,12 +8,12 @@
 // fp64 MFMA GEMMs of gemm_f64.hip instead of a ZGEMM port:
 //   trailing update  A -= U W^H + W U^H :  Ar -= [Ur Ui Wr Wi][Wr Wi Ur Ui]^T ,  Ai -= [Ui -Ur Wi -Wr][Wr Wi Ur Ui]^T  (K = 4m)
 //   back-transform   Z -= V (S^-H (V^H Z))  : 4 real GEMMs each for V^H Z and V X, 4 small ones for the block Gram matrix
-// The reduction keeps BOTH triangles of A (the Hermitian mat-vec is then a plain coalesced streaming GEMV over the planes)
-// and forms each column lazily from the panel (dlatrd style), one column per step as the reference does:
+// The reduction keeps both triangles of A up to date (the trailing update is a full GEMM), but the Hermitian mat-vec
+// streams only the upper triangle (64 x 64 tiles transposed through LDS).  Each column is formed lazily from the panel (dlatrd style), one column per step as the reference does:
 //   x = A_eff(0:L, i);  g = -sign(||x||, Re x_{L-1});  u = x, u_{L-1} -= g;  beta = -u_{L-1} g       (src/eigen_hrd_t4.F:40-95)
 //   q = A_eff u;  s = u^H q;  alpha = s / (2 beta);  v = (q - alpha u) / conj(beta)                 (src/eigen_hrd_t6_3.F:256-272)
 //   A_eff = A - U W^H - W U^H  (panel of m columns, applied every m steps)                          (src/eigen_hrd_t1.F:2-110)
-// Five small kernels per column (form x | reflector | panel dots | GEMV partials | combine | v): this version is
+// Six small kernels per column (form x | reflector | panel dots | tiled mat-vec | combine | v): this version is
 // latency-bound per step like the first real-symmetric version was; the fused / tiled structure of band_reduce.hip is the
 // template for the next one.  All cross-workgroup reductions are two-phase and deterministic (no atomics).
 #include "eigx_context.h"
@@ -30,7 +30,7 @@ namespace {
 
 constexpr int HT = 256;      // threads per workgroup
 constexpr int HM = 128;      // max panel width (LDS arrays)
-constexpr int GC = 256;      // GEMV column chunk
+constexpr int HTL = 64;      // tile edge of the Hermitian mat-vec
 constexpr int PDR = 1024;    // rows per panel-dot chunk
 constexpr int HMB = 64;      // reflectors per back-transformation block (S^H of a block lives in LDS)
 
@@ -41,7 +41,7 @@ struct HArgs {
   double *beta, *d, *e;
   double *pn;      // norm partials [workgroup]
   double *pd;      // panel-dot partials [chunk][HM][4]
-  double *qr, *qi; // GEMV partials [column chunk][ldp]
+  double *yrr, *yri, *ycr, *yci;  // mat-vec partials: row sums [tile column][ldp], column sums [tile row][ldp]
   double *ps;      // s partials [workgroup][2]
 };
 
@@ -181,31 +181,131 @@ __global__ __launch_bounds__(HT) void h_paneldot_kernel(HArgs H, int L, int k) {
   }
 }
 
-// K3: q = A(0:L, 0:L) u, partial sums over a chunk of GC columns; grid (row blocks, column chunks)
-__global__ __launch_bounds__(HT) void h_gemv_kernel(HArgs H, int L, int k) {
-  __shared__ double sur[GC], sui[GC];
-  const int c0 = blockIdx.y * GC;
-  const int nc = (c0 + GC < L) ? GC : L - c0;
-  for (int t = threadIdx.x; t < nc; t += HT) {
-    sur[t] = H.Ur[(size_t)(c0 + t) + (size_t)k * H.ldp]; sui[t] = H.Ui[(size_t)(c0 + t) + (size_t)k * H.ldp];
+// lane exchanges on the VALU (no LDS crossbar), as in band_reduce.hip: DPP moves inside a row of 16 lanes, gfx950
+// v_permlane{16,32}_swap across rows
+template <int CTRL>
+__device__ __forceinline__ double hdpp_mov(double v) {
+  const int lo2 = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi2, lo2);
+}
+// lanes 0..31 get a[i] + a[i+32], lanes 32..63 get b[i-32] + b[i]
+__device__ __forceinline__ double hswapadd32(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+// even rows of 16 lanes get a[row] + a[row+1], odd rows get b[row-1] + b[row]
+__device__ __forceinline__ double hswapadd16(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+// 16 per-lane values (one per tile column of the wave) -> their sums over the 64 lanes.  Halving butterfly: every
+// step pairs two columns and two lane groups, so 16 -> 8 -> 4 -> 2 -> 1 values per lane, then the four lanes of a quad
+// are added.  Afterwards every lane holds the total of column  8*bit5 + 4*bit4 + 2*bit3 + bit2  (bits of the lane id).
+__device__ __forceinline__ double hcolsum16(const double (&v)[16], int lane) {
+  double v8[8], v4[4], v2[2], v1;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v8[j] = hswapadd32(v[j], v[j + 8]);        // lanes < 32: column j, others: j + 8
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v4[j] = hswapadd16(v8[j], v8[j + 4]);      // even rows: j, odd rows: j + 4
+  {
+    const bool hi = lane & 8;                                           // row_ror:8 = lane ^ 8 inside the row of 16
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const double keep = hi ? v4[j + 2] : v4[j];
+      const double send = hi ? v4[j] : v4[j + 2];
+      v2[j] = keep + hdpp_mov<0x128>(send);
+    }
+  }
+  {
+    const bool hi = lane & 4;                                           // row_half_mirror: lane i <-> 7 - i of its 8
+    const double keep = hi ? v2[1] : v2[0];
+    const double send = hi ? v2[0] : v2[1];
+    v1 = keep + hdpp_mov<0x141>(send);
+  }
+  v1 += hdpp_mov<0xB1>(v1);                                             // quad_perm [1,0,3,2]
+  v1 += hdpp_mov<0x4E>(v1);                                             // quad_perm [2,3,0,1]
+  return v1;
+}
+
+// K3: q = A(0:L, 0:L) u from the UPPER triangle only (half the HBM bytes of a GEMV over both triangles): one workgroup
+// per 64 x 64 tile (ty <= tx) of the upper block triangle, 1-D grid in row-major tile order.  Wave w owns the tile columns
+// [16w, 16w+16), a lane owns one tile row: the tile lives in registers (32 coalesced loads per thread, all issued before
+// anything is consumed).  The same registers give the row sums  sum_c A(r,c) u(c)  (combined over the four waves through
+// LDS) and the column sums  sum_r conj(A(r,c)) u(r)  of the mirrored lower-triangle block (halving butterfly over the
+// lanes).  Row partials are indexed by tile column (YR[tx][r]), column partials by tile row (YC[ty][c]); K4 adds the
+// nt + 1 partials of a row in fixed order.
+__global__ __launch_bounds__(HT) void h_hemv_kernel(HArgs H, int L, int k, int nt) {
+  __shared__ double ucr[HTL], uci[HTL], urr[HTL], uri[HTL];
+  __shared__ double part[4][HTL][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // tile index -> (ty, tx), row-major over the upper block triangle
+  const int bid = blockIdx.x;
+  const float fn = 2.0f * (float)nt + 1.0f;
+  int ty = (int)((fn - sqrtf(fn * fn - 8.0f * (float)bid)) * 0.5f);
+  if (ty < 0) ty = 0;
+  if (ty > nt - 1) ty = nt - 1;
+  while (ty > 0 && ty * nt - ty * (ty - 1) / 2 > bid) --ty;
+  while ((ty + 1) * nt - (ty + 1) * ty / 2 <= bid) ++ty;
+  const int tx = ty + (bid - (ty * nt - ty * (ty - 1) / 2));
+  const int row0 = ty * HTL, col0 = tx * HTL;
+  const bool diag = (ty == tx);
+  const int r = row0 + lane;
+  const int rc = (r < L) ? r : 0;
+  double ar[16], ai[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int c = col0 + wave * 16 + t;
+    const int ccl = (c < L) ? c : 0;
+    ar[t] = H.Ar[(size_t)rc + (size_t)ccl * H.ld];
+    ai[t] = H.Ai[(size_t)rc + (size_t)ccl * H.ld];
+  }
+  if (tid < HTL) {
+    const int c = col0 + tid;
+    ucr[tid] = (c < L) ? H.Ur[(size_t)c + (size_t)k * H.ldp] : 0.0;
+    uci[tid] = (c < L) ? H.Ui[(size_t)c + (size_t)k * H.ldp] : 0.0;
+  } else if (tid < 2 * HTL) {
+    const int rr = row0 + tid - HTL;
+    urr[tid - HTL] = (rr < L) ? H.Ur[(size_t)rr + (size_t)k * H.ldp] : 0.0;
+    uri[tid - HTL] = (rr < L) ? H.Ui[(size_t)rr + (size_t)k * H.ldp] : 0.0;
   }
   __syncthreads();
-  const int r = blockIdx.x * HT + threadIdx.x;
-  if (r >= L) return;
-  const double* ar = H.Ar + (size_t)r + (size_t)c0 * H.ld;
-  const double* ai = H.Ai + (size_t)r + (size_t)c0 * H.ld;
-  double qr = 0.0, qi = 0.0;
-#pragma unroll 4
-  for (int t = 0; t < nc; ++t) {
-    const double xr = ar[(size_t)t * H.ld], xi = ai[(size_t)t * H.ld];
-    qr += xr * sur[t] - xi * sui[t];
-    qi += xr * sui[t] + xi * sur[t];
+  const double mur = urr[lane], mui = uri[lane];   // u at my row
+  double sr = 0.0, si = 0.0;                       // row sums over the wave's 16 columns
+  double cr[16], ci[16];                           // my row's contribution to the 16 column sums
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int cc = wave * 16 + t, c = col0 + cc;
+    const bool inr = r < L && c < L;
+    const bool up = inr && (!diag || lane <= cc);          // upper part incl. diagonal -> row sums
+    const bool su = inr && (!diag || lane < cc);           // strictly upper -> column sums of the mirrored block
+    const double xr = up ? ar[t] : 0.0;
+    const double xi = (up && !(diag && lane == cc)) ? ai[t] : 0.0;
+    const double vr = ucr[cc], vi = uci[cc];
+    sr += xr * vr - xi * vi;
+    si += xr * vi + xi * vr;
+    const double yr = su ? ar[t] : 0.0, yi = su ? ai[t] : 0.0;
+    cr[t] = yr * mur + yi * mui;                           // conj(a) u(row)
+    ci[t] = yr * mui - yi * mur;
   }
-  H.qr[(size_t)blockIdx.y * H.ldp + r] = qr; H.qi[(size_t)blockIdx.y * H.ldp + r] = qi;
+  part[wave][lane][0] = sr; part[wave][lane][1] = si;
+  const double tcr = hcolsum16(cr, lane), tci = hcolsum16(ci, lane);
+  if ((lane & 3) == 0) {
+    const int j = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+    const int c = col0 + wave * 16 + j;
+    if (c < L) { H.ycr[(size_t)ty * H.ldp + c] = tcr; H.yci[(size_t)ty * H.ldp + c] = tci; }
+  }
+  __syncthreads();
+  if (tid < HTL && r < L) {
+    H.yrr[(size_t)tx * H.ldp + r] = (part[0][tid][0] + part[1][tid][0]) + (part[2][tid][0] + part[3][tid][0]);
+    H.yri[(size_t)tx * H.ldp + r] = (part[0][tid][1] + part[1][tid][1]) + (part[2][tid][1] + part[3][tid][1]);
+  }
 }
 
 // K4: p = q - U (W^H u) - W (U^H u); partial s = sum p conj(u)
-__global__ __launch_bounds__(HT) void h_combine_kernel(HArgs H, int L, int k, int nqc, int npdc) {
+__global__ __launch_bounds__(HT) void h_combine_kernel(HArgs H, int L, int k, int nt, int npdc) {
   __shared__ double dwr[HM], dwi[HM], dur[HM], dui[HM];
   __shared__ double red[8];
   const int tid = threadIdx.x;
@@ -222,7 +322,30 @@ __global__ __launch_bounds__(HT) void h_combine_kernel(HArgs H, int L, int k, in
   double s[2] = {0.0, 0.0};
   if (r < L) {
     double pr = 0.0, pi = 0.0;
-    for (int c = 0; c < nqc; ++c) { pr += H.qr[(size_t)c * H.ldp + r]; pi += H.qi[(size_t)c * H.ldp + r]; }
+    const int R = r / HTL;        // my tile row: column sums of tiles (t <= R, R), then row sums of tiles (R, t >= R)
+    // batches of 8 independent loads per plane (the chain of dependent adds, not the bytes, is what costs here);
+    // fixed summation order: column partials t = 0..R, then row partials t = R..nt-1
+    {
+      int t = 0;
+      for (; t + 8 <= R + 1; t += 8) {
+        double a[8], b[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { a[q] = H.ycr[(size_t)(t + q) * H.ldp + r]; b[q] = H.yci[(size_t)(t + q) * H.ldp + r]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { pr += a[q]; pi += b[q]; }
+      }
+      for (; t <= R; ++t) { pr += H.ycr[(size_t)t * H.ldp + r]; pi += H.yci[(size_t)t * H.ldp + r]; }
+      t = R;
+      for (; t + 8 <= nt; t += 8) {
+        double a[8], b[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { a[q] = H.yrr[(size_t)(t + q) * H.ldp + r]; b[q] = H.yri[(size_t)(t + q) * H.ldp + r]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { pr += a[q]; pi += b[q]; }
+      }
+      for (; t < nt; ++t) { pr += H.yrr[(size_t)t * H.ldp + r]; pi += H.yri[(size_t)t * H.ldp + r]; }
+    }
+#pragma unroll 4
     for (int j = 0; j < k; ++j) {
       const double ur = H.Ur[(size_t)r + (size_t)j * H.ldp], ui = H.Ui[(size_t)r + (size_t)j * H.ldp];
       const double wr = H.Wr[(size_t)r + (size_t)j * H.ldp], wi = H.Wi[(size_t)r + (size_t)j * H.ldp];
@@ -403,13 +526,15 @@ int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w,
   H.d = ctx.pool.get_t<double>("h.d", (size_t)n);
   H.e = ctx.pool.get_t<double>("h.e", (size_t)lde);
   const int nwg = ceil_div(n, HT) + 1;
-  const int nqc_max = ceil_div(n, GC) + 1;
+  const int nt_max = ceil_div(n, HTL) + 1;
   const int npdc_max = ceil_div(n, PDR) + 1;
   H.pn = ctx.pool.get_t<double>("h.pn", (size_t)nwg);
   H.ps = ctx.pool.get_t<double>("h.ps", (size_t)2 * nwg);
   H.pd = ctx.pool.get_t<double>("h.pd", (size_t)npdc_max * HM * 4);
-  H.qr = ctx.pool.get_t<double>("h.qr", (size_t)nqc_max * ldp);
-  H.qi = ctx.pool.get_t<double>("h.qi", (size_t)nqc_max * ldp);
+  H.yrr = ctx.pool.get_t<double>("h.yrr", (size_t)nt_max * ldp);
+  H.yri = ctx.pool.get_t<double>("h.yri", (size_t)nt_max * ldp);
+  H.ycr = ctx.pool.get_t<double>("h.ycr", (size_t)nt_max * ldp);
+  H.yci = ctx.pool.get_t<double>("h.yci", (size_t)nt_max * ldp);
 
   hipLaunchKernelGGL(h_split_kernel, dim3(8, n), dim3(256), 0, st, a, lda, n, H.Ar, H.Ai, ld);
   hipLaunchKernelGGL(h_fill_kernel, dim3(64), dim3(256), 0, st, H.e, (size_t)lde, 0.0);
@@ -432,9 +557,9 @@ int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w,
     hipLaunchKernelGGL(h_reflector_kernel, dim3(nbl), dim3(HT), 0, st, H, i, k, nb1);
     const int npdc = ceil_div(L, PDR);
     if (k > 0) hipLaunchKernelGGL(h_paneldot_kernel, dim3(k, npdc), dim3(HT), 0, st, H, L, k);
-    const int nqc = ceil_div(L, GC);
-    hipLaunchKernelGGL(h_gemv_kernel, dim3(nbl, nqc), dim3(HT), 0, st, H, L, k);
-    hipLaunchKernelGGL(h_combine_kernel, dim3(nbl), dim3(HT), 0, st, H, L, k, nqc, npdc);
+    const int nt = ceil_div(L, HTL);
+    hipLaunchKernelGGL(h_hemv_kernel, dim3(nt * (nt + 1) / 2), dim3(HT), 0, st, H, L, k, nt);
+    hipLaunchKernelGGL(h_combine_kernel, dim3(nbl), dim3(HT), 0, st, H, L, k, nt, npdc);
     hipLaunchKernelGGL(h_make_v_kernel, dim3(nbl), dim3(HT), 0, st, H, i, k, nbl);
     ++k;
     if (k == m || i == 1) {
