@@ -7,7 +7,7 @@
 // MI355X design: complex data lives in SPLIT PLANES (re, im) in HBM, so every O(n^3) contraction is a handful of real
 // fp64 MFMA GEMMs of gemm_f64.hip instead of a ZGEMM port:
 //   trailing update  A -= U W^H + W U^H :  Ar -= [Ur Ui Wr Wi][Wr Wi Ur Ui]^T ,  Ai -= [Ui -Ur Wi -Wr][Wr Wi Ur Ui]^T  (K = 4m)
-//   back-transform   Z -= V (S^-H (V^H Z))  : 4 real GEMMs each for V^H Z and V X, 4 small ones for the block Gram matrix
+//   back-transform   Z -= V (T (V^H Z)), T = S^-H : 4 real GEMMs each for V^H Z, T Y and V X, 4 small ones for the Gram matrix
 // The reduction keeps both triangles of A up to date (the trailing update is a full GEMM), but the Hermitian mat-vec
 // streams only the upper triangle (64 x 64 tiles transposed through LDS).  Each column is formed lazily from the panel (dlatrd style), one column per step as the reference does:
 //   x = A_eff(0:L, i);  g = -sign(||x||, Re x_{L-1});  u = x, u_{L-1} -= g;  beta = -u_{L-1} g       (src/eigen_hrd_t4.F:40-95)
@@ -32,7 +32,7 @@ constexpr int HT = 256;      // threads per workgroup
 constexpr int HM = 128;      // max panel width (LDS arrays)
 constexpr int HTL = 64;      // tile edge of the Hermitian mat-vec
 constexpr int PDR = 1024;    // rows per panel-dot chunk
-constexpr int HMB = 64;      // reflectors per back-transformation block (S^H of a block lives in LDS)
+constexpr int HMB = 128;     // reflectors per back-transformation block (the packed triangle S^H of a block lives in LDS)
 
 struct HArgs {
   double *Ar, *Ai; int ld; int n;
@@ -405,33 +405,37 @@ __global__ void h_zero_below_kernel(double* __restrict__ Vr, double* __restrict_
   }
 }
 
-// X = S^-H Y for one block: S^H lower triangular, S^H(a,b) = G(a,b) = v_a^H v_b (a > b), S^H(a,a) = conj(beta_a).
-// One thread per right-hand side, S^H in LDS, X overwrites Y (mb x nvec, column-major, ld = HMB).
-__global__ __launch_bounds__(HT) void h_trsolve_kernel(const double* __restrict__ Gr, const double* __restrict__ Gi,
-                                                        const double* __restrict__ beta, int j0, int nb, int nvec,
-                                                        double* __restrict__ Yr, double* __restrict__ Yi) {
-  extern __shared__ double sm[];   // [2][HMB*HMB]
-  double* sr = sm; double* si = sm + HMB * HMB;
-  for (int t = threadIdx.x; t < nb * nb; t += HT) {
+// T = S^-H for one block: S^H lower triangular, S^H(a,b) = G(a,b) = v_a^H v_b (a > b), S^H(a,a) = conj(beta_a)
+// (T^-1 of the compact WY form has the strictly upper part of V^H V and 1/tau = beta on its diagonal; the reference
+// keeps the same triangle, src/hrbakwy4_body.F:330-470).  One thread per column of T (forward substitution with the unit
+// vector e_c), the packed triangle of S^H in LDS; T (nb x nb, ld = HMB, planes) is then applied by real GEMMs.
+__global__ __launch_bounds__(HMB) void h_tinv_kernel(const double* __restrict__ Gr, const double* __restrict__ Gi,
+                                                      const double* __restrict__ beta, int j0, int nb,
+                                                      double* __restrict__ Tr, double* __restrict__ Ti) {
+  extern __shared__ double sm[];   // packed lower triangle incl. diagonal: [2][HMB*(HMB+1)/2]
+  double* sr = sm; double* si = sm + HMB * (HMB + 1) / 2;
+  for (int t = threadIdx.x; t < nb * nb; t += HMB) {
     const int a = t % nb, b = t / nb;
-    sr[a + b * HMB] = Gr[a + b * HMB]; si[a + b * HMB] = Gi[a + b * HMB];
+    if (a > b) { sr[a * (a + 1) / 2 + b] = Gr[a + b * HMB]; si[a * (a + 1) / 2 + b] = Gi[a + b * HMB]; }
+    else if (a == b) { sr[a * (a + 1) / 2 + a] = beta[2 * (j0 + a)]; si[a * (a + 1) / 2 + a] = -beta[2 * (j0 + a) + 1]; }
   }
   __syncthreads();
-  const int c = blockIdx.x * HT + threadIdx.x;
-  if (c >= nvec) return;
-  double* yr = Yr + (size_t)c * HMB; double* yi = Yi + (size_t)c * HMB;
-  for (int a = 0; a < nb; ++a) {
-    double tr = yr[a], ti = yi[a];
-    for (int b = 0; b < a; ++b) {
-      const double gr = sr[a + b * HMB], gi = si[a + b * HMB];
-      tr -= gr * yr[b] - gi * yi[b];
-      ti -= gr * yi[b] + gi * yr[b];
+  const int c = threadIdx.x;
+  if (c >= nb) return;
+  double* tr = Tr + (size_t)c * HMB; double* ti = Ti + (size_t)c * HMB;
+  for (int a = 0; a < c; ++a) { tr[a] = 0.0; ti[a] = 0.0; }
+  for (int a = c; a < nb; ++a) {
+    double xr = (a == c) ? 1.0 : 0.0, xi = 0.0;
+    const int base = a * (a + 1) / 2;
+    for (int b = c; b < a; ++b) {
+      const double gr = sr[base + b], gi = si[base + b];
+      xr -= gr * tr[b] - gi * ti[b];
+      xi -= gr * ti[b] + gi * tr[b];
     }
-    // divide by conj(beta_a): t * beta / |beta|^2
-    const double br = beta[2 * (j0 + a)], bi = beta[2 * (j0 + a) + 1];
-    const double b2 = br * br + bi * bi;
-    yr[a] = (tr * br - ti * bi) / b2;
-    yi[a] = (tr * bi + ti * br) / b2;
+    const double dr = sr[base + a], di = si[base + a];   // conj(beta_a)
+    const double d2 = dr * dr + di * di;
+    tr[a] = (xr * dr + xi * di) / d2;                    // x / d = x conj(d) / |d|^2
+    ti[a] = (xi * dr - xr * di) / d2;
   }
 }
 
@@ -598,12 +602,16 @@ int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w,
     hipLaunchKernelGGL(h_zero_below_kernel, dim3(8, n), dim3(256), 0, st, H.Ar, H.Ai, ld, n, n);
     double* Gr = ctx.pool.get_t<double>("h.Gr", (size_t)HMB * HMB);
     double* Gi = ctx.pool.get_t<double>("h.Gi", (size_t)HMB * HMB);
+    double* Tr = ctx.pool.get_t<double>("h.Tr", (size_t)HMB * HMB);
+    double* Ti = ctx.pool.get_t<double>("h.Ti", (size_t)HMB * HMB);
     double* Yr = ctx.pool.get_t<double>("h.Yr", (size_t)HMB * nvec);
     double* Yi = ctx.pool.get_t<double>("h.Yi", (size_t)HMB * nvec);
-    const size_t shm = (size_t)2 * HMB * HMB * sizeof(double);
+    double* Xr = ctx.pool.get_t<double>("h.Xr", (size_t)HMB * nvec);
+    double* Xi = ctx.pool.get_t<double>("h.Xi", (size_t)HMB * nvec);
+    const size_t shm = (size_t)2 * (HMB * (HMB + 1) / 2) * sizeof(double);
     static bool attr = false;
     if (!attr) {
-      EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)h_trsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)h_tinv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
       attr = true;
     }
     for (int j0 = 1; j0 < n; j0 += bw) {
@@ -616,17 +624,22 @@ int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w,
       dgemm_dev(st, 'T', 'N', nb, nb, rows, 1.0, Vi, ld, Vi, ld, 1.0, Gr, HMB);
       dgemm_dev(st, 'T', 'N', nb, nb, rows, 1.0, Vr, ld, Vi, ld, 0.0, Gi, HMB);
       dgemm_dev(st, 'T', 'N', nb, nb, rows, -1.0, Vi, ld, Vr, ld, 1.0, Gi, HMB);
+      hipLaunchKernelGGL(h_tinv_kernel, dim3(1), dim3(HMB), shm, st, Gr, Gi, H.beta, j0, nb, Tr, Ti);
       // Y = V^H Z : Yr = Vr^T Zr + Vi^T Zi ; Yi = Vr^T Zi - Vi^T Zr
       dgemm_dev(st, 'T', 'N', nb, nvec, rows, 1.0, Vr, ld, Zr, ldzp, 0.0, Yr, HMB);
       dgemm_dev(st, 'T', 'N', nb, nvec, rows, 1.0, Vi, ld, Zi, ldzp, 1.0, Yr, HMB);
       dgemm_dev(st, 'T', 'N', nb, nvec, rows, 1.0, Vr, ld, Zi, ldzp, 0.0, Yi, HMB);
       dgemm_dev(st, 'T', 'N', nb, nvec, rows, -1.0, Vi, ld, Zr, ldzp, 1.0, Yi, HMB);
-      hipLaunchKernelGGL(h_trsolve_kernel, dim3(ceil_div(nvec, HT)), dim3(HT), shm, st, Gr, Gi, H.beta, j0, nb, nvec, Yr, Yi);
+      // X = T Y : Xr = Tr Yr - Ti Yi ; Xi = Tr Yi + Ti Yr
+      dgemm_dev(st, 'N', 'N', nb, nvec, nb, 1.0, Tr, HMB, Yr, HMB, 0.0, Xr, HMB);
+      dgemm_dev(st, 'N', 'N', nb, nvec, nb, -1.0, Ti, HMB, Yi, HMB, 1.0, Xr, HMB);
+      dgemm_dev(st, 'N', 'N', nb, nvec, nb, 1.0, Tr, HMB, Yi, HMB, 0.0, Xi, HMB);
+      dgemm_dev(st, 'N', 'N', nb, nvec, nb, 1.0, Ti, HMB, Yr, HMB, 1.0, Xi, HMB);
       // Z -= V X : Zr -= Vr Xr - Vi Xi ; Zi -= Vr Xi + Vi Xr
-      dgemm_dev(st, 'N', 'N', rows, nvec, nb, -1.0, Vr, ld, Yr, HMB, 1.0, Zr, ldzp);
-      dgemm_dev(st, 'N', 'N', rows, nvec, nb, 1.0, Vi, ld, Yi, HMB, 1.0, Zr, ldzp);
-      dgemm_dev(st, 'N', 'N', rows, nvec, nb, -1.0, Vr, ld, Yi, HMB, 1.0, Zi, ldzp);
-      dgemm_dev(st, 'N', 'N', rows, nvec, nb, -1.0, Vi, ld, Yr, HMB, 1.0, Zi, ldzp);
+      dgemm_dev(st, 'N', 'N', rows, nvec, nb, -1.0, Vr, ld, Xr, HMB, 1.0, Zr, ldzp);
+      dgemm_dev(st, 'N', 'N', rows, nvec, nb, 1.0, Vi, ld, Xi, HMB, 1.0, Zr, ldzp);
+      dgemm_dev(st, 'N', 'N', rows, nvec, nb, -1.0, Vr, ld, Xi, HMB, 1.0, Zi, ldzp);
+      dgemm_dev(st, 'N', 'N', rows, nvec, nb, -1.0, Vi, ld, Xr, HMB, 1.0, Zi, ldzp);
     }
   }
   if (want_vec) hipLaunchKernelGGL(h_join_kernel, dim3(8, nvec), dim3(256), 0, st, Zr, Zi, ldzp, n, nvec, z, ldz);

@@ -14,7 +14,7 @@ for rep in range(reps + 1):
     z = torch.zeros(n, n, dtype=torch.complex128, device=dev); w = torch.zeros(n, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    _lib.check(lib.eigx_h_dev(n, n, at.data_ptr(), n, w.data_ptr(), z.data_ptr(), n, mf, 64, b"A"), "eigen_h")
+    _lib.check(lib.eigx_h_dev(n, n, at.data_ptr(), n, w.data_ptr(), z.data_ptr(), n, mf, 128, b"A"), "eigen_h")
     dt = time.perf_counter() - t0
     lib.eigx_get_timers(tm.ctypes.data_as(C.POINTER(C.c_double)))
     Z = z.T                        # Z[:, k] = eigenvector k
