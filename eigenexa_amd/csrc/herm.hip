@@ -414,9 +414,14 @@ __global__ __launch_bounds__(HMB) void h_tinv_kernel(const double* __restrict__ 
                                                       double* __restrict__ Tr, double* __restrict__ Ti) {
   extern __shared__ double sm[];   // packed lower triangle incl. diagonal: [2][HMB*(HMB+1)/2]
   double* sr = sm; double* si = sm + HMB * (HMB + 1) / 2;
+  // Gr = stacked Gram Vs^T Vs (2nb x 2nb, ld = 2 HMB; Gi unused): V^H V = (Vr^T Vr + Vi^T Vi) + i (Vr^T Vi - Vi^T Vr)
+  constexpr int LG = 2 * HMB;
   for (int t = threadIdx.x; t < nb * nb; t += HMB) {
     const int a = t % nb, b = t / nb;
-    if (a > b) { sr[a * (a + 1) / 2 + b] = Gr[a + b * HMB]; si[a * (a + 1) / 2 + b] = Gi[a + b * HMB]; }
+    if (a > b) {
+      sr[a * (a + 1) / 2 + b] = Gr[a + b * LG] + Gr[(nb + a) + (nb + b) * LG];
+      si[a * (a + 1) / 2 + b] = Gr[a + (nb + b) * LG] - Gr[(nb + a) + b * LG];
+    }
     else if (a == b) { sr[a * (a + 1) / 2 + a] = beta[2 * (j0 + a)]; si[a * (a + 1) / 2 + a] = -beta[2 * (j0 + a) + 1]; }
   }
   __syncthreads();
@@ -436,6 +441,37 @@ __global__ __launch_bounds__(HMB) void h_tinv_kernel(const double* __restrict__ 
     const double d2 = dr * dr + di * di;
     tr[a] = (xr * dr + xi * di) / d2;                    // x / d = x conj(d) / |d|^2
     ti[a] = (xi * dr - xr * di) / d2;
+  }
+}
+
+// back-transformation block, stacked operands: Vs = [Vr | Vi] (rows x 2nb) so that every pass over a Z plane feeds an
+// M = 2nb (or K = 2nb) GEMM instead of two with nb
+__global__ void h_stack_v_kernel(const double* __restrict__ Vr, const double* __restrict__ Vi, int ld, int rows, int nb,
+                                 double* __restrict__ Vs, int lds) {
+  const int j = blockIdx.y;   // 0 .. 2nb-1
+  const double* src = (j < nb) ? Vr + (size_t)j * ld : Vi + (size_t)(j - nb) * ld;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x)
+    Vs[(size_t)r + (size_t)j * lds] = src[r];
+}
+// Yr = A(0:nb) + B(nb:2nb), Yi = B(0:nb) - A(nb:2nb) with A = Vs^T Zr, B = Vs^T Zi (2nb x nvec each)
+__global__ void h_ycombine_kernel(const double* __restrict__ A, const double* __restrict__ B, int nb, int nvec,
+                                  double* __restrict__ Yr, double* __restrict__ Yi) {
+  const int c = blockIdx.y;
+  for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < nb; a += gridDim.x * blockDim.x) {
+    const size_t o = (size_t)c * (2 * HMB);
+    Yr[(size_t)c * HMB + a] = A[o + a] + B[o + nb + a];
+    Yi[(size_t)c * HMB + a] = B[o + a] - A[o + nb + a];
+  }
+}
+// XA = [Xr; -Xi], XB = [Xi; Xr] (2nb x nvec, ld = 2 HMB): Zr -= Vs XA, Zi -= Vs XB
+__global__ void h_xstack_kernel(const double* __restrict__ Xr, const double* __restrict__ Xi, int nb, int nvec,
+                                double* __restrict__ XA, double* __restrict__ XB) {
+  const int c = blockIdx.y;
+  for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < nb; a += gridDim.x * blockDim.x) {
+    const double xr = Xr[(size_t)c * HMB + a], xi = Xi[(size_t)c * HMB + a];
+    const size_t o = (size_t)c * (2 * HMB);
+    XA[o + a] = xr; XA[o + nb + a] = -xi;
+    XB[o + a] = xi; XB[o + nb + a] = xr;
   }
 }
 
@@ -600,10 +636,13 @@ int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w,
     int bw = mb <= 0 ? HMB : mb;
     if (bw > HMB) bw = HMB;
     hipLaunchKernelGGL(h_zero_below_kernel, dim3(8, n), dim3(256), 0, st, H.Ar, H.Ai, ld, n, n);
-    double* Gr = ctx.pool.get_t<double>("h.Gr", (size_t)HMB * HMB);
-    double* Gi = ctx.pool.get_t<double>("h.Gi", (size_t)HMB * HMB);
+    const int lds = ld;
+    double* Vs = ctx.pool.get_t<double>("h.Vs", (size_t)lds * 2 * HMB);
+    double* Gs = ctx.pool.get_t<double>("h.Gs", (size_t)4 * HMB * HMB);
     double* Tr = ctx.pool.get_t<double>("h.Tr", (size_t)HMB * HMB);
     double* Ti = ctx.pool.get_t<double>("h.Ti", (size_t)HMB * HMB);
+    double* YA = ctx.pool.get_t<double>("h.YA", (size_t)2 * HMB * nvec);
+    double* YB = ctx.pool.get_t<double>("h.YB", (size_t)2 * HMB * nvec);
     double* Yr = ctx.pool.get_t<double>("h.Yr", (size_t)HMB * nvec);
     double* Yi = ctx.pool.get_t<double>("h.Yi", (size_t)HMB * nvec);
     double* Xr = ctx.pool.get_t<double>("h.Xr", (size_t)HMB * nvec);
@@ -617,29 +656,24 @@ int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w,
     for (int j0 = 1; j0 < n; j0 += bw) {
       const int nb = (j0 + bw <= n) ? bw : n - j0;
       const int rows = j0 + nb - 1;               // longest reflector of the block (column j has rows 0..j-1)
-      const double* Vr = H.Ar + (size_t)j0 * ld;
-      const double* Vi = H.Ai + (size_t)j0 * ld;
-      // G = V^H V : Gr = Vr^T Vr + Vi^T Vi ; Gi = Vr^T Vi - Vi^T Vr
-      dgemm_dev(st, 'T', 'N', nb, nb, rows, 1.0, Vr, ld, Vr, ld, 0.0, Gr, HMB);
-      dgemm_dev(st, 'T', 'N', nb, nb, rows, 1.0, Vi, ld, Vi, ld, 1.0, Gr, HMB);
-      dgemm_dev(st, 'T', 'N', nb, nb, rows, 1.0, Vr, ld, Vi, ld, 0.0, Gi, HMB);
-      dgemm_dev(st, 'T', 'N', nb, nb, rows, -1.0, Vi, ld, Vr, ld, 1.0, Gi, HMB);
-      hipLaunchKernelGGL(h_tinv_kernel, dim3(1), dim3(HMB), shm, st, Gr, Gi, H.beta, j0, nb, Tr, Ti);
-      // Y = V^H Z : Yr = Vr^T Zr + Vi^T Zi ; Yi = Vr^T Zi - Vi^T Zr
-      dgemm_dev(st, 'T', 'N', nb, nvec, rows, 1.0, Vr, ld, Zr, ldzp, 0.0, Yr, HMB);
-      dgemm_dev(st, 'T', 'N', nb, nvec, rows, 1.0, Vi, ld, Zi, ldzp, 1.0, Yr, HMB);
-      dgemm_dev(st, 'T', 'N', nb, nvec, rows, 1.0, Vr, ld, Zi, ldzp, 0.0, Yi, HMB);
-      dgemm_dev(st, 'T', 'N', nb, nvec, rows, -1.0, Vi, ld, Zr, ldzp, 1.0, Yi, HMB);
+      hipLaunchKernelGGL(h_stack_v_kernel, dim3(8, 2 * nb), dim3(256), 0, st, H.Ar + (size_t)j0 * ld, H.Ai + (size_t)j0 * ld,
+                         ld, rows, nb, Vs, lds);
+      // stacked Gram matrix Vs^T Vs and T = S^-H
+      dgemm_dev(st, 'T', 'N', 2 * nb, 2 * nb, rows, 1.0, Vs, lds, Vs, lds, 0.0, Gs, 2 * HMB);
+      hipLaunchKernelGGL(h_tinv_kernel, dim3(1), dim3(HMB), shm, st, Gs, Gs, H.beta, j0, nb, Tr, Ti);
+      // Y = V^H Z from two passes: YA = Vs^T Zr, YB = Vs^T Zi
+      dgemm_dev(st, 'T', 'N', 2 * nb, nvec, rows, 1.0, Vs, lds, Zr, ldzp, 0.0, YA, 2 * HMB);
+      dgemm_dev(st, 'T', 'N', 2 * nb, nvec, rows, 1.0, Vs, lds, Zi, ldzp, 0.0, YB, 2 * HMB);
+      hipLaunchKernelGGL(h_ycombine_kernel, dim3(1, nvec), dim3(128), 0, st, YA, YB, nb, nvec, Yr, Yi);
       // X = T Y : Xr = Tr Yr - Ti Yi ; Xi = Tr Yi + Ti Yr
       dgemm_dev(st, 'N', 'N', nb, nvec, nb, 1.0, Tr, HMB, Yr, HMB, 0.0, Xr, HMB);
       dgemm_dev(st, 'N', 'N', nb, nvec, nb, -1.0, Ti, HMB, Yi, HMB, 1.0, Xr, HMB);
       dgemm_dev(st, 'N', 'N', nb, nvec, nb, 1.0, Tr, HMB, Yi, HMB, 0.0, Xi, HMB);
       dgemm_dev(st, 'N', 'N', nb, nvec, nb, 1.0, Ti, HMB, Yr, HMB, 1.0, Xi, HMB);
-      // Z -= V X : Zr -= Vr Xr - Vi Xi ; Zi -= Vr Xi + Vi Xr
-      dgemm_dev(st, 'N', 'N', rows, nvec, nb, -1.0, Vr, ld, Xr, HMB, 1.0, Zr, ldzp);
-      dgemm_dev(st, 'N', 'N', rows, nvec, nb, 1.0, Vi, ld, Xi, HMB, 1.0, Zr, ldzp);
-      dgemm_dev(st, 'N', 'N', rows, nvec, nb, -1.0, Vr, ld, Xi, HMB, 1.0, Zi, ldzp);
-      dgemm_dev(st, 'N', 'N', rows, nvec, nb, -1.0, Vi, ld, Xr, HMB, 1.0, Zi, ldzp);
+      // Z -= V X : Zr -= Vs [Xr; -Xi] ; Zi -= Vs [Xi; Xr]   (K = 2nb)
+      hipLaunchKernelGGL(h_xstack_kernel, dim3(1, nvec), dim3(128), 0, st, Xr, Xi, nb, nvec, YA, YB);
+      dgemm_dev(st, 'N', 'N', rows, nvec, 2 * nb, -1.0, Vs, lds, YA, 2 * HMB, 1.0, Zr, ldzp);
+      dgemm_dev(st, 'N', 'N', rows, nvec, 2 * nb, -1.0, Vs, lds, YB, 2 * HMB, 1.0, Zi, ldzp);
     }
   }
   if (want_vec) hipLaunchKernelGGL(h_join_kernel, dim3(8, nvec), dim3(256), 0, st, Zr, Zi, ldzp, n, nvec, z, ldz);
