@@ -13,7 +13,7 @@
 //   x = A_eff(0:L, i);  g = -sign(||x||, Re x_{L-1});  u = x, u_{L-1} -= g;  beta = -u_{L-1} g       (src/eigen_hrd_t4.F:40-95)
 //   q = A_eff u;  s = u^H q;  alpha = s / (2 beta);  v = (q - alpha u) / conj(beta)                 (src/eigen_hrd_t6_3.F:256-272)
 //   A_eff = A - U W^H - W U^H  (panel of m columns, applied every m steps)                          (src/eigen_hrd_t1.F:2-110)
-// Six small kernels per column (form x | reflector | panel dots | tiled mat-vec | combine | v): this version is
+// Four launches per column (form x [+ previous v] | reflector | panel dots + tiled mat-vec | combine): this version is
 // latency-bound per step like the first real-symmetric version was; the fused / tiled structure of band_reduce.hip is the
 // template for the next one.  All cross-workgroup reductions are two-phase and deterministic (no atomics).
 #include "eigx_context.h"
@@ -108,13 +108,36 @@ __global__ void h_fill_kernel(double* p, size_t n, double v) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
-// K1: x = A_eff(0:i, i) (rows 0..i-1), d_i = Re A_eff(i,i); partial ||x||^2 per workgroup
-__global__ __launch_bounds__(HT) void h_form_x_kernel(HArgs H, int i, int k) {
+// K1: x = A_eff(0:i, i) (rows 0..i-1), d_i = Re A_eff(i,i); partial ||x||^2 per workgroup.
+// If `pend` is set, the previous step's v (panel column k-1) is still pending: every workgroup reduces the s partials,
+// forms v = (p - alpha u) / conj(beta) for its rows on the fly (and stores it into W), so the separate v kernel -- one
+// launch per step -- only runs before a trailing update.
+__global__ __launch_bounds__(HT) void h_form_x_kernel(HArgs H, int i, int k, int pend, int nparts_prev) {
   __shared__ double cwr[HM], cwi[HM], cur[HM], cui[HM];
-  __shared__ double red[4];
+  __shared__ double red[8];
   const int tid = threadIdx.x;
-  if (tid < k) {   // conj of row i of the panel
+  double alr = 0.0, ali = 0.0, br = 1.0, bi = 0.0, b2 = 1.0;
+  if (pend) {
+    double s[2] = {0.0, 0.0};
+    for (int q = tid; q < nparts_prev; q += HT) { s[0] += H.ps[2 * q]; s[1] += H.ps[2 * q + 1]; }
+    hblock_sum<2>(s, red);
+    br = H.beta[2 * (i + 1)]; bi = H.beta[2 * (i + 1) + 1];
+    b2 = br * br + bi * bi;
+    alr = (s[0] * br + s[1] * bi) / (2.0 * b2); ali = (s[1] * br - s[0] * bi) / (2.0 * b2);
+  }
+  auto pending_v = [&](int r, double& vr, double& vi) {   // v_r of panel column k-1
+    const double ur = H.Ur[(size_t)r + (size_t)(k - 1) * H.ldp], ui = H.Ui[(size_t)r + (size_t)(k - 1) * H.ldp];
+    const double tr = H.pr[r] - (alr * ur - ali * ui), ti = H.pi[r] - (alr * ui + ali * ur);
+    vr = (tr * br - ti * bi) / b2; vi = (tr * bi + ti * br) / b2;
+  };
+  const int kc = pend ? k - 1 : k;      // panel columns that are complete in memory
+  if (tid < kc) {   // conj of row i of the panel
     cwr[tid] = H.Wr[(size_t)i + (size_t)tid * H.ldp]; cwi[tid] = -H.Wi[(size_t)i + (size_t)tid * H.ldp];
+    cur[tid] = H.Ur[(size_t)i + (size_t)tid * H.ldp]; cui[tid] = -H.Ui[(size_t)i + (size_t)tid * H.ldp];
+  } else if (pend && tid == k - 1) {
+    double vr, vi;
+    pending_v(i, vr, vi);
+    cwr[tid] = vr; cwi[tid] = -vi;
     cur[tid] = H.Ur[(size_t)i + (size_t)tid * H.ldp]; cui[tid] = -H.Ui[(size_t)i + (size_t)tid * H.ldp];
   }
   __syncthreads();
@@ -122,9 +145,19 @@ __global__ __launch_bounds__(HT) void h_form_x_kernel(HArgs H, int i, int k) {
   double nrm[1] = {0.0};
   if (r <= i) {
     double xr = H.Ar[(size_t)r + (size_t)i * H.ld], xi = H.Ai[(size_t)r + (size_t)i * H.ld];
-    for (int j = 0; j < k; ++j) {
+#pragma unroll 4
+    for (int j = 0; j < kc; ++j) {
       const double ur = H.Ur[(size_t)r + (size_t)j * H.ldp], ui = H.Ui[(size_t)r + (size_t)j * H.ldp];
       const double wr = H.Wr[(size_t)r + (size_t)j * H.ldp], wi = H.Wi[(size_t)r + (size_t)j * H.ldp];
+      xr -= (ur * cwr[j] - ui * cwi[j]) + (wr * cur[j] - wi * cui[j]);
+      xi -= (ur * cwi[j] + ui * cwr[j]) + (wr * cui[j] + wi * cur[j]);
+    }
+    if (pend) {
+      const int j = k - 1;
+      double wr, wi;
+      pending_v(r, wr, wi);
+      H.Wr[(size_t)r + (size_t)j * H.ldp] = wr; H.Wi[(size_t)r + (size_t)j * H.ldp] = wi;
+      const double ur = H.Ur[(size_t)r + (size_t)j * H.ldp], ui = H.Ui[(size_t)r + (size_t)j * H.ldp];
       xr -= (ur * cwr[j] - ui * cwi[j]) + (wr * cur[j] - wi * cui[j]);
       xi -= (ur * cwi[j] + ui * cwr[j]) + (wr * cui[j] + wi * cur[j]);
     }
@@ -162,9 +195,8 @@ __global__ __launch_bounds__(HT) void h_reflector_kernel(HArgs H, int i, int k, 
 }
 
 // K2b: panel dots dw_j = W(:,j)^H u, du_j = U(:,j)^H u over a chunk of rows; grid (k, row chunks)
-__global__ __launch_bounds__(HT) void h_paneldot_kernel(HArgs H, int L, int k) {
+__device__ __forceinline__ void h_paneldot_body(const HArgs& H, int L, int k, int j, int c) {
   __shared__ double red[16];
-  const int j = blockIdx.x, c = blockIdx.y;
   const int r1 = (c * PDR + PDR < L) ? c * PDR + PDR : L;
   double v[4] = {0.0, 0.0, 0.0, 0.0};
   for (int r = c * PDR + threadIdx.x; r < r1; r += HT) {
@@ -237,12 +269,17 @@ __device__ __forceinline__ double hcolsum16(const double (&v)[16], int lane) {
 // LDS) and the column sums  sum_r conj(A(r,c)) u(r)  of the mirrored lower-triangle block (halving butterfly over the
 // lanes).  Row partials are indexed by tile column (YR[tx][r]), column partials by tile row (YC[ty][c]); K4 adds the
 // nt + 1 partials of a row in fixed order.
-__global__ __launch_bounds__(HT) void h_hemv_kernel(HArgs H, int L, int k, int nt) {
+__global__ __launch_bounds__(HT) void h_hemv_kernel(HArgs H, int L, int k, int nt, int npdc) {
   __shared__ double ucr[HTL], uci[HTL], urr[HTL], uri[HTL];
   __shared__ double part[4][HTL][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the first k * npdc workgroups of the launch are the panel-dot workgroups (column j, row chunk c)
+  if ((int)blockIdx.x < k * npdc) {
+    h_paneldot_body(H, L, k, (int)blockIdx.x % k, (int)blockIdx.x / k);
+    return;
+  }
   // tile index -> (ty, tx), row-major over the upper block triangle
-  const int bid = blockIdx.x;
+  const int bid = (int)blockIdx.x - k * npdc;
   const float fn = 2.0f * (float)nt + 1.0f;
   int ty = (int)((fn - sqrtf(fn * fn - 8.0f * (float)bid)) * 0.5f);
   if (ty < 0) ty = 0;
@@ -589,21 +626,23 @@ int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w,
 
   // ---- eigen_hrd: Hermitian -> real tridiagonal ---------------------------------------------------------------------
   const double t1 = hnow();
-  int k = 0;
+  int k = 0, pend = 0, nparts_prev = 0;
   for (int i = n - 1; i >= 1; --i) {
     const int L = i;
     const int nb1 = ceil_div(i + 1, HT), nbl = ceil_div(L, HT);
-    hipLaunchKernelGGL(h_form_x_kernel, dim3(nb1), dim3(HT), 0, st, H, i, k);
+    hipLaunchKernelGGL(h_form_x_kernel, dim3(nb1), dim3(HT), 0, st, H, i, k, pend, nparts_prev);
     hipLaunchKernelGGL(h_reflector_kernel, dim3(nbl), dim3(HT), 0, st, H, i, k, nb1);
     const int npdc = ceil_div(L, PDR);
-    if (k > 0) hipLaunchKernelGGL(h_paneldot_kernel, dim3(k, npdc), dim3(HT), 0, st, H, L, k);
     const int nt = ceil_div(L, HTL);
-    hipLaunchKernelGGL(h_hemv_kernel, dim3(nt * (nt + 1) / 2), dim3(HT), 0, st, H, L, k, nt);
+    hipLaunchKernelGGL(h_hemv_kernel, dim3(k * npdc + nt * (nt + 1) / 2), dim3(HT), 0, st, H, L, k, nt, npdc);
     hipLaunchKernelGGL(h_combine_kernel, dim3(nbl), dim3(HT), 0, st, H, L, k, nt, npdc);
-    hipLaunchKernelGGL(h_make_v_kernel, dim3(nbl), dim3(HT), 0, st, H, i, k, nbl);
+    pend = 1; nparts_prev = nbl;
     ++k;
     if (k == m || i == 1) {
-      // trailing update of the remaining i x i block (both triangles), two real GEMMs with K = 4k
+      // trailing update of the remaining i x i block (both triangles), two real GEMMs with K = 4k; the pending v of
+      // this step is needed in memory first
+      hipLaunchKernelGGL(h_make_v_kernel, dim3(nbl), dim3(HT), 0, st, H, i, k - 1, nbl);
+      pend = 0;
       const int nr = i;
       hipLaunchKernelGGL(h_pack_kernel, dim3(ceil_div(nr, 256), k), dim3(256), 0, st, H, nr, k, P1, P2, P3);
       dgemm_dev(st, 'N', 'T', nr, nr, 4 * k, -1.0, P1, ldp, P3, ldp, 1.0, H.Ar, ld);
@@ -612,7 +651,7 @@ int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w,
       k = 0;
     }
   }
-  hipLaunchKernelGGL(h_form_x_kernel, dim3(1), dim3(HT), 0, st, H, 0, 0);   // d_0 = Re A(0,0)
+  hipLaunchKernelGGL(h_form_x_kernel, dim3(1), dim3(HT), 0, st, H, 0, 0, 0, 0);   // d_0 = Re A(0,0)
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
   const double t2 = hnow();
 
