@@ -446,11 +446,16 @@ __global__ void h_zero_below_kernel(double* __restrict__ Vr, double* __restrict_
 // (T^-1 of the compact WY form has the strictly upper part of V^H V and 1/tau = beta on its diagonal; the reference
 // keeps the same triangle, src/hrbakwy4_body.F:330-470).  One thread per column of T (forward substitution with the unit
 // vector e_c), the packed triangle of S^H in LDS; T (nb x nb, ld = HMB, planes) is then applied by real GEMMs.
-__global__ __launch_bounds__(HMB) void h_tinv_kernel(const double* __restrict__ Gr, const double* __restrict__ Gi,
-                                                      const double* __restrict__ beta, int j0, int nb,
-                                                      double* __restrict__ Tr, double* __restrict__ Ti) {
+__global__ __launch_bounds__(HMB) void h_tinv_kernel(const double* __restrict__ Gall, const double* __restrict__ beta,
+                                                      int jfirst, int bw, int n, double* __restrict__ Tall) {
   extern __shared__ double sm[];   // packed lower triangle incl. diagonal: [2][HMB*(HMB+1)/2]
   double* sr = sm; double* si = sm + HMB * (HMB + 1) / 2;
+  // one workgroup per block of reflectors: all T factors of the back-transformation in ONE launch
+  const int j0 = jfirst + (int)blockIdx.x * bw;
+  const int nb = (j0 + bw <= n) ? bw : n - j0;
+  const double* Gr = Gall + (size_t)blockIdx.x * 4 * HMB * HMB;
+  double* Tr = Tall + (size_t)blockIdx.x * 2 * HMB * HMB;
+  double* Ti = Tr + (size_t)HMB * HMB;
   // Gr = stacked Gram Vs^T Vs (2nb x 2nb, ld = 2 HMB; Gi unused): V^H V = (Vr^T Vr + Vi^T Vi) + i (Vr^T Vi - Vi^T Vr)
   constexpr int LG = 2 * HMB;
   for (int t = threadIdx.x; t < nb * nb; t += HMB) {
@@ -677,9 +682,9 @@ int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w,
     hipLaunchKernelGGL(h_zero_below_kernel, dim3(8, n), dim3(256), 0, st, H.Ar, H.Ai, ld, n, n);
     const int lds = ld;
     double* Vs = ctx.pool.get_t<double>("h.Vs", (size_t)lds * 2 * HMB);
-    double* Gs = ctx.pool.get_t<double>("h.Gs", (size_t)4 * HMB * HMB);
-    double* Tr = ctx.pool.get_t<double>("h.Tr", (size_t)HMB * HMB);
-    double* Ti = ctx.pool.get_t<double>("h.Ti", (size_t)HMB * HMB);
+    const int nblk = ceil_div(n - 1, bw);
+    double* Gall = ctx.pool.get_t<double>("h.Gall", (size_t)nblk * 4 * HMB * HMB);
+    double* Tall = ctx.pool.get_t<double>("h.Tall", (size_t)nblk * 2 * HMB * HMB);
     double* YA = ctx.pool.get_t<double>("h.YA", (size_t)2 * HMB * nvec);
     double* YB = ctx.pool.get_t<double>("h.YB", (size_t)2 * HMB * nvec);
     double* Yr = ctx.pool.get_t<double>("h.Yr", (size_t)HMB * nvec);
@@ -692,14 +697,26 @@ int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w,
       EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)h_tinv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
       attr = true;
     }
-    for (int j0 = 1; j0 < n; j0 += bw) {
+    // phase A: stacked Gram matrices Vs^T Vs of all blocks, then every T = S^-H in one launch (the T factors depend on
+    // the reflectors only; a per-block single-workgroup kernel on the critical path cost 37 of 149 ms at N=8192)
+    for (int b = 0; b < nblk; ++b) {
+      const int j0 = 1 + b * bw;
       const int nb = (j0 + bw <= n) ? bw : n - j0;
       const int rows = j0 + nb - 1;               // longest reflector of the block (column j has rows 0..j-1)
       hipLaunchKernelGGL(h_stack_v_kernel, dim3(8, 2 * nb), dim3(256), 0, st, H.Ar + (size_t)j0 * ld, H.Ai + (size_t)j0 * ld,
                          ld, rows, nb, Vs, lds);
-      // stacked Gram matrix Vs^T Vs and T = S^-H
-      dgemm_dev(st, 'T', 'N', 2 * nb, 2 * nb, rows, 1.0, Vs, lds, Vs, lds, 0.0, Gs, 2 * HMB);
-      hipLaunchKernelGGL(h_tinv_kernel, dim3(1), dim3(HMB), shm, st, Gs, Gs, H.beta, j0, nb, Tr, Ti);
+      dgemm_dev(st, 'T', 'N', 2 * nb, 2 * nb, rows, 1.0, Vs, lds, Vs, lds, 0.0, Gall + (size_t)b * 4 * HMB * HMB, 2 * HMB);
+    }
+    hipLaunchKernelGGL(h_tinv_kernel, dim3(nblk), dim3(HMB), shm, st, Gall, H.beta, 1, bw, n, Tall);
+    // phase B: apply the blocks in ascending order
+    for (int b = 0; b < nblk; ++b) {
+      const int j0 = 1 + b * bw;
+      const int nb = (j0 + bw <= n) ? bw : n - j0;
+      const int rows = j0 + nb - 1;
+      const double* Tr = Tall + (size_t)b * 2 * HMB * HMB;
+      const double* Ti = Tr + (size_t)HMB * HMB;
+      hipLaunchKernelGGL(h_stack_v_kernel, dim3(8, 2 * nb), dim3(256), 0, st, H.Ar + (size_t)j0 * ld, H.Ai + (size_t)j0 * ld,
+                         ld, rows, nb, Vs, lds);
       // Y = V^H Z from two passes: YA = Vs^T Zr, YB = Vs^T Zi
       dgemm_dev(st, 'T', 'N', 2 * nb, nvec, rows, 1.0, Vs, lds, Zr, ldzp, 0.0, YA, 2 * HMB);
       dgemm_dev(st, 'T', 'N', 2 * nb, nvec, rows, 1.0, Vs, lds, Zi, ldzp, 0.0, YB, 2 * HMB);
