@@ -22,6 +22,7 @@ module eigen_libs_mod
   public :: eigen_owner_node, eigen_owner_index
   public :: eigen_sx, eigen_s
   public :: eigen_sx_bc, eigen_s_bc   ! ScaLAPACK block-cyclic local blocks in and out (no pdgemr2d step)
+  public :: eigen_h                   ! complex Hermitian solver (src/eigen_h.F)
 
   interface
     integer(c_int) function eigx_init(device) bind(C, name="eigx_init")
@@ -104,6 +105,13 @@ module eigen_libs_mod
       integer(c_int), value :: n, nvec, lda, ldz, mf, mb
       real(c_double), intent(inout) :: a(lda, *)
       real(c_double), intent(out) :: w(*), z(ldz, *)
+      character(kind=c_char), value :: mode
+    end function
+    integer(c_int) function eigx_h(n, nvec, a, lda, w, z, ldz, mf, mb, mode) bind(C, name="eigx_h")
+      import :: c_int, c_double, c_double_complex, c_char
+      integer(c_int), value :: n, nvec, lda, ldz, mf, mb
+      complex(c_double_complex) :: a(*), z(*)
+      real(c_double) :: w(*)
       character(kind=c_char), value :: mode
     end function
     integer(c_int) function eigx_set_grid_dims(px, py) bind(C, name="eigx_set_grid_dims")
@@ -355,6 +363,25 @@ contains
     if (present(mode)) md = mode(1:1)
     rc = eigx_solve_bc(1, n, nvec, a, lda, w, z, ldz, nb, mf, mb, md)
   end subroutine eigen_s_bc
+
+  !> eigen_h(n, nvec, a, lda, w, z, ldz, m_forward, m_backward, mode)   (src/eigen_h.F:30-322): complex Hermitian
+  !> matrix, upper triangle of a significant; w real ascending; z unitary.  complex(8) arrays are passed as they are
+  !> (interleaved re/im = the C-ABI's layout).  One GPU in this version.
+  subroutine eigen_h(n, nvec, a, lda, w, z, ldz, m_forward, m_backward, mode)
+    integer, intent(in) :: n, nvec, lda, ldz
+    complex(8), intent(inout) :: a(lda, *)
+    real(8), intent(out) :: w(*)
+    complex(8), intent(out) :: z(ldz, *)
+    integer, intent(in), optional :: m_forward, m_backward
+    character(*), intent(in), optional :: mode
+    integer :: mf, mb, rc
+    character(kind=c_char) :: md
+    mf = eigen_NB_f; mb = eigen_NB_b; md = 'A'
+    if (present(m_forward)) mf = m_forward
+    if (present(m_backward)) mb = m_backward
+    if (present(mode)) md = mode(1:1)
+    rc = eigx_h(n, nvec, a, lda, w, z, ldz, mf, mb, md)
+  end subroutine eigen_h
 
 end module eigen_libs_mod
 
