@@ -269,3 +269,27 @@ def test_w_dat_formula():
     """spectrum type 10 = the reference's benchmark/W.dat, reproduced by formula (first entries of the file)"""
     w = layout.spectrum(8, 10)
     assert np.array_equal(w, np.array([10.0, 10.8415, 10.9093, 10.1411, 9.2432, 9.04108, 9.72058, 10.657]))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 64, 150])
+def test_oracle_eigen_h(orc, n):
+    """complex Hermitian restatement (orc_eigen_h; PARITY UNPINNED: the reference holds no eigen_h fixtures) against
+    LAPACK, plus the analytic Frank spectrum carried by D F D^H with a unitary diagonal D (benchmark/mat_set.f:638-647)"""
+    from eigenexa_amd import layout
+
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    A = (B + B.conj().T) / 2
+    for mode in ("A", "N", "X"):
+        w, Z = orc.eigen_h(A, mode=mode)
+        wr = np.linalg.eigvalsh(A)
+        assert np.abs(w - wr).max() < 1e-12 * max(1.0, np.abs(wr).max())
+        if mode != "N":
+            eps = np.finfo(float).eps
+            assert np.linalg.norm(A @ Z - Z * w[None, :]) <= 768 * n * eps * max(np.linalg.norm(A), 1e-300)
+            assert np.linalg.norm(Z.conj().T @ Z - np.eye(n)) <= 8 * n * eps
+    ph = np.exp(1j * rng.uniform(0, 2 * np.pi, n))
+    F = (ph[:, None] * layout.frank(n)) * ph.conj()[None, :]
+    w, _ = orc.eigen_h(F)
+    lam = np.sort(layout.frank_eigenvalues(n))
+    assert (np.abs(w - lam) / lam).max() < 1e-10
