@@ -30,7 +30,8 @@ namespace {
 
 constexpr int HT = 256;      // threads per workgroup
 constexpr int HM = 128;      // max panel width (LDS arrays)
-constexpr int HTL = 64;      // tile edge of the Hermitian mat-vec
+constexpr int HTL = 128;     // tile edge of the Hermitian mat-vec
+constexpr int HTH = 512;     // threads of a mat-vec workgroup (8 waves x 16 tile columns)
 constexpr int PDR = 1024;    // rows per panel-dot chunk
 constexpr int HMB = 128;     // reflectors per back-transformation block (the packed triangle S^H of a block lives in LDS)
 
@@ -48,6 +49,25 @@ struct HArgs {
 __device__ __forceinline__ double hwave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+// deterministic block sum of K values over NW waves; result in every thread
+template <int K, int NW>
+__device__ __forceinline__ void hblock_sum_w(double (&v)[K], double* red /* NW*K */) {
+#pragma unroll
+  for (int q = 0; q < K; ++q) v[q] = hwave_sum(v[q]);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) red[(threadIdx.x >> 6) * K + q] = v[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    double a = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) a += red[w * K + q];
+    v[q] = a;
+  }
 }
 // deterministic block sum of K values (256 threads); result in every thread
 template <int K>
@@ -196,17 +216,17 @@ __global__ __launch_bounds__(HT) void h_reflector_kernel(HArgs H, int i, int k, 
 
 // K2b: panel dots dw_j = W(:,j)^H u, du_j = U(:,j)^H u over a chunk of rows; grid (k, row chunks)
 __device__ __forceinline__ void h_paneldot_body(const HArgs& H, int L, int k, int j, int c) {
-  __shared__ double red[16];
+  __shared__ double red[4 * (HTH / 64)];
   const int r1 = (c * PDR + PDR < L) ? c * PDR + PDR : L;
   double v[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int r = c * PDR + threadIdx.x; r < r1; r += HT) {
+  for (int r = c * PDR + threadIdx.x; r < r1; r += HTH) {
     const double ur = H.Ur[(size_t)r + (size_t)k * H.ldp], ui = H.Ui[(size_t)r + (size_t)k * H.ldp];
     const double wr = H.Wr[(size_t)r + (size_t)j * H.ldp], wi = H.Wi[(size_t)r + (size_t)j * H.ldp];
     const double pr = H.Ur[(size_t)r + (size_t)j * H.ldp], pi = H.Ui[(size_t)r + (size_t)j * H.ldp];
     v[0] += wr * ur + wi * ui; v[1] += wr * ui - wi * ur;   // conj(w) u
     v[2] += pr * ur + pi * ui; v[3] += pr * ui - pi * ur;   // conj(U_j) u
   }
-  hblock_sum<4>(v, red);
+  hblock_sum_w<4, HTH / 64>(v, red);
   if (threadIdx.x == 0) {
     double* o = H.pd + ((size_t)c * HM + j) * 4;
     o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
@@ -263,15 +283,16 @@ __device__ __forceinline__ double hcolsum16(const double (&v)[16], int lane) {
 }
 
 // K3: q = A(0:L, 0:L) u from the UPPER triangle only (half the HBM bytes of a GEMV over both triangles): one workgroup
-// per 64 x 64 tile (ty <= tx) of the upper block triangle, 1-D grid in row-major tile order.  Wave w owns the tile columns
-// [16w, 16w+16), a lane owns one tile row: the tile lives in registers (32 coalesced loads per thread, all issued before
-// anything is consumed).  The same registers give the row sums  sum_c A(r,c) u(c)  (combined over the four waves through
-// LDS) and the column sums  sum_r conj(A(r,c)) u(r)  of the mirrored lower-triangle block (halving butterfly over the
-// lanes).  Row partials are indexed by tile column (YR[tx][r]), column partials by tile row (YC[ty][c]); K4 adds the
-// nt + 1 partials of a row in fixed order.
-__global__ __launch_bounds__(HT) void h_hemv_kernel(HArgs H, int L, int k, int nt, int npdc) {
+// of 8 waves per 128 x 128 tile (ty <= tx) of the upper block triangle, 1-D grid in row-major tile order.  Wave w owns the
+// tile columns [16w, 16w+16), a lane owns the row pair (2 lane, 2 lane + 1): the tile lives in registers (32 coalesced
+// 16-byte loads per thread, all issued before anything is consumed).  The same registers give the row sums
+// sum_c A(r,c) u(c)  (combined over the eight waves through LDS) and the column sums  sum_r conj(A(r,c)) u(r)  of the
+// mirrored lower-triangle block (halving butterfly over the lanes).  Row partials are indexed by tile column
+// (YR[tx][r]), column partials by tile row (YC[ty][c]); K4 adds the nt + 1 partials of a row in fixed order.
+typedef double hd2_t __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int nt, int npdc) {
   __shared__ double ucr[HTL], uci[HTL], urr[HTL], uri[HTL];
-  __shared__ double part[4][HTL][2];
+  __shared__ double part[HTH / 64][HTL][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // the first k * npdc workgroups of the launch are the panel-dot workgroups (column j, row chunk c)
   if ((int)blockIdx.x < k * npdc) {
@@ -289,15 +310,16 @@ __global__ __launch_bounds__(HT) void h_hemv_kernel(HArgs H, int L, int k, int n
   const int tx = ty + (bid - (ty * nt - ty * (ty - 1) / 2));
   const int row0 = ty * HTL, col0 = tx * HTL;
   const bool diag = (ty == tx);
-  const int r = row0 + lane;
-  const int rc = (r < L) ? r : 0;
-  double ar[16], ai[16];
+  const int l0 = 2 * lane, l1 = 2 * lane + 1;           // my rows inside the tile
+  const int r0 = row0 + l0, r1 = row0 + l1;
+  const int rc = (r0 < L) ? r0 : 0;
+  hd2_t ar[16], ai[16];
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     const int c = col0 + wave * 16 + t;
     const int ccl = (c < L) ? c : 0;
-    ar[t] = H.Ar[(size_t)rc + (size_t)ccl * H.ld];
-    ai[t] = H.Ai[(size_t)rc + (size_t)ccl * H.ld];
+    ar[t] = *reinterpret_cast<const hd2_t*>(H.Ar + (size_t)rc + (size_t)ccl * H.ld);
+    ai[t] = *reinterpret_cast<const hd2_t*>(H.Ai + (size_t)rc + (size_t)ccl * H.ld);
   }
   if (tid < HTL) {
     const int c = col0 + tid;
@@ -309,25 +331,31 @@ __global__ __launch_bounds__(HT) void h_hemv_kernel(HArgs H, int L, int k, int n
     uri[tid - HTL] = (rr < L) ? H.Ui[(size_t)rr + (size_t)k * H.ldp] : 0.0;
   }
   __syncthreads();
-  const double mur = urr[lane], mui = uri[lane];   // u at my row
-  double sr = 0.0, si = 0.0;                       // row sums over the wave's 16 columns
-  double cr[16], ci[16];                           // my row's contribution to the 16 column sums
+  const double mur0 = urr[l0], mui0 = uri[l0], mur1 = urr[l1], mui1 = uri[l1];   // u at my rows
+  double sr0 = 0.0, si0 = 0.0, sr1 = 0.0, si1 = 0.0;   // row sums over the wave's 16 columns
+  double cr[16], ci[16];                               // my rows' contribution to the 16 column sums
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     const int cc = wave * 16 + t, c = col0 + cc;
-    const bool inr = r < L && c < L;
-    const bool up = inr && (!diag || lane <= cc);          // upper part incl. diagonal -> row sums
-    const bool su = inr && (!diag || lane < cc);           // strictly upper -> column sums of the mirrored block
-    const double xr = up ? ar[t] : 0.0;
-    const double xi = (up && !(diag && lane == cc)) ? ai[t] : 0.0;
+    const bool in0 = r0 < L && c < L, in1 = r1 < L && c < L;
+    const bool up0 = in0 && (!diag || l0 <= cc), up1 = in1 && (!diag || l1 <= cc);   // upper incl. diagonal -> row sums
+    const bool su0 = in0 && (!diag || l0 < cc), su1 = in1 && (!diag || l1 < cc);     // strictly upper -> column sums
     const double vr = ucr[cc], vi = uci[cc];
-    sr += xr * vr - xi * vi;
-    si += xr * vi + xi * vr;
-    const double yr = su ? ar[t] : 0.0, yi = su ? ai[t] : 0.0;
-    cr[t] = yr * mur + yi * mui;                           // conj(a) u(row)
-    ci[t] = yr * mui - yi * mur;
+    {
+      const double xr = up0 ? ar[t].x : 0.0, xi = (up0 && !(diag && l0 == cc)) ? ai[t].x : 0.0;
+      sr0 += xr * vr - xi * vi; si0 += xr * vi + xi * vr;
+    }
+    {
+      const double xr = up1 ? ar[t].y : 0.0, xi = (up1 && !(diag && l1 == cc)) ? ai[t].y : 0.0;
+      sr1 += xr * vr - xi * vi; si1 += xr * vi + xi * vr;
+    }
+    const double y0r = su0 ? ar[t].x : 0.0, y0i = su0 ? ai[t].x : 0.0;
+    const double y1r = su1 ? ar[t].y : 0.0, y1i = su1 ? ai[t].y : 0.0;
+    cr[t] = (y0r * mur0 + y0i * mui0) + (y1r * mur1 + y1i * mui1);                   // conj(a) u(row)
+    ci[t] = (y0r * mui0 - y0i * mur0) + (y1r * mui1 - y1i * mur1);
   }
-  part[wave][lane][0] = sr; part[wave][lane][1] = si;
+  part[wave][l0][0] = sr0; part[wave][l0][1] = si0;
+  part[wave][l1][0] = sr1; part[wave][l1][1] = si1;
   const double tcr = hcolsum16(cr, lane), tci = hcolsum16(ci, lane);
   if ((lane & 3) == 0) {
     const int j = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
@@ -335,9 +363,12 @@ __global__ __launch_bounds__(HT) void h_hemv_kernel(HArgs H, int L, int k, int n
     if (c < L) { H.ycr[(size_t)ty * H.ldp + c] = tcr; H.yci[(size_t)ty * H.ldp + c] = tci; }
   }
   __syncthreads();
-  if (tid < HTL && r < L) {
-    H.yrr[(size_t)tx * H.ldp + r] = (part[0][tid][0] + part[1][tid][0]) + (part[2][tid][0] + part[3][tid][0]);
-    H.yri[(size_t)tx * H.ldp + r] = (part[0][tid][1] + part[1][tid][1]) + (part[2][tid][1] + part[3][tid][1]);
+  if (tid < HTL && row0 + tid < L) {
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int w = 0; w < HTH / 64; ++w) { a0 += part[w][tid][0]; a1 += part[w][tid][1]; }
+    H.yrr[(size_t)tx * H.ldp + row0 + tid] = a0;
+    H.yri[(size_t)tx * H.ldp + row0 + tid] = a1;
   }
 }
 
@@ -639,7 +670,7 @@ int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w,
     hipLaunchKernelGGL(h_reflector_kernel, dim3(nbl), dim3(HT), 0, st, H, i, k, nb1);
     const int npdc = ceil_div(L, PDR);
     const int nt = ceil_div(L, HTL);
-    hipLaunchKernelGGL(h_hemv_kernel, dim3(k * npdc + nt * (nt + 1) / 2), dim3(HT), 0, st, H, L, k, nt, npdc);
+    hipLaunchKernelGGL(h_hemv_kernel, dim3(k * npdc + nt * (nt + 1) / 2), dim3(HTH), 0, st, H, L, k, nt, npdc);
     hipLaunchKernelGGL(h_combine_kernel, dim3(nbl), dim3(HT), 0, st, H, L, k, nt, npdc);
     pend = 1; nparts_prev = nbl;
     ++k;
