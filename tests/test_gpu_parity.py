@@ -826,3 +826,26 @@ def test_eigen_h_known_spectrum_and_modes(gpu_lib, orc):
     z = np.zeros((20, 20), dtype=np.complex128, order="F")
     ee.eigen_h(20, 20, a, 20, w, z, 20)
     assert np.isnan(w).all()
+
+
+def test_fortran_caller_over_iso_c_binding(gpu_lib):
+    """the Fortran module eigen_libs_mod (ISO_C_BINDING over the C-ABI) driven by a Fortran program in the style of
+    benchmark/main2.f: eigen_init / eigen_get_matdims / eigen_sx / eigen_s / eigen_h / eigen_free on the Frank matrix
+    (built by __graft_entry__.build() with the image's flang; skipped where no flang exists)"""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "eigenexa_amd", "fortran", "_build", "example_frank")
+    if not os.path.exists(exe):
+        if not os.path.exists("/opt/rocm/lib/llvm/bin/flang"):
+            pytest.skip("no flang in this image")
+        subprocess.check_call(["bash", os.path.join(root, "eigenexa_amd", "fortran", "build.sh")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    errs = {}
+    for line in out.stdout.splitlines():
+        if "max rel eigenvalue error" in line:
+            name = line.split()[0]
+            errs[name] = float(line.split("=")[2].split()[0])
+    assert set(errs) == {"eigen_sx", "eigen_s", "eigen_h"}, out.stdout
+    assert all(v < 1e-8 for v in errs.values()), errs      # cond(Frank, n=1000) ~ 1.6e6
