@@ -374,9 +374,11 @@ __global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int 
 
 // K4: p = q - U (W^H u) - W (U^H u); partial s = sum p conj(u)
 __global__ __launch_bounds__(HT) void h_combine_kernel(HArgs H, int L, int k, int nt, int npdc) {
+  // 64 rows per workgroup; wave q takes every fourth partial sum and every fourth panel column of those rows (the chain
+  // of dependent loads per row, not the bytes, is what this kernel costs), the four waves are combined through LDS
   __shared__ double dwr[HM], dwi[HM], dur[HM], dui[HM];
-  __shared__ double red[8];
-  const int tid = threadIdx.x;
+  __shared__ double comb[4][64][2];
+  const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
   if (tid < k) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     for (int c = 0; c < npdc; ++c) {
@@ -386,47 +388,44 @@ __global__ __launch_bounds__(HT) void h_combine_kernel(HArgs H, int L, int k, in
     dwr[tid] = a0; dwi[tid] = a1; dur[tid] = a2; dui[tid] = a3;
   }
   __syncthreads();
-  const int r = blockIdx.x * HT + tid;
-  double s[2] = {0.0, 0.0};
+  const int r = blockIdx.x * 64 + lane;
+  double pr = 0.0, pi = 0.0;
   if (r < L) {
-    double pr = 0.0, pi = 0.0;
-    const int R = r / HTL;        // my tile row: column sums of tiles (t <= R, R), then row sums of tiles (R, t >= R)
-    // batches of 8 independent loads per plane (the chain of dependent adds, not the bytes, is what costs here);
-    // fixed summation order: column partials t = 0..R, then row partials t = R..nt-1
-    {
-      int t = 0;
-      for (; t + 8 <= R + 1; t += 8) {
-        double a[8], b[8];
+    const int R = r / HTL;   // my tile row.  Partial u of the row: u <= R -> column sums of tile (u, R); u > R -> row sums of tile (R, u-1)
+    auto ldp_r = [&](int u) { return (u <= R) ? H.ycr[(size_t)u * H.ldp + r] : H.yrr[(size_t)(u - 1) * H.ldp + r]; };
+    auto ldp_i = [&](int u) { return (u <= R) ? H.yci[(size_t)u * H.ldp + r] : H.yri[(size_t)(u - 1) * H.ldp + r]; };
+    int u = q;
+    for (; u + 12 < nt + 1; u += 16) {
+      double a[4], b[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { a[q] = H.ycr[(size_t)(t + q) * H.ldp + r]; b[q] = H.yci[(size_t)(t + q) * H.ldp + r]; }
+      for (int e = 0; e < 4; ++e) { a[e] = ldp_r(u + 4 * e); b[e] = ldp_i(u + 4 * e); }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { pr += a[q]; pi += b[q]; }
-      }
-      for (; t <= R; ++t) { pr += H.ycr[(size_t)t * H.ldp + r]; pi += H.yci[(size_t)t * H.ldp + r]; }
-      t = R;
-      for (; t + 8 <= nt; t += 8) {
-        double a[8], b[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { a[q] = H.yrr[(size_t)(t + q) * H.ldp + r]; b[q] = H.yri[(size_t)(t + q) * H.ldp + r]; }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { pr += a[q]; pi += b[q]; }
-      }
-      for (; t < nt; ++t) { pr += H.yrr[(size_t)t * H.ldp + r]; pi += H.yri[(size_t)t * H.ldp + r]; }
+      for (int e = 0; e < 4; ++e) { pr += a[e]; pi += b[e]; }
     }
-#pragma unroll 4
-    for (int j = 0; j < k; ++j) {
+    for (; u < nt + 1; u += 4) { pr += ldp_r(u); pi += ldp_i(u); }
+#pragma unroll 2
+    for (int j = q; j < k; j += 4) {
       const double ur = H.Ur[(size_t)r + (size_t)j * H.ldp], ui = H.Ui[(size_t)r + (size_t)j * H.ldp];
       const double wr = H.Wr[(size_t)r + (size_t)j * H.ldp], wi = H.Wi[(size_t)r + (size_t)j * H.ldp];
       pr -= (ur * dwr[j] - ui * dwi[j]) + (wr * dur[j] - wi * dui[j]);
       pi -= (ur * dwi[j] + ui * dwr[j]) + (wr * dui[j] + wi * dur[j]);
     }
-    H.pr[r] = pr; H.pi[r] = pi;
-    const double ur = H.Ur[(size_t)r + (size_t)k * H.ldp], ui = H.Ui[(size_t)r + (size_t)k * H.ldp];
-    s[0] = pr * ur + pi * ui;    // p conj(u)
-    s[1] = pi * ur - pr * ui;
   }
-  hblock_sum<2>(s, red);
-  if (tid == 0) { H.ps[2 * blockIdx.x] = s[0]; H.ps[2 * blockIdx.x + 1] = s[1]; }
+  comb[q][lane][0] = pr; comb[q][lane][1] = pi;
+  __syncthreads();
+  if (q == 0) {
+    double s0 = 0.0, s1 = 0.0;
+    if (r < L) {
+      pr = (comb[0][lane][0] + comb[1][lane][0]) + (comb[2][lane][0] + comb[3][lane][0]);
+      pi = (comb[0][lane][1] + comb[1][lane][1]) + (comb[2][lane][1] + comb[3][lane][1]);
+      H.pr[r] = pr; H.pi[r] = pi;
+      const double ur = H.Ur[(size_t)r + (size_t)k * H.ldp], ui = H.Ui[(size_t)r + (size_t)k * H.ldp];
+      s0 = pr * ur + pi * ui;    // p conj(u)
+      s1 = pi * ur - pr * ui;
+    }
+    s0 = hwave_sum(s0); s1 = hwave_sum(s1);
+    if (lane == 0) { H.ps[2 * blockIdx.x] = s0; H.ps[2 * blockIdx.x + 1] = s1; }
+  }
 }
 
 // K5: v = (p - alpha u) / conj(beta), alpha = s / (2 beta)
@@ -638,7 +637,7 @@ int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w,
   const int lde = (n + 3) / 4 * 4;
   H.d = ctx.pool.get_t<double>("h.d", (size_t)n);
   H.e = ctx.pool.get_t<double>("h.e", (size_t)lde);
-  const int nwg = ceil_div(n, HT) + 1;
+  const int nwg = ceil_div(n, 64) + 1;
   const int nt_max = ceil_div(n, HTL) + 1;
   const int npdc_max = ceil_div(n, PDR) + 1;
   H.pn = ctx.pool.get_t<double>("h.pn", (size_t)nwg);
@@ -671,13 +670,14 @@ int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w,
     const int npdc = ceil_div(L, PDR);
     const int nt = ceil_div(L, HTL);
     hipLaunchKernelGGL(h_hemv_kernel, dim3(k * npdc + nt * (nt + 1) / 2), dim3(HTH), 0, st, H, L, k, nt, npdc);
-    hipLaunchKernelGGL(h_combine_kernel, dim3(nbl), dim3(HT), 0, st, H, L, k, nt, npdc);
-    pend = 1; nparts_prev = nbl;
+    const int nbc = ceil_div(L, 64);
+    hipLaunchKernelGGL(h_combine_kernel, dim3(nbc), dim3(HT), 0, st, H, L, k, nt, npdc);
+    pend = 1; nparts_prev = nbc;
     ++k;
     if (k == m || i == 1) {
       // trailing update of the remaining i x i block (both triangles), two real GEMMs with K = 4k; the pending v of
       // this step is needed in memory first
-      hipLaunchKernelGGL(h_make_v_kernel, dim3(nbl), dim3(HT), 0, st, H, i, k - 1, nbl);
+      hipLaunchKernelGGL(h_make_v_kernel, dim3(nbl), dim3(HT), 0, st, H, i, k - 1, nbc);
       pend = 0;
       const int nr = i;
       hipLaunchKernelGGL(h_pack_kernel, dim3(ceil_div(nr, 256), k), dim3(256), 0, st, H, nr, k, P1, P2, P3);
