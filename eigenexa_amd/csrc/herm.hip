@@ -1,4 +1,5 @@
-// herm.hip -- eigen_h: complex Hermitian eigensolver, first version, one GPU.
+// herm.hip -- eigen_h: complex Hermitian eigensolver, first version (one GPU; with more ranks the
+// cyclic blocks are gathered and every rank solves the replicated problem).
 //
 // Replaces eigen_h (src/eigen_h.F:30-322): eigen_scaling_h -> eigen_hrd (Hermitian -> REAL symmetric tridiagonal,
 // src/eigen_hrd.F:1-448) -> dc2 (the real tridiagonal D&C of dc.hip, unchanged) -> eigen_hrbakwyx (complex WY
@@ -18,6 +19,7 @@
 // template for the next one.  All cross-workgroup reductions are two-phase and deterministic (no atomics).
 #include "eigx_context.h"
 #include "eigx_common.h"
+#include "eigx_comm.h"
 #include "../../include/eigenexa_amd.h"
 #include <cfloat>
 #include <chrono>
@@ -570,10 +572,11 @@ double hnow() { return std::chrono::duration<double>(std::chrono::steady_clock::
 }  // namespace
 
 // a, z: device, interleaved complex(8), leading dimensions in complex elements
-int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb,
-                   char mode) {
+// full (global) matrix on this rank's GPU.  With more than one rank every rank runs this on the same replicated input
+// (the D&C inside distributes its GEMMs over the ranks, everything else is redundant): correct, not yet scalable.
+static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb,
+                           char mode) {
   if (!ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
-  if (ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;   // one GPU in this version
   if (n <= 0) {
     fprintf(stderr, "[eigx] warning: non-positive dimension is invalid\n");   // src/eigen_h.F:91-94
     return EIGX_ERR_BAD_ARG;
@@ -782,16 +785,95 @@ int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w,
   return EIGX_OK;
 }
 
+namespace {
+// complex (interleaved) versions of the 2-D cyclic layout kernels of solver.hip
+__global__ void hz_pack_kernel(const double* __restrict__ a, int lda, int nr, int nc, double* __restrict__ out, int bx) {
+  const int lj = blockIdx.y;
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < bx; li += gridDim.x * blockDim.x) {
+    const bool ok = li < nr && lj < nc;
+    out[2 * ((size_t)lj * bx + li)] = ok ? a[2 * ((size_t)lj * lda + li)] : 0.0;
+    out[2 * ((size_t)lj * bx + li) + 1] = ok ? a[2 * ((size_t)lj * lda + li) + 1] : 0.0;
+  }
+}
+__global__ void hz_cyclic_to_full_kernel(const double* __restrict__ recv, int bx, int by, int Px, int Py, int order_r, int n,
+                                         double* __restrict__ F, int ldf) {
+  const int q = blockIdx.z;
+  const int qx = order_r ? q / Py : q % Px, qy = order_r ? q % Py : q / Px;
+  const int lj = blockIdx.y;
+  const int gj = lj * Py + qy;
+  if (gj >= n) return;
+  const double* src = recv + 2 * ((size_t)q * bx * by + (size_t)lj * bx);
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < bx; li += gridDim.x * blockDim.x) {
+    const int gi = li * Px + qx;
+    if (gi < n) { F[2 * ((size_t)gj * ldf + gi)] = src[2 * li]; F[2 * ((size_t)gj * ldf + gi) + 1] = src[2 * li + 1]; }
+  }
+}
+__global__ void hz_full_to_cyclic_kernel(const double* __restrict__ F, int ldf, int nloc_r, int ncols, int Px, int px, int Py,
+                                         int py, double* __restrict__ dst, int ldd) {
+  const int lj = blockIdx.y;
+  const int gj = lj * Py + py;
+  if (gj >= ncols) return;
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < nloc_r; li += gridDim.x * blockDim.x) {
+    dst[2 * ((size_t)lj * ldd + li)] = F[2 * ((size_t)gj * ldf + (size_t)li * Px + px)];
+    dst[2 * ((size_t)lj * ldd + li) + 1] = F[2 * ((size_t)gj * ldf + (size_t)li * Px + px) + 1];
+  }
+}
+}  // namespace
+
+// a, z: this rank's 2-D cyclic blocks (device, interleaved complex), as for eigen_sx / eigen_s
+int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb,
+                   char mode) {
+  if (!ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  const Grid& G = ctx.grid;
+  if (G.nranks == 1) return herm_solve_full(ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode);
+  if (n <= 0) return EIGX_ERR_BAD_ARG;
+  const int nloc_r = local_count(n, G.Px, G.px), nloc_c = local_count(n, G.Py, G.py);
+  if (!a || !w || lda < nloc_r) return EIGX_ERR_BAD_ARG;
+  char md = mode;
+  if (md >= 'a' && md <= 'z') md = (char)(md - 'a' + 'A');
+  int nv = nvec < 0 ? -nvec : nvec;
+  if (nv > n) nv = n;
+  const bool want_vec = !(md == 'N' || nv == 0);
+  if (want_vec && (!z || ldz < nloc_r)) return EIGX_ERR_BAD_ARG;
+  EIGX_HIP_CHECK(hipSetDevice(ctx.device));
+  hipStream_t st = ctx.stream;
+  const int bx = ceil_div(n, G.Px), by = ceil_div(n, G.Py);
+  const int ldf = n + 2;
+  double* sendb = ctx.pool.get_t<double>("hm.send", (size_t)2 * bx * by);
+  double* recvb = ctx.pool.get_t<double>("hm.recv", (size_t)2 * bx * by * G.nranks);
+  double* Af = ctx.pool.get_t<double>("hm.A", (size_t)2 * ldf * n);
+  double* Zf = ctx.pool.get_t<double>("hm.Z", (size_t)2 * ldf * n);
+  hipLaunchKernelGGL(hz_pack_kernel, dim3(8, by), dim3(256), 0, st, a, lda, nloc_r, nloc_c, sendb, bx);
+  comm_allgather(ctx, COMM_WORLD, sendb, recvb, (size_t)2 * bx * by, st);
+  hipLaunchKernelGGL(hz_cyclic_to_full_kernel, dim3(8, by, G.nranks), dim3(256), 0, st, recvb, bx, by, G.Px, G.Py,
+                     G.row_major, n, Af, ldf);
+  const int rc = herm_solve_full(ctx, n, nvec, Af, ldf, w, Zf, ldf, mf, mb, mode);
+  if (rc != EIGX_OK) return rc;
+  if (want_vec) {
+    const int nzc = local_count(nv, G.Py, G.py);
+    if (nzc > 0 && nloc_r > 0)
+      hipLaunchKernelGGL(hz_full_to_cyclic_kernel, dim3(8, nzc), dim3(256), 0, st, Zf, ldf, nloc_r, nv, G.Px, G.px, G.Py,
+                         G.py, z, ldz);
+  }
+  if (G.px == 0 && G.py == 0 && nloc_r > 0 && nloc_c > 0)   // statistics a(1,1), a(2,1) on the owner of the first column
+    EIGX_HIP_CHECK(hipMemcpyAsync(a, Af, (size_t)(nloc_r >= 2 ? 4 : 2) * 8, hipMemcpyDeviceToDevice, st));
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  return EIGX_OK;
+}
+
 int herm_solve_host(Context& ctx, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb,
                     char mode) {
   if (!ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
-  if (n <= 0 || !a || !w || lda < n) return EIGX_ERR_BAD_ARG;
+  const int nr = local_count(n, ctx.grid.Px, ctx.grid.px), nc = local_count(n, ctx.grid.Py, ctx.grid.py);
+  if (n <= 0 || !a || !w || lda < nr) return EIGX_ERR_BAD_ARG;
   EIGX_HIP_CHECK(hipSetDevice(ctx.device));
-  const int ldd = n + 2;
-  double* ad = ctx.pool.get_t<double>("hh.a", (size_t)2 * ldd * n);
-  double* zd = ctx.pool.get_t<double>("hh.z", (size_t)2 * ldd * n);
+  const int ldd = nr + 2;
+  const int ncd = nc > 0 ? nc : 1;
+  double* ad = ctx.pool.get_t<double>("hh.a", (size_t)2 * ldd * ncd);
+  double* zd = ctx.pool.get_t<double>("hh.z", (size_t)2 * ldd * ncd);
   double* wd = ctx.pool.get_t<double>("hh.w", (size_t)n);
-  EIGX_HIP_CHECK(hipMemcpy2D(ad, (size_t)ldd * 16, a, (size_t)lda * 16, (size_t)n * 16, (size_t)n, hipMemcpyHostToDevice));
+  if (nr > 0 && nc > 0)
+    EIGX_HIP_CHECK(hipMemcpy2D(ad, (size_t)ldd * 16, a, (size_t)lda * 16, (size_t)nr * 16, (size_t)nc, hipMemcpyHostToDevice));
   const int rc = herm_solve_dev(ctx, n, nvec, ad, ldd, wd, zd, ldd, mf, mb, mode);
   EIGX_HIP_CHECK(hipMemcpy(w, wd, (size_t)n * 8, hipMemcpyDeviceToHost));
   if (rc != EIGX_OK) return rc;
@@ -799,9 +881,11 @@ int herm_solve_host(Context& ctx, int n, int nvec, double* a, int lda, double* w
   if (md >= 'a' && md <= 'z') md = (char)(md - 'a' + 'A');
   int nv = nvec < 0 ? -nvec : nvec;
   if (nv > n) nv = n;
-  if (z && nv > 0 && md != 'N')
-    EIGX_HIP_CHECK(hipMemcpy2D(z, (size_t)ldz * 16, zd, (size_t)ldd * 16, (size_t)n * 16, (size_t)nv, hipMemcpyDeviceToHost));
-  EIGX_HIP_CHECK(hipMemcpy(a, ad, (size_t)(n >= 2 ? 4 : 2) * 8, hipMemcpyDeviceToHost));   // statistics only: a is destroyed
+  const int nzc = local_count(nv, ctx.grid.Py, ctx.grid.py);
+  if (z && nzc > 0 && nr > 0 && md != 'N')
+    EIGX_HIP_CHECK(hipMemcpy2D(z, (size_t)ldz * 16, zd, (size_t)ldd * 16, (size_t)nr * 16, (size_t)nzc, hipMemcpyDeviceToHost));
+  if (nr > 0 && nc > 0)
+    EIGX_HIP_CHECK(hipMemcpy(a, ad, (size_t)(nr >= 2 ? 4 : 2) * 8, hipMemcpyDeviceToHost));   // statistics only: a is destroyed
   return EIGX_OK;
 }
 

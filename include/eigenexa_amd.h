@@ -136,8 +136,9 @@ int eigx_numroc(int n, int nb, int iproc, int nprocs);
 /* replaces eigen_h(n,nvec,a,lda,w,z,ldz,m_forward,m_backward,mode) src/eigen_h.F:30-322 (complex Hermitian:
  * eigen_scaling_h -> eigen_hrd -> dc2 -> eigen_hrbakwyx).  a, z are complex(8) arrays passed as interleaved (re, im)
  * doubles, column-major, lda / ldz in COMPLEX elements; upper triangle of a significant; a is destroyed
- * (a(1,1) = flops, a(2,1) = seconds); w real, ascending; z = eigenvectors (unitary).  mode 'A', 'N', 'X'.  One GPU in
- * this version (first cut: see csrc/herm.hip). */
+ * (a(1,1) = flops, a(2,1) = seconds); w real, ascending; z = eigenvectors (unitary).  mode 'A', 'N', 'X'.  With more
+ * than one rank a and z are the 2-D cyclic local blocks as for eigx_sx; the blocks are gathered and every rank solves
+ * the replicated problem in this version (first cut: see csrc/herm.hip). */
 int eigx_h(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int m_forward, int m_backward, char mode);
 int eigx_h_dev(int n, int nvec, double* a_dev, int lda, double* w_dev, double* z_dev, int ldz, int m_forward,
                int m_backward, char mode);

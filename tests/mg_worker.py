@@ -22,6 +22,41 @@ idn, xi, yi = ee.eigen_get_id()
 assert (xp, yp) == layout.grid_shape(world) and idn == rank + 1
 px, py = xi - 1, yi - 1
 A = layout.random_symmetric(n)
+if route == "h":
+    # complex Hermitian route: every rank fills its 2-D cyclic block of the same Hermitian matrix
+    rng = np.random.default_rng(4242)
+    B = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    A = (B + B.conj().T) / 2
+    nx, ny = ee.eigen_get_matdims(n)
+    rows = np.arange(px, n, xp)
+    cols = np.arange(py, n, yp)
+    a = np.zeros((nx, ny), dtype=np.complex128, order="F")
+    a[: len(rows), : len(cols)] = A[np.ix_(rows, cols)]
+    z = np.zeros((nx, ny), dtype=np.complex128, order="F")
+    w = np.zeros(n)
+    ee.eigen_h(n, n, a, nx, w, z, nx, m_forward=32, mode="A")
+    assert api.last_status() == 0, api.last_status()
+    zl = np.zeros(((n + xp - 1) // xp, (n + yp - 1) // yp), dtype=np.complex128)
+    zl[: len(rows), : len(cols)] = z[: len(rows), : len(cols)]
+    br = [torch.zeros(zl.shape, dtype=torch.float64) for _ in range(world)]
+    bi = [torch.zeros(zl.shape, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(br, torch.from_numpy(np.ascontiguousarray(zl.real)))
+    dist.all_gather(bi, torch.from_numpy(np.ascontiguousarray(zl.imag)))
+    Z = layout.gather_cyclic([r_.numpy() + 1j * i_.numpy() for r_, i_ in zip(br, bi)], n, n)
+    wr = np.linalg.eigvalsh(A)
+    werr = np.abs(w - wr).max() / np.abs(wr).max()
+    eps = np.finfo(float).eps
+    res = np.linalg.norm(A @ Z - Z * w[None, :]) / (n * eps * np.linalg.norm(A))
+    orth = np.linalg.norm(Z.conj().T @ Z - np.eye(n)) / (n * eps)
+    wt = torch.from_numpy(w.copy())
+    dist.broadcast(wt, src=0)
+    assert np.array_equal(wt.numpy(), w), "w must be bit-identical on every rank (replicated)"
+    assert werr < 1e-12 and res < 768 and orth < 8, (werr, res, orth)
+    ee.eigen_free()
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"OK rank {rank}/{world} n={n} {route} nb={nb}: werr {werr:.2e} res {res:.3e} orth {orth:.3e}", flush=True)
+    sys.exit(0)
 if nb == 0:
     nx, ny = ee.eigen_get_matdims(n)
     # fill the local cyclic block with the reference's index helpers (benchmark/main2.f style)
