@@ -850,3 +850,15 @@ def test_fortran_caller_over_iso_c_binding(gpu_lib):
             errs[name] = float(line.split("=")[2].split()[0])
     assert set(errs) == {"eigen_sx", "eigen_s", "eigen_h"}, out.stdout
     assert all(v < 1e-8 for v in errs.values()), errs      # cond(Frank, n=1000) ~ 1.6e6
+
+
+def test_randomised_call_sequence(gpu_lib):
+    """state that could leak between solves (pooled workspace, prepared back-transformation plans, zero-padding of reused
+    buffers): 150 solves with changing size, route (sx / s / h), mode, nvec and panel widths, with free / init cycles"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_stress.py"), "150", "7"], capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0 and "stress OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
