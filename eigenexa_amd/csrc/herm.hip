@@ -33,7 +33,7 @@ namespace {
 constexpr int HT = 256;      // threads per workgroup
 constexpr int HM = 128;      // max panel width (LDS arrays)
 constexpr int HTL = 128;     // tile edge of the Hermitian mat-vec
-constexpr int HTH = 512;     // threads of a mat-vec workgroup (8 waves x 16 tile columns)
+constexpr int HTH = 256;     // threads of a mat-vec workgroup (4 waves x 32 tile columns, in units of 4 columns)
 constexpr int PDR = 1024;    // rows per panel-dot chunk
 constexpr int HMB = 128;     // reflectors per back-transformation block (the packed triangle S^H of a block lives in LDS)
 
@@ -284,6 +284,20 @@ __device__ __forceinline__ double hcolsum16(const double (&v)[16], int lane) {
   return v1;
 }
 
+// 4 per-lane values -> their sums over the 64 lanes (2 + 1 halving steps, then the 16 lanes of a row are added);
+// afterwards every lane holds the total of column  2*bit5 + bit4  of its lane id
+__device__ __forceinline__ double hcolsum4(const double (&v)[4], int lane) {
+  double v2[2], v1;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) v2[j] = hswapadd32(v[j], v[j + 2]);
+  v1 = hswapadd16(v2[0], v2[1]);
+  v1 += hdpp_mov<0xB1>(v1);
+  v1 += hdpp_mov<0x4E>(v1);
+  v1 += hdpp_mov<0x141>(v1);
+  v1 += hdpp_mov<0x140>(v1);
+  return v1;
+}
+
 // K3: q = A(0:L, 0:L) u from the UPPER triangle only (half the HBM bytes of a GEMV over both triangles): one workgroup
 // of 8 waves per 128 x 128 tile (ty <= tx) of the upper block triangle, 1-D grid in row-major tile order.  Wave w owns the
 // tile columns [16w, 16w+16), a lane owns the row pair (2 lane, 2 lane + 1): the tile lives in registers (32 coalesced
@@ -292,7 +306,11 @@ __device__ __forceinline__ double hcolsum16(const double (&v)[16], int lane) {
 // mirrored lower-triangle block (halving butterfly over the lanes).  Row partials are indexed by tile column
 // (YR[tx][r]), column partials by tile row (YC[ty][c]); K4 adds the nt + 1 partials of a row in fixed order.
 typedef double hd2_t __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int nt, int npdc) {
+// 128 x 128 tile per 4-wave workgroup; wave w owns the tile columns [32w, 32w+32) as eight units of 4 columns, a lane owns
+// the row pair (2 lane, 2 lane + 1) (16-byte loads).  Two units are in flight (register sets av0 / av1); the loop over
+// unit pairs is rolled with a trip count the compiler does not know (`npairs`, always 4), otherwise it hoists every load to
+// the top and the kernel needs all 256 VGPRs + AGPRs.
+__global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int nt, int npdc, int npairs) {
   __shared__ double ucr[HTL], uci[HTL], urr[HTL], uri[HTL];
   __shared__ double part[HTH / 64][HTL][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -315,55 +333,70 @@ __global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int 
   const int l0 = 2 * lane, l1 = 2 * lane + 1;           // my rows inside the tile
   const int r0 = row0 + l0, r1 = row0 + l1;
   const int rc = (r0 < L) ? r0 : 0;
-  hd2_t ar[16], ai[16];
+  const int wc0 = wave * 32;                            // first tile column of this wave
+  hd2_t av0r[4], av0i[4], av1r[4], av1i[4];
+  auto load4 = [&](hd2_t (&vr)[4], hd2_t (&vi)[4], int g) {
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int c = col0 + wave * 16 + t;
-    const int ccl = (c < L) ? c : 0;
-    ar[t] = *reinterpret_cast<const hd2_t*>(H.Ar + (size_t)rc + (size_t)ccl * H.ld);
-    ai[t] = *reinterpret_cast<const hd2_t*>(H.Ai + (size_t)rc + (size_t)ccl * H.ld);
-  }
+    for (int j = 0; j < 4; ++j) {
+      const int c = col0 + wc0 + g * 4 + j;
+      const int ccl = (c < L) ? c : 0;
+      vr[j] = *reinterpret_cast<const hd2_t*>(H.Ar + (size_t)rc + (size_t)ccl * H.ld);
+      vi[j] = *reinterpret_cast<const hd2_t*>(H.Ai + (size_t)rc + (size_t)ccl * H.ld);
+    }
+  };
+  load4(av0r, av0i, 0);
   if (tid < HTL) {
     const int c = col0 + tid;
     ucr[tid] = (c < L) ? H.Ur[(size_t)c + (size_t)k * H.ldp] : 0.0;
     uci[tid] = (c < L) ? H.Ui[(size_t)c + (size_t)k * H.ldp] : 0.0;
-  } else if (tid < 2 * HTL) {
+  } else {
     const int rr = row0 + tid - HTL;
     urr[tid - HTL] = (rr < L) ? H.Ur[(size_t)rr + (size_t)k * H.ldp] : 0.0;
     uri[tid - HTL] = (rr < L) ? H.Ui[(size_t)rr + (size_t)k * H.ldp] : 0.0;
   }
   __syncthreads();
   const double mur0 = urr[l0], mui0 = uri[l0], mur1 = urr[l1], mui1 = uri[l1];   // u at my rows
-  double sr0 = 0.0, si0 = 0.0, sr1 = 0.0, si1 = 0.0;   // row sums over the wave's 16 columns
-  double cr[16], ci[16];                               // my rows' contribution to the 16 column sums
+  double sr0 = 0.0, si0 = 0.0, sr1 = 0.0, si1 = 0.0;   // row sums over the wave's 32 columns
+  auto compute4 = [&](const hd2_t (&vr_)[4], const hd2_t (&vi_)[4], int g) {
+    double cr[4], ci[4];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int cc = wave * 16 + t, c = col0 + cc;
-    const bool in0 = r0 < L && c < L, in1 = r1 < L && c < L;
-    const bool up0 = in0 && (!diag || l0 <= cc), up1 = in1 && (!diag || l1 <= cc);   // upper incl. diagonal -> row sums
-    const bool su0 = in0 && (!diag || l0 < cc), su1 = in1 && (!diag || l1 < cc);     // strictly upper -> column sums
-    const double vr = ucr[cc], vi = uci[cc];
-    {
-      const double xr = up0 ? ar[t].x : 0.0, xi = (up0 && !(diag && l0 == cc)) ? ai[t].x : 0.0;
-      sr0 += xr * vr - xi * vi; si0 += xr * vi + xi * vr;
+    for (int j = 0; j < 4; ++j) {
+      const int cc = wc0 + g * 4 + j, c = col0 + cc;
+      const bool in0 = r0 < L && c < L, in1 = r1 < L && c < L;
+      const bool up0 = in0 && (!diag || l0 <= cc), up1 = in1 && (!diag || l1 <= cc);   // upper incl. diagonal -> row sums
+      const bool su0 = in0 && (!diag || l0 < cc), su1 = in1 && (!diag || l1 < cc);     // strictly upper -> column sums
+      const double vr = ucr[cc], vi = uci[cc];
+      {
+        const double xr = up0 ? vr_[j].x : 0.0, xi = (up0 && !(diag && l0 == cc)) ? vi_[j].x : 0.0;
+        sr0 += xr * vr - xi * vi; si0 += xr * vi + xi * vr;
+      }
+      {
+        const double xr = up1 ? vr_[j].y : 0.0, xi = (up1 && !(diag && l1 == cc)) ? vi_[j].y : 0.0;
+        sr1 += xr * vr - xi * vi; si1 += xr * vi + xi * vr;
+      }
+      const double y0r = su0 ? vr_[j].x : 0.0, y0i = su0 ? vi_[j].x : 0.0;
+      const double y1r = su1 ? vr_[j].y : 0.0, y1i = su1 ? vi_[j].y : 0.0;
+      cr[j] = (y0r * mur0 + y0i * mui0) + (y1r * mur1 + y1i * mui1);                   // conj(a) u(row)
+      ci[j] = (y0r * mui0 - y0i * mur0) + (y1r * mui1 - y1i * mur1);
     }
-    {
-      const double xr = up1 ? ar[t].y : 0.0, xi = (up1 && !(diag && l1 == cc)) ? ai[t].y : 0.0;
-      sr1 += xr * vr - xi * vi; si1 += xr * vi + xi * vr;
+    const double tcr = hcolsum4(cr, lane), tci = hcolsum4(ci, lane);
+    if ((lane & 15) == 0) {
+      const int j = ((lane >> 5) & 1) * 2 + ((lane >> 4) & 1);
+      const int c = col0 + wc0 + g * 4 + j;
+      if (c < L) { H.ycr[(size_t)ty * H.ldp + c] = tcr; H.yci[(size_t)ty * H.ldp + c] = tci; }
     }
-    const double y0r = su0 ? ar[t].x : 0.0, y0i = su0 ? ai[t].x : 0.0;
-    const double y1r = su1 ? ar[t].y : 0.0, y1i = su1 ? ai[t].y : 0.0;
-    cr[t] = (y0r * mur0 + y0i * mui0) + (y1r * mur1 + y1i * mui1);                   // conj(a) u(row)
-    ci[t] = (y0r * mui0 - y0i * mur0) + (y1r * mui1 - y1i * mur1);
+  };
+  // software pipeline: av0 holds unit g (loaded one iteration ahead), av1 unit g + 1
+#pragma unroll 1
+  for (int p = 0; p < npairs; ++p) {
+    const int g = 2 * p;
+    load4(av1r, av1i, g + 1);
+    compute4(av0r, av0i, g);
+    if (p + 1 < npairs) load4(av0r, av0i, g + 2);
+    compute4(av1r, av1i, g + 1);
   }
   part[wave][l0][0] = sr0; part[wave][l0][1] = si0;
   part[wave][l1][0] = sr1; part[wave][l1][1] = si1;
-  const double tcr = hcolsum16(cr, lane), tci = hcolsum16(ci, lane);
-  if ((lane & 3) == 0) {
-    const int j = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-    const int c = col0 + wave * 16 + j;
-    if (c < L) { H.ycr[(size_t)ty * H.ldp + c] = tcr; H.yci[(size_t)ty * H.ldp + c] = tci; }
-  }
   __syncthreads();
   if (tid < HTL && row0 + tid < L) {
     double a0 = 0.0, a1 = 0.0;
@@ -672,7 +705,7 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
     hipLaunchKernelGGL(h_reflector_kernel, dim3(nbl), dim3(HT), 0, st, H, i, k, nb1);
     const int npdc = ceil_div(L, PDR);
     const int nt = ceil_div(L, HTL);
-    hipLaunchKernelGGL(h_hemv_kernel, dim3(k * npdc + nt * (nt + 1) / 2), dim3(HTH), 0, st, H, L, k, nt, npdc);
+    hipLaunchKernelGGL(h_hemv_kernel, dim3(k * npdc + nt * (nt + 1) / 2), dim3(HTH), 0, st, H, L, k, nt, npdc, 4);
     const int nbc = ceil_div(L, 64);
     hipLaunchKernelGGL(h_combine_kernel, dim3(nbc), dim3(HT), 0, st, H, L, k, nt, npdc);
     pend = 1; nparts_prev = nbc;
