@@ -560,7 +560,10 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
 //                      cg < ncg : panel columns [cg*PD_COLS, +PD_COLS) of U and W against the NV new vectors
 //                      cg == ncg: store the reflectors into the panel (both U copies) and into `a`, uA.uB
 // =================================================================================================
-struct KBArgs { int i, L, nt, ngp, k, ncg, toprows, pdr, npd; };
+struct KBArgs { int i, L, nt, ngp, k, ncg, toprows, pdr, npd;
+  int ng;   // column groups per wave (= T / 32): a kernel ARGUMENT so that the pipeline loops stay rolled (hipcc would
+            // otherwise unroll them and hoist loads: more registers, lower occupancy)
+};
 
 // K_L (multi-GPU only): reduce this rank's SYMV partials (owned tile columns) into RB before the allreduce
 template <int NB>
@@ -972,21 +975,25 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
         compute8(av1, g + 1, IC<0>());
       }
     } else if (RB == 2) {
-      for (int g = 0; g < NG; ++g) {
+      const int ng = B.ng;
+#pragma unroll 1
+      for (int g = 0; g < ng; ++g) {
         load8(av1, g, 1);
         compute8(av0, g, IC<0>());
-        if (g + 1 < NG) load8(av0, g + 1, 0);
+        if (g + 1 < ng) load8(av0, g + 1, 0);
         compute8(av1, g, IC<(RB > 1 ? 1 : 0)>());
       }
     } else {
-      for (int g = 0; g < NG; ++g) {
+      const int ng = B.ng;
+#pragma unroll 1
+      for (int g = 0; g < ng; ++g) {
         load8(av1, g, 1);
         compute8(av0, g, IC<0>());
         load8(av0, g, 2);
         compute8(av1, g, IC<(RB > 1 ? 1 : 0)>());
         load8(av1, g, 3);
         compute8(av0, g, IC<(RB > 2 ? 2 : 0)>());
-        if (g + 1 < NG) load8(av0, g + 1, 0);
+        if (g + 1 < ng) load8(av0, g + 1, 0);
         compute8(av1, g, IC<(RB > 3 ? 3 : 0)>());
       }
     }
@@ -1108,6 +1115,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     B.pdr = pd_rows_for(B.toprows);
     const int npd = (B.toprows + B.pdr - 1) / B.pdr;
     B.npd = npd;
+    B.ng = g.T / 32;
     const int gx = g.nt * (g.nt + 1) / 2 + npd * (B.ncg + 1);   // tiles of the upper block triangle + K_P workgroups
     B.ngp = nb_ka;
     const bool prof = ctx.prof_stride > 0 && (n_symv % ctx.prof_stride) == 0;
