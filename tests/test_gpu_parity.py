@@ -862,3 +862,26 @@ def test_randomised_call_sequence(gpu_lib):
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_stress.py"), "150", "7"], capture_output=True,
                          text=True, timeout=900)
     assert out.returncode == 0 and "stress OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_eigen_h_leading_dimensions(gpu_lib):
+    """eigen_h with lda, ldz > n (arrays sized by eigen_get_matdims, as a reference caller allocates them) and rows
+    beyond n poisoned: nothing outside a(1:n, 1:n) may be read, nothing outside z(1:n, 1:nvec) written"""
+    import eigenexa_amd as ee
+
+    ee.eigen_init()
+    n = 150
+    nx, ny = ee.eigen_get_matdims(n)
+    assert nx > n
+    A = _herm_random(n, seed=3)
+    a = np.full((nx, ny), np.nan + 1j * np.nan, dtype=np.complex128, order="F")
+    a[:n, :n] = np.triu(A)
+    a[:n, :n][np.tril_indices(n, -1)] = np.nan
+    z = np.full((nx, ny), 7.0 + 7.0j, dtype=np.complex128, order="F")
+    w = np.zeros(n)
+    ee.eigen_h(n, n, a, nx, w, z, nx)
+    assert ee.api.last_status() == 0
+    assert np.abs(w - np.linalg.eigvalsh(A)).max() < 1e-12 * np.abs(A).sum(axis=1).max()
+    res, orth = _herm_check(A, w, z[:n, :n])
+    assert res < GATE_RES and orth < GATE_ORTH
+    assert (z[n:, :] == 7.0 + 7.0j).all() and (z[:, n:] == 7.0 + 7.0j).all()
