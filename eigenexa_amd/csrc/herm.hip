@@ -14,7 +14,7 @@
 //   x = A_eff(0:L, i);  g = -sign(||x||, Re x_{L-1});  u = x, u_{L-1} -= g;  beta = -u_{L-1} g       (src/eigen_hrd_t4.F:40-95)
 //   q = A_eff u;  s = u^H q;  alpha = s / (2 beta);  v = (q - alpha u) / conj(beta)                 (src/eigen_hrd_t6_3.F:256-272)
 //   A_eff = A - U W^H - W U^H  (panel of m columns, applied every m steps)                          (src/eigen_hrd_t1.F:2-110)
-// Four launches per column (form x [+ previous v] | reflector | panel dots + tiled mat-vec | combine): this version is
+// Three launches per column (form x [+ previous v] | reflector scalars + panel dots + tiled mat-vec | combine + store): this version is
 // latency-bound per step like the first real-symmetric version was; the fused / tiled structure of band_reduce.hip is the
 // template for the next one.  All cross-workgroup reductions are two-phase and deterministic (no atomics).
 #include "eigx_context.h"
@@ -190,39 +190,38 @@ __global__ __launch_bounds__(HT) void h_form_x_kernel(HArgs H, int i, int k, int
   if (tid == 0) H.pn[blockIdx.x] = nrm[0];
 }
 
-// K2: reflector of column i (L = i rows): every workgroup reduces the norm partials in the same order
-__global__ __launch_bounds__(HT) void h_reflector_kernel(HArgs H, int i, int k, int nparts) {
-  __shared__ double red[4];
-  const int tid = threadIdx.x, L = i;
+// Reflector scalars of column i (L = i rows) from the norm partials of K1: every workgroup of the mat-vec and of the
+// combine kernel recomputes them in the same order (bit-identical everywhere), so no separate reflector kernel runs.
+struct HRef { double nrm2, g, unr, uni, br, bi; };
+__device__ __forceinline__ HRef h_scalars(const HArgs& H, int L, int nparts, double* red /* >= 4 doubles */) {
   double nr[1] = {0.0};
-  for (int q = tid; q < nparts; q += HT) nr[0] += H.pn[q];
-  hblock_sum<1>(nr, red);
-  const double nrm2 = nr[0];
-  const double anr = H.xr[L - 1], ani = H.xi[L - 1];
-  double g = 0.0, unr = 0.0, uni = 0.0, br = 1.0, bi = 0.0;
-  if (nrm2 != 0.0) {
-    const double mag = sqrt(nrm2);
-    g = (anr >= 0.0) ? -mag : mag;
-    unr = anr - g; uni = ani;
-    br = -unr * g; bi = -uni * g;
+  for (int q = threadIdx.x; q < nparts; q += HT) nr[0] += H.pn[q];
+  hblock_sum_w<1, HT / 64>(nr, red);
+  HRef f;
+  f.nrm2 = nr[0]; f.g = 0.0; f.unr = 0.0; f.uni = 0.0; f.br = 1.0; f.bi = 0.0;
+  if (f.nrm2 != 0.0) {
+    const double anr = H.xr[L - 1], ani = H.xi[L - 1];
+    const double mag = sqrt(f.nrm2);
+    f.g = (anr >= 0.0) ? -mag : mag;
+    f.unr = anr - f.g; f.uni = ani;
+    f.br = -f.unr * f.g; f.bi = -f.uni * f.g;
   }
-  const int r = blockIdx.x * HT + tid;
-  if (r < L) {
-    double ur = 0.0, ui = 0.0;
-    if (nrm2 != 0.0) { ur = (r == L - 1) ? unr : H.xr[r]; ui = (r == L - 1) ? uni : H.xi[r]; }
-    H.Ur[(size_t)r + (size_t)k * H.ldp] = ur; H.Ui[(size_t)r + (size_t)k * H.ldp] = ui;
-    H.Ar[(size_t)r + (size_t)i * H.ld] = ur; H.Ai[(size_t)r + (size_t)i * H.ld] = ui;   // reflector stays in column i
-  }
-  if (blockIdx.x == 0 && tid == 0) { H.beta[2 * i] = br; H.beta[2 * i + 1] = bi; H.e[i] = g; }
+  return f;
+}
+// u_r = x_r, except the pivot row L-1 (x_{L-1} - g) ; zero vector for a trivial reflector
+__device__ __forceinline__ void h_u_of(const HArgs& H, const HRef& f, int L, int r, double& ur, double& ui) {
+  if (f.nrm2 == 0.0 || r >= L) { ur = 0.0; ui = 0.0; return; }
+  if (r == L - 1) { ur = f.unr; ui = f.uni; return; }
+  ur = H.xr[r]; ui = H.xi[r];
 }
 
-// K2b: panel dots dw_j = W(:,j)^H u, du_j = U(:,j)^H u over a chunk of rows; grid (k, row chunks)
-__device__ __forceinline__ void h_paneldot_body(const HArgs& H, int L, int k, int j, int c) {
+__device__ __forceinline__ void h_paneldot_body(const HArgs& H, const HRef& f, int L, int k, int j, int c) {
   __shared__ double red[4 * (HTH / 64)];
   const int r1 = (c * PDR + PDR < L) ? c * PDR + PDR : L;
   double v[4] = {0.0, 0.0, 0.0, 0.0};
   for (int r = c * PDR + threadIdx.x; r < r1; r += HTH) {
-    const double ur = H.Ur[(size_t)r + (size_t)k * H.ldp], ui = H.Ui[(size_t)r + (size_t)k * H.ldp];
+    double ur, ui;
+    h_u_of(H, f, L, r, ur, ui);
     const double wr = H.Wr[(size_t)r + (size_t)j * H.ldp], wi = H.Wi[(size_t)r + (size_t)j * H.ldp];
     const double pr = H.Ur[(size_t)r + (size_t)j * H.ldp], pi = H.Ui[(size_t)r + (size_t)j * H.ldp];
     v[0] += wr * ur + wi * ui; v[1] += wr * ui - wi * ur;   // conj(w) u
@@ -310,13 +309,16 @@ typedef double hd2_t __attribute__((ext_vector_type(2)));
 // the row pair (2 lane, 2 lane + 1) (16-byte loads).  Two units are in flight (register sets av0 / av1); the loop over
 // unit pairs is rolled with a trip count the compiler does not know (`npairs`, always 4), otherwise it hoists every load to
 // the top and the kernel needs all 256 VGPRs + AGPRs.
-__global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int nt, int npdc, int npairs) {
+__global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int nt, int npdc, int npairs, int nparts) {
   __shared__ double ucr[HTL], uci[HTL], urr[HTL], uri[HTL];
   __shared__ double part[HTH / 64][HTL][2];
+  __shared__ double sred[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const HRef f = h_scalars(H, L, nparts, sred);
+  if (blockIdx.x == 0 && tid == 0) { H.beta[2 * L] = f.br; H.beta[2 * L + 1] = f.bi; H.e[L] = f.g; }   // column i = L
   // the first k * npdc workgroups of the launch are the panel-dot workgroups (column j, row chunk c)
   if ((int)blockIdx.x < k * npdc) {
-    h_paneldot_body(H, L, k, (int)blockIdx.x % k, (int)blockIdx.x / k);
+    h_paneldot_body(H, f, L, k, (int)blockIdx.x % k, (int)blockIdx.x / k);
     return;
   }
   // tile index -> (ty, tx), row-major over the upper block triangle
@@ -346,13 +348,13 @@ __global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int 
   };
   load4(av0r, av0i, 0);
   if (tid < HTL) {
-    const int c = col0 + tid;
-    ucr[tid] = (c < L) ? H.Ur[(size_t)c + (size_t)k * H.ldp] : 0.0;
-    uci[tid] = (c < L) ? H.Ui[(size_t)c + (size_t)k * H.ldp] : 0.0;
+    double a_, b_;
+    h_u_of(H, f, L, col0 + tid, a_, b_);
+    ucr[tid] = a_; uci[tid] = b_;
   } else {
-    const int rr = row0 + tid - HTL;
-    urr[tid - HTL] = (rr < L) ? H.Ur[(size_t)rr + (size_t)k * H.ldp] : 0.0;
-    uri[tid - HTL] = (rr < L) ? H.Ui[(size_t)rr + (size_t)k * H.ldp] : 0.0;
+    double a_, b_;
+    h_u_of(H, f, L, row0 + tid - HTL, a_, b_);
+    urr[tid - HTL] = a_; uri[tid - HTL] = b_;
   }
   __syncthreads();
   const double mur0 = urr[l0], mui0 = uri[l0], mur1 = urr[l1], mui1 = uri[l1];   // u at my rows
@@ -408,12 +410,14 @@ __global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int 
 }
 
 // K4: p = q - U (W^H u) - W (U^H u); partial s = sum p conj(u)
-__global__ __launch_bounds__(HT) void h_combine_kernel(HArgs H, int L, int k, int nt, int npdc) {
+__global__ __launch_bounds__(HT) void h_combine_kernel(HArgs H, int L, int k, int nt, int npdc, int nparts) {
   // 64 rows per workgroup; wave q takes every fourth partial sum and every fourth panel column of those rows (the chain
   // of dependent loads per row, not the bytes, is what this kernel costs), the four waves are combined through LDS
   __shared__ double dwr[HM], dwi[HM], dur[HM], dui[HM];
   __shared__ double comb[4][64][2];
+  __shared__ double sred[4];
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+  const HRef f = h_scalars(H, L, nparts, sred);
   if (tid < k) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     for (int c = 0; c < npdc; ++c) {
@@ -454,7 +458,11 @@ __global__ __launch_bounds__(HT) void h_combine_kernel(HArgs H, int L, int k, in
       pr = (comb[0][lane][0] + comb[1][lane][0]) + (comb[2][lane][0] + comb[3][lane][0]);
       pi = (comb[0][lane][1] + comb[1][lane][1]) + (comb[2][lane][1] + comb[3][lane][1]);
       H.pr[r] = pr; H.pi[r] = pi;
-      const double ur = H.Ur[(size_t)r + (size_t)k * H.ldp], ui = H.Ui[(size_t)r + (size_t)k * H.ldp];
+      double ur, ui;
+      h_u_of(H, f, L, r, ur, ui);
+      // the reflector goes into the panel and stays in column i = L of A (rows 0..L-1), as the reference leaves it
+      H.Ur[(size_t)r + (size_t)k * H.ldp] = ur; H.Ui[(size_t)r + (size_t)k * H.ldp] = ui;
+      H.Ar[(size_t)r + (size_t)L * H.ld] = ur; H.Ai[(size_t)r + (size_t)L * H.ld] = ui;
       s0 = pr * ur + pi * ui;    // p conj(u)
       s1 = pi * ur - pr * ui;
     }
@@ -702,12 +710,11 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
     const int L = i;
     const int nb1 = ceil_div(i + 1, HT), nbl = ceil_div(L, HT);
     hipLaunchKernelGGL(h_form_x_kernel, dim3(nb1), dim3(HT), 0, st, H, i, k, pend, nparts_prev);
-    hipLaunchKernelGGL(h_reflector_kernel, dim3(nbl), dim3(HT), 0, st, H, i, k, nb1);
     const int npdc = ceil_div(L, PDR);
     const int nt = ceil_div(L, HTL);
-    hipLaunchKernelGGL(h_hemv_kernel, dim3(k * npdc + nt * (nt + 1) / 2), dim3(HTH), 0, st, H, L, k, nt, npdc, 4);
+    hipLaunchKernelGGL(h_hemv_kernel, dim3(k * npdc + nt * (nt + 1) / 2), dim3(HTH), 0, st, H, L, k, nt, npdc, 4, nb1);
     const int nbc = ceil_div(L, 64);
-    hipLaunchKernelGGL(h_combine_kernel, dim3(nbc), dim3(HT), 0, st, H, L, k, nt, npdc);
+    hipLaunchKernelGGL(h_combine_kernel, dim3(nbc), dim3(HT), 0, st, H, L, k, nt, npdc, nb1);
     pend = 1; nparts_prev = nbc;
     ++k;
     if (k == m || i == 1) {
