@@ -78,6 +78,7 @@ int eigx_init_multi(int device, int rank, int nranks, const void* uid, char orde
   for (int q = 0; q <= Context::kAux; ++q)
     EIGX_HIP_CHECK(hipEventCreateWithFlags(&g_ctx.aux_ev[q], hipEventDisableTiming));
   EIGX_HIP_CHECK(hipEventCreateWithFlags(&g_ctx.bt_ev, hipEventDisableTiming));
+  EIGX_HIP_CHECK(hipEventCreateWithFlags(&g_ctx.dc_ev, hipEventDisableTiming));
   if (nranks > 1) {
     int rc = comm_init(g_ctx, uid);
     if (rc != 0) return rc;
@@ -99,6 +100,7 @@ int eigx_free(void) {
   for (int q = 0; q < Context::kAux; ++q) EIGX_HIP_CHECK(hipStreamDestroy(g_ctx.aux[q]));
   for (int q = 0; q <= Context::kAux; ++q) EIGX_HIP_CHECK(hipEventDestroy(g_ctx.aux_ev[q]));
   EIGX_HIP_CHECK(hipEventDestroy(g_ctx.bt_ev));
+  EIGX_HIP_CHECK(hipEventDestroy(g_ctx.dc_ev));
   g_ctx = Context();
   return EIGX_OK;
 }

@@ -545,6 +545,18 @@ struct DeflOut {
 
 }  // namespace
 
+// The two Q buffers must be zero outside the diagonal blocks before the leaves are written: 2 n^2 doubles of memset
+// that depend on nothing.  The solver calls this before the reduction; the fills run on the side stream underneath it.
+void band_dc_prepare(Context& ctx, int n) {
+  const int ldq = pad_ld(n);
+  double* Qa = ctx.pool.get_t<double>("dc.Qa", (size_t)ldq * n);
+  double* Qb = ctx.pool.get_t<double>("dc.Qb", (size_t)ldq * n);
+  EIGX_HIP_CHECK(hipMemsetAsync(Qa, 0, (size_t)ldq * n * 8, ctx.side_stream));
+  EIGX_HIP_CHECK(hipMemsetAsync(Qb, 0, (size_t)ldq * n * 8, ctx.side_stream));
+  EIGX_HIP_CHECK(hipEventRecord(ctx.dc_ev, ctx.side_stream));
+  ctx.dc_zero_n = n; ctx.dc_zero_qa = Qa; ctx.dc_zero_qb = Qb;
+}
+
 void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const double* e_dev, int lde, int band,
                  double* w_dev, double* z_dev, int ldz) {
   hipStream_t st = ctx.stream;
@@ -626,8 +638,14 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
 
   EIGX_HIP_CHECK(hipMemcpyAsync(dd, H.d.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
   EIGX_HIP_CHECK(hipMemcpyAsync(de, H.e.data(), (size_t)lde * band * 8, hipMemcpyHostToDevice, st));
-  EIGX_HIP_CHECK(hipMemsetAsync(Qa, 0, (size_t)ldq * n * 8, st));
-  EIGX_HIP_CHECK(hipMemsetAsync(Qb, 0, (size_t)ldq * n * 8, st));
+  if (ctx.dc_zero_n == n && ctx.dc_zero_qa == Qa && ctx.dc_zero_qb == Qb) {
+    // zero-filled ahead on the side stream while the reduction ran (band_dc_prepare)
+    EIGX_HIP_CHECK(hipStreamWaitEvent(st, ctx.dc_ev, 0));
+  } else {
+    EIGX_HIP_CHECK(hipMemsetAsync(Qa, 0, (size_t)ldq * n * 8, st));
+    EIGX_HIP_CHECK(hipMemsetAsync(Qb, 0, (size_t)ldq * n * 8, st));
+  }
+  ctx.dc_zero_n = 0;
   {
     std::vector<int> iota(n);
     for (int q = 0; q < n; ++q) iota[q] = q;

@@ -63,6 +63,8 @@ struct Context {
   hipEvent_t aux_ev[kAux + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // back-transformation plan prepared ahead (trbak_prepare_dev on the side stream during the D&C): event + key
   hipEvent_t bt_ev = nullptr;
+  hipEvent_t dc_ev = nullptr;          // D&C buffers zero-filled ahead (band_dc_prepare)
+  int dc_zero_n = 0; const double* dc_zero_qa = nullptr; const double* dc_zero_qb = nullptr;
   bool bt_ready = false;
   const double* bt_a = nullptr; double* bt_V = nullptr;
   int bt_n = 0, bt_mb = 0, bt_band = 0, bt_ldv = 0;
@@ -101,6 +103,8 @@ void comm_free(Context& ctx);
 // band_reduce.hip: A (upper triangle) -> band (d, e(:,1..band)); reflectors left in A's columns
 void band_reduce_dev(Context& ctx, int n, double* A, int lda, double* d, double* e, int lde, int m, int band);
 
+// dc.hip: zero-fill of the D&C's Q buffers on the side stream, ahead of band_dc_dev (optional)
+void band_dc_prepare(Context& ctx, int n);
 // dc.hip: eigen-decomposition of the band matrix (d, e(:,1..band)); w ascending, z(ldz, nvec)
 void band_dc_dev(Context& ctx, int n, int nvec, const double* d, const double* e, int lde, int band, double* w,
                  double* z, int ldz);

@@ -134,6 +134,7 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   EIGX_HIP_CHECK(hipSetDevice(ctx.device));
   hipStream_t st = ctx.stream;
   ctx.errinfo = 0;
+  ctx.dc_zero_n = 0;
   for (int q = 0; q < 16; ++q) ctx.timers[q] = 0.0;
   const double t0 = now_s();
 
@@ -198,6 +199,8 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   double* d = ctx.pool.get_t<double>("sol.d", (size_t)n);
   double* e = ctx.pool.get_t<double>("sol.e", (size_t)lde * 2);
   const double t1 = now_s();
+  // modes that run the D&C: zero its two Q buffers on the side stream underneath the reduction
+  if (!(mode == 'N' || mode == 'S' || mode == 'C')) band_dc_prepare(ctx, n);
   band_reduce_dev(ctx, n, a, lda, d, e, lde, mf, band);
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
   const double t2 = now_s();
