@@ -21,6 +21,8 @@
  * Two families of solver entry points:
  *   eigx_sx / eigx_s          host arrays in, host arrays out     (drop-in for the Fortran API)
  *   eigx_sx_dev / eigx_s_dev  device (HBM-resident) arrays        (what bench.py times)
+ * and, on top of them: eigx_solve_bc[_dev] (block-cyclic local blocks of a ScaLAPACK descriptor),
+ * eigx_gev[_dev] (KMATH_EIGEN_GEV), eigx_h[_dev] (complex Hermitian eigen_h).
  */
 #ifndef EIGENEXA_AMD_H
 #define EIGENEXA_AMD_H
