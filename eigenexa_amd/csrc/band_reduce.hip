@@ -622,7 +622,19 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   const bool panel_role = (int)blockIdx.x < nkp;     // K_P first: its workgroups are the long ones at small L
   const int bid = (int)blockIdx.x - nkp;
   int tyv = 0, txv = 0;
-  if (!panel_role) {
+  if (!panel_role && R.P > 1) {
+    // multi-GPU: only this rank's tile columns tx = p, p + P, ... are launched (a workgroup that returns at once
+    // still costs ~4 ns of dispatch: all nt(nt+1)/2 tiles on every rank were ~50 us per step at nt = 181, P = 8).
+    // Owned column number m (tx = p + m P) has tx + 1 tiles and starts at  m (p + 1) + P m (m - 1) / 2.
+    const float fp = (float)R.P, fb = (float)(2 * (R.p + 1) - R.P);
+    int m = (int)((-fb + sqrtf(fb * fb + 8.0f * fp * (float)bid)) / (2.0f * fp));
+    if (m < 0) m = 0;
+    auto start = [&](int q) { return q * (R.p + 1) + R.P * (q * (q - 1) / 2); };
+    while (m > 0 && start(m) > bid) --m;
+    while (start(m + 1) <= bid) ++m;
+    txv = R.p + m * R.P;
+    tyv = bid - start(m);
+  } else if (!panel_role) {
     // row ty starts at ty*nt - ty(ty-1)/2: invert with a float sqrt and fix up by at most one step each way
     const float fn = 2.0f * (float)B.nt + 1.0f;
     int ty = (int)((fn - sqrtf(fn * fn - 8.0f * (float)bid)) * 0.5f);
@@ -632,7 +644,6 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
     while ((ty + 1) * B.nt - (ty + 1) * ty / 2 <= bid) ++ty;
     tyv = ty;
     txv = ty + (bid - (ty * B.nt - ty * (ty - 1) / 2));
-    if (R.P > 1 && (txv % R.P) != R.p) return;  // not my tile column
   } else {
     const int q = blockIdx.x;
     tyv = B.nt + q / (B.ncg + 1);   // nt + row chunk
@@ -1116,7 +1127,12 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     const int npd = (B.toprows + B.pdr - 1) / B.pdr;
     B.npd = npd;
     B.ng = g.T / 32;
-    const int gx = g.nt * (g.nt + 1) / 2 + npd * (B.ncg + 1);   // tiles of the upper block triangle + K_P workgroups
+    int ntiles = g.nt * (g.nt + 1) / 2;                      // tiles of the upper block triangle
+    if (R.P > 1) {                                            // ... of this rank's tile columns only
+      const int M = (g.nt > R.p) ? (g.nt - R.p + R.P - 1) / R.P : 0;
+      ntiles = M * (R.p + 1) + R.P * (M * (M - 1) / 2);
+    }
+    const int gx = ntiles + npd * (B.ncg + 1);               // + K_P workgroups
     B.ngp = nb_ka;
     const bool prof = ctx.prof_stride > 0 && (n_symv % ctx.prof_stride) == 0;
     if (prof) ctx.prof_begin(0, 8.0 * ((double)L * (L + 1) / 2) / R.P, st);  // this rank's share of the triangle
