@@ -568,27 +568,47 @@ struct KBArgs { int i, L, nt, ngp, k, ncg, toprows, pdr, npd;
 // K_L (multi-GPU only): reduce this rank's SYMV partials (owned tile columns) into RB before the allreduce
 template <int NB>
 __global__ __launch_bounds__(256) void kl_kernel(RedArgs R, int L, int nt) {
+  // 64 rows per workgroup; wave q takes every fourth partial sum of those rows (up to nt + 1 of them sit behind a cold
+  // L2: one thread per row walking them one after the other is a chain of ~nt memory round trips), the four waves are
+  // combined through LDS in a fixed order
+  __shared__ double comb[4][64][2];
   __shared__ double red[16];
   const int Lp = (L + 7) / 8 * 8;
   const int ldp = R.ldp;
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r < Lp) {
-    double pA = 0.0, pB = 0.0;
-    if (r < L) {
-      const int ty = r / 128;
-      if (ty % R.P == R.p)  // column r belongs to an owned tile column: column sums of tiles (t, ty)
-        for (int t = 0; t <= ty; ++t) {
-          pA += R.YC[((size_t)t * NB + 0) * ldp + r];
-          if (NB == 2) pB += R.YC[((size_t)t * NB + 1) * ldp + r];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int r = blockIdx.x * 64 + lane;
+  double pA = 0.0, pB = 0.0;
+  if (r < L) {
+    const int ty = r / 128;
+    if (ty % R.P == R.p) {   // column r belongs to an owned tile column: column sums of tiles (t, ty), t = 0..ty
+      int t = q;
+      for (; t + 12 <= ty; t += 16) {
+        double a[4], b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] = R.YC[((size_t)(t + 4 * e) * NB + 0) * ldp + r];
+          b[e] = (NB == 2) ? R.YC[((size_t)(t + 4 * e) * NB + 1) * ldp + r] : 0.0;
         }
-      for (int tx = ty; tx < nt; ++tx)
-        if (tx % R.P == R.p) {  // row sums of owned tiles (ty, tx)
-          pA += R.YR[((size_t)tx * NB + 0) * ldp + r];
-          if (NB == 2) pB += R.YR[((size_t)tx * NB + 1) * ldp + r];
-        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pA += a[e]; pB += b[e]; }
+      }
+      for (; t <= ty; t += 4) {
+        pA += R.YC[((size_t)t * NB + 0) * ldp + r];
+        if (NB == 2) pB += R.YC[((size_t)t * NB + 1) * ldp + r];
+      }
     }
-    R.RB[r] = pA;
-    if (NB == 2) R.RB[Lp + r] = pB;
+    // row sums of owned tiles (ty, tx): tx = first owned column >= ty, then every P-th; wave q takes every fourth
+    const int first = ty + ((R.p - ty % R.P) + R.P) % R.P;
+    for (int tx = first + q * R.P; tx < nt; tx += 4 * R.P) {
+      pA += R.YR[((size_t)tx * NB + 0) * ldp + r];
+      if (NB == 2) pB += R.YR[((size_t)tx * NB + 1) * ldp + r];
+    }
+  }
+  comb[q][lane][0] = pA; comb[q][lane][1] = pB;
+  __syncthreads();
+  if (q == 0 && r < Lp) {
+    R.RB[r] = (comb[0][lane][0] + comb[1][lane][0]) + (comb[2][lane][0] + comb[3][lane][0]);
+    if (NB == 2) R.RB[Lp + r] = (comb[0][lane][1] + comb[1][lane][1]) + (comb[2][lane][1] + comb[3][lane][1]);
   }
   if (blockIdx.x == 0) {
     double v[3] = {0.0, 0.0, 0.0};
@@ -1145,7 +1165,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     if (prof) ctx.prof_end(st);
     if (R.P > 1) {
       const int Lp = (L + 7) / 8 * 8;
-      hipLaunchKernelGGL((kl_kernel<NB>), dim3((Lp + 255) / 256), dim3(256), 0, st, R, L, g.nt);
+      hipLaunchKernelGGL((kl_kernel<NB>), dim3((Lp + 63) / 64), dim3(256), 0, st, R, L, g.nt);
       comm_allreduce_sum(ctx, COMM_WORLD, R.RB, (size_t)NB * Lp + 8, st);
     }
     t_symv_bytes += 8.0 * ((double)L * (L + 1) / 2);

@@ -335,7 +335,7 @@ def test_baseline_size_properties(gpu_lib, route):
 
 @pytest.mark.parametrize("world,n,route,nb", [(2, 300, "sx", 0), (4, 517, "sx", 0), (4, 300, "s", 0), (3, 260, "sx", 0),
                                               (4, 517, "sx", 32), (4, 301, "s", 7), (2, 260, "sx", 64),
-                                              (4, 200, "h", 0), (3, 131, "h", 0)])
+                                              (4, 200, "h", 0), (3, 131, "h", 0), (2, 1900, "sx", 0)])
 def test_multi_rank_solver_on_one_gpu(world, n, route, nb):
     """the N>1 path (tile-column sharded reduction, replicated D&C, column-parallel back-transform, 2-D cyclic
     API layout) with `world` ranks sharing the GPU over the host-staged gloo transport; nb > 0: ScaLAPACK-style
