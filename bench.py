@@ -231,7 +231,7 @@ def main():
                 "parallelism": "1 GPU (1x1 grid)" if world == 1 else (
                     f"{world} independent replicas (fallback)" if replicas else
                     f"{world} GPUs, {Px}x{Py} 2-D cyclic API layout; reduction sharded by 128-column tile ownership "
-                    f"(1 RCCL allreduce/step + panel bcast), D&C GEMMs row-distributed (z allreduce per merge), "
+                    f"(1 RCCL allreduce/step; look-ahead panel bcast on a side stream under the trailing update), D&C GEMMs row-distributed (z allreduce per merge), "
                     f"back-transform column-parallel; "
                     f"weak scaling N = {args.n}*sqrt(P)"),
                 "stage_ms": {"reduction": round(tm[1] * 1e3, 2), "dc": round(tm[2] * 1e3, 2),
