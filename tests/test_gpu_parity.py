@@ -696,35 +696,97 @@ def test_gev_device_api_and_indefinite_b(gpu_lib):
     assert api.last_status() == -7
 
 
-def test_large_n_eigenvalues_only_invariants(gpu_lib):
-    """mode 'N' (reduction + bisection, no eigenvectors) at N = 16384 -- the single-GPU stand-in for BASELINE.json
-    configs[4] (N = 65536 runs the same code in 43 s, tools/gpu_big_n.py): size-independent invariants
-    sum(w) = trace(A), ||w||_2 = ||A||_F, sortedness"""
+def _random_symmetric_dev(n, lda, chunk=4096):
+    """the seeded random symmetric matrix of layout.random_symmetric(), generated on the GPU in column chunks into a
+    column-major (lda x n) buffer; returns (a, trace, ||A||_F^2)"""
     import torch
     from eigenexa_amd import layout
 
-    n = 16384
     dev = _dev()
-    lda = n + 34
     a = torch.empty(n, lda, dtype=torch.float64, device=dev)
     a[:, n:] = 0.0
     tr = 0.0
     fro2 = 0.0
-    for c0 in range(0, n, 4096):
-        cols = np.arange(c0, c0 + 4096)
+    for c0 in range(0, n, chunk):
+        cols = np.arange(c0, min(n, c0 + chunk))
         blk = layout.random_symmetric_torch(n, dev, rows=np.arange(n), cols=cols)
-        a[c0:c0 + 4096, :n] = blk.T
+        a[c0:c0 + len(cols), :n] = blk.T
         fro2 += float((blk * blk).sum().item())
-        tr += float(torch.diagonal(blk[c0:c0 + 4096, :]).sum().item())
+        tr += float(torch.diagonal(blk[c0:c0 + len(cols), :]).sum().item())
         del blk
-    w = torch.zeros(n, dtype=torch.float64, device=dev)
-    z = torch.zeros(8, dtype=torch.float64, device=dev)
+    return a, tr, fro2
+
+
+def _spectrum_invariants(wh, tr, fro2, n):
+    assert (np.diff(wh) >= 0).all()                                                   # ascending
+    assert abs(wh.sum() - tr) / np.sqrt(fro2) < 1e-12 * np.sqrt(n)                    # sum(w) = trace(A)
+    assert abs(np.sqrt((wh * wh).sum()) - np.sqrt(fro2)) / np.sqrt(fro2) < 1e-12      # ||w||_2 = ||A||_F
+
+
+def test_large_n_eigenvalues_only_invariants(gpu_lib):
+    """mode 'N' (reduction + bisection, no eigenvectors) at N = 16384: size-independent invariants
+    sum(w) = trace(A), ||w||_2 = ||A||_F, sortedness"""
+    import torch
+
+    n = 16384
+    lda = n + 34
+    a, tr, fro2 = _random_symmetric_dev(n, lda)
+    w = torch.zeros(n, dtype=torch.float64, device=_dev())
+    z = torch.zeros(8, dtype=torch.float64, device=_dev())
     torch.cuda.synchronize()
     assert gpu_lib.eigx_sx_dev(n, 0, a.data_ptr(), lda, w.data_ptr(), z.data_ptr(), lda, 128, 128, b"N") == 0
-    wh = w.cpu().numpy()
-    assert (np.diff(wh) >= 0).all()
-    assert abs(wh.sum() - tr) / np.sqrt(fro2) < 1e-12 * np.sqrt(n)
-    assert abs(np.sqrt((wh * wh).sum()) - np.sqrt(fro2)) / np.sqrt(fro2) < 1e-12
+    _spectrum_invariants(w.cpu().numpy(), tr, fro2, n)
+
+
+@pytest.mark.parametrize("route", ["sx", "s"])
+def test_baseline_config_n32768_all_eigenpairs(gpu_lib, route):
+    """BASELINE.json configs[2] (N=32768 random symmetric, eigen_sx) and configs[3] (N=32768 eigen_s: eigen_trd +
+    trbakwy4), all eigenpairs, at the full size on this one GPU (the 8-GPU partition of the same solve is covered by
+    test_multi_rank_solver_on_one_gpu at sizes the ranks of one card can hold): the complete gates of
+    benchmark/ev_test.f:181-204 through GPU matmuls -- ||AZ-ZW||_F/(N eps ||A||_F) < 768, ||Z^T Z - I||_F/(N eps) < 8,
+    north_star's ||AZ-ZW||/||A|| <= 1e-12 N -- plus trace / Frobenius invariants and sortedness."""
+    import torch
+
+    n = 32768
+    dev = _dev()
+    lda = n + 34
+    a, tr, fro2 = _random_symmetric_dev(n, lda)
+    A = a[:, :n].clone()                         # A is symmetric: the row-major view of the column-major copy is A itself
+    w = torch.zeros(n, dtype=torch.float64, device=dev)
+    z = torch.empty(n, lda, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    fn = gpu_lib.eigx_sx_dev if route == "sx" else gpu_lib.eigx_s_dev
+    assert fn(n, n, a.data_ptr(), lda, w.data_ptr(), z.data_ptr(), lda, 128, 128, b"A") == 0
+    del a
+    _spectrum_invariants(w.cpu().numpy(), tr, fro2, n)
+    Z = z[:, :n].T                               # (n, n) eigenvectors in columns
+    anorm = np.sqrt(fro2)
+    R = A @ Z
+    R -= Z * w[None, :]
+    r = torch.linalg.norm(R).item()
+    del R, A
+    assert r / anorm <= 1e-12 * n
+    assert r / (n * EPS * anorm) < GATE_RES
+    G = Z.T @ Z
+    G.diagonal().sub_(1.0)
+    assert torch.linalg.norm(G).item() / (n * EPS) < GATE_ORTH
+
+
+def test_baseline_config_n65536_eigenvalues_only(gpu_lib):
+    """BASELINE.json configs[4]: N = 65536, eigenvalues only (eigen_prd + bisection on the pentadiagonal, mode 'N',
+    no back-transformation) at the full size on one GPU: sum(w) = trace(A), ||w||_2 = ||A||_F, sortedness"""
+    import torch
+
+    n = 65536
+    lda = n + 34
+    a, tr, fro2 = _random_symmetric_dev(n, lda)
+    w = torch.zeros(n, dtype=torch.float64, device=_dev())
+    z = torch.zeros(8, dtype=torch.float64, device=_dev())
+    torch.cuda.synchronize()
+    assert gpu_lib.eigx_sx_dev(n, 0, a.data_ptr(), lda, w.data_ptr(), z.data_ptr(), lda, 128, 128, b"N") == 0
+    del a
+    _spectrum_invariants(w.cpu().numpy(), tr, fro2, n)
+    torch.cuda.empty_cache()
 
 
 # ------------------------------------------------------------------ eigen_h: complex Hermitian route (SURVEY 8f-4)
