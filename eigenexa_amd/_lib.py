@@ -17,7 +17,9 @@ SIGNATURES = {
     "eigx_init": (C.c_int, [C.c_int]),
     "eigx_init_multi": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_char]),
     "eigx_get_rccl_unique_id": (C.c_int, [C.c_void_p]),
-    "eigx_set_comm_callbacks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eigx_get_device_count": (C.c_int, []),
+    "eigx_get_comm": (C.c_int, [C.POINTER(C.c_int)] * 4),
+    "eigx_comm_seconds": (C.c_double, []),
     "eigx_rccl_selftest": (C.c_int, []),
     "eigx_free": (C.c_int, []),
     "eigx_get_version": (C.c_int, [_c_int_p, C.c_char_p, C.c_char_p]),
@@ -25,6 +27,7 @@ SIGNATURES = {
     "eigx_get_id": (C.c_int, [_c_int_p, _c_int_p, _c_int_p]),
     "eigx_get_errinfo": (C.c_int, [C.POINTER(C.c_int64)]),
     "eigx_get_matdims": (C.c_int, [C.c_int, _c_int_p, _c_int_p, C.c_int, C.c_int, C.c_char]),
+    "eigx_matdims_for_grid": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char, _c_int_p, _c_int_p]),
     "eigx_memory_internal": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "eigx_loop_start": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "eigx_loop_end": (C.c_int, [C.c_int, C.c_int, C.c_int]),

@@ -66,56 +66,26 @@ def eigen_init(comm=None, order="C", device=None, dims=None):
     else:
         import torch
 
+        # the 128-byte session id (an ncclUniqueId when RCCL is installed) is made on rank 0 and broadcast over the
+        # caller's process group; everything else -- the shared-memory board, the hipIpc window exchange, the RCCL
+        # world / X / Y communicators -- happens inside eigx_init_multi
         group = None if comm is True else comm
         be = dist.get_backend(group)
+        uid = (C.c_char * 128)()
+        if rank == 0:
+            _lib.check(lib.eigx_get_rccl_unique_id(uid), "eigx_get_rccl_unique_id")
+        t = torch.tensor(list(bytes(uid)), dtype=torch.uint8)
         if be == "nccl":
-            uid = (C.c_char * 128)()
-            if rank == 0:
-                _lib.check(lib.eigx_get_rccl_unique_id(uid), "eigx_get_rccl_unique_id")
-            t = torch.tensor(list(bytes(uid)), dtype=torch.uint8).cuda(int(device))
-            dist.broadcast(t, src=0, group=group)
-            raw = bytes(t.cpu().tolist())
-            buf = C.create_string_buffer(raw, 128)
-            rc = lib.eigx_init_multi(int(device), rank, nranks, buf, _char(order, "C"))
-        else:
-            # host-staged test transport over the given (gloo) group: lets several ranks share one GPU
-            _register_host_callbacks(lib, dist, group)
-            rc = lib.eigx_init_multi(int(device), rank, nranks, None, _char(order, "C"))
+            t = t.cuda(int(device))
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(t, src=src, group=group)
+        raw = bytes(t.cpu().tolist())
+        buf = C.create_string_buffer(raw, 128)
+        rc = lib.eigx_init_multi(int(device), rank, nranks, buf, _char(order, "C"))
     _lib.check(rc, "eigen_init")
     _state["initialized"] = True
     _state["comm"] = comm
     return None
-
-
-_cb_keepalive = []
-
-
-def _register_host_callbacks(lib, dist, group):
-    import torch
-
-    AR = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_long, C.c_int, C.c_int)
-    BC = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_long, C.c_int, C.c_int)
-    AG = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_long, C.c_int)
-
-    def _arr(ptr, count):
-        return torch.from_numpy(np.ctypeslib.as_array(ptr, shape=(count,)))
-
-    def allreduce(buf, count, op, grp):
-        t = _arr(buf, count)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 2 else dist.ReduceOp.SUM, group=group)
-
-    def bcast(buf, count, root, grp):
-        t = _arr(buf, count)
-        dist.broadcast(t, src=dist.get_global_rank(group, root) if group is not None else root, group=group)
-
-    def allgather(send, recv, count, grp):
-        ws = dist.get_world_size(group)
-        out = _arr(recv, count * ws)
-        dist.all_gather_into_tensor(out, _arr(send, count).clone(), group=group)
-
-    cbs = (AR(allreduce), BC(bcast), AG(allgather))
-    _cb_keepalive.append(cbs)
-    lib.eigx_set_comm_callbacks(C.cast(cbs[0], C.c_void_p), C.cast(cbs[1], C.c_void_p), C.cast(cbs[2], C.c_void_p))
 
 
 def eigen_free():

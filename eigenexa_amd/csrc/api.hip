@@ -1,6 +1,7 @@
 // api.hip -- C-ABI entry points (include/eigenexa_amd.h): life cycle, queries, memory helpers.
 // The solver entry points live in solver.hip.
 #include "eigx_context.h"
+#include "eigx_comm.h"
 #include "../../include/eigenexa_amd.h"
 #include <cstring>
 
@@ -14,6 +15,12 @@ extern "C" {
 
 int eigx_init(int device) {
   return eigx_init_multi(device, 0, 1, nullptr, 'C');
+}
+
+int eigx_get_device_count(void) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return ndev;
 }
 
 int eigx_get_rccl_unique_id(void* out128) {
@@ -48,8 +55,10 @@ int eigx_init_multi(int device, int rank, int nranks, const void* uid, char orde
   int Px = 1;
   for (int x = 1; x * x <= nranks; ++x)
     if (nranks % x == 0) Px = x;
+  int req_px = 0, req_py = 0;
   if (g_next_px > 0) {   // explicit (cartesian) shape requested
     const int rx = g_next_px, ry = g_next_py;
+    req_px = rx; req_py = ry;
     g_next_px = g_next_py = 0;
     if (rx * ry != nranks) {
       fprintf(stderr, "[eigx] illegal grid dimensions %d x %d for %d ranks\n", rx, ry, nranks);
@@ -57,7 +66,9 @@ int eigx_init_multi(int device, int rank, int nranks, const void* uid, char orde
     }
     Px = rx;
   }
-  Grid& g = g_ctx.grid;
+  // A rejected call must leave nothing behind (no streams, no half-built grid): build the grid in a local, bring up
+  // the communicator first, create the streams last.
+  Grid g;
   g.Px = Px;
   g.Py = nranks / Px;
   g.rank = rank;
@@ -71,6 +82,15 @@ int eigx_init_multi(int device, int rank, int nranks, const void* uid, char orde
     g.py = rank / g.Px;
     g.row_major = 0;
   }
+  g_ctx.grid = g;
+  if (nranks > 1) {
+    const int rc = comm_init(g_ctx, uid);
+    if (rc != 0) {   // nothing was created; a requested grid shape stays pending for the retry
+      g_ctx.grid = Grid();
+      g_next_px = req_px; g_next_py = req_py;
+      return rc;
+    }
+  }
   EIGX_HIP_CHECK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
   EIGX_HIP_CHECK(hipStreamCreateWithFlags(&g_ctx.side_stream, hipStreamNonBlocking));
   for (int q = 0; q < Context::kAux; ++q)
@@ -79,10 +99,6 @@ int eigx_init_multi(int device, int rank, int nranks, const void* uid, char orde
     EIGX_HIP_CHECK(hipEventCreateWithFlags(&g_ctx.aux_ev[q], hipEventDisableTiming));
   EIGX_HIP_CHECK(hipEventCreateWithFlags(&g_ctx.bt_ev, hipEventDisableTiming));
   EIGX_HIP_CHECK(hipEventCreateWithFlags(&g_ctx.dc_ev, hipEventDisableTiming));
-  if (nranks > 1) {
-    int rc = comm_init(g_ctx, uid);
-    if (rc != 0) return rc;
-  }
   g_ctx.initialized = true;
   g_ctx.errinfo = 0;
   return EIGX_OK;
@@ -128,6 +144,18 @@ int eigx_get_id(int* id, int* x_id, int* y_id) {
   return EIGX_OK;
 }
 
+int eigx_get_comm(int* x_color, int* x_key, int* y_color, int* y_key) {
+  if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  const Grid& g = g_ctx.grid;
+  if (x_color) *x_color = g.py + 1;
+  if (x_key) *x_key = g.px + 1;
+  if (y_color) *y_color = g.px + 1;
+  if (y_key) *y_key = g.py + 1;
+  return EIGX_OK;
+}
+
+double eigx_comm_seconds(void) { return g_ctx.timers[4]; }
+
 int eigx_get_errinfo(int64_t* info) {
   if (info) *info = g_ctx.errinfo;
   return EIGX_OK;
@@ -144,46 +172,68 @@ int eigx_owner_index(int ictr, int nnod, int inod) {
   return ((ictr - 1) % nnod + 1 == inod) ? (ictr - 1) / nnod + 1 : -1;
 }
 
-// ---- matdims ------------------------------------------------------------------------------------
-// The reference picks nx by a cache-set heuristic (CSTAB_get_optdim, src/CSTAB.F:73-131: an odd
-// multiple of 32 nudged off A64FX cache aliasing) and ny so that z can double as D&C workspace
-// (src/eigen_libs0.F:1297-1343).  The contract that matters to callers is "allocate a(nx,ny),
-// z(nx,ny)"; we return extents >= the reference's: nx = ceil(n/Px) rounded up to an odd multiple of
-// 32 plus one more 64 step of slack, ny from the same nmz/nmw formula.
-int eigx_get_matdims(int n, int* nx, int* ny, int m_forward, int m_backward, char mode) {
-  if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
-  if (!nx || !ny) return EIGX_ERR_BAD_ARG;
+int eigx_matdims_for_grid(int n, int x_procs, int y_procs, int m_forward, int m_backward, char mode, int* nx, int* ny) {
+  if (!nx || !ny || x_procs < 1 || y_procs < 1) return EIGX_ERR_BAD_ARG;
   (void)m_forward;
-  const Grid& g = g_ctx.grid;
   if (n <= 0) { *nx = -1; *ny = -1; return EIGX_ERR_BAD_ARG; }
+  const int Px = x_procs, Py = y_procs;
   const int mb = m_backward > 0 ? m_backward : 128;
-  int n1 = ceil_div(n, g.Px);
+  const int n1 = ceil_div(n, Px);
+  const int n2 = ceil_div(n, Py);
   int lnx;
-  if (mode == 'M' || mode == 'm') {
-    lnx = n1;
-  } else if (mode == 'L' || mode == 'l') {
-    lnx = ceil_div(n1, 32) * 32;
+  int64_t lny;
+  if (mode == 'M' || mode == 'm') {            // minimal extents (src/eigen_libs0.F:1283-1287)
+    lnx = n1; lny = n2;
+  } else if (mode == 'L' || mode == 'l') {     // nx rounded to 32 (src/eigen_libs0.F:1288-1293)
+    lnx = ceil_div(n1, 32) * 32; lny = n2;
   } else {
     lnx = ceil_div(n1, 64) * 64 + 32;  // odd multiple of 32, >= CSTAB's choice + slack
     if (lnx < n1 + 64) lnx += 64;
+    const int NB = mb > 64 ? mb : 64;
+    // nmz / nmw of src/eigen_libs0.F:1318-1330: the larger of "local extent rounded to NB, plus one" and "blocks of NB
+    // dealt to the processes"
+    int64_t nmz = (int64_t)ceil_div(n1, NB) * NB + 1;
+    const int64_t nmz2 = (int64_t)ceil_div(ceil_div(n, NB), Px) * NB;
+    if (nmz2 > nmz) nmz = nmz2;
+    int64_t nmw = (int64_t)ceil_div(n2, NB) * NB + 1;
+    const int64_t nmw2 = (int64_t)ceil_div(ceil_div(n, NB), Py) * NB;
+    if (nmw2 > nmw) nmw = nmw2;
+    nmz += NB; nmw += NB;                // slack of one more block (the reference's z doubles as D&C workspace)
+    const int64_t big = nmz > lnx ? nmz : lnx;
+    lny = ceil_div64(big * nmw, lnx);
+    if (lny < n2) lny = n2;
   }
-  const int NB = mb > 64 ? mb : 64;
-  const int64_t nmz = (int64_t)ceil_div(ceil_div(n, g.Px), NB) * NB + NB + 1;
-  const int64_t nmw = (int64_t)ceil_div(ceil_div(n, g.Py), NB) * NB + NB + 1;
-  const int64_t big = nmz > lnx ? nmz : lnx;
-  int64_t lny = ceil_div64(big * nmw, lnx);
-  const int64_t n2 = ceil_div(n, g.Py);
-  if (lny < n2) lny = n2;
+  // the default build of the reference takes the maximum with FS_get_matdims (src/eigen_libs.F:139-146,
+  // src/FS_libs.F90:356-375), for every mode
+  {
+    const int P = Px * Py;
+    const int nf = ceil_div(n, P);
+    const int64_t nx0 = (int64_t)nf * (P / Px), ny0 = (int64_t)nf * (P / Py);
+    if (nx0 > lnx) lnx = (int)nx0;
+    if (ny0 > lny) lny = ny0;
+  }
   // 32-bit index guard of src/eigen_libs0.F:1349-1365
-  const int pmin = g.Px < g.Py ? g.Px : g.Py;
+  const int pmin = Px < Py ? Px : Py;
   const int64_t side = ceil_div64(ceil_div(n, pmin), 64) * 64;
-  if (side * side >= ((int64_t)1 << 31) && !(getenv("EIGX_ALLOW_64BIT"))) {
+  if ((side * side >= ((int64_t)1 << 31) || lny >= ((int64_t)1 << 31)) && !(getenv("EIGX_ALLOW_64BIT"))) {
     *nx = -1; *ny = -1;
     return EIGX_ERR_TOO_LARGE;
   }
   *nx = lnx;
   *ny = (int)lny;
   return EIGX_OK;
+}
+
+// ---- matdims ------------------------------------------------------------------------------------
+// The reference picks nx by a cache-set heuristic (CSTAB_get_optdim, src/CSTAB.F:73-131: an odd
+// multiple of 32 nudged off A64FX cache aliasing) and ny so that z can double as D&C workspace
+// (src/eigen_libs0.F:1297-1343).  The contract that matters to callers is "allocate a(nx,ny),
+// z(nx,ny)"; we return extents >= the reference's (tests/test_host.py sweeps sizes and grids against a restatement
+// of the reference's formulas): nx = ceil(n/Px) rounded up to an odd multiple of 32 plus one more 64 step of
+// slack, ny from the same nmz/nmw formula.
+int eigx_get_matdims(int n, int* nx, int* ny, int m_forward, int m_backward, char mode) {
+  if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  return eigx_matdims_for_grid(n, g_ctx.grid.Px, g_ctx.grid.Py, m_forward, m_backward, mode, nx, ny);
 }
 
 int64_t eigx_memory_internal(int n, int lda, int ldz, int m_forward, int m_backward) {

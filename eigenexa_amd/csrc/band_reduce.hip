@@ -66,11 +66,20 @@ struct RedArgs {
   double* sc;                     // scalars
   double* d; double* e; int lde;
   int maxseg, maxrs, maxchunk, gp2_off, kdab_off;
-  // multi-GPU (P > 1): A is the full matrix, replicated; this rank owns the 128-column tile columns
-  // tx with tx % P == p.  RB = [pA(0:Lp) | pB(0:Lp) | 3 bilinear scalars]: locally reduced SYMV partials,
-  // allreduced over the ranks once per step.
-  int P, p;
-  double* RB;
+  // multi-GPU (P > 1), 2-D cyclic like the reference (src/eigen_libs0.F:1825-2258): A is this rank's LOCAL block
+  // a(lda, *), local (li, lj) = global (li*Px + px, lj*Py + py); nothing of A is replicated.  The panel [U | W | U], the
+  // x vectors and every scalar are replicated (computed redundantly from bit-identical inputs).  Once per step every
+  // rank writes its locally reduced SYMV partial sums -- row sums of its local rows, column sums of its local
+  // columns, 3 bilinear scalars: one "step message" -- into every rank's step window (comm.hip); the consumer
+  // (K_A) adds the Py + Px contributions of a row in a fixed order.  This one exchange replaces the reference's
+  // allreduce over X, allreduce over Y and row->column transpose per column (src/eigen_prd_t2.F:179,:203,
+  // src/comm.F:1377-1528).
+  int P;
+  int Px, Py, px, py, row_major;
+  int nxs, nys;                   // padded maximal local extents = strides inside a step message
+  const double* MSG;              // my step window: message of source q, parity h at MSG + (h*P + q)*msg_stride
+  int msg_stride;                 // doubles per message: NB*(nxs + nys) + 8
+  const double* PAN; int ldpan;   // columns of the current panel gathered from their owners (global row order)
   int abl;                        // EIGX_STAMPS diagnostic build only: ablation mask (timing experiments)
   unsigned long long* dbg;        // EIGX_STAMPS diagnostic build only: accumulated s_memtime stamps
 };
@@ -89,10 +98,10 @@ struct SymvGeom { int L, T, nt; };
 int g_symv_t128 = 4500, g_symv_t256 = 20000;
 int g_symv_nt = 9000;
 
-inline SymvGeom symv_geom(int L, int P = 1) {
+inline SymvGeom symv_geom(int L) {
   SymvGeom g;
   g.L = L;
-  g.T = (L <= g_symv_t128 || P > 1) ? 128 : (L <= g_symv_t256 ? 256 : 512);  // P > 1: ownership granularity = 128 columns
+  g.T = (L <= g_symv_t128) ? 128 : (L <= g_symv_t256 ? 256 : 512);
   g.nt = (L + g.T - 1) / g.T;
   return g;
 }
@@ -167,6 +176,10 @@ __device__ __forceinline__ void block_sum_multi(double (&v)[K], double* red /* >
 
 __device__ __forceinline__ double sign_of(double mag, double s) { return s >= 0.0 ? fabs(mag) : -fabs(mag); }
 
+// loads / stores of bytes that another rank's kernel writes / reads while this one runs: system scope, cache-bypassing
+__device__ __forceinline__ double ld_sys(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_sys(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 // =================================================================================================
 // K_A : finish previous step (if has_prev) and form the next columns (ncols = 0,1,2).
 // Workgroup = 32 rows x 8 slices: slice ks handles panel columns kk = ks (mod 8) and SYMV partials
@@ -184,7 +197,22 @@ struct KAArgs {
   int k;          // panel fill to use for the new columns (= kprev+NB if has_prev)
   int rows;       // rows to cover: max(iprev+1, i+1)
   int nt_prev, lgT_prev;  // SYMV tiling of the previous step: tiles per dimension, log2(tile edge)
+  int par;                // multi-GPU: parity of the step messages that hold the previous step's SYMV partial sums
+  int pan_c0;             // multi-GPU: first global column held by the gathered panel R.PAN
 };
+
+// multi-GPU: partial number t (0 <= t < Py + Px) of global row r in the step messages of parity `par`:
+// t < Py  -> row sums of rank (r % Px, t), which holds row r at local r / Px;
+// t >= Py -> column sums of rank (t - Py, r % Py), which holds column r at local r / Py.
+// Returns the address for vector 0; vector 1 follows `stride` doubles later.
+template <int NB>
+__device__ __forceinline__ const double* mg_partial(const RedArgs& R, int par, int t, int r, int& stride) {
+  int qx, qy, off;
+  if (t < R.Py) { qx = r % R.Px; qy = t; off = r / R.Px; stride = R.nxs; }
+  else { qx = t - R.Py; qy = r % R.Py; off = NB * R.nxs + r / R.Py; stride = R.nys; }
+  const int src = R.row_major ? qx * R.Py + qy : qx + qy * R.Px;
+  return R.MSG + ((size_t)par * R.P + src) * R.msg_stride + off;
+}
 
 template <int NB>
 __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
@@ -201,7 +229,6 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   const int nt = S.nt_prev, lgT = S.lgT_prev;      // SYMV tiling of the previous step (T = 1 << lgT)
   const bool mg = R.P > 1;
   const bool hp = S.has_prev != 0;
-  const int Lp = (S.Lprev + 7) / 8 * 8;  // RB stride
   const int kp = hp ? S.kprev : 0;
   const int kloop = hp ? S.kprev : S.k;
   const int kold = hp ? S.kprev : S.k;  // panel slots that are final in memory
@@ -257,8 +284,11 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       }
     }
     if (ks == 0 && r <= S.i) {
-      a_i = R.A[(size_t)S.i * R.lda + r];
-      if (S.ncols > 1 && r <= S.i - 1) a_im = R.A[(size_t)(S.i - 1) * R.lda + r];
+      // column i of the (lazily updated) matrix: from A itself, or from the gathered panel on several GPUs
+      const double* ci = mg ? R.PAN + (size_t)(S.i - S.pan_c0) * R.ldpan : R.A + (size_t)S.i * R.lda;
+      const double* cm = mg ? R.PAN + (size_t)(S.i - 1 - S.pan_c0) * R.ldpan : R.A + (size_t)(S.i - 1) * R.lda;
+      a_i = ci[r];
+      if (S.ncols > 1 && r <= S.i - 1) a_im = cm[r];
     }
   }
   if (hp) {
@@ -283,6 +313,14 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
           if (NB == 2) tb[j] = base[ldp + rc];
         }
       }
+    } else {
+      // several GPUs: slice ks < Py + Px takes one rank's contribution to this row from the step messages
+      const int rc = rowp ? r : 0;
+      const int t = (ks < R.Px + R.Py) ? ks : 0;
+      int stv;
+      const double* b = mg_partial<NB>(R, S.par, t, rc, stv);
+      ta[0] = ld_sys(b);
+      if (NB == 2) tb[0] = ld_sys(b + stv);
     }
     // panel dots: thread kk = tid (< kp <= 256) sums entry (kind, kk) over the K_P row chunks
     {
@@ -327,6 +365,19 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
         if (NB == 2) pcl[cc][1] = base[ldp + c];
       }
     }
+    if (mg) {
+      for (int cc = 0; cc < S.ncols; ++cc) {
+        const int t = (tid < R.Px + R.Py) ? tid : 0;
+        int stv;
+        const double* b = mg_partial<NB>(R, S.par, t, S.i - cc, stv);
+        pcl[cc][0] = ld_sys(b);
+        if (NB == 2) pcl[cc][1] = ld_sys(b + stv);
+      }
+      // bilinear scalars: one message per rank
+      const double* b = R.MSG + ((size_t)S.par * R.P + (tid < R.P ? tid : 0)) * R.msg_stride + NB * (R.nxs + R.nys);
+      spl[0][0] = ld_sys(b);
+      if (NB == 2) { spl[0][1] = ld_sys(b + 1); spl[0][2] = ld_sys(b + 2); }
+    }
   }
   EIGX_STAMP(0);
   // ---- everything is in flight; now consume -----------------------------------------------------------
@@ -337,11 +388,11 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   const double tBB = (hp && bB != 0.0) ? 1.0 / bB : 0.0;
   if (hp) {
     if (mg) {
-      if (ks == 0 && rowp) { prA = R.RB[r]; if (NB == 2) prB = R.RB[Lp + r]; }
-      if (tid == 0) { v[0] = R.RB[NB * Lp + 0]; if (NB == 2) { v[1] = R.RB[NB * Lp + 1]; v[2] = R.RB[NB * Lp + 2]; } }
+      const int npart = R.Px + R.Py;
+      if (rowp && ks < npart) { prA = ta[0]; if (NB == 2) prB = tb[0]; }
+      if (tid < R.P) { v[0] = spl[0][0]; if (NB == 2) { v[1] = spl[0][1]; v[2] = spl[0][2]; } }
       for (int cc = 0; cc < S.ncols; ++cc) {
-        const int c = S.i - cc;
-        if (tid == 0) { v[7 + 2 * cc] += R.RB[c]; if (NB == 2) v[8 + 2 * cc] += R.RB[Lp + c]; }
+        if (tid < npart) { v[7 + 2 * cc] += pcl[cc][0]; if (NB == 2) v[8 + 2 * cc] += pcl[cc][1]; }
       }
     } else {
 #pragma unroll
@@ -563,70 +614,119 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
 struct KBArgs { int i, L, nt, ngp, k, ncg, toprows, pdr, npd;
   int ng;   // column groups per wave (= T / 32): a kernel ARGUMENT so that the pipeline loops stay rolled (hipcc would
             // otherwise unroll them and hoist loads: more registers, lower occupancy)
+  // multi-GPU tile enumeration of the local block (see symv_kernel): Lr / Lc = local rows / columns below L,
+  // ntc tile columns; the last (clipped) tile column has nty_last tiles and comes first in the grid; tile column
+  // tx < ntc - 1 has slope*tx + c1 tiles when Px divides Py (slope = Py / Px), otherwise slope = 0 and the kernel counts
+  int Lr, Lc, ntc, nty_last, slope, c1;
 };
 
-// K_L (multi-GPU only): reduce this rank's SYMV partials (owned tile columns) into RB before the allreduce
+// tiles of tile column tx of the local block (T-row tile ty exists iff its first global row <= the last global
+// column of the tile column):  floor((last global column - px) / (Px T)) + 1
+__host__ __device__ inline int mg_nty(int tx, int T, int Lc, int Px, int px, int Py, int py) {
+  const int lc = (tx * T + T - 1 < Lc - 1) ? tx * T + T - 1 : Lc - 1;
+  const long num = (long)lc * Py + py - px;
+  return num >= 0 ? (int)(num / ((long)Px * T)) + 1 : 0;
+}
+
+// K_L (multi-GPU only): reduce this rank's SYMV partials over its tiles -- row sums of the local rows, column sums
+// of the local columns, bilinear scalars -- and WRITE the result into every rank's step window (system-scope stores
+// over xGMI; the ranks of a node are all directly linked), then publish the step's flag on every rank.
+struct KLArgs {
+  int L, Lr, Lc, T, ntc, nbr, par;
+  unsigned long long epoch;
+  StepPeers peers;
+};
 template <int NB>
-__global__ __launch_bounds__(256) void kl_kernel(RedArgs R, int L, int nt) {
-  // 64 rows per workgroup; wave q takes every fourth partial sum of those rows (up to nt + 1 of them sit behind a cold
-  // L2: one thread per row walking them one after the other is a chain of ~nt memory round trips), the four waves are
-  // combined through LDS in a fixed order
+__global__ __launch_bounds__(256) void kl_kernel(RedArgs R, KLArgs K) {
+  // 64 rows (columns) per workgroup; wave q takes every fourth partial sum of them (up to ~64 partials sit behind a
+  // cold L2: one thread per row walking them one after the other is a chain of memory round trips), the four waves
+  // are combined through LDS in a fixed order
   __shared__ double comb[4][64][2];
   __shared__ double red[16];
-  const int Lp = (L + 7) / 8 * 8;
+  __shared__ int last;
   const int ldp = R.ldp;
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int r = blockIdx.x * 64 + lane;
+  const int T = K.T;
+  const bool rows = (int)blockIdx.x < K.nbr;
+  const int l = (rows ? blockIdx.x : blockIdx.x - K.nbr) * 64 + lane;   // local row / local column
   double pA = 0.0, pB = 0.0;
-  if (r < L) {
-    const int ty = r / 128;
-    if (ty % R.P == R.p) {   // column r belongs to an owned tile column: column sums of tiles (t, ty), t = 0..ty
-      int t = q;
-      for (; t + 12 <= ty; t += 16) {
-        double a[4], b[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          a[e] = R.YC[((size_t)(t + 4 * e) * NB + 0) * ldp + r];
-          b[e] = (NB == 2) ? R.YC[((size_t)(t + 4 * e) * NB + 1) * ldp + r] : 0.0;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { pA += a[e]; pB += b[e]; }
-      }
-      for (; t <= ty; t += 4) {
-        pA += R.YC[((size_t)t * NB + 0) * ldp + r];
-        if (NB == 2) pB += R.YC[((size_t)t * NB + 1) * ldp + r];
+  if (rows && l < K.Lr) {
+    // row sums: tiles (ty, tx) with tx >= txmin, the tile column that holds the first local column at or right of
+    // the tile row's first global row
+    const int ty = l / T;
+    const long g0 = (long)ty * T * R.Px + R.px;
+    const long cneed = g0 > R.py ? (g0 - R.py + R.Py - 1) / R.Py : 0;
+    if (cneed <= K.Lc - 1) {
+      for (int tx = (int)(cneed / T) + q; tx < K.ntc; tx += 4) {
+        pA += R.YR[((size_t)tx * NB + 0) * ldp + l];
+        if (NB == 2) pB += R.YR[((size_t)tx * NB + 1) * ldp + l];
       }
     }
-    // row sums of owned tiles (ty, tx): tx = first owned column >= ty, then every P-th; wave q takes every fourth
-    const int first = ty + ((R.p - ty % R.P) + R.P) % R.P;
-    for (int tx = first + q * R.P; tx < nt; tx += 4 * R.P) {
-      pA += R.YR[((size_t)tx * NB + 0) * ldp + r];
-      if (NB == 2) pB += R.YR[((size_t)tx * NB + 1) * ldp + r];
+  } else if (!rows && l < K.Lc) {
+    const int tx = l / T;
+    const int nty = mg_nty(tx, T, K.Lc, R.Px, R.px, R.Py, R.py);
+    int t = q;
+    for (; t + 12 < nty; t += 16) {
+      double a[4], b[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = R.YC[((size_t)(t + 4 * e) * NB + 0) * ldp + l];
+        b[e] = (NB == 2) ? R.YC[((size_t)(t + 4 * e) * NB + 1) * ldp + l] : 0.0;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pA += a[e]; pB += b[e]; }
+    }
+    for (; t < nty; t += 4) {
+      pA += R.YC[((size_t)t * NB + 0) * ldp + l];
+      if (NB == 2) pB += R.YC[((size_t)t * NB + 1) * ldp + l];
     }
   }
   comb[q][lane][0] = pA; comb[q][lane][1] = pB;
   __syncthreads();
-  if (q == 0 && r < Lp) {
-    R.RB[r] = (comb[0][lane][0] + comb[1][lane][0]) + (comb[2][lane][0] + comb[3][lane][0]);
-    if (NB == 2) R.RB[Lp + r] = (comb[0][lane][1] + comb[1][lane][1]) + (comb[2][lane][1] + comb[3][lane][1]);
+  const size_t pbase = (size_t)K.par * K.peers.parity_stride;
+  if (q == 0 && l < (rows ? K.Lr : K.Lc)) {
+    const double sA = (comb[0][lane][0] + comb[1][lane][0]) + (comb[2][lane][0] + comb[3][lane][0]);
+    const double sB = (comb[0][lane][1] + comb[1][lane][1]) + (comb[2][lane][1] + comb[3][lane][1]);
+    const size_t off = pbase + (rows ? 0 : (size_t)NB * R.nxs) + l;
+    const int stv = rows ? R.nxs : R.nys;
+    for (int d = 0; d < K.peers.n; ++d) {
+      st_sys(K.peers.slot[d] + off, sA);
+      if (NB == 2) st_sys(K.peers.slot[d] + off + stv, sB);
+    }
   }
   if (blockIdx.x == 0) {
     double v[3] = {0.0, 0.0, 0.0};
-    for (int w = threadIdx.x; w < nt * nt; w += 256) {
-      const int ty = w / nt, tx = w - ty * nt;
-      if (tx >= ty && tx % R.P == R.p) {
+    // every tile of this rank: tile column tx holds mg_nty(tx) tiles
+    for (int tx = q; tx < K.ntc; tx += 4) {
+      const int nty = mg_nty(tx, T, K.Lc, R.Px, R.px, R.Py, R.py);
+      for (int ty = lane; ty < nty; ty += 64) {
         const double* sp = R.SP + ((size_t)ty * R.maxseg + tx) * 3;
         v[0] += sp[0]; v[1] += sp[1]; v[2] += sp[2];
       }
     }
     block_sum_multi<3>(v, red);
-    if (threadIdx.x < 8) R.RB[NB * Lp + threadIdx.x] = threadIdx.x < 3 ? v[threadIdx.x] : 0.0;
+    if (threadIdx.x < 3) {
+      const size_t off = pbase + (size_t)NB * (R.nxs + R.nys) + threadIdx.x;
+      for (int d = 0; d < K.peers.n; ++d) st_sys(K.peers.slot[d] + off, v[threadIdx.x]);
+    }
   }
+  // every storing wave drains its stores; the last workgroup to arrive publishes the flag on every rank
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned tk = atomicAdd(K.peers.counter, 1u);
+    last = (tk == gridDim.x - 1);
+    if (last) *K.peers.counter = 0;
+  }
+  __syncthreads();
+  if (last && (int)threadIdx.x < K.peers.n)
+    __hip_atomic_store(K.peers.flag[threadIdx.x] + K.par * EIGX_MAXP, K.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <int K> struct IC { static constexpr int value = K; };
 
-template <int NV, int RB, bool NTL>
+template <int NV, int RB, bool NTL, bool MG>
 __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   constexpr int T = 128 * RB;
   // NTL: non-temporal A loads, chosen by the launch for triangles far beyond L2 + Infinity Cache (g_symv_nt)
@@ -642,18 +742,37 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   const bool panel_role = (int)blockIdx.x < nkp;     // K_P first: its workgroups are the long ones at small L
   const int bid = (int)blockIdx.x - nkp;
   int tyv = 0, txv = 0;
-  if (!panel_role && R.P > 1) {
-    // multi-GPU: only this rank's tile columns tx = p, p + P, ... are launched (a workgroup that returns at once
-    // still costs ~4 ns of dispatch: all nt(nt+1)/2 tiles on every rank were ~50 us per step at nt = 181, P = 8).
-    // Owned column number m (tx = p + m P) has tx + 1 tiles and starts at  m (p + 1) + P m (m - 1) / 2.
-    const float fp = (float)R.P, fb = (float)(2 * (R.p + 1) - R.P);
-    int m = (int)((-fb + sqrtf(fb * fb + 8.0f * fp * (float)bid)) / (2.0f * fp));
-    if (m < 0) m = 0;
-    auto start = [&](int q) { return q * (R.p + 1) + R.P * (q * (q - 1) / 2); };
-    while (m > 0 && start(m) > bid) --m;
-    while (start(m + 1) <= bid) ++m;
-    txv = R.p + m * R.P;
-    tyv = bid - start(m);
+  if (!panel_role && MG) {
+    // multi-GPU: tiles of the LOCAL block a(Lr, Lc) that touch the global upper triangle.  Grid order: the tiles of
+    // the last (clipped) tile column, then tile column 0, 1, ...; column tx holds mg_nty(tx) tiles, ty = 0 .. nty-1.
+    if (bid < B.nty_last) {
+      txv = B.ntc - 1;
+      tyv = bid;
+    } else {
+      const int b2 = bid - B.nty_last;
+      int tx;
+      if (B.slope > 0) {
+        // Px divides Py: nty(tx) = slope tx + c1, column tx starts at slope tx (tx - 1) / 2 + c1 tx
+        const float sl = (float)B.slope, h = (float)B.c1 - 0.5f * sl;
+        tx = (int)((-h + sqrtf(h * h + 2.0f * sl * (float)b2)) / sl);
+        if (tx < 0) tx = 0;
+        if (tx > B.ntc - 2) tx = B.ntc - 2;
+        auto start = [&](int q) { return B.slope * (q * (q - 1) / 2) + B.c1 * q; };
+        while (tx > 0 && start(tx) > b2) --tx;
+        while (tx < B.ntc - 2 && start(tx + 1) <= b2) ++tx;
+        tyv = b2 - start(tx);
+      } else {
+        int acc = 0;
+        tx = 0;
+        for (; tx < B.ntc - 2; ++tx) {
+          const int c = mg_nty(tx, T, B.Lc, R.Px, R.px, R.Py, R.py);
+          if (b2 < acc + c) break;
+          acc += c;
+        }
+        tyv = b2 - acc;
+      }
+      txv = tx;
+    }
   } else if (!panel_role) {
     // row ty starts at ty*nt - ty(ty-1)/2: invert with a float sqrt and fix up by at most one step each way
     const float fn = 2.0f * (float)B.nt + 1.0f;
@@ -674,6 +793,10 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   // raw x values of this tile's columns / this lane's rows and the first 8-column unit of A
   const int ty = tyv, tx = txv;
   const int row0 = ty * T, col0 = tx * T;
+  // local <-> global indices (multi-GPU: 2-D cyclic; one GPU: identity) and the local extents below L
+  const int Lr = MG ? B.Lr : L, Lc = MG ? B.Lc : L;
+  auto grow = [&](int lr) { return MG ? lr * R.Px + R.px : lr; };
+  auto gcol = [&](int lc) { return MG ? lc * R.Py + R.py : lc; };
   EIGX_STAMP_INIT
   const int wcol0 = wave * (T / 4);       // first tile column of this wave
   // Loads that feed the reflector scalars go FIRST (vmcnt retires in order: behind the A-tile loads below they
@@ -698,28 +821,30 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
 #pragma unroll
     for (int q = 0; q < (T + 255) / 256; ++q) {
       const int c = col0 + tid + 256 * q;
-      const bool ok = (tid + 256 * q < T) && c < L;
-      craw[0][q] = ok ? R.X[c] : 0.0;
-      if (NV == 2) craw[NV - 1][q] = ok ? R.X[ldp + c] : 0.0;
+      const bool ok = (tid + 256 * q < T) && c < Lc;
+      const int gc = ok ? gcol(c) : 0;
+      craw[0][q] = ok ? R.X[gc] : 0.0;
+      if (NV == 2) craw[NV - 1][q] = ok ? R.X[ldp + gc] : 0.0;
     }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       const int r0 = row0 + rb * 128 + lane * 2;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const bool ok = r0 + h < L;
-        rraw[0][rb][h] = ok ? R.X[r0 + h] : 0.0;
-        if (NV == 2) rraw[NV - 1][rb][h] = ok ? R.X[ldp + r0 + h] : 0.0;
+        const bool ok = r0 + h < Lr;
+        const int gr = ok ? grow(r0 + h) : 0;
+        rraw[0][rb][h] = ok ? R.X[gr] : 0.0;
+        if (NV == 2) rraw[NV - 1][rb][h] = ok ? R.X[ldp + gr] : 0.0;
       }
     }
     {
       const int r0 = row0 + lane * 2;
-      const bool rok = r0 < L;
+      const bool rok = r0 < Lr;
       const double* Ap = R.A + (rok ? r0 : 0);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = col0 + wcol0 + j;
-        if (rok && c < L) av0[j] = ld2<NTL>(Ap + (size_t)c * R.lda);
+        if (rok && c < Lc) av0[j] = ld2<NTL>(Ap + (size_t)c * R.lda);
         else av0[j] = make_double2(0.0, 0.0);
       }
     }
@@ -814,8 +939,14 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
         U2[(size_t)k * ldp + r] = uA;
         if (NV == 2) { Up[(size_t)(k + 1) * ldp + r] = uB; U2[(size_t)(k + 1) * ldp + r] = uB; }
         if (r < L) {
-          R.A[(size_t)i * R.lda + r] = uA;
-          if (NV == 2) R.A[(size_t)(i - 1) * R.lda + r] = uB;  // row L-1 gets 0 (src/eigen_prd_t4x.F:333-343)
+          if (!MG) {
+            R.A[(size_t)i * R.lda + r] = uA;
+            if (NV == 2) R.A[(size_t)(i - 1) * R.lda + r] = uB;  // row L-1 gets 0 (src/eigen_prd_t4x.F:333-343)
+          } else if (r % R.Px == R.px) {
+            // the owners of columns i, i-1 keep their rows of the reflectors (2-D cyclic, as in the reference)
+            if (i % R.Py == R.py) R.A[(size_t)(i / R.Py) * R.lda + r / R.Px] = uA;
+            if (NV == 2 && (i - 1) % R.Py == R.py) R.A[(size_t)((i - 1) / R.Py) * R.lda + r / R.Px] = uB;
+          }
         }
         ab[0] += uA * uB;
       }
@@ -882,7 +1013,8 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
 
   // ================================================================== K_B (SYMV tile)
   EIGX_STAMP(9);
-  const bool diag = (tx == ty);
+  // tiles that the diagonal crosses mask element-wise; a tile is interior iff its last global row < its first global column
+  const bool diag = MG ? (grow(row0 + T - 1) >= gcol(col0)) : (tx == ty);
   double* yrs = dyn;            // [4 waves][NV][T]
   double* ucs = dyn + DYN;      // [NV][T] : u_a at the tile's columns
 #pragma unroll
@@ -890,7 +1022,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
     const int t = tid + 256 * q;
     if (t < T) {
 #pragma unroll
-      for (int a = 0; a < NV; ++a) ucs[a * T + t] = ufix2(a, col0 + t, craw[0][q], craw[NV - 1][q]);
+      for (int a = 0; a < NV; ++a) ucs[a * T + t] = (col0 + t < Lc) ? ufix2(a, gcol(col0 + t), craw[0][q], craw[NV - 1][q]) : 0.0;
     }
   }
   __syncthreads();
@@ -901,8 +1033,8 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
     const int r0 = row0 + rb * 128 + lane * 2;
 #pragma unroll
     for (int a = 0; a < NV; ++a) {
-      ux[a][rb][0] = ufix2(a, r0, rraw[0][rb][0], rraw[NV - 1][rb][0]);
-      ux[a][rb][1] = ufix2(a, r0 + 1, rraw[0][rb][1], rraw[NV - 1][rb][1]);
+      ux[a][rb][0] = (r0 < Lr) ? ufix2(a, grow(r0), rraw[0][rb][0], rraw[NV - 1][rb][0]) : 0.0;
+      ux[a][rb][1] = (r0 + 1 < Lr) ? ufix2(a, grow(r0 + 1), rraw[0][rb][1], rraw[NV - 1][rb][1]) : 0.0;
       yr[a][rb][0] = 0.0; yr[a][rb][1] = 0.0;
     }
   }
@@ -912,12 +1044,12 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
 
   auto load8 = [&](double2 (&av)[8], int g, int rb) {
     const int r0 = row0 + rb * 128 + lane * 2;
-    const bool rok = r0 < L;
+    const bool rok = r0 < Lr;
     const double* Ap = R.A + (rok ? r0 : 0);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = col0 + wcol0 + g * 8 + j;
-      if (rok && c < L) av[j] = ld2<NTL>(Ap + (size_t)c * R.lda);
+      if (rok && c < Lc) av[j] = ld2<NTL>(Ap + (size_t)c * R.lda);
       else av[j] = make_double2(0.0, 0.0);
     }
   };
@@ -944,11 +1076,12 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
         }
       }
     } else {
+      const int g0 = grow(r0), g1 = MG ? g0 + R.Px : r1;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int c = col0 + tc0 + j;
-        const double ax_s = (r0 < c) ? av[j].x : 0.0, ay_s = (r1 < c) ? av[j].y : 0.0;     // strict upper
-        const double ax_d = (r0 <= c) ? av[j].x : 0.0, ay_d = (r1 <= c) ? av[j].y : 0.0;   // with diagonal
+        const int c = gcol(col0 + tc0 + j);
+        const double ax_s = (g0 < c) ? av[j].x : 0.0, ay_s = (g1 < c) ? av[j].y : 0.0;     // strict upper
+        const double ax_d = (g0 <= c) ? av[j].x : 0.0, ay_d = (g1 <= c) ? av[j].y : 0.0;   // with diagonal
 #pragma unroll
         for (int a = 0; a < NV; ++a) {
           const double uc = ucs[a * T + tc0 + j];
@@ -984,7 +1117,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
       if ((lane & 7) == 0) {
         const int j = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
         const int c = col0 + tc0 + j;
-        if (c < L) {
+        if (c < Lc) {
 #pragma unroll
           for (int a = 0; a < NV; ++a) R.YC[((size_t)ty * NV + a) * ldp + c] = fin[a];
           const double ua = ucs[tc0 + j];
@@ -1049,7 +1182,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   __syncthreads();
   for (int t = tid; t < T; t += 256) {
     const int r = row0 + t;
-    if (r < L) {
+    if (r < Lr) {
 #pragma unroll
       for (int a = 0; a < NV; ++a) {
         const double s = (yrs[((size_t)0 * NV + a) * T + t] + yrs[((size_t)1 * NV + a) * T + t]) +
@@ -1072,6 +1205,44 @@ __global__ void fill_kernel(double* p, size_t n, double v) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// ---- multi-GPU helpers ---------------------------------------------------------------------------------------
+// compact copies of the panel for the local trailing update: UWr(li, :) = [U | W](global row of li, :),
+// UWc(lj, :) = [W | U](global row = global column of lj, :)   (the reference keeps the same four arrays: ur, vr
+// row-distributed and uyr, vyr column-distributed, src/eigen_t1.F:68-309)
+__global__ void compact_panel_kernel(const double* __restrict__ UW, int ldp, int m, int nrl, int ncl, int Px, int px,
+                                     int Py, int py, double* __restrict__ UWr, int ldr, double* __restrict__ UWc, int ldc) {
+  const int k = blockIdx.y;                    // 0 .. 2m-1
+  const double* rsrc = UW + (size_t)k * ldp;         // [U | W] column k
+  const double* csrc = UW + (size_t)(k + m) * ldp;   // [W | U] column k
+  for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < (nrl > ncl ? nrl : ncl); l += gridDim.x * blockDim.x) {
+    if (l < nrl) UWr[(size_t)k * ldr + l] = rsrc[(size_t)l * Px + px];
+    if (l < ncl) UWc[(size_t)k * ldc + l] = csrc[(size_t)l * Py + py];
+  }
+}
+
+// my rows of my columns of the panel, columns [clo, chi] (global), rows < toprows (global): send[ljr*nxs + li]
+__global__ void pack_panel_kernel(const double* __restrict__ A, int lda, int lj0, int mloc, int nrl, int nxs,
+                                  double* __restrict__ send) {
+  const int ljr = blockIdx.y;
+  if (ljr >= mloc) return;
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < nrl; li += gridDim.x * blockDim.x)
+    send[(size_t)ljr * nxs + li] = A[(size_t)(lj0 + ljr) * lda + li];
+}
+// PAN(r, c - clo) = the owner's copy:  recv[src][ (c/Py - lj0(src's py)) * nxs + r/Px ]
+__global__ void unpack_panel_kernel(const double* __restrict__ recv, size_t count, int nxs, int clo, int chi, int toprows,
+                                    int Px, int Py, int row_major, double* __restrict__ PAN, int ldpan) {
+  const int c = clo + blockIdx.y;
+  if (c > chi) return;
+  const int qy = c % Py;
+  const int lj0 = (clo - qy + Py - 1) / Py;
+  const int ljr = c / Py - lj0;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < toprows; r += gridDim.x * blockDim.x) {
+    const int qx = r % Px;
+    const int src = row_major ? qx * Py + qy : qx + qy * Px;
+    PAN[(size_t)(c - clo) * ldpan + r] = ld_sys(recv + (size_t)src * count + (size_t)ljr * nxs + r / Px);
+  }
+}
+
 template <int NB>
 void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double* e, int lde, int m) {
   hipStream_t st = ctx.stream;
@@ -1079,14 +1250,24 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   if (m > 256) m = 256;
   if (NB == 2 && (m & 1)) ++m;
   const int ldp = pad_ld((n + 127) / 128 * 128 + 128);
+  const Grid& G = ctx.grid;
+  const bool mg = G.nranks > 1;
   RedArgs R;
   R.A = A; R.lda = lda; R.n = n; R.ldp = ldp; R.m = m;
   R.d = d; R.e = e; R.lde = lde;
-  R.P = ctx.grid.nranks; R.p = ctx.grid.rank;
+  R.P = G.nranks; R.Px = G.Px; R.Py = G.Py; R.px = G.px; R.py = G.py; R.row_major = G.row_major;
+  R.nxs = (ceil_div(n, G.Px) + 7) / 8 * 8;
+  R.nys = (ceil_div(n, G.Py) + 7) / 8 * 8;
+  R.msg_stride = NB * (R.nxs + R.nys) + 8;
+  R.MSG = nullptr; R.PAN = nullptr; R.ldpan = ldp;
   int maxseg = 0;
-  for (int L = n; L >= 1; --L) {  // nt is not monotone in L: scan
-    const SymvGeom g = symv_geom(L, R.P);
-    if (g.nt > maxseg) maxseg = g.nt;
+  if (!mg) {
+    for (int L = n; L >= 1; --L) {  // nt is not monotone in L: scan
+      const SymvGeom g = symv_geom(L);
+      if (g.nt > maxseg) maxseg = g.nt;
+    }
+  } else {
+    maxseg = ceil_div(R.nxs > R.nys ? R.nxs : R.nys, 128) + 1;
   }
   maxseg += 1;
   R.maxseg = maxseg;
@@ -1103,13 +1284,51 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   R.gp2_off = 0;
   R.GP = ctx.pool.get_t<double>("red.GP", (size_t)maxgp * 3 + 8);
   R.sc = ctx.pool.get_t<double>("red.sc", SC_COUNT);
-  R.RB = ctx.pool.get_t<double>("red.RB", (size_t)NB * (n + 8) + 16);
   R.dbg = nullptr;
   R.abl = getenv("EIGX_ABL") ? atoi(getenv("EIGX_ABL")) : 0;
 #ifdef EIGX_STAMPS
   R.dbg = ctx.pool.get_t<unsigned long long>("red.dbg", 32);
   EIGX_HIP_CHECK(hipMemsetAsync(R.dbg, 0, 32 * sizeof(unsigned long long), st));
 #endif
+  // ---- multi-GPU state: step window, gathered panel, compact panels ------------------------------------------
+  StepPeers peers;
+  unsigned long long epoch = 0;          // epoch of the step message that the NEXT K_A consumes
+  PeerBuf* panr = nullptr;               // receive window of the panel gather: [rank][mloc_max][nxs]
+  double *pan = nullptr, *pan_send = nullptr, *UWr = nullptr, *UWc = nullptr;
+  // a gathered panel holds the m columns of the next panel and, when fewer than NB + 1 columns would remain below it,
+  // those too (they are finished without another trailing update)
+  auto panel_lo = [&](int itop) { const int clo = itop - m + 1; return clo <= NB ? 0 : clo; };
+  const int mloc_max = ceil_div(m + NB, G.Py) + 1;
+  const size_t pan_count = (size_t)mloc_max * R.nxs;
+  const int ldr = pad_ld(R.nxs + 2), ldc = pad_ld(R.nys + 2);
+  if (mg) {
+    R.MSG = comm_step_window(ctx, (size_t)R.msg_stride, &peers);
+    epoch = comm_step_epoch_base(ctx, (unsigned long long)(n / NB + 2));
+    panr = comm_buffer(ctx, "red.panr", (size_t)G.nranks * pan_count * sizeof(double));
+    pan = ctx.pool.get_t<double>("red.pan", (size_t)ldp * (m + NB));
+    pan_send = ctx.pool.get_t<double>("red.pansend", pan_count);
+    UWr = ctx.pool.get_t<double>("red.UWr", (size_t)ldr * 2 * m);
+    UWc = ctx.pool.get_t<double>("red.UWc", (size_t)ldc * 2 * m);
+    R.PAN = pan;
+    EIGX_HIP_CHECK(hipMemsetAsync(pan_send, 0, pan_count * sizeof(double), st));
+  }
+  // gather the panel columns [clo, chi], rows < chi + 1, from their owners into `pan` (enqueued on stream s)
+  auto gather_panel = [&](int clo, int chi, hipStream_t s, CommChannel ch) {
+    const int toprows = chi + 1;
+    const int nxc = (ceil_div(toprows, G.Px) + 7) / 8 * 8;       // row stride of this gather (same on every rank)
+    const size_t cnt = (size_t)mloc_max * nxc;
+    const int lj0 = (clo - G.py + G.Py - 1) / G.Py;
+    const int lj1 = chi >= G.py ? (chi - G.py) / G.Py : -1;
+    const int mloc = lj1 - lj0 + 1;
+    const int nrl = local_count(toprows, G.Px, G.px);
+    if (mloc > 0 && nrl > 0)
+      hipLaunchKernelGGL(pack_panel_kernel, dim3(ceil_div(nrl, 256) < 64 ? ceil_div(nrl, 256) : 64, mloc), dim3(256), 0, s,
+                         (const double*)A, lda, lj0, mloc, nrl, nxc, pan_send);
+    comm_exchange(ctx, COMM_WORLD, pan_send, 0, panr, 0, cnt, s, ch);
+    hipLaunchKernelGGL(unpack_panel_kernel, dim3(ceil_div(toprows, 256) < 64 ? ceil_div(toprows, 256) : 64, chi - clo + 1),
+                       dim3(256), 0, s, (const double*)panr->local, cnt, nxc, clo, chi, toprows, G.Px, G.Py,
+                       G.row_major, pan, ldp);
+  };
   hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, st, R.UW, (size_t)ldp * m * 3, 0.0);
   hipLaunchKernelGGL(fill_kernel, dim3(8), dim3(256), 0, st, e, (size_t)lde * NB, 0.0);
   hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, R.sc, (size_t)SC_COUNT, 0.0);
@@ -1118,8 +1337,13 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   KAArgs S;
   S.has_prev = 0; S.iprev = 0; S.Lprev = 0; S.kprev = 0; S.nchunk_prev = 0; S.nt_prev = 0; S.lgT_prev = 7;
+  S.par = 0; S.pan_c0 = 0;
   int k = 0;        // panel fill
   int i = n - 1;    // top column of the current block
+  if (mg) {
+    S.pan_c0 = panel_lo(n - 1);
+    gather_panel(S.pan_c0, n - 1, st, CH_BULK);
+  }
   double t_symv_bytes = 0.0;
   long n_symv = 0, n_k1 = 0;
   double k1_flops = 0.0;
@@ -1135,77 +1359,115 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     S.rows = i + 1;
     if (S.has_prev && S.iprev + 1 > S.rows) S.rows = S.iprev + 1;
     const int nb_ka = (S.rows + KA_ROWS - 1) / KA_ROWS;
-    if (S.rows > 0 && (S.has_prev || ncols > 0))
+    if (S.rows > 0 && (S.has_prev || ncols > 0)) {
+      if (mg && S.has_prev) comm_step_wait(ctx, epoch, st);      // the previous step's messages of every rank are in
       hipLaunchKernelGGL((ka_kernel<NB>), dim3(nb_ka), dim3(256), 0, st, R, S);
+    }
     if (!do_step) break;
-    const SymvGeom g = symv_geom(L, R.P);
     KBArgs B;
-    B.i = i; B.L = L; B.nt = g.nt; B.k = k;
+    B.i = i; B.L = L; B.k = k;
     B.ncg = (k + PD_COLS - 1) / PD_COLS;
     B.toprows = i + 1;
     B.pdr = pd_rows_for(B.toprows);
     const int npd = (B.toprows + B.pdr - 1) / B.pdr;
     B.npd = npd;
-    B.ng = g.T / 32;
-    int ntiles = g.nt * (g.nt + 1) / 2;                      // tiles of the upper block triangle
-    if (R.P > 1) {                                            // ... of this rank's tile columns only
-      const int M = (g.nt > R.p) ? (g.nt - R.p + R.P - 1) / R.P : 0;
-      ntiles = M * (R.p + 1) + R.P * (M * (M - 1) / 2);
-    }
-    const int gx = ntiles + npd * (B.ncg + 1);               // + K_P workgroups
     B.ngp = nb_ka;
+    B.Lr = L; B.Lc = L; B.ntc = 0; B.nty_last = 0; B.slope = 0; B.c1 = 0;
+    int T, ntiles;
+    if (!mg) {
+      const SymvGeom g = symv_geom(L);
+      T = g.T;
+      B.nt = g.nt;
+      ntiles = g.nt * (g.nt + 1) / 2;                        // tiles of the upper block triangle
+    } else {
+      // local block below L: Lr x Lc; tile edge from the size of the local trapezoid
+      B.Lr = local_count(L, G.Px, G.px);
+      B.Lc = local_count(L, G.Py, G.py);
+      const double leq = sqrt((double)(B.Lr > 1 ? B.Lr : 1) * (double)(B.Lc > 1 ? B.Lc : 1));
+      T = (leq <= g_symv_t128) ? 128 : (leq <= g_symv_t256 ? 256 : 512);
+      B.ntc = ceil_div(B.Lc, T);
+      B.nt = B.ntc;
+      B.nty_last = B.ntc > 0 ? mg_nty(B.ntc - 1, T, B.Lc, G.Px, G.px, G.Py, G.py) : 0;
+      ntiles = B.nty_last;
+      for (int tx = 0; tx + 1 < B.ntc; ++tx) ntiles += mg_nty(tx, T, B.Lc, G.Px, G.px, G.Py, G.py);
+      if (G.Py % G.Px == 0) {
+        B.slope = G.Py / G.Px;
+        B.c1 = (int)(((long)(T - 1) * G.Py + G.py - G.px) / ((long)G.Px * T)) + 1;
+      }
+    }
+    B.ng = T / 32;
+    const int gx = ntiles + npd * (B.ncg + 1);               // + K_P workgroups
     const bool prof = ctx.prof_stride > 0 && (n_symv % ctx.prof_stride) == 0;
     if (prof) ctx.prof_begin(0, 8.0 * ((double)L * (L + 1) / 2) / R.P, st);  // this rank's share of the triangle
-    const bool nt_loads = L > g_symv_nt;
-    if (g.T == 128) hipLaunchKernelGGL((symv_kernel<NB, 1, false>), dim3(gx), dim3(256), 0, st, R, B);
-    else if (g.T == 256 && !nt_loads) hipLaunchKernelGGL((symv_kernel<NB, 2, false>), dim3(gx), dim3(256), 0, st, R, B);
-    else if (g.T == 256) hipLaunchKernelGGL((symv_kernel<NB, 2, true>), dim3(gx), dim3(256), 0, st, R, B);
-    else if (!nt_loads) hipLaunchKernelGGL((symv_kernel<NB, 4, false>), dim3(gx), dim3(256), 0, st, R, B);
-    else hipLaunchKernelGGL((symv_kernel<NB, 4, true>), dim3(gx), dim3(256), 0, st, R, B);
+    const bool nt_loads = (mg ? sqrt((double)B.Lr * B.Lc) : (double)L) > g_symv_nt;
+#define EIGX_SYMV(RBv, NTv)                                                                                         \
+  do {                                                                                                              \
+    if (mg) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true>), dim3(gx), dim3(256), 0, st, R, B);                \
+    else hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false>), dim3(gx), dim3(256), 0, st, R, B);                  \
+  } while (0)
+    if (T == 128) EIGX_SYMV(1, false);
+    else if (T == 256 && !nt_loads) EIGX_SYMV(2, false);
+    else if (T == 256) EIGX_SYMV(2, true);
+    else if (!nt_loads) EIGX_SYMV(4, false);
+    else EIGX_SYMV(4, true);
+#undef EIGX_SYMV
     if (prof) ctx.prof_end(st);
-    if (R.P > 1) {
-      const int Lp = (L + 7) / 8 * 8;
-      hipLaunchKernelGGL((kl_kernel<NB>), dim3((Lp + 63) / 64), dim3(256), 0, st, R, L, g.nt);
-      comm_allreduce_sum(ctx, COMM_WORLD, R.RB, (size_t)NB * Lp + 8, st);
+    if (mg) {
+      ++epoch;
+      KLArgs K;
+      K.L = L; K.Lr = B.Lr; K.Lc = B.Lc; K.T = T; K.ntc = B.ntc;
+      K.nbr = ceil_div(B.Lr > 0 ? B.Lr : 1, 64);
+      K.par = (int)(epoch & 1);
+      K.epoch = epoch;
+      K.peers = peers;
+      const int nbc = ceil_div(B.Lc > 0 ? B.Lc : 1, 64);
+      hipLaunchKernelGGL((kl_kernel<NB>), dim3(K.nbr + nbc), dim3(256), 0, st, R, K);
+      S.par = K.par;
     }
     t_symv_bytes += 8.0 * ((double)L * (L + 1) / 2);
     ++n_symv;
     // bookkeeping for the next K_A
     S.has_prev = 1; S.iprev = i; S.Lprev = L; S.kprev = k;
     S.nchunk_prev = npd;
-    S.nt_prev = g.nt; S.lgT_prev = (g.T == 128) ? 7 : (g.T == 256 ? 8 : 9);
+    S.nt_prev = B.nt; S.lgT_prev = (T == 128) ? 7 : (T == 256 ? 8 : 9);
     k += NB;
     i -= NB;
     if (k >= m && i - NB + 1 >= 1) {
       // panel full and more reflectors to come: finish W, trailing update, start a new panel
       KAArgs F = S;
       F.ncols = 0; F.i = i; F.L = 0; F.k = k; F.rows = S.iprev + 1;
+      if (mg) comm_step_wait(ctx, epoch, st);
       hipLaunchKernelGGL((ka_kernel<NB>), dim3((F.rows + KA_ROWS - 1) / KA_ROWS), dim3(256), 0, st, R, F);
       const int nr = i + 1;
       if (ctx.prof_stride > 0) ctx.prof_begin(1, 2.0 * (double)nr * nr * m / R.P, st);
-      if (R.P == 1) {
+      if (!mg) {
         dgemm_dev(st, 'N', 'T', nr, nr, 2 * m, -1.0, R.UW, ldp, R.UW + (size_t)ldp * m, ldp, 1.0, A, lda, 1);
       } else {
-        // Look-ahead: the tile columns that hold the next panel, columns (i-m, i], are updated first; their
-        // owners then broadcast them on the side stream (the reference's panel-load allgather,
-        // src/eigen_prd_t7.F:74-250) while the compute stream updates the rest of the trailing matrix.  Whole
-        // 128-column blocks travel, so already-reduced columns that share a block are re-sent unchanged.
-        const int clo = (i - m + 1 > 0) ? i - m + 1 : 0;
-        const int tb0 = clo / 128;
-        dgemm_dev(st, 'N', 'T', nr, nr, 2 * m, -1.0, R.UW, ldp, R.UW + (size_t)ldp * m, ldp, 1.0, A, lda, 1,
-                  nullptr, nullptr, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, R.P, R.p, nullptr, tb0, 0x7fffffff);
+        // Local trailing update A_loc -= [U W](rows) [W U](cols)^T: needs no communication (src/eigen_t1.F:250-306).
+        // Look-ahead: the local tile columns that hold the NEXT panel, global columns (i-m, i], are updated first;
+        // they are then gathered from their owners on the side stream (the reference's panel-load allgather,
+        // src/eigen_prd_t7.F:114-128) while the compute stream updates the rest of the trailing matrix.
+        const int nrl = local_count(nr, G.Px, G.px), ncl = local_count(nr, G.Py, G.py);
+        const int clo = panel_lo(i);
+        const int lj0 = (clo - G.py + G.Py - 1) / G.Py;
+        const int tb0 = lj0 / 128;
+        const int lmax = nrl > ncl ? nrl : ncl;
+        if (lmax > 0)
+          hipLaunchKernelGGL(compact_panel_kernel, dim3(ceil_div(lmax, 256) < 64 ? ceil_div(lmax, 256) : 64, 2 * m), dim3(256),
+                             0, st, (const double*)R.UW, ldp, m, nrl, ncl, G.Px, G.px, G.Py, G.py, UWr, ldr, UWc, ldc);
+        if (nrl > 0 && ncl > 0)
+          dgemm_dev(st, 'N', 'T', nrl, ncl, 2 * m, -1.0, UWr, ldr, UWc, ldc, 1.0, A, lda, 2, &G, nullptr, nullptr, 1, 0, 0,
+                    0, 1, 0, 0, 0, 1, 0, nullptr, tb0, 0x7fffffff);
         EIGX_HIP_CHECK(hipEventRecord(ctx.aux_ev[0], st));
-        if (tb0 > 0)
-          dgemm_dev(st, 'N', 'T', nr, nr, 2 * m, -1.0, R.UW, ldp, R.UW + (size_t)ldp * m, ldp, 1.0, A, lda, 1,
-                    nullptr, nullptr, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, R.P, R.p, nullptr, 0, tb0);
+        if (tb0 > 0 && nrl > 0 && ncl > 0)
+          dgemm_dev(st, 'N', 'T', nrl, ncl, 2 * m, -1.0, UWr, ldr, UWc, ldc, 1.0, A, lda, 2, &G, nullptr, nullptr, 1, 0, 0,
+                    0, 1, 0, 0, 0, 1, 0, nullptr, 0, tb0);
         hipStream_t sd = ctx.side_stream;
         EIGX_HIP_CHECK(hipStreamWaitEvent(sd, ctx.aux_ev[0], 0));
-        for (int b = tb0; b <= i / 128; ++b) {
-          const int c0 = b * 128, c1 = (c0 + 128 < n) ? c0 + 128 : n;
-          comm_bcast(ctx, COMM_WORLD, A + (size_t)c0 * lda, (size_t)(c1 - c0) * lda, b % R.P, sd);
-        }
+        gather_panel(clo, i, sd, CH_SIDE);
         EIGX_HIP_CHECK(hipEventRecord(ctx.aux_ev[1], sd));
         EIGX_HIP_CHECK(hipStreamWaitEvent(st, ctx.aux_ev[1], 0));
+        S.pan_c0 = clo;
       }
       if (ctx.prof_stride > 0) ctx.prof_end(st);
       k1_flops += 2.0 * (double)nr * nr * m;  // 2*nr*nr*(2m)/2 : upper triangle only

@@ -1,24 +1,38 @@
-// comm.hip -- RCCL-over-xGMI communicators for the 2-D cyclic grid.
+// comm.hip -- inter-GPU transport for the 2-D cyclic process grid of one xGMI node.
 //
 // Replaces the MPI layer of the reference: comm_mod wrappers bcast_dbl / reduce_dbl (= allreduce) /
-// allgather_dbl / datacast_dbl (src/comm.F:726-1528) and the hand-rolled reproducible allreduces
-// (src/comm.F:2035-2580).  Communicator structure follows eigen_init_cartesian_check
+// allgather_dbl / datacast_dbl (src/comm.F:726-1528), the hand-rolled reproducible allreduces
+// (src/comm.F:2035-2580) and the X / Y communicator split of eigen_init_cartesian_check
 // (src/eigen_libs0.F:579-585): "X" = ranks that share my column coordinate py (size Px),
 // "Y" = ranks that share my row coordinate px (size Py), plus world.
 //
-// librccl is dlopen'ed on first multi-rank init so the single-GPU path carries no RCCL dependency.
-// RCCL reductions over a fixed communicator use a fixed ring/tree order, so every rank receives
-// bit-identical sums -- the property the reference's hand allreduce exists for (manual 5.5.1).
+// MI355X design (eigx_comm.h): the ranks of a node map each other's communication buffers (hipIpcMemHandle)
+// and write into them from kernels over xGMI -- one hop, no host, no protocol -- with 8-byte epoch flags; RCCL
+// (dlopen'ed, world / X / Y communicators) carries the bulk collectives when every rank owns a GPU.  Handles are
+// exchanged through a POSIX shared-memory board named after the 128-byte session id that the host broadcasts
+// (MPI_Bcast in the Fortran module, torch.distributed in bench.py), so eigx_init_multi needs nothing else from
+// the host.  Every reduction sums the members' contributions in rank order on every rank: replicated results
+// are bit-identical (the property the reference's hand allreduce exists for, manual 5.5.1).
+//
+// Failure model: no collective aborts.  A bounded spin that runs out, a failed mapping or an RCCL error sets a
+// sticky failure flag (comm_failed); the solver then returns EIGX_ERR_INTERNAL and later waits return at once.
 #include "eigx_context.h"
 #include "eigx_comm.h"
 #include "../../include/eigenexa_amd.h"
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <vector>
 
 namespace eigx {
 
 namespace {
+struct ncclUniqueIdBlob { char internal[128]; };
 struct RcclApi {
   void* lib = nullptr;
   int (*GetUniqueId)(void*) = nullptr;
@@ -63,153 +77,673 @@ bool load_rccl() {
   return true;
 }
 
-#define EIGX_NCCL_CHECK(expr)                                                              \
-  do {                                                                                     \
-    int _r = (expr);                                                                       \
-    if (_r != 0) {                                                                         \
-      fprintf(stderr, "[eigx] RCCL error %d (%s) at %s:%d\n", _r,                          \
-              api.GetErrorString ? api.GetErrorString(_r) : "?", __FILE__, __LINE__);     \
-      abort();                                                                             \
-    }                                                                                      \
-  } while (0)
-
 constexpr int kNcclFloat64 = 8;  // ncclDouble
 constexpr int kNcclSum = 0, kNcclMax = 2;
 
-// Host-staged test transport: the collectives are delegated to callbacks (tests register gloo-backed
-// Python functions), so the distributed algorithm can be exercised with several processes on ONE GPU,
-// where RCCL refuses duplicate devices.  Never used by bench.py.
-struct Callbacks {
-  eigx_allreduce_cb allreduce = nullptr;  // (buf, count, op: 0 sum / 2 max, group)
-  eigx_bcast_cb bcast = nullptr;          // (buf, count, root, group)
-  eigx_allgather_cb allgather = nullptr;  // (send, recv, count, group)
-} cbs;
-std::vector<double> stage_a, stage_b;
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- bootstrap board: a few hundred bytes of POSIX shared memory, one slot per rank ------------------------
+struct Board {
+  std::atomic<uint32_t> attached;
+  std::atomic<uint64_t> seq_written[EIGX_MAXP];
+  std::atomic<uint64_t> seq_read[EIGX_MAXP];
+  unsigned char slot[EIGX_MAXP][128];
+};
+
+struct InitBlob {          // what the ranks tell each other at init
+  hipIpcMemHandle_t flags_handle;   // 64 bytes
+  char bus_id[32];                  // PCI bus id of the rank's GPU: equal ids = shared device
+  int pid;
+  int ipc_ok;
+};
+static_assert(sizeof(InitBlob) <= 128, "board slot too small");
+struct BufBlob { hipIpcMemHandle_t handle; uint64_t bytes; int ok; };
+static_assert(sizeof(BufBlob) <= 128, "board slot too small");
+
 }  // namespace
 
-bool comm_uses_callbacks(const Context& ctx) { return ctx.comm && ctx.comm->callbacks; }
+// flag block of a rank (u64 words): [channel][kind 0 = data / parity 0, 1 = ready / parity 1][source rank]
+constexpr int kFlagWords = CH_COUNT * 2 * EIGX_MAXP;
+__host__ __device__ inline int flag_index(int ch, int kind, int src) { return (ch * 2 + kind) * EIGX_MAXP + src; }
+
+struct CommState {
+  int P = 1, me = 0;
+  Board* board = nullptr;
+  uint64_t board_seq = 0;
+  bool ipc = false;            // peer windows usable
+  bool shared_device = false;  // two ranks on one GPU (tests): RCCL unusable
+  bool failed = false;
+  double timeout_s = 120.0;
+  // RCCL
+  void* world = nullptr;
+  void* x = nullptr;
+  void* y = nullptr;
+  bool rccl = false;
+  // peer-mapped flag block + local bookkeeping words
+  PeerBuf flags;
+  unsigned long long epoch[CH_COUNT] = {0, 0, 0, 0};
+  unsigned* counters = nullptr;          // [CH_COUNT] last-workgroup tickets (device)
+  int* err_dev = nullptr;                // sticky device-side failure word (a bounded spin ran out)
+  unsigned long long* ticks_dev = nullptr;   // accumulated 100 MHz ticks spent in waits / pushes
+  std::map<std::string, PeerBuf> bufs;
+  size_t step_msg = 0;
+  double rccl_seconds = 0.0;
+  std::vector<hipEvent_t> tev;           // event pairs around RCCL calls
+  size_t tev_used = 0;
+};
+
+namespace {
+
+void comm_fail(CommState* cs, const char* what) {
+  if (!cs->failed) fprintf(stderr, "[eigx] rank %d: communication failure: %s\n", cs->me, what);
+  cs->failed = true;
+  if (cs->err_dev) { const int one = 1; (void)hipMemcpy(cs->err_dev, &one, sizeof(int), hipMemcpyHostToDevice); }
+}
+
+#define EIGX_NCCL_TRY(cs, expr)                                                                      \
+  do {                                                                                               \
+    int _r = (expr);                                                                                 \
+    if (_r != 0) {                                                                                   \
+      fprintf(stderr, "[eigx] RCCL error %d (%s) at %s:%d\n", _r,                                    \
+              api.GetErrorString ? api.GetErrorString(_r) : "?", __FILE__, __LINE__);               \
+      comm_fail(cs, "RCCL call failed");                                                             \
+    }                                                                                                \
+  } while (0)
+
+// every rank contributes len <= 128 bytes and receives everybody's; false on time-out
+bool board_exchange(CommState* cs, const void* mine, size_t len, unsigned char (*all)[128]) {
+  Board* b = cs->board;
+  const uint64_t seq = ++cs->board_seq;
+  const double t0 = now_s();
+  auto timed_out = [&]() { return now_s() - t0 > cs->timeout_s; };
+  for (int q = 0; q < cs->P; ++q)
+    while (b->seq_read[q].load(std::memory_order_acquire) + 1 < seq) {
+      if (timed_out()) return false;
+      usleep(50);
+    }
+  memset(b->slot[cs->me], 0, 128);
+  memcpy(b->slot[cs->me], mine, len);
+  b->seq_written[cs->me].store(seq, std::memory_order_release);
+  for (int q = 0; q < cs->P; ++q)
+    while (b->seq_written[q].load(std::memory_order_acquire) < seq) {
+      if (timed_out()) return false;
+      usleep(50);
+    }
+  for (int q = 0; q < cs->P; ++q) memcpy(all[q], b->slot[q], 128);
+  b->seq_read[cs->me].store(seq, std::memory_order_release);
+  return true;
+}
+
+uint64_t fnv1a(const void* p, size_t n) {
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n; ++i) { h ^= ((const unsigned char*)p)[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+// fine-grained device memory: stores from a peer (or from another process on the same GPU) are visible to
+// system-scope loads without a kernel boundary (RCCL allocates its protocol buffers the same way)
+double* alloc_window(size_t bytes) {
+  void* p = nullptr;
+  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  }
+  return (double*)p;
+}
+
+// ---- device side -----------------------------------------------------------------------------------------------
+typedef unsigned long long u64;
+
+// Bounded spin on an epoch flag.  A spin that runs out sets the sticky error word; once it is set every later wait
+// of this rank returns at once (the solver reports the failure at the next stage boundary).
+__device__ __forceinline__ bool spin_until(const u64* flag, u64 epoch, int* err, long long limit_ticks) {
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+    __builtin_amdgcn_s_sleep(1);
+    if (wall_clock64() - t0 > limit_ticks) {
+      __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+  }
+  return true;
+}
+
+struct WaitArgs {
+  const u64* flag[EIGX_MAXP];
+  int n;
+  u64 epoch;
+  int* err;
+  u64* ticks;
+  long long limit_ticks;
+};
+// one wave: lane q waits for member q's flag.  Every exit is bounded (time-out -> sticky error word).
+__global__ void wait_kernel(WaitArgs W) {
+  const long long t0 = wall_clock64();
+  if ((int)threadIdx.x < W.n) spin_until(W.flag[threadIdx.x], W.epoch, W.err, W.limit_ticks);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  if (threadIdx.x == 0) atomicAdd(W.ticks, (u64)(wall_clock64() - t0));
+}
+
+struct ReadyArgs {
+  u64* remote[EIGX_MAXP];       // my "ready" word in member q's flag block
+  const u64* local[EIGX_MAXP];  // member q's "ready" word in mine
+  int n;
+  u64 epoch;
+  int* err;
+  u64* ticks;
+  long long limit_ticks;
+};
+// barrier in front of a bulk push: nobody writes into a receive buffer before its owner's stream has reached the
+// operation (i.e. has finished consuming what the previous operation left there)
+__global__ void ready_kernel(ReadyArgs R) {
+  const long long t0 = wall_clock64();
+  if ((int)threadIdx.x < R.n) {
+    __hip_atomic_store(R.remote[threadIdx.x], R.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    spin_until(R.local[threadIdx.x], R.epoch, R.err, R.limit_ticks);
+  }
+  if (threadIdx.x == 0) atomicAdd(R.ticks, (u64)(wall_clock64() - t0));
+}
+
+struct PushArgs {
+  const double* src;
+  size_t src_stride;            // member q reads src + q * src_stride
+  double* dst[EIGX_MAXP];       // destination in member q's window (already offset to my slot)
+  u64* flag[EIGX_MAXP];         // my data flag in member q's flag block
+  int n;
+  size_t count;
+  u64 epoch;
+  unsigned* counter;
+  u64* ticks;
+};
+__global__ __launch_bounds__(256) void push_kernel(PushArgs A) {
+  const long long t0 = wall_clock64();
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int q = 0; q < A.n; ++q) {
+    const double* s = A.src + (size_t)q * A.src_stride;
+    double* d = A.dst[q];
+    if (((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
+      const size_t n2 = A.count / 2;
+      for (size_t i = t; i < n2; i += nthreads) {
+        const double2 v = reinterpret_cast<const double2*>(s)[i];
+        __builtin_nontemporal_store(v.x, d + 2 * i);
+        __builtin_nontemporal_store(v.y, d + 2 * i + 1);
+      }
+      if ((A.count & 1) && t == 0) __builtin_nontemporal_store(s[A.count - 1], d + A.count - 1);
+    } else {
+      for (size_t i = t; i < A.count; i += nthreads) __builtin_nontemporal_store(s[i], d + i);
+    }
+  }
+  // every storing wave drains its stores; the last workgroup to arrive publishes the flags
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __threadfence_system();
+  __syncthreads();
+  __shared__ int last;
+  if (threadIdx.x == 0) {
+    const unsigned tk = atomicAdd(A.counter, 1u);
+    last = (tk == gridDim.x - 1);
+    if (last) *A.counter = 0;
+  }
+  __syncthreads();
+  if (last) {
+    if ((int)threadIdx.x < A.n) __hip_atomic_store(A.flag[threadIdx.x], A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) atomicAdd(A.ticks, (u64)(wall_clock64() - t0));
+  }
+}
+
+// out[i] = op over members r (in group order) of  in[r * stride + i]      (fixed order: bit-identical on every rank)
+__global__ void reduce_members_kernel(const double* __restrict__ in, size_t stride, int n, size_t count, int op,
+                                      double* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    double v = __hip_atomic_load(in + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int r = 1; r < n; ++r) {
+      const double x = __hip_atomic_load(in + (size_t)r * stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      v = (op == kNcclMax) ? fmax(v, x) : v + x;
+    }
+    out[i] = v;
+  }
+}
+__global__ void copy_sys_kernel(const double* __restrict__ in, size_t count, double* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = __hip_atomic_load(in + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+long long limit_ticks(const CommState* cs) { return (long long)(cs->timeout_s * 1e8); }   // wall_clock64: 100 MHz
+
+void* pick(const CommState* cs, CommGroup grp) { return grp == COMM_X ? cs->x : grp == COMM_Y ? cs->y : cs->world; }
+
+void rccl_time_begin(CommState* cs, hipStream_t s) {
+  if (cs->tev_used + 2 > cs->tev.size())
+    for (int q = 0; q < 2; ++q) { hipEvent_t e; EIGX_HIP_CHECK(hipEventCreate(&e)); cs->tev.push_back(e); }
+  EIGX_HIP_CHECK(hipEventRecord(cs->tev[cs->tev_used], s));
+}
+void rccl_time_end(CommState* cs, hipStream_t s) {
+  EIGX_HIP_CHECK(hipEventRecord(cs->tev[cs->tev_used + 1], s));
+  cs->tev_used += 2;
+}
+
+}  // namespace
+
+int comm_group(const Context& ctx, CommGroup grp, int* members, int* my_index) {
+  const Grid& g = ctx.grid;
+  auto world_rank = [&](int qx, int qy) { return g.row_major ? qx * g.Py + qy : qx + qy * g.Px; };
+  int n = 0, mine = 0;
+  if (grp == COMM_X) {
+    for (int qx = 0; qx < g.Px; ++qx) members[n++] = world_rank(qx, g.py);
+    mine = g.px;
+  } else if (grp == COMM_Y) {
+    for (int qy = 0; qy < g.Py; ++qy) members[n++] = world_rank(g.px, qy);
+    mine = g.py;
+  } else {
+    for (int q = 0; q < g.nranks; ++q) members[n++] = q;
+    mine = g.rank;
+  }
+  if (my_index) *my_index = mine;
+  return n;
+}
+int comm_size(const Context& ctx, CommGroup grp) {
+  return grp == COMM_X ? ctx.grid.Px : grp == COMM_Y ? ctx.grid.Py : ctx.grid.nranks;
+}
+bool comm_failed(const Context& ctx) {   // synchronous (reads one device word): call at stage boundaries only
+  CommState* cs = ctx.comm;
+  if (!cs) return false;
+  if (!cs->failed && cs->err_dev) {
+    int e = 0;
+    if (hipMemcpy(&e, cs->err_dev, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); e = 1; }
+    if (e != 0) {
+      fprintf(stderr, "[eigx] rank %d: a wait for a peer ran out after %.0f s\n", cs->me, cs->timeout_s);
+      cs->failed = true;
+    }
+  }
+  return cs->failed;
+}
+bool comm_shared_device(const Context& ctx) { return ctx.comm && ctx.comm->shared_device; }
+
+double comm_seconds(Context& ctx, bool reset) {
+  CommState* cs = ctx.comm;
+  if (!cs) return 0.0;
+  u64 ticks = 0;
+  EIGX_HIP_CHECK(hipMemcpy(&ticks, cs->ticks_dev, sizeof(u64), hipMemcpyDeviceToHost));
+  for (size_t q = 0; q + 1 < cs->tev_used; q += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, cs->tev[q], cs->tev[q + 1]) == hipSuccess) cs->rccl_seconds += 1e-3 * ms;
+    else (void)hipGetLastError();
+  }
+  cs->tev_used = 0;
+  const double sec = 1e-8 * (double)ticks + cs->rccl_seconds;
+  if (reset) {
+    EIGX_HIP_CHECK(hipMemset(cs->ticks_dev, 0, sizeof(u64)));
+    cs->rccl_seconds = 0.0;
+  }
+  return sec;
+}
 
 int comm_get_unique_id(void* out128) {
   if (!out128) return EIGX_ERR_BAD_ARG;
-  if (!load_rccl()) return EIGX_ERR_INTERNAL;
-  const int rc_id = api.GetUniqueId(out128);
-  if (rc_id != 0) { fprintf(stderr, "[eigx] ncclGetUniqueId failed: %d\n", rc_id); return EIGX_ERR_INTERNAL; }
+  memset(out128, 0, 128);
+  // an ncclUniqueId when RCCL is present (it seeds the RCCL communicators as well); otherwise random bytes --
+  // either way the 128 bytes name the session (and its shared-memory board)
+  if (load_rccl() && api.GetUniqueId(out128) == 0) return EIGX_OK;
+  FILE* f = fopen("/dev/urandom", "rb");
+  size_t got = f ? fread(out128, 1, 128, f) : 0;
+  if (f) fclose(f);
+  if (got != 128) {
+    uint64_t h = fnv1a(&got, sizeof(got)) ^ (uint64_t)getpid() ^ (uint64_t)(now_s() * 1e6);
+    for (int i = 0; i < 16; ++i) { h = h * 6364136223846793005ull + 1442695040888963407ull; memcpy((char*)out128 + 8 * i, &h, 8); }
+  }
   return EIGX_OK;
 }
 
 int comm_init(Context& ctx, const void* uid) {
-  if (!uid) {
-    if (!cbs.allreduce || !cbs.bcast || !cbs.allgather) return EIGX_ERR_BAD_ARG;
-    CommState* cs = new CommState();
-    cs->callbacks = true;
-    ctx.comm = cs;
-    return EIGX_OK;
-  }
-  if (!load_rccl()) return EIGX_ERR_INTERNAL;
-  CommState* cs = new CommState();
-  ncclUniqueIdBlob id;
-  memcpy(id.internal, uid, 128);
+  if (!uid) return EIGX_ERR_BAD_ARG;
   const Grid& g = ctx.grid;
-  // a failed communicator is reported, not fatal: bench.py then falls back to independent replicas
-  const int rc_init = api.CommInitRank(&cs->world, g.nranks, id, g.rank);
-  if (rc_init != 0) {
-    fprintf(stderr, "[eigx] ncclCommInitRank failed: %d (%s)\n", rc_init, api.GetErrorString ? api.GetErrorString(rc_init) : "?");
-    delete cs;
+  if (g.nranks > EIGX_MAXP) {
+    fprintf(stderr, "[eigx] at most %d ranks (one xGMI node) are supported\n", EIGX_MAXP);
+    return EIGX_ERR_BAD_ARG;
+  }
+  CommState* cs = new CommState();
+  cs->P = g.nranks; cs->me = g.rank;
+  if (const char* t = getenv("EIGX_COMM_TIMEOUT_S")) { const double v = atof(t); if (v > 0.0) cs->timeout_s = v; }
+  // ---- board ------------------------------------------------------------------------------------------
+  char name[64];
+  snprintf(name, sizeof(name), "/eigx-%016llx", (unsigned long long)fnv1a(uid, 128));
+  const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+  if (fd < 0) { perror("[eigx] shm_open"); delete cs; return EIGX_ERR_INTERNAL; }
+  if (ftruncate(fd, sizeof(Board)) != 0) { perror("[eigx] ftruncate"); close(fd); delete cs; return EIGX_ERR_INTERNAL; }
+  void* mp = mmap(nullptr, sizeof(Board), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (mp == MAP_FAILED) { perror("[eigx] mmap"); delete cs; return EIGX_ERR_INTERNAL; }
+  cs->board = (Board*)mp;
+  cs->board->attached.fetch_add(1);
+  {
+    const double t0 = now_s();
+    while (cs->board->attached.load() < (uint32_t)cs->P) {
+      if (now_s() - t0 > cs->timeout_s) {
+        fprintf(stderr, "[eigx] rank %d: only %u of %d ranks reached eigx_init_multi\n", cs->me, cs->board->attached.load(), cs->P);
+        shm_unlink(name);
+        munmap(mp, sizeof(Board)); delete cs; return EIGX_ERR_INTERNAL;
+      }
+      usleep(100);
+    }
+  }
+  // ---- local words ------------------------------------------------------------------------------------
+  EIGX_HIP_CHECK(hipMalloc(&cs->counters, CH_COUNT * sizeof(unsigned)));
+  EIGX_HIP_CHECK(hipMemset(cs->counters, 0, CH_COUNT * sizeof(unsigned)));
+  EIGX_HIP_CHECK(hipMalloc(&cs->ticks_dev, sizeof(u64)));
+  EIGX_HIP_CHECK(hipMemset(cs->ticks_dev, 0, sizeof(u64)));
+  EIGX_HIP_CHECK(hipMalloc(&cs->err_dev, sizeof(int)));
+  EIGX_HIP_CHECK(hipMemset(cs->err_dev, 0, sizeof(int)));
+  // ---- flag block + identity exchange -----------------------------------------------------------------
+  InitBlob mine;
+  memset(&mine, 0, sizeof(mine));
+  mine.pid = (int)getpid();
+  if (hipDeviceGetPCIBusId(mine.bus_id, sizeof(mine.bus_id), ctx.device) != hipSuccess) { (void)hipGetLastError(); mine.bus_id[0] = 0; }
+  cs->flags.bytes = kFlagWords * sizeof(u64);
+  cs->flags.local = alloc_window(cs->flags.bytes);
+  mine.ipc_ok = 0;
+  if (cs->flags.local) {
+    EIGX_HIP_CHECK(hipMemset(cs->flags.local, 0, cs->flags.bytes));
+    if (hipIpcGetMemHandle(&mine.flags_handle, cs->flags.local) == hipSuccess) mine.ipc_ok = 1;
+    else (void)hipGetLastError();
+  }
+  if (getenv("EIGX_NO_IPC")) mine.ipc_ok = 0;
+  unsigned char all[EIGX_MAXP][128];
+  if (!board_exchange(cs, &mine, sizeof(mine), all)) {
+    fprintf(stderr, "[eigx] rank %d: bootstrap exchange timed out\n", cs->me);
+    delete cs; return EIGX_ERR_INTERNAL;
+  }
+  if (cs->me == 0) shm_unlink(name);   // everybody has it mapped: the name can go (the memory lives until the last munmap)
+  bool all_ipc = true;
+  for (int q = 0; q < cs->P; ++q) {
+    InitBlob b; memcpy(&b, all[q], sizeof(b));
+    if (!b.ipc_ok) all_ipc = false;
+    for (int r = 0; r < q; ++r) {
+      InitBlob c; memcpy(&c, all[r], sizeof(c));
+      if (b.bus_id[0] && strncmp(b.bus_id, c.bus_id, sizeof(b.bus_id)) == 0) cs->shared_device = true;
+    }
+  }
+  int map_ok = all_ipc ? 1 : 0;
+  if (all_ipc) {
+    for (int q = 0; q < cs->P; ++q) {
+      if (q == cs->me) { cs->flags.peer[q] = cs->flags.local; continue; }
+      InitBlob b; memcpy(&b, all[q], sizeof(b));
+      void* p = nullptr;
+      if (hipIpcOpenMemHandle(&p, b.flags_handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+        (void)hipGetLastError();
+        map_ok = 0;
+        break;
+      }
+      cs->flags.peer[q] = (double*)p;
+    }
+  }
+  {  // the decision must be the same everywhere
+    unsigned char ok_all[EIGX_MAXP][128];
+    if (!board_exchange(cs, &map_ok, sizeof(map_ok), ok_all)) { delete cs; return EIGX_ERR_INTERNAL; }
+    for (int q = 0; q < cs->P; ++q) { int v; memcpy(&v, ok_all[q], sizeof(v)); if (!v) map_ok = 0; }
+  }
+  cs->ipc = map_ok != 0;
+  cs->flags.mapped = cs->ipc;
+  // ---- RCCL: needs one GPU per rank ---------------------------------------------------------------------
+  const char* want = getenv("EIGX_BULK");   // "ipc" forces the peer-window transport for the bulk collectives too
+  const bool try_rccl = !cs->shared_device && !(want && strcmp(want, "ipc") == 0 && cs->ipc);
+  int rccl_ok = 0;
+  if (try_rccl && load_rccl()) {
+    ncclUniqueIdBlob id;
+    memcpy(id.internal, uid, 128);
+    const int rc_init = api.CommInitRank(&cs->world, g.nranks, id, g.rank);
+    if (rc_init != 0) {
+      fprintf(stderr, "[eigx] ncclCommInitRank failed: %d (%s)\n", rc_init, api.GetErrorString ? api.GetErrorString(rc_init) : "?");
+      cs->world = nullptr;
+    } else {
+      // X: ranks that share my py, ordered by px; Y: ranks that share my px, ordered by py (src/eigen_libs0.F:579-585)
+      const int rx = api.CommSplit(cs->world, g.py, g.px, &cs->x, nullptr);
+      const int ry = api.CommSplit(cs->world, g.px, g.py, &cs->y, nullptr);
+      if (rx == 0 && ry == 0) rccl_ok = 1;
+      else fprintf(stderr, "[eigx] ncclCommSplit failed: %d %d\n", rx, ry);
+    }
+  }
+  {
+    unsigned char ok_all[EIGX_MAXP][128];
+    if (!board_exchange(cs, &rccl_ok, sizeof(rccl_ok), ok_all)) { delete cs; return EIGX_ERR_INTERNAL; }
+    for (int q = 0; q < cs->P; ++q) { int v; memcpy(&v, ok_all[q], sizeof(v)); if (!v) rccl_ok = 0; }
+  }
+  cs->rccl = rccl_ok != 0;
+  if (!cs->ipc && !cs->rccl) {
+    fprintf(stderr, "[eigx] rank %d: neither peer windows (hipIpc) nor RCCL are usable between the ranks\n", cs->me);
+    ctx.comm = cs;
+    comm_free(ctx);
     return EIGX_ERR_INTERNAL;
   }
-  // round 1 uses the world communicator only; X / Y groups are split on demand
+  if (getenv("EIGX_TRACE_COMM") && cs->me == 0)
+    fprintf(stderr, "[eigx] transport: peer windows %s, RCCL %s, shared device %s\n", cs->ipc ? "yes" : "no",
+            cs->rccl ? "yes" : "no", cs->shared_device ? "yes" : "no");
   ctx.comm = cs;
   return EIGX_OK;
 }
 
 void comm_free(Context& ctx) {
-  if (!ctx.comm) return;
-  if (ctx.comm->callbacks) { delete ctx.comm; ctx.comm = nullptr; return; }
-  if (ctx.comm->x) api.CommDestroy(ctx.comm->x);
-  if (ctx.comm->y) api.CommDestroy(ctx.comm->y);
-  if (ctx.comm->world) api.CommDestroy(ctx.comm->world);
-  delete ctx.comm;
+  CommState* cs = ctx.comm;
+  if (!cs) return;
+  // nobody unmaps while a peer may still be writing: meet at the board first (bounded)
+  if (cs->board) { int z = 0; unsigned char all[EIGX_MAXP][128]; (void)board_exchange(cs, &z, sizeof(z), all); }
+  for (auto& kv : cs->bufs) {
+    PeerBuf& b = kv.second;
+    for (int q = 0; q < cs->P; ++q)
+      if (q != cs->me && b.peer[q] && b.mapped) { if (hipIpcCloseMemHandle(b.peer[q]) != hipSuccess) (void)hipGetLastError(); }
+  }
+  for (int q = 0; q < cs->P; ++q)
+    if (q != cs->me && cs->flags.peer[q] && cs->flags.mapped) { if (hipIpcCloseMemHandle(cs->flags.peer[q]) != hipSuccess) (void)hipGetLastError(); }
+  if (cs->board) { int z = 0; unsigned char all[EIGX_MAXP][128]; (void)board_exchange(cs, &z, sizeof(z), all); }
+  for (auto& kv : cs->bufs)
+    if (kv.second.local) { if (hipFree(kv.second.local) != hipSuccess) (void)hipGetLastError(); }
+  if (cs->flags.local) { if (hipFree(cs->flags.local) != hipSuccess) (void)hipGetLastError(); }
+  if (cs->x) api.CommDestroy(cs->x);
+  if (cs->y) api.CommDestroy(cs->y);
+  if (cs->world) api.CommDestroy(cs->world);
+  if (cs->counters) (void)hipFree(cs->counters);
+  if (cs->ticks_dev) (void)hipFree(cs->ticks_dev);
+  if (cs->err_dev) (void)hipFree(cs->err_dev);
+  for (hipEvent_t e : cs->tev) (void)hipEventDestroy(e);
+  if (cs->board) munmap(cs->board, sizeof(Board));
+  delete cs;
   ctx.comm = nullptr;
 }
 
-static void* pick(const Context& ctx, CommGroup grp) {
-  return grp == COMM_X ? ctx.comm->x : grp == COMM_Y ? ctx.comm->y : ctx.comm->world;
-}
-int comm_size(const Context& ctx, CommGroup grp) {
-  return grp == COMM_X ? ctx.grid.Px : grp == COMM_Y ? ctx.grid.Py : ctx.grid.nranks;
+PeerBuf* comm_buffer(Context& ctx, const std::string& name, size_t bytes) {
+  CommState* cs = ctx.comm;
+  PeerBuf& b = cs->bufs[name];
+  if (b.bytes >= bytes && b.local) return &b;
+  // (re)allocation is collective: every rank asks for the same size at the same point of the program
+  EIGX_HIP_CHECK(hipDeviceSynchronize());
+  if (cs->ipc) {  // meet before anybody unmaps the old copy
+    int z = 0; unsigned char all[EIGX_MAXP][128];
+    if (!board_exchange(cs, &z, sizeof(z), all)) comm_fail(cs, "buffer exchange timed out");
+  }
+  if (b.local) {
+    for (int q = 0; q < cs->P; ++q)
+      if (q != cs->me && b.peer[q] && b.mapped) { if (hipIpcCloseMemHandle(b.peer[q]) != hipSuccess) (void)hipGetLastError(); }
+    if (cs->ipc) { int z = 0; unsigned char all[EIGX_MAXP][128]; (void)board_exchange(cs, &z, sizeof(z), all); }
+    EIGX_HIP_CHECK(hipFree(b.local));
+    b = PeerBuf();
+  }
+  const size_t want = bytes + bytes / 16 + 256;
+  b.local = cs->ipc ? alloc_window(want) : nullptr;
+  if (!b.local) EIGX_HIP_CHECK(hipMalloc((void**)&b.local, want));
+  b.bytes = want;
+  b.peer[cs->me] = b.local;
+  if (cs->ipc) {
+    BufBlob mine; memset(&mine, 0, sizeof(mine));
+    mine.bytes = want;
+    mine.ok = hipIpcGetMemHandle(&mine.handle, b.local) == hipSuccess ? 1 : 0;
+    if (!mine.ok) (void)hipGetLastError();
+    unsigned char all[EIGX_MAXP][128];
+    if (!board_exchange(cs, &mine, sizeof(mine), all)) { comm_fail(cs, "buffer exchange timed out"); return &b; }
+    bool ok = true;
+    for (int q = 0; q < cs->P && ok; ++q) {
+      BufBlob o; memcpy(&o, all[q], sizeof(o));
+      if (!o.ok || o.bytes != want) { ok = false; break; }
+      if (q == cs->me) continue;
+      void* p = nullptr;
+      if (hipIpcOpenMemHandle(&p, o.handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+      b.peer[q] = (double*)p;
+    }
+    if (!ok) comm_fail(cs, "mapping a peer buffer failed (sizes differ between ranks, or hipIpcOpenMemHandle refused)");
+    b.mapped = ok;
+  }
+  return &b;
 }
 
-static void cb_roundtrip_begin(double* dev, size_t count, std::vector<double>& h, hipStream_t s) {
-  h.resize(count);
-  EIGX_HIP_CHECK(hipMemcpyAsync(h.data(), dev, count * 8, hipMemcpyDeviceToHost, s));
-  EIGX_HIP_CHECK(hipStreamSynchronize(s));
-}
-static void cb_roundtrip_end(double* dev, size_t count, std::vector<double>& h, hipStream_t s) {
-  EIGX_HIP_CHECK(hipMemcpyAsync(dev, h.data(), count * 8, hipMemcpyHostToDevice, s));
-  EIGX_HIP_CHECK(hipStreamSynchronize(s));
+static u64* flag_word(double* block, int ch, int kind, int src) { return (u64*)block + flag_index(ch, kind, src); }
+
+void comm_exchange(Context& ctx, CommGroup grp, const double* send, size_t send_stride, PeerBuf* recv, size_t recv_off,
+                   size_t count, hipStream_t s, CommChannel ch) {
+  CommState* cs = ctx.comm;
+  int members[EIGX_MAXP], mine = 0;
+  const int n = comm_group(ctx, grp, members, &mine);
+  if (n == 1) {
+    if (count && send != recv->local + recv_off)
+      EIGX_HIP_CHECK(hipMemcpyAsync(recv->local + recv_off, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
+    return;
+  }
+  if (cs->failed) return;
+  if (cs->rccl) {
+    rccl_time_begin(cs, s);
+    if (send_stride == 0) {
+      EIGX_NCCL_TRY(cs, api.AllGather(send, recv->local + recv_off, count, kNcclFloat64, pick(cs, grp), s));
+    } else {
+      EIGX_NCCL_TRY(cs, api.GroupStart());
+      for (int r = 0; r < n; ++r) {
+        EIGX_NCCL_TRY(cs, api.Send(send + (size_t)r * send_stride, count, kNcclFloat64, r, pick(cs, grp), s));
+        EIGX_NCCL_TRY(cs, api.Recv(recv->local + recv_off + (size_t)r * count, count, kNcclFloat64, r, pick(cs, grp), s));
+      }
+      EIGX_NCCL_TRY(cs, api.GroupEnd());
+    }
+    rccl_time_end(cs, s);
+    return;
+  }
+  if (!recv->mapped) { comm_fail(cs, "exchange into an unmapped buffer"); return; }
+  const u64 epoch = ++cs->epoch[ch];
+  ReadyArgs R;
+  WaitArgs W;
+  PushArgs A;
+  R.n = W.n = A.n = n;
+  R.epoch = W.epoch = A.epoch = epoch;
+  R.err = W.err = cs->err_dev;
+  R.ticks = W.ticks = A.ticks = cs->ticks_dev;
+  R.limit_ticks = W.limit_ticks = limit_ticks(cs);
+  A.src = send; A.src_stride = send_stride; A.count = count; A.counter = cs->counters + ch;
+  for (int r = 0; r < n; ++r) {
+    const int q = members[r];
+    R.remote[r] = flag_word(cs->flags.peer[q], ch, 1, cs->me);
+    R.local[r] = flag_word(cs->flags.local, ch, 1, q);
+    A.dst[r] = recv->peer[q] + recv_off + (size_t)mine * count;
+    A.flag[r] = flag_word(cs->flags.peer[q], ch, 0, cs->me);
+    W.flag[r] = flag_word(cs->flags.local, ch, 0, q);
+  }
+  hipLaunchKernelGGL(ready_kernel, dim3(1), dim3(64), 0, s, R);
+  if (count > 0) {
+    size_t blocks = (count * n + 4095) / 4096;
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(push_kernel, dim3((unsigned)blocks), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(wait_kernel, dim3(1), dim3(64), 0, s, W);
+  }
 }
 
-void comm_allreduce_sum(const Context& ctx, CommGroup grp, double* buf, size_t count, hipStream_t s) {
-  if (comm_size(ctx, grp) == 1 || count == 0) return;
-  if (ctx.comm->callbacks) {
-    cb_roundtrip_begin(buf, count, stage_a, s);
-    cbs.allreduce(stage_a.data(), (long)count, 0, (int)grp);
-    cb_roundtrip_end(buf, count, stage_a, s);
+static void allreduce_impl(Context& ctx, CommGroup grp, double* buf, size_t count, hipStream_t s, CommChannel ch, int op) {
+  CommState* cs = ctx.comm;
+  const int n = comm_size(ctx, grp);
+  if (n == 1 || count == 0 || cs->failed) return;
+  if (cs->rccl) {
+    rccl_time_begin(cs, s);
+    EIGX_NCCL_TRY(cs, api.AllReduce(buf, buf, count, kNcclFloat64, op, pick(cs, grp), s));
+    rccl_time_end(cs, s);
     return;
   }
-  EIGX_NCCL_CHECK(api.AllReduce(buf, buf, count, kNcclFloat64, kNcclSum, pick(ctx, grp), s));
+  // gather every member's vector, then reduce in member order (same order on every rank)
+  PeerBuf* w = comm_buffer(ctx, ch == CH_SIDE ? "comm.ar.side" : "comm.ar", (size_t)EIGX_MAXP * count * sizeof(double));
+  comm_exchange(ctx, grp, buf, 0, w, 0, count, s, ch);
+  size_t blocks = (count + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(reduce_members_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w->local, count, n, count, op, buf);
 }
-void comm_allreduce_max(const Context& ctx, CommGroup grp, double* buf, size_t count, hipStream_t s) {
-  if (comm_size(ctx, grp) == 1 || count == 0) return;
-  if (ctx.comm->callbacks) {
-    cb_roundtrip_begin(buf, count, stage_a, s);
-    cbs.allreduce(stage_a.data(), (long)count, 2, (int)grp);
-    cb_roundtrip_end(buf, count, stage_a, s);
-    return;
-  }
-  EIGX_NCCL_CHECK(api.AllReduce(buf, buf, count, kNcclFloat64, kNcclMax, pick(ctx, grp), s));
+void comm_allreduce_sum(Context& ctx, CommGroup grp, double* buf, size_t count, hipStream_t s, CommChannel ch) {
+  allreduce_impl(ctx, grp, buf, count, s, ch, kNcclSum);
 }
-void comm_bcast(const Context& ctx, CommGroup grp, double* buf, size_t count, int root, hipStream_t s) {
-  if (comm_size(ctx, grp) == 1 || count == 0) return;
-  if (ctx.comm->callbacks) {
-    cb_roundtrip_begin(buf, count, stage_a, s);
-    cbs.bcast(stage_a.data(), (long)count, root, (int)grp);
-    cb_roundtrip_end(buf, count, stage_a, s);
-    return;
-  }
-  EIGX_NCCL_CHECK(api.Broadcast(buf, buf, count, kNcclFloat64, root, pick(ctx, grp), s));
+void comm_allreduce_max(Context& ctx, CommGroup grp, double* buf, size_t count, hipStream_t s, CommChannel ch) {
+  allreduce_impl(ctx, grp, buf, count, s, ch, kNcclMax);
 }
-void comm_allgather(const Context& ctx, CommGroup grp, const double* send, double* recv, size_t count,
-                    hipStream_t s) {
-  if (comm_size(ctx, grp) == 1) {
-    if (send != recv && count)
-      EIGX_HIP_CHECK(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
+
+void comm_allgather(Context& ctx, CommGroup grp, const double* send, double* recv, size_t count, hipStream_t s,
+                    CommChannel ch) {
+  CommState* cs = ctx.comm;
+  const int n = comm_size(ctx, grp);
+  if (n == 1) {
+    if (send != recv && count) EIGX_HIP_CHECK(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
     return;
   }
-  if (ctx.comm->callbacks) {
-    const size_t np = (size_t)comm_size(ctx, grp);
-    cb_roundtrip_begin(const_cast<double*>(send), count, stage_a, s);
-    stage_b.resize(count * np);
-    cbs.allgather(stage_a.data(), stage_b.data(), (long)count, (int)grp);
-    cb_roundtrip_end(recv, count * np, stage_b, s);
+  if (cs->failed || count == 0) return;
+  if (cs->rccl) {
+    rccl_time_begin(cs, s);
+    EIGX_NCCL_TRY(cs, api.AllGather(send, recv, count, kNcclFloat64, pick(cs, grp), s));
+    rccl_time_end(cs, s);
     return;
   }
-  EIGX_NCCL_CHECK(api.AllGather(send, recv, count, kNcclFloat64, pick(ctx, grp), s));
+  PeerBuf* w = comm_buffer(ctx, ch == CH_SIDE ? "comm.ag.side" : "comm.ag", (size_t)n * count * sizeof(double));
+  comm_exchange(ctx, grp, send, 0, w, 0, count, s, ch);
+  size_t blocks = ((size_t)n * count + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(copy_sys_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w->local, (size_t)n * count, recv);
+}
+
+// ---- per-step exchange ---------------------------------------------------------------------------------------
+double* comm_step_window(Context& ctx, size_t msg_doubles, StepPeers* peers) {
+  CommState* cs = ctx.comm;
+  PeerBuf* w = comm_buffer(ctx, "comm.step", (size_t)2 * cs->P * msg_doubles * sizeof(double));
+  cs->step_msg = msg_doubles;
+  peers->n = cs->P;
+  peers->parity_stride = (size_t)cs->P * msg_doubles;
+  peers->counter = cs->counters + CH_STEP;
+  for (int q = 0; q < EIGX_MAXP; ++q) { peers->slot[q] = nullptr; peers->flag[q] = nullptr; }
+  for (int q = 0; q < cs->P; ++q) {
+    peers->slot[q] = (w->mapped ? w->peer[q] : w->local) + (size_t)cs->me * msg_doubles;
+    peers->flag[q] = flag_word(cs->flags.mapped ? cs->flags.peer[q] : cs->flags.local, CH_STEP, 0, cs->me);
+  }
+  if (!w->mapped) comm_fail(cs, "the per-step exchange needs peer windows (hipIpc) between the ranks");
+  return w->local;
+}
+
+unsigned long long comm_step_epoch_base(Context& ctx, unsigned long long nsteps) {
+  CommState* cs = ctx.comm;
+  const u64 base = cs->epoch[CH_STEP];
+  cs->epoch[CH_STEP] += nsteps;
+  return base;
+}
+
+void comm_step_wait(Context& ctx, unsigned long long epoch, hipStream_t s) {
+  CommState* cs = ctx.comm;
+  WaitArgs W;
+  W.n = cs->P; W.epoch = epoch; W.err = cs->err_dev; W.ticks = cs->ticks_dev; W.limit_ticks = limit_ticks(cs);
+  const int kind = (int)(epoch & 1);
+  for (int q = 0; q < cs->P; ++q) W.flag[q] = flag_word(cs->flags.local, CH_STEP, kind, q);
+  hipLaunchKernelGGL(wait_kernel, dim3(1), dim3(64), 0, s, W);
 }
 
 }  // namespace eigx
 
-// 1-rank RCCL self-test: exercises dlopen, ncclCommInitRank from a unique id and the three collectives the
-// multi-GPU solvers use, on the library's compute stream (a one-GPU box cannot host more RCCL ranks)
+// RCCL self-test on one rank: exercises dlopen, ncclCommInitRank from a unique id, ncclCommSplit and the
+// collectives the multi-GPU solvers use, on the library's compute stream (a one-GPU box cannot host more RCCL ranks)
 extern "C" int eigx_rccl_selftest(void) {
   using namespace eigx;
   if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
   if (!load_rccl()) return EIGX_ERR_INTERNAL;
   EIGX_HIP_CHECK(hipSetDevice(g_ctx.device));
   ncclUniqueIdBlob id;
-  EIGX_NCCL_CHECK(api.GetUniqueId(&id));
-  void* comm = nullptr;
-  EIGX_NCCL_CHECK(api.CommInitRank(&comm, 1, id, 0));
+  if (api.GetUniqueId(&id) != 0) return EIGX_ERR_INTERNAL;
+  void *comm = nullptr, *sub = nullptr;
+  if (api.CommInitRank(&comm, 1, id, 0) != 0) return EIGX_ERR_INTERNAL;
+  if (api.CommSplit(comm, 0, 0, &sub, nullptr) != 0 || !sub) return EIGX_ERR_INTERNAL;
   const int cnt = 1000;
   double *a = nullptr, *b = nullptr;
   EIGX_HIP_CHECK(hipMalloc(&a, cnt * 8));
@@ -218,27 +752,20 @@ extern "C" int eigx_rccl_selftest(void) {
   for (int i = 0; i < cnt; ++i) h[i] = 0.5 * i - 3.0;
   EIGX_HIP_CHECK(hipMemcpy(a, h.data(), cnt * 8, hipMemcpyHostToDevice));
   hipStream_t s = g_ctx.stream;
-  EIGX_NCCL_CHECK(api.AllReduce(a, a, cnt, kNcclFloat64, kNcclSum, comm, s));
-  EIGX_NCCL_CHECK(api.Broadcast(a, a, cnt, kNcclFloat64, 0, comm, s));
-  EIGX_NCCL_CHECK(api.AllGather(a, b, cnt, kNcclFloat64, comm, s));
-  EIGX_NCCL_CHECK(api.AllGather(b, b, cnt, kNcclFloat64, comm, s));  // in-place form used for Z
-  EIGX_HIP_CHECK(hipStreamSynchronize(s));
-  EIGX_HIP_CHECK(hipMemcpy(r.data(), b, cnt * 8, hipMemcpyDeviceToHost));
   int bad = 0;
+  bad += api.AllReduce(a, a, cnt, kNcclFloat64, kNcclSum, sub, s) != 0;
+  bad += api.AllReduce(a, a, cnt, kNcclFloat64, kNcclMax, comm, s) != 0;
+  bad += api.AllGather(a, b, cnt, kNcclFloat64, sub, s) != 0;
+  bad += api.GroupStart() != 0;
+  bad += api.Send(b, cnt, kNcclFloat64, 0, comm, s) != 0;
+  bad += api.Recv(a, cnt, kNcclFloat64, 0, comm, s) != 0;
+  bad += api.GroupEnd() != 0;
+  EIGX_HIP_CHECK(hipStreamSynchronize(s));
+  EIGX_HIP_CHECK(hipMemcpy(r.data(), a, cnt * 8, hipMemcpyDeviceToHost));
   for (int i = 0; i < cnt; ++i) bad += (r[i] != h[i]);
-  EIGX_NCCL_CHECK(api.CommDestroy(comm));
+  api.CommDestroy(sub);
+  api.CommDestroy(comm);
   EIGX_HIP_CHECK(hipFree(a));
   EIGX_HIP_CHECK(hipFree(b));
   return bad == 0 ? EIGX_OK : EIGX_ERR_INTERNAL;
 }
-
-extern "C" int eigx_set_comm_callbacks(eigx_allreduce_cb ar, eigx_bcast_cb bc, eigx_allgather_cb ag) {
-  eigx::cbs.allreduce = ar;
-  eigx::cbs.bcast = bc;
-  eigx::cbs.allgather = ag;
-  return 0;
-}
-
-namespace eigx {
-
-}  // namespace eigx

@@ -1,28 +1,75 @@
-// eigx_comm.h -- collective wrappers over RCCL (see comm.hip).
+// eigx_comm.h -- inter-GPU transport of the multi-rank solvers (see comm.hip).
+//
+// Two layers:
+//   * peer windows: every rank allocates its communication buffers collectively (comm_buffer), exports them with
+//     hipIpcGetMemHandle and maps the other ranks' copies.  Kernels then STORE into the peers' HBM directly
+//     (xGMI is point-to-point and every GPU pair of a node is linked) and signal with 8-byte epoch flags; a
+//     one-wave wait kernel polls the flags on the consumer's stream.  This carries the latency-bound per-step
+//     exchange of the reduction (replaces the hand-written reproducible allreduce, src/comm.F:2035-2580) and,
+//     when RCCL cannot be used (several ranks sharing one GPU in the tests), the bulk collectives as well.
+//   * RCCL communicators world / X / Y (ncclCommSplit, the MPI_Comm_split of src/eigen_libs0.F:579-585) for the
+//     bulk collectives (panel allgather, eigenvector redistribution) when every rank owns its own GPU.
 #pragma once
 #include "eigx_context.h"
+#include <string>
+#include <map>
 
 namespace eigx {
 
-struct ncclUniqueIdBlob { char internal[128]; };
+constexpr int EIGX_MAXP = 8;   // ranks of one xGMI node
 
-struct CommState {
-  void* world = nullptr;  // ncclComm_t
-  void* x = nullptr;      // ranks sharing my py (size Px)
-  void* y = nullptr;      // ranks sharing my px (size Py)
-  bool callbacks = false; // host-staged test transport (see comm.hip)
+// A device buffer that every rank allocated collectively and that is mapped on every peer.
+struct PeerBuf {
+  double* local = nullptr;
+  double* peer[EIGX_MAXP] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // peer[me] == local
+  size_t bytes = 0;
+  bool mapped = false;   // false: plain local allocation (RCCL-only transport)
 };
-
-bool comm_uses_callbacks(const Context& ctx);
 
 enum CommGroup { COMM_WORLD = 0, COMM_X = 1, COMM_Y = 2 };
 
+// flag channels: one per (stream, purpose) so that operations in flight on different streams never share an epoch
+enum CommChannel { CH_STEP = 0, CH_BULK = 1, CH_SIDE = 2, CH_COUNT = 4 };
+
+struct CommState;
+
+// members of a group as world ranks, in group order; returns the group size and my index in it
+int comm_group(const Context& ctx, CommGroup grp, int* members, int* my_index);
 int comm_size(const Context& ctx, CommGroup grp);
-// all in place on device buffers, enqueued on stream s; no-ops for groups of one rank
-void comm_allreduce_sum(const Context& ctx, CommGroup grp, double* buf, size_t count, hipStream_t s);
-void comm_allreduce_max(const Context& ctx, CommGroup grp, double* buf, size_t count, hipStream_t s);
-void comm_bcast(const Context& ctx, CommGroup grp, double* buf, size_t count, int root, hipStream_t s);
-void comm_allgather(const Context& ctx, CommGroup grp, const double* send, double* recv, size_t count,
-                    hipStream_t s);
+bool comm_failed(const Context& ctx);            // a collective timed out or RCCL returned an error
+bool comm_shared_device(const Context& ctx);     // at least two ranks share a GPU (tests)
+double comm_seconds(Context& ctx, bool reset);   // time spent in communication since the last reset (this rank)
+
+// collectively (re)allocated, peer-mapped buffer; grows on demand (every rank must ask for the same size)
+PeerBuf* comm_buffer(Context& ctx, const std::string& name, size_t bytes);
+
+// recv.local[recv_off + r*count + i] = send_r[send_stride * (my index) + i] for every member r of the group
+// (send_stride = 0: allgather; send_stride = count: all-to-all).  Enqueued on s; ch names the flag channel.
+void comm_exchange(Context& ctx, CommGroup grp, const double* send, size_t send_stride, PeerBuf* recv, size_t recv_off,
+                   size_t count, hipStream_t s, CommChannel ch);
+// in place on a device buffer; every rank gets bit-identical results (fixed summation order over the members)
+void comm_allreduce_sum(Context& ctx, CommGroup grp, double* buf, size_t count, hipStream_t s, CommChannel ch = CH_BULK);
+void comm_allreduce_max(Context& ctx, CommGroup grp, double* buf, size_t count, hipStream_t s, CommChannel ch = CH_BULK);
+// plain allgather into a local buffer (staged through an internal peer window)
+void comm_allgather(Context& ctx, CommGroup grp, const double* send, double* recv, size_t count, hipStream_t s,
+                    CommChannel ch = CH_BULK);
+
+// ---- per-step exchange of the reduction (channel CH_STEP, double-buffered by step parity) ---------------------
+// View handed to the producer kernel (band_reduce.hip kl_kernel): where rank `me`'s message of the given parity lives
+// in every rank's window, and which flag word announces it.
+struct StepPeers {
+  double* slot[EIGX_MAXP];                 // slot[q] = start of my message area (parity 0) in rank q's window
+  unsigned long long* flag[EIGX_MAXP];     // flag[q] = my arrival flag (parity 0) in rank q's flag block; parity 1 at +EIGX_MAXP
+  size_t parity_stride;                    // doubles between the parity-0 and parity-1 message areas
+  unsigned* counter;                       // local last-workgroup counter
+  int n;                                   // ranks
+};
+// (re)allocates the step window for messages of msg_doubles each; returns my window (all sources, both parities):
+// message of source q, parity p at  win + (p * P + q) * msg_doubles
+double* comm_step_window(Context& ctx, size_t msg_doubles, StepPeers* peers);
+// one-wave kernel on s: wait until every rank's message of step `epoch` (1-based) has arrived
+void comm_step_wait(Context& ctx, unsigned long long epoch, hipStream_t s);
+// first epoch number of the next reduction (epochs are monotone over the life of the communicator)
+unsigned long long comm_step_epoch_base(Context& ctx, unsigned long long nsteps);
 
 }  // namespace eigx

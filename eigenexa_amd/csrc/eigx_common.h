@@ -57,7 +57,8 @@ static inline int numroc(int n, int nb, int p, int P) {
 
 // C = alpha*op(A)*op(B) + beta*C ; opA/opB in {'N','T'}.
 // tri_mode: 0 = full, 1 = only tiles that intersect the upper triangle (global row <= global col)
-// of a matrix whose local element (i,j) is global (i*Px+px, j*Py+py).
+// of a matrix whose local element (i,j) is global (i*Px+px, j*Py+py), square tile grid, block-triangular order;
+// 2 = the same test on the rectangular local block of a 2-D cyclic distribution (full-mode tile order).
 // batch > 1: `batch` independent products, operand b at A + b*strideA etc. (elements).
 // kmapA (device, optional, opA='N'): A's column for k-index k; cmapC (device, optional): C's column for n.
 // tri mode: ownP/ownp = multi-GPU ownership of 128-column tile columns; [tn_lo, tn_hi) restricts the launch to a

@@ -50,7 +50,7 @@ struct Pool {
   }
 };
 
-struct CommState;  // comm.hip (RCCL communicators for world / X / Y groups)
+struct CommState;  // comm.hip (peer windows + RCCL communicators for world / X / Y groups)
 
 struct Context {
   bool initialized = false;

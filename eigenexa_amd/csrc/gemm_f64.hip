@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   }
   const int m0 = tm * BM, n0 = tn * BN;
 
-  if (g.tri_mode == 1) {
+  if (g.tri_mode != 0) {
     if (g.ownP > 1 && (tn % g.ownP) != g.ownp) return;
     if (tn < g.tn_lo || tn >= g.tn_hi) return;
     // skip tiles strictly below the diagonal: min global row > max global col
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmArgs g) {
     tm = rg * 8 + rem - tn * rows;
   }
   const int m0 = tm * 128, n0 = tn * 128;
-  if (g.tri_mode == 1) {
+  if (g.tri_mode != 0) {
     if (g.ownP > 1 && (tn % g.ownP) != g.ownp) return;
     if (tn < g.tn_lo || tn >= g.tn_hi) return;
     const long grow_min = (long)m0 * g.Px + g.px;
@@ -602,7 +602,7 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128) * batch * batch2;
     if (tri_mode != 0 || t128 >= 192 || g_gemm_variant == 3) {
       int gx2 = ceil_div(M, 128) * ceil_div(N, 128);
-      if (tri_mode != 0) {
+      if (tri_mode == 1) {
         // block-triangular order: needs a square tile grid; GB x GB tile blocks, dealt to the 8 XCDs
         const int t = ceil_div(N > M ? N : M, 128);
         g.tri_gb = (t >= 96) ? 8 : (t >= 24 ? 4 : (t >= 8 ? 2 : 1));

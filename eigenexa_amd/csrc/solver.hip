@@ -17,17 +17,22 @@ void trbak_prepare_dev(Context& ctx, int n, double* A, int lda, const double* e,
                        hipStream_t s);
 void trbak_dev(Context& ctx, int n, int nvec, double* A, int lda, double* Z, int ldz, const double* e,
                int lde, int mb, int band);
+void trbak_mg_dev(Context& ctx, int n, int nvec, const double* Aloc, int lda, double* Z, int ldz, const double* e,
+                  int lde, int mb, int band);
 
 namespace {
 
 // max |a_ij| over the upper triangle and a non-finite flag (eigen_scaling, src/eigen_scaling.F:86-150)
-__global__ __launch_bounds__(256) void absmax_kernel(const double* __restrict__ A, int lda, int n,
-                                                     double* __restrict__ out /* [gridDim.x][2] */) {
+// A is the local block of a 2-D cyclic distribution: local (i, j) = global (i*Px + px, j*Py + py); ncl local columns
+__global__ __launch_bounds__(256) void absmax_kernel(const double* __restrict__ A, int lda, int ncl, int Px, int px, int Py,
+                                                     int py, double* __restrict__ out /* [gridDim.x][2] */) {
   __shared__ double smax[4], sbad[4];
   double mx = 0.0, bad = 0.0;
-  for (int j = blockIdx.x; j < n; j += gridDim.x) {
+  for (int j = blockIdx.x; j < ncl; j += gridDim.x) {
     const double* col = A + (size_t)j * lda;
-    for (int i = threadIdx.x; i <= j; i += 256) {
+    const int gj = j * Py + py;
+    const int iend = gj >= px ? (gj - px) / Px : -1;   // last local row with global row <= gj
+    for (int i = threadIdx.x; i <= iend; i += 256) {
       const double v = fabs(col[i]);
       if (!(v <= DBL_MAX)) bad = 1.0;
       else mx = fmax(mx, v);
@@ -42,10 +47,26 @@ __global__ __launch_bounds__(256) void absmax_kernel(const double* __restrict__ 
   }
 }
 
-__global__ void scale_upper_kernel(double* __restrict__ A, int lda, int n, double s) {
-  for (int j = blockIdx.x; j < n; j += gridDim.x) {
+__global__ void scale_upper_kernel(double* __restrict__ A, int lda, int ncl, int Px, int px, int Py, int py, double s) {
+  for (int j = blockIdx.x; j < ncl; j += gridDim.x) {
     double* col = A + (size_t)j * lda;
-    for (int i = threadIdx.x; i <= j; i += blockDim.x) col[i] *= s;
+    const int gj = j * Py + py;
+    const int iend = gj >= px ? (gj - px) / Px : -1;
+    for (int i = threadIdx.x; i <= iend; i += blockDim.x) col[i] *= s;
+  }
+}
+
+// two-number reduction of the absmax partials on the device (so that the cross-rank MAX can follow on the stream)
+__global__ void absmax_final_kernel(const double* __restrict__ part, int nb, double* __restrict__ out2) {
+  __shared__ double smax[4], sbad[4];
+  double mx = 0.0, bad = 0.0;
+  for (int q = threadIdx.x; q < nb; q += 256) { mx = fmax(mx, part[2 * q]); bad = fmax(bad, part[2 * q + 1]); }
+  for (int o = 32; o > 0; o >>= 1) { mx = fmax(mx, __shfl_xor(mx, o, 64)); bad = fmax(bad, __shfl_xor(bad, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = mx; sbad[threadIdx.x >> 6] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out2[0] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+    out2[1] = fmax(fmax(sbad[0], sbad[1]), fmax(sbad[2], sbad[3]));
   }
 }
 
@@ -105,6 +126,21 @@ __global__ void identity_kernel(double* __restrict__ z, int ldz, int n) {
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) col[r] = (r == j) ? 1.0 : 0.0;
 }
 
+// local blocks of every rank (2-D block-cyclic, block size nb; nb = 1: cyclic) -> replicated full matrix F(ldf, ncols)
+static void gather_full(Context& ctx, const double* a, int lda, int nrows, int ncols, int nb, double* F, int ldf,
+                        hipStream_t st) {
+  const Grid& G = ctx.grid;
+  const int P = G.nranks;
+  const int bx = numroc(nrows, nb, 0, G.Px), by = numroc(ncols, nb, 0, G.Py);   // process 0 holds the largest block
+  const int nr = numroc(nrows, nb, G.px, G.Px), nc = numroc(ncols, nb, G.py, G.Py);
+  double* sendb = ctx.pool.get_t<double>("mg.send", (size_t)bx * by);
+  double* recvb = ctx.pool.get_t<double>("mg.recv", (size_t)bx * by * P);
+  hipLaunchKernelGGL(pack_block_kernel, dim3(8, by), dim3(256), 0, st, a, lda, nr, nc, sendb, bx, by);
+  comm_allgather(ctx, COMM_WORLD, sendb, recvb, (size_t)bx * by, st);
+  hipLaunchKernelGGL(cyclic_to_full_kernel, dim3(8, by, P), dim3(256), 0, st, recvb, bx, by, G.Px, G.Py, G.row_major,
+                     nrows > ncols ? nrows : ncols, nb, F, ldf);
+}
+
 // nb = block size of the 2-D block-cyclic layout of a and z over the process grid (1 = the cyclic layout of the
 // EigenExa API; a ScaLAPACK caller passes its descriptor's MB = NB and needs no pdgemr2d redistribution, manual 3.4)
 int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb,
@@ -118,17 +154,13 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   const int P = G.nranks;
   if (nb < 1) return EIGX_ERR_BAD_ARG;
   const int nloc_r = numroc(n, nb, G.px, G.Px), nloc_c = numroc(n, nb, G.py, G.Py);
-  if (P == 1) {
-    if (lda < n || (lda & 1) || !a || !w) return EIGX_ERR_BAD_ARG;
-  } else {
-    if (lda < nloc_r || !a || !w) return EIGX_ERR_BAD_ARG;
-  }
+  if (lda < (nloc_r > 1 ? nloc_r : 1) || !a || !w) return EIGX_ERR_BAD_ARG;
   if (mode >= 'a' && mode <= 'z') mode = (char)(mode - 'a' + 'A');
   if (nvec == 0) mode = 'N';                      // src/eigen_sx.F:108-110
   if (nvec < 0) nvec = -nvec;
   if (nvec > n) nvec = n;
   const bool want_vec = (mode != 'N');
-  if (want_vec && (!z || ldz < (P == 1 ? n : nloc_r))) return EIGX_ERR_BAD_ARG;
+  if (want_vec && (!z || ldz < (nloc_r > 1 ? nloc_r : 1))) return EIGX_ERR_BAD_ARG;
   if (mf <= 0) mf = 128;
   if (mb <= 0) mb = 128;
   EIGX_HIP_CHECK(hipSetDevice(ctx.device));
@@ -136,29 +168,42 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   ctx.errinfo = 0;
   ctx.dc_zero_n = 0;
   for (int q = 0; q < 16; ++q) ctx.timers[q] = 0.0;
+  if (P > 1) (void)comm_seconds(ctx, true);
   const double t0 = now_s();
 
-  // ---- multi-GPU: gather the 2-D cyclic blocks into a replicated full matrix;
-  // the solver below then works in global indices and shards the reduction by tile-column ownership.
   double* a_user = a;
   double* z_user = z;
-  const int lda_user = lda, ldz_user = ldz;
+  const int ldz_user = ldz;
+  // The kernels read columns in 16-byte pieces: an odd leading dimension (eigen_get_matdims mode 'M' with an odd
+  // ceil(n/Px) produces one) is served from an internal padded copy; `a` is destroyed by contract anyway.
+  // Several GPUs: the cyclic block a(lda, *) is used IN PLACE -- nothing of A is replicated; a block-cyclic caller
+  // (nb > 1, the ScaLAPACK interop entry) is converted to the cyclic layout through a gathered copy first.
+  const int clr = local_count(n, G.Px, G.px), clc = local_count(n, G.Py, G.py);   // cyclic local extents
+  if ((lda & 1) || ((uintptr_t)a & 15) || (P > 1 && nb > 1)) {
+    const int ldi = pad_ld(clr + 2);
+    double* ai = ctx.pool.get_t<double>("sol.apad", (size_t)ldi * (clc > 0 ? clc : 1));
+    if (P > 1 && nb > 1) {
+      const int ldf = pad_ld(n);
+      double* F = ctx.pool.get_t<double>("mg.F", (size_t)ldf * n);
+      gather_full(ctx, a, lda, n, n, nb, F, ldf, st);
+      if (clr > 0 && clc > 0)
+        hipLaunchKernelGGL(full_to_cyclic_kernel, dim3(8, clc), dim3(256), 0, st, F, ldf, clr, n, 1, G.Px, G.px, G.Py, G.py,
+                           ai, ldi);
+    } else if (clr > 0 && clc > 0) {
+      EIGX_HIP_CHECK(hipMemcpy2DAsync(ai, (size_t)ldi * 8, a, (size_t)lda * 8, (size_t)clr * 8, (size_t)clc,
+                                      hipMemcpyDeviceToDevice, st));
+    }
+    a = ai;
+    lda = ldi;
+  }
+  // eigenvector workspace.  One GPU: the caller's z.  Several GPUs: the D&C and the back-transformation work on
+  // whole eigenvector COLUMNS (rank r: columns [r*zc, (r+1)*zc) of the n x nvec matrix); the result is dealt back
+  // into the caller's cyclic z(ldz, *) at the end.
   int zcols_per_rank = 0;
-  if (P > 1) {
-    const int bx = numroc(n, nb, 0, G.Px), by = numroc(n, nb, 0, G.Py);   // process 0 holds the largest block
-    const int ldf = pad_ld(n);
-    double* sendb = ctx.pool.get_t<double>("mg.send", (size_t)bx * by);
-    double* recvb = ctx.pool.get_t<double>("mg.recv", (size_t)bx * by * P);
-    double* Afull = ctx.pool.get_t<double>("mg.A", (size_t)ldf * n);
-    hipLaunchKernelGGL(pack_block_kernel, dim3(8, by), dim3(256), 0, st, a, lda, nloc_r, nloc_c, sendb, bx, by);
-    comm_allgather(ctx, COMM_WORLD, sendb, recvb, (size_t)bx * by, st);
-    const int order_r = G.row_major;
-    hipLaunchKernelGGL(cyclic_to_full_kernel, dim3(8, by, P), dim3(256), 0, st, recvb, bx, by, G.Px, G.Py, order_r, n,
-                       nb, Afull, ldf);
-    a = Afull;
-    lda = ldf;
+  if (P > 1 || (want_vec && ((ldz & 1) || ((uintptr_t)z & 15)))) {
     zcols_per_rank = ceil_div(nvec > 0 ? nvec : 1, P);
     if (want_vec) {
+      const int ldf = pad_ld(n);
       z = ctx.pool.get_t<double>("mg.Z", (size_t)ldf * (size_t)zcols_per_rank * P);
       ldz = ldf;
     }
@@ -167,14 +212,15 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   // ---- eigen_scaling ---------------------------------------------------------------------------
   double sigma = 1.0;
   {
-    const int nb = 512;
-    double* part = ctx.pool.get_t<double>("sol.absmax", (size_t)2 * nb);
-    hipLaunchKernelGGL(absmax_kernel, dim3(nb), dim3(256), 0, st, a, lda, n, part);
-    std::vector<double> hp(2 * nb);
-    EIGX_HIP_CHECK(hipMemcpyAsync(hp.data(), part, hp.size() * 8, hipMemcpyDeviceToHost, st));
+    const int nbk = 512;
+    double* part = ctx.pool.get_t<double>("sol.absmax", (size_t)2 * nbk + 8);
+    hipLaunchKernelGGL(absmax_kernel, dim3(nbk), dim3(256), 0, st, a, lda, clc, G.Px, G.px, G.Py, G.py, part);
+    hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, st, part, nbk, part + 2 * nbk);
+    if (P > 1) comm_allreduce_max(ctx, COMM_WORLD, part + 2 * nbk, 2, st);       // src/eigen_scaling.F:118-123
+    double hp[2] = {0.0, 0.0};
+    EIGX_HIP_CHECK(hipMemcpyAsync(hp, part + 2 * nbk, sizeof(hp), hipMemcpyDeviceToHost, st));
     EIGX_HIP_CHECK(hipStreamSynchronize(st));
-    double anrm = 0.0, bad = 0.0;
-    for (int q = 0; q < nb; ++q) { anrm = std::max(anrm, hp[2 * q]); bad = std::max(bad, hp[2 * q + 1]); }
+    const double anrm = hp[0], bad = hp[1];
     if (bad != 0.0) {  // NaN/Inf in the input: w(:) = NaN and return (src/eigen_sx.F:151-155)
       hipLaunchKernelGGL(fill_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, n,
                          std::numeric_limits<double>::quiet_NaN());
@@ -191,7 +237,8 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
       (void)frexp(anrm, &ex);
       sigma = ldexp(1.0, -ex);
     }
-    if (sigma != 1.0) hipLaunchKernelGGL(scale_upper_kernel, dim3(1024), dim3(256), 0, st, a, lda, n, sigma);
+    if (sigma != 1.0)
+      hipLaunchKernelGGL(scale_upper_kernel, dim3(1024), dim3(256), 0, st, a, lda, clc, G.Px, G.px, G.Py, G.py, sigma);
   }
 
   // ---- forward reduction --------------------------------------------------------------------------
@@ -203,6 +250,7 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   if (!(mode == 'N' || mode == 'S' || mode == 'C')) band_dc_prepare(ctx, n);
   band_reduce_dev(ctx, n, a, lda, d, e, lde, mf, band);
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  if (P > 1 && comm_failed(ctx)) return EIGX_ERR_INTERNAL;
   const double t2 = now_s();
 
   // ---- divide and conquer --------------------------------------------------------------------------
@@ -212,7 +260,7 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   // The T factors of the back-transformation depend on the reflectors only: build them on the side stream while the
   // divide and conquer (launch-bound at its low levels) has the compute stream.  The reduction is complete here
   // (the host synchronised the compute stream above).
-  if (do_bt && nvec > 0) trbak_prepare_dev(ctx, n, a, lda, e, lde, mb, band, ctx.side_stream);
+  if (do_bt && nvec > 0 && P == 1) trbak_prepare_dev(ctx, n, a, lda, e, lde, mb, band, ctx.side_stream);
   if (mode == 'N' || mode == 'S' || mode == 'C') {
     if (want_vec) hipLaunchKernelGGL(identity_kernel, dim3(8, nvec), dim3(256), 0, st, z, ldz, n);
     band_bisect_dev(ctx, n, d, e, lde, band, w);
@@ -227,22 +275,30 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
     if (P == 1) {
       trbak_dev(ctx, n, nvec, a, lda, z, ldz, e, lde, mb, band);
     } else {
-      // eigenvector columns are split over the ranks; every rank holds all reflectors (replicated panels)
+      // eigenvector columns are split over the ranks; the reflectors stay distributed and stream past in column
+      // groups (trbak.hip); no communication inside a group's sweep
       const int c0 = G.rank * zcols_per_rank;
-      const int cnt = (nvec - c0 < zcols_per_rank) ? nvec - c0 : zcols_per_rank;
-      if (cnt > 0) trbak_dev(ctx, n, cnt, a, lda, z + (size_t)c0 * ldz, ldz, e, lde, mb, band);
-      comm_allgather(ctx, COMM_WORLD, z + (size_t)c0 * ldz, z, (size_t)zcols_per_rank * ldz, st);
+      int cnt = (nvec - c0 < zcols_per_rank) ? nvec - c0 : zcols_per_rank;
+      if (cnt < 0) cnt = 0;
+      trbak_mg_dev(ctx, n, cnt, a, lda, z + (size_t)(c0 < nvec ? c0 : 0) * ldz, ldz, e, lde, mb, band);
     }
   }
   if (P > 1 && want_vec) {
+    // column blocks -> the caller's layout
+    const int c0 = G.rank * zcols_per_rank;
+    comm_allgather(ctx, COMM_WORLD, z + (size_t)c0 * ldz, z, (size_t)zcols_per_rank * ldz, st);
     const int nzc = numroc(nvec, nb, G.py, G.Py);
     if (nzc > 0 && nloc_r > 0)
       hipLaunchKernelGGL(full_to_cyclic_kernel, dim3(8, nzc), dim3(256), 0, st, z, ldz, nloc_r, nvec, nb, G.Px, G.px,
                          G.Py, G.py, z_user, ldz_user);
+  } else if (want_vec && z != z_user) {
+    EIGX_HIP_CHECK(hipMemcpy2DAsync(z_user, (size_t)ldz_user * 8, z, (size_t)ldz * 8, (size_t)n * 8, (size_t)nvec,
+                                    hipMemcpyDeviceToDevice, st));
   }
   if (sigma != 1.0 && sigma != 0.0)
     hipLaunchKernelGGL(scale_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, n, 1.0 / sigma);
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  if (P > 1 && comm_failed(ctx)) return EIGX_ERR_INTERNAL;
   const double t4 = now_s();
 
   // ---- statistics (src/eigen_sx.F:285-296) -----------------------------------------------------------
@@ -251,12 +307,14 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   const double f_bt = do_bt ? 2.0 * (double)nvec * n * n : 0.0;
   double ret = f_red + f_dc + f_bt;
   if (f_dc == 0.0) ret = -ret;
+  // a(3,1): seconds this rank spent communicating (waits for peers included), as the reference returns
+  // (src/eigen_sx.F:285-296); -1 on one GPU, where there is none
+  const double t_comm = (P > 1) ? comm_seconds(ctx, false) : -1.0;
   ctx.timers[0] = t4 - t0; ctx.timers[1] = t2 - t1; ctx.timers[2] = t3 - t2; ctx.timers[3] = t4 - t3;
-  ctx.timers[4] = 0.0; ctx.timers[12] = ret;
-  const double stats[3] = {ret, t4 - t0, -1.0};
-  int nst = n >= 3 ? 3 : n;  // a(1:3,1) lives in the first column
-  if (P > 1) { nst = nloc_r >= 3 ? 3 : nloc_r; if (nloc_c == 0) nst = 0; }
-  (void)lda_user;
+  ctx.timers[4] = (P > 1) ? t_comm : 0.0; ctx.timers[12] = ret;
+  const double stats[3] = {ret, t4 - t0, t_comm};
+  int nst = nloc_r >= 3 ? 3 : nloc_r;  // a(1:3,1) lives in the first local column
+  if (nloc_c == 0) nst = 0;
   if (nst > 0) EIGX_HIP_CHECK(hipMemcpyAsync(a_user, stats, (size_t)nst * 8, hipMemcpyHostToDevice, st));
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
   return EIGX_OK;

@@ -16,6 +16,7 @@
 //   4. W = V^T Z,  X = T W,  Z -= V X : three fp64 MFMA GEMMs (the reference's dgemm('T','N') +
 //      dtrsm + dgemm('N','N'))
 #include "eigx_context.h"
+#include "eigx_comm.h"
 #include "../../include/eigenexa_amd.h"
 
 namespace eigx {
@@ -261,6 +262,89 @@ void trbak_dev(Context& ctx, int n, int nvec, double* A, int lda, double* Z, int
   const BtPlan p = bt_plan(n, mb, band);
   bt_apply_range(ctx, nvec, ctx.bt_V, ctx.bt_ldv, Z, ldz, band, band, p.js, p.mb, 1);
   if (p.js < n) bt_apply_range(ctx, nvec, ctx.bt_V, ctx.bt_ldv, Z, ldz, band, p.js, n, p.mb, p.q);
+  EIGX_HIP_CHECK(hipGetLastError());
+}
+
+// ---- several GPUs: reflectors stay 2-D cyclic in the ranks' local blocks and stream past in column groups ---------
+namespace {
+// my rows of my columns of the group [j0, j1): send[ljr*nxc + li], li < nrl (local rows with global row < j1 - band)
+__global__ void pack_refl_kernel(const double* __restrict__ A, int lda, int lj0, int mloc, int nrl, int nxc,
+                                 double* __restrict__ send) {
+  const int ljr = blockIdx.y;
+  if (ljr >= mloc) return;
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < nrl; li += gridDim.x * blockDim.x)
+    send[(size_t)ljr * nxc + li] = A[(size_t)(lj0 + ljr) * lda + li];
+}
+// V(r, c - j0) = reflector entry u_c(r) for r <= c - band (taken from its owner's piece), 0 below: the zero-padded panel
+__global__ void unpack_refl_kernel(const double* __restrict__ recv, size_t count, int nxc, int j0, int j1, int band,
+                                   int rows_pad, int Px, int Py, int row_major, double* __restrict__ V, int ldv) {
+  const int c = j0 + blockIdx.y;
+  if (c >= j1) return;
+  const int qy = c % Py;
+  const int lj0 = (j0 - qy + Py - 1) / Py;
+  const int ljr = c / Py - lj0;
+  const int len = c - band + 1;   // reflector length
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows_pad; r += gridDim.x * blockDim.x) {
+    double v = 0.0;
+    if (r < len) {
+      const int qx = r % Px;
+      const int src = row_major ? qx * Py + qy : qx + qy * Px;
+      v = __hip_atomic_load(recv + (size_t)src * count + (size_t)ljr * nxc + r / Px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    V[(size_t)(c - j0) * ldv + r] = v;
+  }
+}
+}  // namespace
+
+// Z(:, 0:nvec) <- H_n ... H_{1+band} Z for THIS rank's eigenvector columns.  Aloc(lda, *) is the rank's block of the
+// reduced matrix (reflectors in its columns, 2-D cyclic).  The reflectors are gathered group by group -- the plain
+// 128-column blocks of the head range first, then a few super-blocks at a time -- into a zero-padded panel that
+// every rank builds (the reference broadcasts the same panels block by block: trbakwy_datacast + bcast,
+// src/trbakwy4.F:227-650); T factors are formed redundantly (O(mb^2 n) per block), the sweep over Z is local.
+void trbak_mg_dev(Context& ctx, int n, int nvec, const double* Aloc, int lda, double* Z, int ldz, const double* e,
+                  int lde, int mb, int band) {
+  ctx.bt_ready = false;
+  if (n <= band) return;
+  const Grid& G = ctx.grid;
+  hipStream_t st = ctx.stream;
+  const BtPlan p = bt_plan(n, mb, band);
+  const int total = n - band;
+  int rp = p.rows_pad;
+  if (rp < total + 2 * ceil_div(total, 4096) + 2) rp = total + 2 * ceil_div(total, 4096) + 2;   // chunk padding of any group
+  const int ldv = pad_ld(rp);
+  const int group_cols = (p.mbe * 4 > 2048) ? p.mbe * 4 : 2048;          // super-block columns gathered at a time
+  const int plain_cols = (2048 / p.mb > 0 ? 2048 / p.mb : 1) * p.mb;      // plain-block columns gathered at a time
+  const int gmax = group_cols > plain_cols ? group_cols : plain_cols;
+  double* Vg = ctx.pool.get_t<double>("bt.Vgroup", (size_t)ldv * gmax);
+  const int mloc_max = ceil_div(gmax, G.Py) + 1;
+  const int nxs = (ceil_div(n, G.Px) + 7) / 8 * 8;
+  PeerBuf* recv = comm_buffer(ctx, "bt.recv", (size_t)G.nranks * mloc_max * nxs * sizeof(double));
+  double* send = ctx.pool.get_t<double>("bt.send", (size_t)mloc_max * nxs);
+  auto run_group = [&](int j0, int j1, int q) {
+    if (j1 <= j0) return;
+    const int toprows = j1 - band;                      // longest reflector of the group
+    const int nxc = (ceil_div(toprows, G.Px) + 7) / 8 * 8;
+    const size_t cnt = (size_t)(ceil_div(j1 - j0, G.Py) + 1) * nxc;
+    const int lj0 = (j0 - G.py + G.Py - 1) / G.Py;
+    const int lj1 = (j1 - 1 >= G.py) ? (j1 - 1 - G.py) / G.Py : -1;
+    const int mloc = lj1 - lj0 + 1;
+    const int nrl = local_count(toprows, G.Px, G.px);
+    if (mloc > 0 && nrl > 0)
+      hipLaunchKernelGGL(pack_refl_kernel, dim3(ceil_div(nrl, 256) < 64 ? ceil_div(nrl, 256) : 64, mloc), dim3(256), 0, st,
+                         Aloc, lda, lj0, mloc, nrl, nxc, send);
+    comm_exchange(ctx, COMM_WORLD, send, 0, recv, 0, cnt, st, CH_BULK);
+    // zero padding: the Gram chunks of the range read whole chunks of rows
+    const BtRange g = bt_range_geom(ctx, band, j0, j1, p.mb, q);
+    int rows_pad = g.maxchunks * g.gch;
+    if (rows_pad > ldv) rows_pad = ldv;
+    hipLaunchKernelGGL(unpack_refl_kernel, dim3(ceil_div(rows_pad, 256) < 64 ? ceil_div(rows_pad, 256) : 64, j1 - j0), dim3(256),
+                       0, st, (const double*)recv->local, cnt, nxc, j0, j1, band, rows_pad, G.Px, G.Py, G.row_major, Vg, ldv);
+    double* Vs = Vg - (size_t)j0 * ldv;                 // so that column j of the panel is Vs + j*ldv
+    bt_prepare_range(ctx, st, n, Vs, ldv, e, lde, band, j0, j1, p.mb, q);
+    if (nvec > 0) bt_apply_range(ctx, nvec, Vs, ldv, Z, ldz, band, j0, j1, p.mb, q);
+  };
+  for (int j0 = band; j0 < p.js; j0 += plain_cols) run_group(j0, (j0 + plain_cols < p.js) ? j0 + plain_cols : p.js, 1);
+  for (int j0 = p.js; j0 < n; j0 += group_cols) run_group(j0, (j0 + group_cols < n) ? j0 + group_cols : n, p.q);
   EIGX_HIP_CHECK(hipGetLastError());
 }
 

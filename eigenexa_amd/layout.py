@@ -46,13 +46,16 @@ def scatter_cyclic(a_global, nranks, rank, order="C", nx=None, ny=None):
     return out
 
 
-def gather_cyclic(blocks, n0, n1, order="C"):
-    """inverse of scatter_cyclic: blocks[rank] -> global (n0, n1) matrix."""
+def gather_cyclic(blocks, n0, n1, order="C", dims=None):
+    """inverse of scatter_cyclic: blocks[rank] -> global (n0, n1) matrix; dims = explicit (Px, Py) grid"""
     nranks = len(blocks)
-    Px, Py = grid_shape(nranks)
+    Px, Py = dims or grid_shape(nranks)
     out = np.zeros((n0, n1), dtype=blocks[0].dtype)
     for rank, b in enumerate(blocks):
-        px, py = rank_coords(rank, nranks, order)
+        if dims:
+            px, py = (rank // Py, rank % Py) if order in ("R", "r") else (rank % Px, rank // Px)
+        else:
+            px, py = rank_coords(rank, nranks, order)
         r = local_count(n0, px, Px)
         c = local_count(n1, py, Py)
         out[px::Px, py::Py] = b[:r, :c]

@@ -48,30 +48,38 @@ extern "C" {
  * Single-rank form: 1x1 grid on HIP device `device`. */
 int eigx_init(int device);
 
-/* Multi-rank form (one process per GPU).  `nranks` processes call this collectively; the grid is
- * Px = largest divisor of nranks <= sqrt(nranks), Py = nranks/Px, column-major rank order
- * (src/eigen_libs0.F:526-570).  `rccl_unique_id` is the 128-byte ncclUniqueId created by
- * eigx_get_rccl_unique_id() on rank 0 and broadcast by the caller (MPI_Bcast in a Fortran/MPI
- * host, torch.distributed in bench.py).  Replaces MPI_Comm_dup/MPI_Comm_split of
- * eigen_init_comm_setup/eigen_init_cartesian_check, src/eigen_libs0.F:382-428, :579-715. */
-int eigx_init_multi(int device, int rank, int nranks, const void* rccl_unique_id, char order);
+/* Multi-rank form (one process per GPU, all on one xGMI node).  `nranks` processes call this collectively; the
+ * grid is Px = largest divisor of nranks <= sqrt(nranks), Py = nranks/Px, column-major rank order
+ * (src/eigen_libs0.F:526-570).  `session_id` is the 128-byte id created by eigx_get_rccl_unique_id() on rank 0
+ * and broadcast by the caller (MPI_Bcast in a Fortran/MPI host, torch.distributed in bench.py): an ncclUniqueId
+ * when RCCL is installed (it also seeds the world / X / Y RCCL communicators), random bytes otherwise.  The ranks
+ * find each other through a POSIX shared-memory board named after it, exchange hipIpcMemHandles of their
+ * communication windows and map them: kernels then write into the peers' HBM over xGMI directly.
+ * Replaces MPI_Comm_dup/MPI_Comm_split of eigen_init_comm_setup/eigen_init_cartesian_check,
+ * src/eigen_libs0.F:382-428, :579-715.  Several ranks may share one GPU (the tests do): RCCL is then not used and
+ * every collective goes through the peer windows.  Environment: EIGX_COMM_TIMEOUT_S (default 120) bounds every wait
+ * for a peer; EIGX_BULK=ipc keeps the bulk collectives off RCCL. */
+int eigx_init_multi(int device, int rank, int nranks, const void* session_id, char order);
+/* visible HIP devices (0 without a GPU): lets an MPI host map its node-local rank to a device
+ * (eigen_libs_mod.F90: MPI_Comm_split_type + modulo) */
+int eigx_get_device_count(void);
 int eigx_get_rccl_unique_id(void* out128);
 /* Explicit Px x Py process grid for the NEXT eigx_init_multi call (one-shot; 0, 0 clears): the 2-D cartesian
  * communicator form of eigen_init (eigen_init_cartesian_check, src/eigen_libs0.F:579-715), which the reference's
  * benchmark driver builds for its -x option (benchmark/main2.f:193-211). */
 int eigx_set_grid_dims(int px, int py);
 
-/* Test transport for the N>1 path on machines where RCCL cannot be used (several ranks sharing one GPU):
- * the collectives of the multi-rank solvers are delegated to host callbacks (buffers are host pointers;
- * op 0 = sum, 2 = max; group 0 = world, 1 = X, 2 = Y).  Register them, then call
- * eigx_init_multi(..., rccl_unique_id = NULL, ...).  tests/ use gloo-backed callbacks; bench.py never does. */
-typedef void (*eigx_allreduce_cb)(double* buf, long count, int op, int group);
-typedef void (*eigx_bcast_cb)(double* buf, long count, int root, int group);
-typedef void (*eigx_allgather_cb)(const double* send, double* recv, long count, int group);
-int eigx_set_comm_callbacks(eigx_allreduce_cb allreduce, eigx_bcast_cb bcast, eigx_allgather_cb allgather);
+/* replaces eigen_get_comm src/eigen_libs0.F:1655-1669 as far as a GPU library can: what the caller needs to build
+ * its own row / column communicators -- the colour and key of this rank in the X group (ranks sharing my column
+ * coordinate: colour = y_id, key = x_id) and in the Y group (colour = x_id, key = y_id), 1-based ids. */
+int eigx_get_comm(int* x_color, int* x_key, int* y_color, int* y_key);
 
-/* 1-rank RCCL self-test (dlopen, communicator from a unique id, allreduce / broadcast / allgather on the
- * library stream): validates the RCCL plumbing on a one-GPU box.  Returns 0 on success. */
+/* Seconds this rank spent in communication (pushes, waits for peers, RCCL calls) during the last solve:
+ * the a(3,1) statistic of src/eigen_sx.F:285-296 and the "COMM_STAT" tables of src/eigen_devel.F:364-526. */
+double eigx_comm_seconds(void);
+
+/* 1-rank RCCL self-test (dlopen, communicator from a unique id, ncclCommSplit, allreduce / allgather / send-recv on
+ * the library stream): validates the RCCL plumbing on a one-GPU box.  Returns 0 on success. */
 int eigx_rccl_selftest(void);
 
 /* replaces eigen_free  src/eigen_libs.F:204-216 */
@@ -91,6 +99,8 @@ int eigx_get_errinfo(int64_t* info);
  * src/eigen_libs0.F:1254-1371.  Returns local array extents that are >= the reference's for the
  * same (n, grid) so existing callers' allocations stay valid; nx = ny = -1 if too large. */
 int eigx_get_matdims(int n, int* nx, int* ny, int m_forward, int m_backward, char mode);
+/* the same rule for an explicit x_procs x y_procs grid; pure arithmetic (usable before eigx_init, without a GPU) */
+int eigx_matdims_for_grid(int n, int x_procs, int y_procs, int m_forward, int m_backward, char mode, int* nx, int* ny);
 
 /* replaces eigen_memory_internal src/eigen_libs0.F:1395-1549: bytes of device workspace a solve needs */
 int64_t eigx_memory_internal(int n, int lda, int ldz, int m_forward, int m_backward);

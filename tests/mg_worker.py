@@ -1,5 +1,8 @@
-"""Worker of the multi-rank GPU test: `world` processes share GPU 0, collectives go through the host-staged
-gloo transport (RCCL refuses duplicate devices).  argv: rank world port n route [nb]
+"""Worker of the multi-rank GPU test: `world` processes share GPU 0 and run the complete N>1 path -- 2-D cyclic
+ownership of A, per-step peer-write exchange, panel gathers, streamed back-transformation -- over the device-side
+peer-window transport (hipIpc-mapped buffers: the same kernels that run over xGMI between the GPUs of a node; RCCL
+refuses duplicate devices).  gloo only carries the 128-byte session id and the test's own result gathering.
+argv: rank world port n route [nb] [PxxPy]
 nb > 0: the local blocks are those of a 2-D block-cyclic (nb x nb) distribution and go through eigen_sx_bc / eigen_s_bc"""
 import os
 import sys
@@ -12,14 +15,16 @@ import torch.distributed as dist
 
 rank, world, port, n, route = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
 nb = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+dims = tuple(int(v) for v in sys.argv[7].split("x")) if len(sys.argv) > 7 and "x" in sys.argv[7] else None
+os.environ.setdefault("EIGX_COMM_TIMEOUT_S", "60")
 dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
 import eigenexa_amd as ee
 from eigenexa_amd import api, layout
 
-ee.eigen_init(comm=True, device=0)
+ee.eigen_init(comm=True, device=0, dims=dims)
 procs, xp, yp = ee.eigen_get_procs()
 idn, xi, yi = ee.eigen_get_id()
-assert (xp, yp) == layout.grid_shape(world) and idn == rank + 1
+assert (xp, yp) == (dims or layout.grid_shape(world)) and idn == rank + 1
 px, py = xi - 1, yi - 1
 A = layout.random_symmetric(n)
 if route == "h":
@@ -42,7 +47,7 @@ if route == "h":
     bi = [torch.zeros(zl.shape, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(br, torch.from_numpy(np.ascontiguousarray(zl.real)))
     dist.all_gather(bi, torch.from_numpy(np.ascontiguousarray(zl.imag)))
-    Z = layout.gather_cyclic([r_.numpy() + 1j * i_.numpy() for r_, i_ in zip(br, bi)], n, n)
+    Z = layout.gather_cyclic([r_.numpy() + 1j * i_.numpy() for r_, i_ in zip(br, bi)], n, n, dims=dims)
     wr = np.linalg.eigvalsh(A)
     werr = np.abs(w - wr).max() / np.abs(wr).max()
     eps = np.finfo(float).eps
@@ -73,7 +78,7 @@ if nb == 0:
     zl[: len(rows), : len(cols)] = z[: len(rows), : len(cols)]
     blocks = [torch.zeros(zl.shape, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(blocks, torch.from_numpy(np.ascontiguousarray(zl)))
-    Z = layout.gather_cyclic([b.numpy() for b in blocks], n, n)
+    Z = layout.gather_cyclic([b.numpy() for b in blocks], n, n, dims=dims)
 else:
     # ScaLAPACK-style caller: descriptor MB = NB = nb on the same process grid, local extents from NUMROC
     rows = layout.block_cyclic_indices(n, nb, px, xp)
@@ -99,7 +104,16 @@ wt = torch.from_numpy(w.copy())
 dist.broadcast(wt, src=0)
 assert np.array_equal(wt.numpy(), w), "w must be bit-identical on every rank (replicated)"
 assert werr < 1e-12 and res < 768 and orth < 8, (werr, res, orth)
-assert abs(a[0, 0]) > 0 if (px == 0 and py == 0) else True
+if rank == 0 and n <= 1200:
+    # the CPU oracle on the same matrix (tests only): eigenvalues to 1e-12, and the oracle's own eigenvectors must
+    # span the same invariant subspaces (checked through the residual of the GPU vectors, above)
+    from oracle import orc
+
+    wo = orc.eigen(A, route)[0]
+    assert np.abs(w - wo).max() / np.abs(wo).max() < 1e-12
+if px == 0 and py == 0 and len(rows) >= 3:
+    # a(1:3,1) statistics: flops, seconds, communication seconds (src/eigen_sx.F:285-296)
+    assert abs(a[0, 0]) > 0 and a[1, 0] > 0 and 0 <= a[2, 0] <= a[1, 0] * 1.5, (a[0, 0], a[1, 0], a[2, 0])
 ee.eigen_free()
 dist.barrier()
 dist.destroy_process_group()

@@ -333,13 +333,21 @@ def test_baseline_size_properties(gpu_lib, route):
     assert (w[1:] >= w[:-1]).all()                                             # ascending
 
 
-@pytest.mark.parametrize("world,n,route,nb", [(2, 300, "sx", 0), (4, 517, "sx", 0), (4, 300, "s", 0), (3, 260, "sx", 0),
-                                              (4, 517, "sx", 32), (4, 301, "s", 7), (2, 260, "sx", 64),
-                                              (4, 200, "h", 0), (3, 131, "h", 0), (2, 1900, "sx", 0)])
-def test_multi_rank_solver_on_one_gpu(world, n, route, nb):
-    """the N>1 path (tile-column sharded reduction, replicated D&C, column-parallel back-transform, 2-D cyclic
-    API layout) with `world` ranks sharing the GPU over the host-staged gloo transport; nb > 0: ScaLAPACK-style
-    block-cyclic local blocks through eigen_sx_bc / eigen_s_bc (ragged last blocks, ranks without a last block)"""
+@pytest.mark.parametrize("world,n,route,nb,dims", [
+    (2, 300, "sx", 0, ""), (2, 301, "s", 0, "2x1"), (4, 517, "sx", 0, ""), (4, 300, "s", 0, ""), (3, 260, "sx", 0, ""),
+    (6, 700, "sx", 0, "2x3"), (6, 333, "s", 0, "3x2"), (4, 1111, "sx", 0, "1x4"), (4, 515, "s", 0, "4x1"),
+    (4, 517, "sx", 32, ""), (4, 301, "s", 7, ""), (2, 260, "sx", 64, ""),
+    (2, 97, "sx", 0, ""), (4, 129, "sx", 0, ""), (3, 65, "s", 0, ""), (4, 3, "sx", 0, ""), (4, 1, "s", 0, ""),
+    (2, 2, "sx", 0, ""), (4, 5, "s", 0, ""), (6, 7, "sx", 0, "2x3"),
+    (4, 200, "h", 0, ""), (3, 131, "h", 0, ""), (2, 1900, "sx", 0, ""), (4, 2500, "sx", 0, "")])
+def test_multi_rank_solver_on_one_gpu(world, n, route, nb, dims):
+    """the N>1 path -- 2-D cyclic ownership of A (nothing replicated), one peer-write exchange per reduction step,
+    panel gathers, local trailing update, streamed back-transformation -- with `world` ranks sharing the GPU over
+    the hipIpc peer-window transport (the device code that runs over xGMI on a multi-GPU node), on 1x2, 2x1, 2x2,
+    1x3, 2x3, 3x2, 1x4 and 4x1 grids, against LAPACK and the CPU oracle; nb > 0: ScaLAPACK-style block-cyclic local
+    blocks through eigen_sx_bc / eigen_s_bc (ragged last blocks, ranks without a last block).  The box admits six
+    processes on the card, so the 2x4 grid of the 8-GPU node is covered by the CPU tests of the index arithmetic
+    (tests/test_host.py) and by the 2x3 / 3x2 / 1x4 / 4x1 grids here."""
     import socket
     import subprocess
     import sys
@@ -349,7 +357,7 @@ def test_multi_rank_solver_on_one_gpu(world, n, route, nb):
     port = s.getsockname()[1]
     s.close()
     script = os.path.join(os.path.dirname(__file__), "mg_worker.py")
-    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port), str(n), route, str(nb)],
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port), str(n), route, str(nb), dims or "-"],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
@@ -912,6 +920,32 @@ def test_fortran_caller_over_iso_c_binding(gpu_lib):
             errs[name] = float(line.split("=")[2].split()[0])
     assert set(errs) == {"eigen_sx", "eigen_s", "eigen_h"}, out.stdout
     assert all(v < 1e-8 for v in errs.values()), errs      # cond(Frank, n=1000) ~ 1.6e6
+
+
+@pytest.mark.parametrize("np_", [1, 2, 4])
+def test_reference_style_mpi_caller(gpu_lib, np_):
+    """tests/fortran/ref_caller.F90 -- a caller that uses exactly the eigen_libs_mod symbol set of the reference's own
+    benchmark sources (benchmark/main2.f, benchmark/mat_set.f: eigen_init(order=), eigen_get_comm, eigen_get_version(date=),
+    get_constant_pai/eps, eigen_get_matdims(mode='O'), eigen_memory_internal, eigen_loop_start/_end, eigen_translate_l2g/_g2l,
+    eigen_owner_node, eigen_sx / eigen_s with keyword arguments, eigen_show_version, eigen_NB) -- compiled against the
+    module's MPI build (`include 'mpif.h'`, the image's flang + MPICH) and run with 1, 2 and 4 MPI ranks on this GPU:
+    the session id travels by MPI_Bcast, the ranks talk through hipIpc peer windows."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "eigenexa_amd", "fortran", "_build", "mpi", "ref_caller")
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not os.path.exists(exe):
+        if not (os.path.exists("/opt/rocm/lib/llvm/bin/flang") and os.path.exists("/opt/conda/include/mpif.h")):
+            pytest.skip("no flang / MPI in this image")
+        subprocess.check_call(["bash", os.path.join(root, "eigenexa_amd", "fortran", "build.sh")])
+    if np_ > 1 and not os.path.exists(mpiexec):
+        pytest.skip("no mpiexec in this image")
+    cmd = [exe] if np_ == 1 else [mpiexec, "-np", str(np_), exe]
+    env = dict(os.environ, EIGX_COMM_TIMEOUT_S="60")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "REF_CALLER PASSED" in out.stdout, out.stdout + out.stderr
+    assert f"ranks {np_} " in out.stdout
 
 
 def test_randomised_call_sequence(gpu_lib):

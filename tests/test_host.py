@@ -219,3 +219,163 @@ def test_numroc_and_block_cyclic_layout():
     # nb = 1 block-cyclic == cyclic
     for r in range(4):
         assert (layout.scatter_block_cyclic(A, 1, 4, r) == layout.scatter_cyclic(A, 4, r)).all()
+
+
+# ---------------------------------------------------------------------------- eigen_get_matdims >= the reference's
+def _ref_cstab_optdim(n_min, n_unroll=6, delta_l1=64, delta_l2=128):
+    """CSTAB_get_optdim restated (src/CSTAB.F:73-131) with the A64FX constants of src/CSTAB.h (the ones compiled in)"""
+    L1_SIZE, L1_WAY, L1_LINE = 64 * 1024, 4, 256
+    L2_SIZE, L2_WAY = 8 * 1024 * 1024, 16
+    L1_LSIZE, L1_WINDOW, L2_LSIZE = (L1_SIZE // L1_WAY) // 8, L1_LINE // 8, (L2_SIZE // L2_WAY) // 8
+
+    def fmod(a, b):  # Fortran MOD: sign of the dividend
+        return int(np.fmod(a, b))
+
+    n_opt = n_min
+    while True:
+        n_opt = (n_opt - 1) // L1_WINDOW + 1
+        n_opt = (n_opt // 2) * 2 + 1
+        n_opt *= L1_WINDOW
+        n_delta = 0
+        for lsize, way, delta in ((L1_LSIZE, L1_WAY, delta_l1), (L2_LSIZE, L2_WAY, delta_l2)):
+            for i in range(1, int((n_unroll * 1.2 - 1.0) / way + 1) + 1):
+                k = fmod(i * n_opt + lsize // 2, lsize) - lsize // 2
+                if abs(k) <= delta // 2:
+                    n_delta = (delta // 2 - k - 1) // i + 1
+                    break
+            if n_delta:
+                break
+        if n_delta == 0:
+            return n_opt
+        n_opt += n_delta
+
+
+def _ref_matdims(n, Px, Py, m_b=128, mode="O"):
+    """eigen_get_matdims of the reference's default build: eigen_get_matdims0 (src/eigen_libs0.F:1270-1343) max-ed
+    with FS_get_matdims (src/eigen_libs.F:139-146, src/FS_libs.F90:356-375)"""
+    if mode == "M":
+        nx, ny = (n - 1) // Px + 1, (n - 1) // Py + 1
+    elif mode == "L":
+        nx = ((n - 1) // Px + 1 - 1) // 32 * 32 + 32
+        ny = (n - 1) // Py + 1
+    else:
+        nm = _ref_cstab_optdim((n - 1) // Px + 1)
+        NB = max(m_b, 64)
+
+        def ext(P):
+            v = (n - 1) // P + 1
+            v = ((v - 1) // NB + 1) * NB + 1
+            v2 = (((n - 1) // NB + 1) - 1) // P + 1
+            return max(v, v2 * NB)
+
+        larray = max(ext(Px), nm) * ext(Py)
+        nx, ny = nm, (larray - 1) // nm + 1
+    P = Px * Py
+    n1 = (n + P - 1) // P
+    return max(nx, n1 * (P // Px)), max(ny, n1 * (P // Py))
+
+
+def test_matdims_not_smaller_than_reference():
+    """callers allocate a(nx, ny), z(nx, ny) from eigen_get_matdims, so the extents returned here must be
+    >= the reference's for the same (n, grid, m_backward, mode) -- sizes 1..70000, every grid of up to 8 ranks"""
+    import ctypes as C
+
+    from eigenexa_amd import _lib
+
+    lib = _lib.load()
+    sizes = list(range(1, 140)) + [255, 256, 257, 1000, 1024, 4095, 4096, 4097, 8192, 10000, 16384, 23168, 32768,
+                                   40000, 65536, 70000]
+    grids = [(1, 1), (1, 2), (2, 1), (1, 3), (2, 2), (1, 5), (2, 3), (3, 2), (1, 7), (2, 4), (4, 2), (1, 8)]
+    for Px, Py in grids:
+        for mode in "OML":
+            for mb in (128, 48, 256):
+                for n in sizes:
+                    nx, ny = C.c_int(), C.c_int()
+                    rc = lib.eigx_matdims_for_grid(n, Px, Py, 48, mb, mode.encode(), C.byref(nx), C.byref(ny))
+                    rx, ry = _ref_matdims(n, Px, Py, mb, mode)
+                    if rc == -3:   # 32-bit guard (src/eigen_libs0.F:1349-1365): the reference refuses as well
+                        side = (((n - 1) // min(Px, Py) + 1 - 1) // 64 + 1) * 64
+                        assert side * side >= 2 ** 31
+                        continue
+                    assert rc == 0 and nx.value >= rx and ny.value >= ry, (n, Px, Py, mode, mb, nx.value, ny.value, rx, ry)
+                    assert nx.value >= (n + Px - 1) // Px and ny.value >= (n + Py - 1) // Py
+
+
+# ------------------------------------------------- 2-D cyclic partition of the reduction step: index arithmetic on the CPU
+def _mg_nty(tx, T, Lc, Px, px, Py, py):
+    """tiles of tile column tx of a rank's local block (band_reduce.hip mg_nty)"""
+    lc = min(tx * T + T - 1, Lc - 1)
+    num = lc * Py + py - px
+    return num // (Px * T) + 1 if num >= 0 else 0
+
+
+@pytest.mark.parametrize("Px,Py", [(1, 2), (2, 1), (2, 2), (1, 3), (2, 3), (3, 2), (2, 4), (4, 2), (1, 8)])
+def test_step_partition_covers_the_upper_triangle(Px, Py):
+    """What one reduction step does on a Px x Py grid (the 2x4 grid of the 8-GPU node included, which the one-GPU box
+    cannot host: it admits six processes), restated with numpy from the kernels' index formulas: every rank walks
+    the tiles of its local block that mg_nty enumerates, masks by global indices, forms row / column partial sums;
+    the consumer adds the Py row-sum and Px column-sum contributions of a row.  Checks (a) every element of the
+    global upper triangle is visited exactly once over all ranks, (b) the assembled vector equals A_sym u, (c) the
+    closed form the GPU uses to invert the tile numbering (Px | Py) agrees with the enumeration, (d) the first
+    tile column with work for a tile row (kl_kernel's txmin) is the first enumerated one."""
+    rng = np.random.default_rng(5)
+    for L, T in ((37, 8), (64, 8), (130, 16), (257, 32)):
+        A = rng.standard_normal((L, L))
+        A = A + A.T
+        u = rng.standard_normal(L)
+        visits = np.zeros((L, L), dtype=int)
+        yr = {}
+        yc = {}
+        for px in range(Px):
+            for py in range(Py):
+                rows = np.arange(px, L, Px)
+                cols = np.arange(py, L, Py)
+                Lr, Lc = len(rows), len(cols)
+                r_sum = np.zeros(Lr)
+                c_sum = np.zeros(Lc)
+                ntc = -(-Lc // T) if Lc else 0
+                ntiles = 0
+                starts = []
+                for tx in range(ntc):
+                    nty = _mg_nty(tx, T, Lc, Px, px, Py, py)
+                    starts.append(ntiles)
+                    ntiles += nty
+                    for ty in range(nty):
+                        rr = rows[ty * T:(ty + 1) * T]
+                        cc = cols[tx * T:(tx + 1) * T]
+                        assert len(rr) > 0, "an enumerated tile has rows"
+                        blk = A[np.ix_(rr, cc)]
+                        strict = rr[:, None] < cc[None, :]
+                        upper = rr[:, None] <= cc[None, :]
+                        visits[np.ix_(rr, cc)] += upper
+                        r_sum[ty * T:ty * T + len(rr)] += (blk * strict) @ u[cc]
+                        c_sum[tx * T:tx * T + len(cc)] += (blk * upper).T @ u[rr]
+                    # no tile below the enumerated ones touches the upper triangle
+                    for ty in range(nty, -(-Lr // T) if Lr else 0):
+                        assert rows[ty * T] > cols[min(tx * T + T - 1, Lc - 1)]
+                # closed form of the numbering when Px divides Py (symv_kernel): column tx starts at s tx(tx-1)/2 + c1 tx
+                if Py % Px == 0 and ntc > 1:
+                    s = Py // Px
+                    c1 = ((T - 1) * Py + py - px) // (Px * T) + 1
+                    for tx in range(ntc - 1):
+                        assert starts[tx] == s * (tx * (tx - 1) // 2) + c1 * tx
+                # kl_kernel: first tile column with a tile in tile row ty
+                for ty in range(-(-Lr // T) if Lr else 0):
+                    g0 = ty * T * Px + px
+                    cneed = (g0 - py + Py - 1) // Py if g0 > py else 0
+                    have = [tx for tx in range(ntc) if _mg_nty(tx, T, Lc, Px, px, Py, py) > ty]
+                    if cneed <= Lc - 1:
+                        assert have and have[0] == cneed // T and have == list(range(cneed // T, ntc))
+                    else:
+                        assert not have
+                yr[(px, py)] = r_sum
+                yc[(px, py)] = c_sum
+        iu = np.triu_indices(L)
+        assert (visits[iu] == 1).all() and (np.tril(visits, -1) == 0).all()
+        y = np.zeros(L)
+        for r in range(L):
+            for qy in range(Py):            # K_A: Py row-sum contributions, then Px column-sum contributions
+                y[r] += yr[(r % Px, qy)][r // Px]
+            for qx in range(Px):
+                y[r] += yc[(qx, r % Py)][r // Py]
+        assert np.allclose(y, A @ u, rtol=1e-12, atol=1e-12)
