@@ -241,6 +241,13 @@ int64_t eigx_memory_internal(int n, int lda, int ldz, int m_forward, int m_backw
   return solver_workspace_bytes(g_ctx, n, lda, ldz, m_forward, m_backward);
 }
 
+int64_t eigx_held_bytes(void) {
+  if (!g_ctx.initialized) return -1;
+  int64_t t = 0;
+  for (const auto& kv : g_ctx.pool.bufs) t += (int64_t)kv.second.bytes;
+  return t + comm_held_bytes(g_ctx);
+}
+
 int eigx_get_timers(double* out16) {
   if (!out16) return EIGX_ERR_BAD_ARG;
   for (int i = 0; i < 16; ++i) out16[i] = g_ctx.timers[i];

@@ -126,6 +126,7 @@ struct CommState {
   int* err_dev = nullptr;                // sticky device-side failure word (a bounded spin ran out)
   unsigned long long* ticks_dev = nullptr;   // accumulated 100 MHz ticks spent in waits / pushes
   std::map<std::string, PeerBuf> bufs;
+  std::vector<PeerBuf> retired;          // outgrown buffers: stay mapped until comm_free
   size_t step_msg = 0;
   double rccl_seconds = 0.0;
   std::vector<hipEvent_t> tev;           // event pairs around RCCL calls
@@ -360,6 +361,15 @@ bool comm_failed(const Context& ctx) {   // synchronous (reads one device word):
 }
 bool comm_shared_device(const Context& ctx) { return ctx.comm && ctx.comm->shared_device; }
 
+int64_t comm_held_bytes(const Context& ctx) {
+  const CommState* cs = ctx.comm;
+  if (!cs) return 0;
+  int64_t t = (int64_t)cs->flags.bytes;
+  for (const auto& kv : cs->bufs) t += (int64_t)kv.second.bytes;
+  for (const PeerBuf& b : cs->retired) t += (int64_t)b.bytes;
+  return t;
+}
+
 double comm_seconds(Context& ctx, bool reset) {
   CommState* cs = ctx.comm;
   if (!cs) return 0.0;
@@ -527,16 +537,17 @@ void comm_free(Context& ctx) {
   if (!cs) return;
   // nobody unmaps while a peer may still be writing: meet at the board first (bounded)
   if (cs->board) { int z = 0; unsigned char all[EIGX_MAXP][128]; (void)board_exchange(cs, &z, sizeof(z), all); }
-  for (auto& kv : cs->bufs) {
-    PeerBuf& b = kv.second;
+  std::vector<PeerBuf> allb(cs->retired);
+  for (auto& kv : cs->bufs) allb.push_back(kv.second);
+  for (PeerBuf& b : allb) {
     for (int q = 0; q < cs->P; ++q)
       if (q != cs->me && b.peer[q] && b.mapped) { if (hipIpcCloseMemHandle(b.peer[q]) != hipSuccess) (void)hipGetLastError(); }
   }
   for (int q = 0; q < cs->P; ++q)
     if (q != cs->me && cs->flags.peer[q] && cs->flags.mapped) { if (hipIpcCloseMemHandle(cs->flags.peer[q]) != hipSuccess) (void)hipGetLastError(); }
   if (cs->board) { int z = 0; unsigned char all[EIGX_MAXP][128]; (void)board_exchange(cs, &z, sizeof(z), all); }
-  for (auto& kv : cs->bufs)
-    if (kv.second.local) { if (hipFree(kv.second.local) != hipSuccess) (void)hipGetLastError(); }
+  for (PeerBuf& b : allb)
+    if (b.local) { if (hipFree(b.local) != hipSuccess) (void)hipGetLastError(); }
   if (cs->flags.local) { if (hipFree(cs->flags.local) != hipSuccess) (void)hipGetLastError(); }
   if (cs->x) api.CommDestroy(cs->x);
   if (cs->y) api.CommDestroy(cs->y);
@@ -554,20 +565,16 @@ PeerBuf* comm_buffer(Context& ctx, const std::string& name, size_t bytes) {
   CommState* cs = ctx.comm;
   PeerBuf& b = cs->bufs[name];
   if (b.bytes >= bytes && b.local) return &b;
-  // (re)allocation is collective: every rank asks for the same size at the same point of the program
+  // (re)allocation is collective: every rank asks for the same size at the same point of the program.
+  // A buffer that has to grow is RETIRED, not freed: its mappings stay valid on every peer until comm_free, so no
+  // rank can ever store through a stale pointer and no IPC handle is closed and re-opened in the life of the
+  // communicator (sizes grow geometrically, so the retired copies add up to less than the live one).
   EIGX_HIP_CHECK(hipDeviceSynchronize());
-  if (cs->ipc) {  // meet before anybody unmaps the old copy
-    int z = 0; unsigned char all[EIGX_MAXP][128];
-    if (!board_exchange(cs, &z, sizeof(z), all)) comm_fail(cs, "buffer exchange timed out");
-  }
   if (b.local) {
-    for (int q = 0; q < cs->P; ++q)
-      if (q != cs->me && b.peer[q] && b.mapped) { if (hipIpcCloseMemHandle(b.peer[q]) != hipSuccess) (void)hipGetLastError(); }
-    if (cs->ipc) { int z = 0; unsigned char all[EIGX_MAXP][128]; (void)board_exchange(cs, &z, sizeof(z), all); }
-    EIGX_HIP_CHECK(hipFree(b.local));
+    cs->retired.push_back(b);
     b = PeerBuf();
   }
-  const size_t want = bytes + bytes / 16 + 256;
+  const size_t want = bytes + bytes / 2 + 256;
   b.local = cs->ipc ? alloc_window(want) : nullptr;
   if (!b.local) EIGX_HIP_CHECK(hipMalloc((void**)&b.local, want));
   b.bytes = want;
@@ -575,20 +582,33 @@ PeerBuf* comm_buffer(Context& ctx, const std::string& name, size_t bytes) {
   if (cs->ipc) {
     BufBlob mine; memset(&mine, 0, sizeof(mine));
     mine.bytes = want;
-    mine.ok = hipIpcGetMemHandle(&mine.handle, b.local) == hipSuccess ? 1 : 0;
-    if (!mine.ok) (void)hipGetLastError();
+    hipError_t e1 = hipIpcGetMemHandle(&mine.handle, b.local);
+    mine.ok = (e1 == hipSuccess) ? 1 : 0;
+    if (!mine.ok) { fprintf(stderr, "[eigx] rank %d: hipIpcGetMemHandle(%s, %zu bytes): %s\n", cs->me, name.c_str(), want, hipGetErrorString(e1)); (void)hipGetLastError(); }
     unsigned char all[EIGX_MAXP][128];
     if (!board_exchange(cs, &mine, sizeof(mine), all)) { comm_fail(cs, "buffer exchange timed out"); return &b; }
     bool ok = true;
     for (int q = 0; q < cs->P && ok; ++q) {
       BufBlob o; memcpy(&o, all[q], sizeof(o));
-      if (!o.ok || o.bytes != want) { ok = false; break; }
+      if (!o.ok || o.bytes != want) {
+        fprintf(stderr, "[eigx] rank %d: buffer %s: rank %d offers %llu bytes (ok %d), expected %zu\n", cs->me, name.c_str(), q,
+                (unsigned long long)o.bytes, o.ok, want);
+        ok = false;
+        break;
+      }
       if (q == cs->me) continue;
       void* p = nullptr;
-      if (hipIpcOpenMemHandle(&p, o.handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+      hipError_t e2 = hipIpcOpenMemHandle(&p, o.handle, hipIpcMemLazyEnablePeerAccess);
+      if (e2 != hipSuccess) {
+        fprintf(stderr, "[eigx] rank %d: hipIpcOpenMemHandle(%s of rank %d, %zu bytes): %s\n", cs->me, name.c_str(), q, want,
+                hipGetErrorString(e2));
+        (void)hipGetLastError();
+        ok = false;
+        break;
+      }
       b.peer[q] = (double*)p;
     }
-    if (!ok) comm_fail(cs, "mapping a peer buffer failed (sizes differ between ranks, or hipIpcOpenMemHandle refused)");
+    if (!ok) comm_fail(cs, "mapping a peer buffer failed");
     b.mapped = ok;
   }
   return &b;

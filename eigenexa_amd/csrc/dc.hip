@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void jacobi_leaf_kernel(const double* __restri
                                                           const double* __restrict__ e, int lde, int band,
                                                           const int* __restrict__ leaf_off,
                                                           const int* __restrict__ leaf_n, double* __restrict__ D,
-                                                          double* __restrict__ Q, int ldq) {
+                                                          double* __restrict__ Q, int ldq, int r0, int r1) {
   __shared__ double A[LEAF][LEAF + 1];
   __shared__ double V[LEAF][LEAF + 1];
   __shared__ double cs[LEAF / 2][2];
@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void jacobi_leaf_kernel(const double* __restri
     const int pj = perm[j];
     double acc = 0.0;
     for (int k = 0; k < m; ++k) acc += V[r][k] * A[k][pj];
-    Q[(size_t)(off + j) * ldq + off + r] = V[r][pj] - 0.5 * acc;
+    if (off + r >= r0 && off + r < r1)   // several GPUs: a rank keeps rows [r0, r1) of Q only
+      Q[(size_t)(off + j) * ldq + off + r] = V[r][pj] - 0.5 * acc;
   }
 }
 
@@ -258,19 +259,26 @@ __device__ __forceinline__ double group_sum(double v) {
   return v;
 }
 
+// Several GPUs (P > 1): the roots of every merge are split over the ranks by root index -- rank r solves roots
+// [K r / P, K (r + 1) / P) -- and nothing K x K is stored: a root is kept as (origin_j, tau_j), from which
+// S'(j, i) = (d_i - origin_j) - tau_j is recomputed wherever it is needed; sec = [lambda | origin | tau] (n each) is
+// summed over the ranks afterwards (every entry is written by exactly one rank).
 template <int LPR>
 __global__ __launch_bounds__(256) void secular_kernel(const MergeDev* __restrict__ md,
                                                       const double* __restrict__ dlam,
                                                       const double* __restrict__ wz, double* __restrict__ Dn,
-                                                      double* __restrict__ S, int lds) {
+                                                      double* __restrict__ S, int lds, int P, int rank,
+                                                      double* __restrict__ sec, int nsec) {
   const MergeDev M = md[blockIdx.y];
   const int K = M.K;
   constexpr int RPW = 256 / LPR;   // roots per workgroup
   __shared__ double so[RPW], stau[RPW];
-  if ((int)(blockIdx.x * RPW) >= K) return;
+  const int jbase = (P > 1) ? (int)((long)K * rank / P) : 0;
+  const int jend = (P > 1) ? (int)((long)K * (rank + 1) / P) : K;
+  if (jbase + (int)(blockIdx.x * RPW) >= jend) return;
   const int sub = threadIdx.x & (LPR - 1);
-  const int jraw = blockIdx.x * RPW + threadIdx.x / LPR;
-  const bool act = jraw < K;
+  const int jraw = jbase + blockIdx.x * RPW + threadIdx.x / LPR;
+  const bool act = jraw < jend;
   const int j = act ? jraw : K - 1;  // idle groups recompute the last root (keeps every lane in the shuffles)
   const double* __restrict__ d = dlam + M.off;
   const double* __restrict__ z = wz + M.off;
@@ -280,8 +288,8 @@ __global__ __launch_bounds__(256) void secular_kernel(const MergeDev* __restrict
   if (K == 1) {
     if (threadIdx.x == 0) {
       const double t = rho * z[0] * z[0];
-      Dn[M.off] = d[0] + t;
-      Sp[0] = -t;
+      if (sec) { sec[M.off] = d[0] + t; sec[nsec + M.off] = d[0]; sec[2 * nsec + M.off] = t; }
+      else { Dn[M.off] = d[0] + t; Sp[0] = -t; }
     }
     return;
   }
@@ -350,6 +358,10 @@ __global__ __launch_bounds__(256) void secular_kernel(const MergeDev* __restrict
   }
   // S'(j, i) = (d_i - origin_j) - tau_j: the workgroup's RPW roots are consecutive j, so the store is re-mapped to
   // lanes = (root, pole) pairs with the root index fastest: RPW * 8-byte segments instead of one element per line
+  if (sec) {
+    if (sub == 0 && act) { sec[M.off + j] = origin + tau; sec[nsec + M.off + j] = origin; sec[2 * nsec + M.off + j] = tau; }
+    return;
+  }
   if (sub == 0) { so[threadIdx.x / LPR] = origin; stau[threadIdx.x / LPR] = tau; if (act) Dn[M.off + j] = origin + tau; }
   __syncthreads();
   {
@@ -437,6 +449,88 @@ __global__ __launch_bounds__(256) void vectors2_kernel(const MergeDev* __restric
   const int i0 = blockIdx.y * VEC_IC;
   const int i1 = (i0 + VEC_IC < K) ? i0 + VEC_IC : K;
   for (int i = i0 + wave; i < i1; i += 4) Sp[(size_t)i * lds] *= sc;
+}
+
+// ---- several GPUs: the same three steps from (origin, tau) instead of a stored K x K matrix ----------------------
+// lambda of the non-deflated roots into the eigenvalue array (the deflated ones are already there)
+__global__ void scatter_lambda_kernel(const MergeDev* __restrict__ md, const double* __restrict__ sec, double* __restrict__ Dn) {
+  const MergeDev M = md[blockIdx.y];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < M.K) Dn[M.off + j] = sec[M.off + j];
+}
+// Gu-Eisenstat zhat (see loewner_kernel): lam_j - d_i = (origin_j - d_i) + tau_j
+__global__ __launch_bounds__(256) void loewner_mg_kernel(const MergeDev* __restrict__ md, const double* __restrict__ dlam,
+                                                         const double* __restrict__ wz, const double* __restrict__ sec,
+                                                         int nsec, double* __restrict__ zh) {
+  const MergeDev M = md[blockIdx.y];
+  const int K = M.K;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= K) return;
+  const double* d = dlam + M.off;
+  const double* org = sec + nsec + M.off;
+  const double* tau = sec + 2 * nsec + M.off;
+  const double di = d[i];
+  double prod = 1.0;
+  for (int j = lane; j < K; j += 64) {
+    const double num = (org[j] - di) + tau[j];
+    prod *= (j == i) ? num : num / (d[j] - di);
+  }
+  for (int o = 32; o > 0; o >>= 1) prod *= __shfl_xor(prod, o, 64);
+  if (lane == 0) {
+    const double v = sqrt(fabs(prod));
+    zh[M.off + i] = (wz[M.off + i] >= 0.0) ? v : -v;
+  }
+}
+// normalised eigenvector rows of the roots [j0, j1) of merge number mi0 + blockIdx.z:
+//   Sc(j - j0, i) = zh_i / ((d_i - origin_j) - tau_j) / norm_j   at Sc[base + (j - j0) + i * ldsc],
+// base = M.off * ldsc when `compact` (all merges of a height side by side), 0 otherwise (one chunk of one merge).
+// workgroup = 64 roots (lanes) x 4 waves striding the poles; two sweeps (norm, then store): nothing K x K is read.
+__global__ __launch_bounds__(256) void vectors_mg_kernel(const MergeDev* __restrict__ md, int mi0, const double* __restrict__ dlam,
+                                                         const double* __restrict__ zh, const double* __restrict__ sec, int nsec,
+                                                         int j0, int j1, int compact, double* __restrict__ Sc, int ldsc) {
+  __shared__ double part[4][64];
+  const MergeDev M = md[mi0 + blockIdx.z];
+  const int K = M.K;
+  const int jhi = (j1 < K) ? j1 : K;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = j0 + blockIdx.x * 64 + lane;
+  if (j0 + (int)(blockIdx.x * 64) >= jhi) return;
+  const bool act = j < jhi;
+  const double* d = dlam + M.off;
+  const double* zz = zh + M.off;
+  const double oj = act ? sec[nsec + M.off + j] : 0.0, tj = act ? sec[2 * nsec + M.off + j] : 1.0;
+  double nrm = 0.0;
+  for (int i = wave; i < K; i += 4) {
+    const double v = zz[i] / ((d[i] - oj) - tj);
+    nrm += v * v;
+  }
+  part[wave][lane] = nrm;
+  __syncthreads();
+  const double sc = 1.0 / sqrt((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+  if (!act) return;
+  double* dst = Sc + (compact ? (size_t)M.off * ldsc : 0) + (j - j0);
+  for (int i = wave; i < K; i += 4) dst[(size_t)i * ldsc] = zz[i] / ((d[i] - oj) - tj) * sc;
+}
+
+// row blocks of Q -> column blocks of the sorted eigenvector matrix (all-to-all): rank q packs, for every destination p,
+// its rows [r0, r0 + nr) of the eigenvector columns that p owns, sorted order: send[p][c * rp + r]
+__global__ void pack_q_for_cols_kernel(const int* __restrict__ perm, const double* __restrict__ Q, int ldq, int r0, int nr,
+                                       int rp, int zc, int nvec, double* __restrict__ send) {
+  const int c = blockIdx.y, p = blockIdx.z;
+  const int g = p * zc + c;       // global (sorted) eigenvector index
+  if (c >= zc) return;
+  double* dst = send + ((size_t)p * zc + c) * rp;
+  if (g >= nvec) { for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rp; r += gridDim.x * blockDim.x) dst[r] = 0.0; return; }
+  const double* src = Q + (size_t)perm[g] * ldq + r0;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rp; r += gridDim.x * blockDim.x) dst[r] = (r < nr) ? src[r] : 0.0;
+}
+// Z(q * rp + r, c) = recv[q][c * rp + r]
+__global__ void unpack_cols_kernel(const double* __restrict__ recv, int rp, int zc, int n, double* __restrict__ Z, int ldz) {
+  const int c = blockIdx.y, q = blockIdx.z;
+  const double* src = recv + ((size_t)q * zc + c) * rp;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rp; r += gridDim.x * blockDim.x)
+    if (q * rp + r < n) Z[(size_t)c * ldz + q * rp + r] = __hip_atomic_load(src + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void copycols_kernel(const int* __restrict__ src, const int* __restrict__ dst,
@@ -548,7 +642,8 @@ struct DeflOut {
 // The two Q buffers must be zero outside the diagonal blocks before the leaves are written: 2 n^2 doubles of memset
 // that depend on nothing.  The solver calls this before the reduction; the fills run on the side stream underneath it.
 void band_dc_prepare(Context& ctx, int n) {
-  const int ldq = pad_ld(n);
+  const int P = ctx.grid.nranks;
+  const int ldq = (P > 1) ? pad_ld((n + P - 1) / P + 2) : pad_ld(n);   // several GPUs: a rank keeps ceil(n/P) rows of Q
   double* Qa = ctx.pool.get_t<double>("dc.Qa", (size_t)ldq * n);
   double* Qb = ctx.pool.get_t<double>("dc.Qb", (size_t)ldq * n);
   EIGX_HIP_CHECK(hipMemsetAsync(Qa, 0, (size_t)ldq * n * 8, ctx.side_stream));
@@ -561,8 +656,18 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
                  double* w_dev, double* z_dev, int ldz) {
   hipStream_t st = ctx.stream;
   const double eps = DBL_EPSILON / 2.0;
-  // multi-GPU: Q is row-distributed in contiguous blocks of rp rows; everything that is O(n) or O(K^2)
-  // (leaves, z, deflation, secular equation, S) is replicated, the O(n K^2) GEMMs touch only the rank's rows
+  // Several GPUs (replaces the process tree / ring GEMM of dc2_FS, src/FS_PDLAED0.F90:62-323, src/FS_PDLAED3.F90:526-860):
+  //   * Q is row-distributed in contiguous blocks of rp = ceil(n/P) rows and only those rows are ALLOCATED
+  //     (buffers of rp x n; the kernels index global rows through a shifted base pointer);
+  //   * the secular equation is split by root index (rank r: roots [K r/P, K (r+1)/P) of every merge), the roots
+  //     travel as (lambda, origin, tau) triples in one small allreduce; no K x K matrix is stored or sent:
+  //     eigenvector rows are regenerated from the triples, a chunk of roots at a time, right before the GEMM
+  //     that consumes them;
+  //   * the O(n K^2) GEMMs touch the rank's rows only; z = Q^T w needs one allreduce of n doubles per pass;
+  //   * deflation runs on every host on bit-identical inputs (O(n) per height);
+  //   * at the end an all-to-all turns row blocks of Q into column blocks of the sorted eigenvector matrix:
+  //     z_dev receives columns [rank*zc, rank*zc + zc), zc = ceil(nvec/P), all n rows (what the column-parallel
+  //     back-transformation works on).
   const int P = ctx.grid.nranks;
   const int rp = (n + P - 1) / P;
   const int r0 = P > 1 ? std::min(n, ctx.grid.rank * rp) : 0;
@@ -591,10 +696,19 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   const int maxh = H.nodes[root].height;
 
   // ---- device workspace --------------------------------------------------------------------------
-  const int ldq = pad_ld(n);
-  double* Qa = ctx.pool.get_t<double>("dc.Qa", (size_t)ldq * n);
-  double* Qb = ctx.pool.get_t<double>("dc.Qb", (size_t)ldq * n);
-  double* S = ctx.pool.get_t<double>("dc.S", (size_t)ldq * n);
+  const int ldq = (P > 1) ? pad_ld(rp + 2) : pad_ld(n);
+  double* Qa_base = ctx.pool.get_t<double>("dc.Qa", (size_t)ldq * n);
+  double* Qb_base = ctx.pool.get_t<double>("dc.Qb", (size_t)ldq * n);
+  // several GPUs: element (row, col) of the rank's block lives at base[(row - r0) + col*ldq]; the shifted pointers
+  // let every kernel keep global row indices (all of them clip to [r0, r1))
+  double* Qa = Qa_base - r0;
+  double* Qb = Qb_base - r0;
+  // eigenvector rows of the rank-one updates.  One GPU: block diagonal K x K blocks in an n x n array.  Several GPUs:
+  // a chunk buffer of n x SCW doubles (all merges of a low height side by side, or one chunk of roots of a big merge)
+  constexpr int SCW = 2048;
+  const int lds_mg = SCW;
+  double* S = ctx.pool.get_t<double>("dc.S", (P > 1) ? (size_t)n * SCW + 64 : (size_t)ldq * n);
+  double* sec = (P > 1) ? ctx.pool.get_t<double>("dc.sec", (size_t)3 * n) : nullptr;
   double* dd = ctx.pool.get_t<double>("dc.d", (size_t)n);
   double* de = ctx.pool.get_t<double>("dc.e", (size_t)lde * band);
   double* zh = ctx.pool.get_t<double>("dc.zh", (size_t)n);
@@ -638,12 +752,12 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
 
   EIGX_HIP_CHECK(hipMemcpyAsync(dd, H.d.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
   EIGX_HIP_CHECK(hipMemcpyAsync(de, H.e.data(), (size_t)lde * band * 8, hipMemcpyHostToDevice, st));
-  if (ctx.dc_zero_n == n && ctx.dc_zero_qa == Qa && ctx.dc_zero_qb == Qb) {
+  if (ctx.dc_zero_n == n && ctx.dc_zero_qa == Qa_base && ctx.dc_zero_qb == Qb_base) {
     // zero-filled ahead on the side stream while the reduction ran (band_dc_prepare)
     EIGX_HIP_CHECK(hipStreamWaitEvent(st, ctx.dc_ev, 0));
   } else {
-    EIGX_HIP_CHECK(hipMemsetAsync(Qa, 0, (size_t)ldq * n * 8, st));
-    EIGX_HIP_CHECK(hipMemsetAsync(Qb, 0, (size_t)ldq * n * 8, st));
+    EIGX_HIP_CHECK(hipMemsetAsync(Qa_base, 0, (size_t)ldq * n * 8, st));
+    EIGX_HIP_CHECK(hipMemsetAsync(Qb_base, 0, (size_t)ldq * n * 8, st));
   }
   ctx.dc_zero_n = 0;
   {
@@ -664,7 +778,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
     EIGX_HIP_CHECK(hipMemcpyAsync(leafinfo, both.data(), (size_t)2 * nl * 4, hipMemcpyHostToDevice, st));
     EIGX_HIP_CHECK(hipStreamSynchronize(st));  // `both` is a stack vector
     hipLaunchKernelGGL(jacobi_leaf_kernel, dim3(nl), dim3(256), 0, st, dd, de, lde, band, leafinfo, leafinfo + nl,
-                       Dcur, Qa, ldq);
+                       Dcur, Qa, ldq, r0, r1);
   }
 
   // ---- merges, height by height ---------------------------------------------------------------------
@@ -808,17 +922,40 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
                            rpj_dev, rjj_dev, rc_dev, rs_dev, Qa, ldq, r0, r1);
       int maxK = 0;
       for (const MergeDev& M : mds) maxK = std::max(maxK, M.K);
+      // several GPUs: chunked eigenvector rows.  compact = all merges of this height fit side by side into S
+      // (lds = SCW >= merge size); otherwise the (one or two) big merges go chunk by chunk below.
+      const bool mg = P > 1;
+      const bool compact = mg && maxnm <= lds_mg;
       if (maxK > 0) {
         const unsigned nmg = (unsigned)ids.size();
+        if (mg) {
+          const int kmx = maxK / P + 2;   // roots per rank and merge
+          EIGX_HIP_CHECK(hipMemsetAsync(sec, 0, (size_t)3 * n * 8, st));
+          if (maxK >= 512)
+            hipLaunchKernelGGL(secular_kernel<32>, dim3((kmx + 7) / 8, nmg), dim3(256), 0, st, md_dev, dlam, wz, Dcur, S, ldq, P,
+                               ctx.grid.rank, sec, n);
+          else
+            hipLaunchKernelGGL(secular_kernel<8>, dim3((kmx + 31) / 32, nmg), dim3(256), 0, st, md_dev, dlam, wz, Dcur, S, ldq, P,
+                               ctx.grid.rank, sec, n);
+          comm_allreduce_sum(ctx, COMM_WORLD, sec, (size_t)3 * n, st);
+          hipLaunchKernelGGL(scatter_lambda_kernel, dim3((maxK + 255) / 256, nmg), dim3(256), 0, st, md_dev, sec, Dcur);
+          hipLaunchKernelGGL(loewner_mg_kernel, dim3((maxK + 3) / 4, nmg), dim3(256), 0, st, md_dev, dlam, wz, sec, n, zh);
+          if (compact)
+            hipLaunchKernelGGL(vectors_mg_kernel, dim3((maxK + 63) / 64, 1, nmg), dim3(256), 0, st, md_dev, 0, dlam, zh, sec, n, 0,
+                               maxK, 1, S, lds_mg);
+        } else {
         if (maxK >= 512)
-          hipLaunchKernelGGL(secular_kernel<32>, dim3((maxK + 7) / 8, nmg), dim3(256), 0, st, md_dev, dlam, wz, Dcur, S, ldq);
+          hipLaunchKernelGGL(secular_kernel<32>, dim3((maxK + 7) / 8, nmg), dim3(256), 0, st, md_dev, dlam, wz, Dcur, S, ldq, 1, 0,
+                             (double*)nullptr, 0);
         else
-          hipLaunchKernelGGL(secular_kernel<8>, dim3((maxK + 31) / 32, nmg), dim3(256), 0, st, md_dev, dlam, wz, Dcur, S, ldq);
+          hipLaunchKernelGGL(secular_kernel<8>, dim3((maxK + 31) / 32, nmg), dim3(256), 0, st, md_dev, dlam, wz, Dcur, S, ldq, 1, 0,
+                             (double*)nullptr, 0);
         hipLaunchKernelGGL(loewner_kernel, dim3((maxK + 3) / 4, nmg), dim3(256), 0, st, md_dev, dlam, wz, S, ldq, zh);
         {
           const dim3 vg((maxK + 63) / 64, (maxK + VEC_IC - 1) / VEC_IC, nmg);
           hipLaunchKernelGGL(vectors1_kernel, vg, dim3(256), 0, st, md_dev, zh, S, ldq, vnp, n);
           hipLaunchKernelGGL(vectors2_kernel, vg, dim3(256), 0, st, md_dev, S, ldq, vnp, n);
+        }
         }
         // the merges of one height are independent: when there are several, spread their GEMMs over the aux
         // streams so that small products run side by side instead of one after another
@@ -832,37 +969,51 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
         for (size_t q = 0; q < mds.size(); ++q) {
           const MergeDev& M = mds[q];
           if (M.K <= 0) continue;
-          const double* Sb = S + (size_t)M.off * ldq + M.off;
-          double* Cb = Qb + (size_t)M.off * ldq + M.off;
+          // root chunks [j0, j0 + cw): one chunk = all K roots, except for the big merges of several GPUs, whose
+          // eigenvector rows are regenerated chunk by chunk into the n x SCW buffer right before their GEMM
+          const bool chunked = mg && !compact;
+          int cwq = M.K;
+          if (chunked) { cwq = (int)(((size_t)n * SCW / (size_t)M.K) / 64 * 64); if (cwq > M.K) cwq = M.K; if (cwq < 64) cwq = 64; }
+          for (int j0 = 0; j0 < M.K; j0 += cwq) {
+          const int cw = (M.K - j0 < cwq) ? M.K - j0 : cwq;
+          const int ldsb = mg ? (chunked ? ((cw + 1) & ~1) : lds_mg) : ldq;
+          const double* Sb = mg ? (chunked ? S : S + (size_t)M.off * lds_mg) : S + (size_t)M.off * ldq + M.off;
+          if (chunked) {
+            // the chunk buffer is reused: order this chunk's generation after the previous chunk's GEMMs
+            hipLaunchKernelGGL(vectors_mg_kernel, dim3((cw + 63) / 64, 1, 1), dim3(256), 0, st, md_dev, (int)q, dlam, zh, sec, n, j0,
+                               j0 + cw, 0, S, ldsb);
+          }
+          double* Cb = Qb + (size_t)(M.off + j0) * ldq + M.off;
           // Qb(rows, off+j) = sum_i Qa(rows, nd[i]) * U(i,j),  U(i,j) = S'(j,i)
           if (k == 0) {
             // first update: Q = diag(Q1, Q2) up to the Givens-mixed columns, so the top rows only see the
             // columns of type 1/3 and the bottom rows those of type 2/3 (DLAED3's compressed Q2 idea)
             hipStream_t g1 = fan ? ctx.aux[rr++ % Context::kAux] : st;
-            hipStream_t g2 = fan ? ctx.aux[rr++ % Context::kAux] : (mds.size() == 1 ? ctx.aux[0] : st);
+            hipStream_t g2 = fan ? ctx.aux[rr++ % Context::kAux] : ((mds.size() == 1 && !chunked) ? ctx.aux[0] : st);
             if (!fan && g2 != st) {
               EIGX_HIP_CHECK(hipEventRecord(ctx.aux_ev[Context::kAux], st));
               EIGX_HIP_CHECK(hipStreamWaitEvent(g2, ctx.aux_ev[Context::kAux], 0));
             }
             int ga, gb;
             if (clip(M.off, M.off + M.n1, ga, gb))
-              dgemm_dev(g1, 'N', 'T', gb - ga, M.K, ktop[q], 1.0, Qa + ga, ldq, Sb, ldq, 0.0, Cb + (ga - M.off), ldq, 0,
+              dgemm_dev(g1, 'N', 'T', gb - ga, cw, ktop[q], 1.0, Qa + ga, ldq, Sb, ldsb, 0.0, Cb + (ga - M.off), ldq, 0,
                         nullptr, topA_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, topB_dev + M.off);
             if (clip(M.off + M.n1, M.off + M.nm, ga, gb))
-              dgemm_dev(g2, 'N', 'T', gb - ga, M.K, kbot[q], 1.0, Qa + ga, ldq, Sb, ldq, 0.0, Cb + (ga - M.off), ldq, 0,
+              dgemm_dev(g2, 'N', 'T', gb - ga, cw, kbot[q], 1.0, Qa + ga, ldq, Sb, ldsb, 0.0, Cb + (ga - M.off), ldq, 0,
                         nullptr, botA_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, botB_dev + M.off);
             if (!fan && g2 != st) {
               EIGX_HIP_CHECK(hipEventRecord(ctx.aux_ev[0], g2));
               EIGX_HIP_CHECK(hipStreamWaitEvent(st, ctx.aux_ev[0], 0));
             }
-            gemm_flops += 2.0 * (double)M.K * ((double)M.n1 * ktop[q] + (double)(M.nm - M.n1) * kbot[q]);
+            gemm_flops += 2.0 * (double)cw * ((double)M.n1 * ktop[q] + (double)(M.nm - M.n1) * kbot[q]);
           } else {
             hipStream_t gs = fan ? ctx.aux[rr++ % Context::kAux] : st;
             int ga, gb;
             if (clip(M.off, M.off + M.nm, ga, gb))
-              dgemm_dev(gs, 'N', 'T', gb - ga, M.K, M.K, 1.0, Qa + ga, ldq, Sb, ldq, 0.0, Cb + (ga - M.off), ldq, 0,
+              dgemm_dev(gs, 'N', 'T', gb - ga, cw, M.K, 1.0, Qa + ga, ldq, Sb, ldsb, 0.0, Cb + (ga - M.off), ldq, 0,
                         nullptr, nd_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, iota_dev);
-            gemm_flops += 2.0 * M.nm * (double)M.K * M.K;
+            gemm_flops += 2.0 * M.nm * (double)M.K * cw;
+          }
           }
         }
         if (fan)
@@ -904,16 +1055,6 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
     }
   }
 
-  // ---- multi-GPU: every rank needs all rows of Q for its slice of the back-transformation ----------------
-  if (P > 1) {
-    double* packb = ctx.pool.get_t<double>("dc.pack", (size_t)rp * n);
-    double* allb = Qb;  // free now: P * rp * n <= ldq * n + slack? use a dedicated buffer to be safe
-    allb = ctx.pool.get_t<double>("dc.packall", (size_t)rp * n * P);
-    hipLaunchKernelGGL(pack_rows_kernel, dim3(8, n), dim3(256), 0, st, Qa, ldq, n, r0, r1 - r0, rp, packb);
-    comm_allgather(ctx, COMM_WORLD, packb, allb, (size_t)rp * n, st);
-    hipLaunchKernelGGL(unpack_rows_kernel, dim3(8, n, P), dim3(256), 0, st, allb, n, rp, Qa, ldq);
-  }
-
   // ---- final sort + copy-out ----------------------------------------------------------------------------
   EIGX_HIP_CHECK(hipMemcpyAsync(Dh, Dcur, (size_t)n * 8, hipMemcpyDeviceToHost, st));
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
@@ -926,8 +1067,19 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   if (nrm == 0.0) for (int i = 0; i < n; ++i) wh[i] = 0.0;
   EIGX_HIP_CHECK(hipMemcpyAsync(perm_dev, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
   EIGX_HIP_CHECK(hipMemcpyAsync(w_dev, wh.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-  if (nvec > 0 && z_dev)
+  if (nvec > 0 && z_dev && P == 1)
     hipLaunchKernelGGL(final_permute_kernel, dim3(8, nvec), dim3(256), 0, st, perm_dev, Qa, ldq, n, z_dev, ldz, nvec);
+  if (nvec > 0 && z_dev && P > 1) {
+    // row blocks of Q -> column blocks of the sorted eigenvector matrix: one all-to-all of rp x zc pieces
+    const int zc = (nvec + P - 1) / P;
+    const size_t piece = (size_t)rp * zc;
+    double* sendb = ctx.pool.get_t<double>("mg.xsend", piece * P);
+    PeerBuf* recvb = comm_buffer(ctx, "mg.xrecv", piece * P * sizeof(double));
+    hipLaunchKernelGGL(pack_q_for_cols_kernel, dim3(8, zc, P), dim3(256), 0, st, perm_dev, Qa, ldq, r0, r1 - r0, rp, zc, nvec,
+                       sendb);
+    comm_exchange(ctx, COMM_WORLD, sendb, piece, recvb, 0, piece, st, CH_BULK);
+    hipLaunchKernelGGL(unpack_cols_kernel, dim3(8, zc, P), dim3(256), 0, st, (const double*)recvb->local, rp, zc, n, z_dev, ldz);
+  }
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
   EIGX_HIP_CHECK(hipGetLastError());
   ctx.timers[11] = gemm_flops;

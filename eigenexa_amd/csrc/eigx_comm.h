@@ -39,6 +39,7 @@ int comm_size(const Context& ctx, CommGroup grp);
 bool comm_failed(const Context& ctx);            // a collective timed out or RCCL returned an error
 bool comm_shared_device(const Context& ctx);     // at least two ranks share a GPU (tests)
 double comm_seconds(Context& ctx, bool reset);   // time spent in communication since the last reset (this rank)
+int64_t comm_held_bytes(const Context& ctx);     // bytes of communication windows this rank holds (retired ones included)
 
 // collectively (re)allocated, peer-mapped buffer; grows on demand (every rank must ask for the same size)
 PeerBuf* comm_buffer(Context& ctx, const std::string& name, size_t bytes);

@@ -120,10 +120,54 @@ double now_s() {
 }
 
 // z(:, j) = e_j for the first gridDim.y columns (modes 'S', 'C': eigen_identity, src/eigen_sx.F:214)
-__global__ void identity_kernel(double* __restrict__ z, int ldz, int n) {
-  const int j = blockIdx.y;
+__global__ void identity_kernel(double* __restrict__ z, int ldz, int n, int c0) {
+  const int j = blockIdx.y;   // local column; global column c0 + j
   double* col = z + (size_t)j * ldz;
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) col[r] = (r == j) ? 1.0 : 0.0;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) col[r] = (r == c0 + j) ? 1.0 : 0.0;
+}
+
+__device__ __host__ __forceinline__ int bc_owner(int g, int nb, int P) { return (g / nb) % P; }
+__device__ __host__ __forceinline__ int bc_g2l(int g, int nb, int P) { return ((g / nb) / P) * nb + g % nb; }
+// number of indices g < n that process p owns (NUMROC), usable on the device
+__device__ __host__ __forceinline__ int bc_count(int n, int nb, int p, int P) {
+  const int nblocks = n / nb;
+  int cnt = (nblocks / P) * nb;
+  const int extra = nblocks % P;
+  if (p < extra) cnt += nb;
+  else if (p == extra) cnt += n % nb;
+  return cnt;
+}
+
+// Eigenvector column block of this rank (columns [c0, c0 + cnt), all n rows) -> pieces for the all-to-all that deals
+// the matrix into the callers' 2-D (block-)cyclic blocks: the piece for rank (qx, qy) holds the rows that qx owns of
+// those of my columns that qy owns: send[rank][ljr * nrmax + li]   (src/dc_redist1.F / dc_redist2.F play this role
+// in the reference, between its D&C layout and the API layout)
+__global__ void pack_z_pieces_kernel(const double* __restrict__ Z, int ldz, int n, int c0, int cnt, int nb, int Px, int Py,
+                                     int row_major, int nrmax, size_t piece, double* __restrict__ send) {
+  const int cl = blockIdx.y, qx = blockIdx.z;
+  if (cl >= cnt) return;
+  const int c = c0 + cl;
+  const int qy = bc_owner(c, nb, Py);
+  const int ljr = bc_g2l(c, nb, Py) - bc_count(c0, nb, qy, Py);
+  const int dst = row_major ? qx * Py + qy : qx + qy * Px;
+  const int nr = bc_count(n, nb, qx, Px);
+  double* out = send + (size_t)dst * piece + (size_t)ljr * nrmax;
+  const double* col = Z + (size_t)cl * ldz;
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < nr; li += gridDim.x * blockDim.x)
+    out[li] = col[bc_l2g(li, nb, Px, qx)];
+}
+// z_user(li, lj) for my local columns that lie in source rank q's column range [q*zc, min((q+1)*zc, nvec))
+__global__ void unpack_z_pieces_kernel(const double* __restrict__ recv, size_t piece, int nrmax, int nvec, int zc, int nb,
+                                       int py, int Py, int nr, double* __restrict__ z, int ldz) {
+  const int q = blockIdx.z;
+  const int g0 = q * zc < nvec ? q * zc : nvec, g1 = (q + 1) * zc < nvec ? (q + 1) * zc : nvec;
+  const int l0 = bc_count(g0, nb, py, Py), l1 = bc_count(g1, nb, py, Py);
+  const int ljr = blockIdx.y;
+  if (ljr >= l1 - l0) return;
+  const double* src = recv + (size_t)q * piece + (size_t)ljr * nrmax;
+  double* col = z + (size_t)(l0 + ljr) * ldz;
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < nr; li += gridDim.x * blockDim.x)
+    col[li] = __hip_atomic_load(src + li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // local blocks of every rank (2-D block-cyclic, block size nb; nb = 1: cyclic) -> replicated full matrix F(ldf, ncols)
@@ -204,7 +248,7 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
     zcols_per_rank = ceil_div(nvec > 0 ? nvec : 1, P);
     if (want_vec) {
       const int ldf = pad_ld(n);
-      z = ctx.pool.get_t<double>("mg.Z", (size_t)ldf * (size_t)zcols_per_rank * P);
+      z = ctx.pool.get_t<double>("mg.Z", (size_t)ldf * (size_t)zcols_per_rank);   // this rank's column block only
       ldz = ldf;
     }
   }
@@ -261,8 +305,11 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   // divide and conquer (launch-bound at its low levels) has the compute stream.  The reduction is complete here
   // (the host synchronised the compute stream above).
   if (do_bt && nvec > 0 && P == 1) trbak_prepare_dev(ctx, n, a, lda, e, lde, mb, band, ctx.side_stream);
+  // several GPUs: this rank's eigenvector columns [zc0, zc0 + zcnt) (the D&C delivers them, all n rows each)
+  const int zc0 = (P > 1) ? ((G.rank * zcols_per_rank < nvec) ? G.rank * zcols_per_rank : nvec) : 0;
+  const int zcnt = (P > 1) ? ((nvec - zc0 < zcols_per_rank) ? nvec - zc0 : zcols_per_rank) : nvec;
   if (mode == 'N' || mode == 'S' || mode == 'C') {
-    if (want_vec) hipLaunchKernelGGL(identity_kernel, dim3(8, nvec), dim3(256), 0, st, z, ldz, n);
+    if (want_vec && zcnt > 0) hipLaunchKernelGGL(identity_kernel, dim3(8, zcnt), dim3(256), 0, st, z, ldz, n, zc0);
     band_bisect_dev(ctx, n, d, e, lde, band, w);
   } else {
     band_dc_dev(ctx, n, nvec, d, e, lde, band, w, z, ldz);
@@ -277,20 +324,23 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
     } else {
       // eigenvector columns are split over the ranks; the reflectors stay distributed and stream past in column
       // groups (trbak.hip); no communication inside a group's sweep
-      const int c0 = G.rank * zcols_per_rank;
-      int cnt = (nvec - c0 < zcols_per_rank) ? nvec - c0 : zcols_per_rank;
-      if (cnt < 0) cnt = 0;
-      trbak_mg_dev(ctx, n, cnt, a, lda, z + (size_t)(c0 < nvec ? c0 : 0) * ldz, ldz, e, lde, mb, band);
+      trbak_mg_dev(ctx, n, zcnt, a, lda, z, ldz, e, lde, mb, band);
     }
   }
   if (P > 1 && want_vec) {
-    // column blocks -> the caller's layout
-    const int c0 = G.rank * zcols_per_rank;
-    comm_allgather(ctx, COMM_WORLD, z + (size_t)c0 * ldz, z, (size_t)zcols_per_rank * ldz, st);
-    const int nzc = numroc(nvec, nb, G.py, G.Py);
-    if (nzc > 0 && nloc_r > 0)
-      hipLaunchKernelGGL(full_to_cyclic_kernel, dim3(8, nzc), dim3(256), 0, st, z, ldz, nloc_r, nvec, nb, G.Px, G.px,
-                         G.Py, G.py, z_user, ldz_user);
+    // column blocks -> the caller's 2-D (block-)cyclic blocks: one all-to-all of (rows of qx) x (my columns of qy) pieces
+    const int nrmax = numroc(n, nb, 0, G.Px);
+    const int ncmax = (zcols_per_rank / (nb * G.Py) + 2) * nb;
+    const size_t piece = (size_t)nrmax * ncmax;
+    double* sendb = ctx.pool.get_t<double>("mg.xsend", piece * P);
+    PeerBuf* recvb = comm_buffer(ctx, "mg.xrecv", piece * P * sizeof(double));
+    if (zcnt > 0)
+      hipLaunchKernelGGL(pack_z_pieces_kernel, dim3(8, zcnt, G.Px), dim3(256), 0, st, (const double*)z, ldz, n, zc0, zcnt, nb, G.Px,
+                         G.Py, G.row_major, nrmax, piece, sendb);
+    comm_exchange(ctx, COMM_WORLD, sendb, piece, recvb, 0, piece, st, CH_BULK);
+    if (nloc_r > 0)
+      hipLaunchKernelGGL(unpack_z_pieces_kernel, dim3(8, ncmax, P), dim3(256), 0, st, (const double*)recvb->local, piece, nrmax,
+                         nvec, zcols_per_rank, nb, G.py, G.Py, nloc_r, z_user, ldz_user);
   } else if (want_vec && z != z_user) {
     EIGX_HIP_CHECK(hipMemcpy2DAsync(z_user, (size_t)ldz_user * 8, z, (size_t)ldz * 8, (size_t)n * 8, (size_t)nvec,
                                     hipMemcpyDeviceToDevice, st));
@@ -430,15 +480,41 @@ int gev_host(Context& ctx, int n, double* a, int lda, double* b, int ldb, double
 
 }  // namespace
 
-int64_t solver_workspace_bytes(const Context&, int n, int lda, int ldz, int mf, int mb) {
+int64_t solver_workspace_bytes(const Context& ctx, int n, int lda, int ldz, int mf, int mb) {
   (void)lda; (void)ldz;
   if (mf <= 0) mf = 128;
   if (mb <= 0) mb = 128;
-  const int64_t nn = (int64_t)pad_ld(n) * n;
-  // D&C: Qa, Qb, S ; reduction: panels + partials ; back-transform: V, W, X
-  return 8 * (3 * nn + (int64_t)(n + 256) * (3 * mf + 2 * (n / 128 + 2) * 2 + 8) + (int64_t)(n + 512) * mb +
-              2 * (int64_t)mb * n);
+  if (mf > 256) mf = 256;
+  const int P = ctx.grid.nranks;
+  const int64_t ldn = pad_ld(n);
+  const int64_t ldp = pad_ld((n + 127) / 128 * 128 + 128);
+  if (P == 1) {
+    const int64_t nn = ldn * n;
+    // D&C: Qa, Qb, S ; reduction: panels + partials ; back-transform: V, W, X
+    return 8 * (3 * nn + (int64_t)(n + 256) * (3 * mf + 2 * (n / 128 + 2) * 2 + 8) + (int64_t)(n + 512) * mb +
+                2 * (int64_t)mb * n);
+  }
+  // Several GPUs: everything of size n^2 is divided by P (the caller's a and z blocks are n^2/P each as well):
+  //   D&C       Qa, Qb row blocks (2 n^2/P), the eigenvector-row chunk buffer (2048 n), Z column block (n^2/P),
+  //   exchanges send + receive pieces of the two all-to-alls (2 n^2/P, the peer window with its growth slack),
+  //   reduction replicated panels [U|W|U] + gathered panel (ldp (4 m + 2)), tile partial sums, compact panels,
+  //             step window (2 P messages of 2 (nx + ny) doubles), panel-gather window,
+  //   back-transformation: reflector group (2048 columns), its gather window, W / X / T / Gram blocks.
+  const int64_t rp = (n + P - 1) / P, zc = rp;
+  const int64_t nxs = (n + ctx.grid.Px - 1) / ctx.grid.Px + 8, nys = (n + ctx.grid.Py - 1) / ctx.grid.Py + 8;
+  const int64_t maxseg = (nxs > nys ? nxs : nys) / 128 + 3;
+  int64_t w = 0;
+  w += 2 * (int64_t)pad_ld((int)rp + 2) * n + (int64_t)n * 2048 + ldn * zc;              // D&C + Z block
+  w += (int64_t)(2.6 * (double)((nxs + 8) * ((zc / ctx.grid.Py) + 2) * P)) + 3 * rp * zc;     // the two all-to-alls
+  w += ldp * (4 * mf + 2) + 2 * maxseg * 2 * ldp + 3 * ldp + (nxs + nys + 128) * 2 * mf;   // reduction panels / partials
+  w += (int64_t)(1.5 * (double)(2 * P * (2 * (nxs + nys) + 8))) + (int64_t)(2.5 * (double)(P + 1) * (mf / ctx.grid.Py + 3) * nxs);
+  w += (int64_t)pad_ld(n + 1024) * 2048 + (int64_t)(2.5 * (double)(P + 1) * (2048 / ctx.grid.Py + 2) * nxs);   // reflector groups
+  w += 2 * (int64_t)512 * zc + 6 * (int64_t)512 * 512 * ((n + 511) / 512) / 4 + 8 * (int64_t)n;               // W, X, T, Gram
+  w += (int64_t)(1.5 * 8 * 3 * n) + 16 * (int64_t)n;                                                              // small allreduces, D&C vectors
+  return 8 * w;
 }
+
+
 
 }  // namespace eigx
 

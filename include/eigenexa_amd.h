@@ -104,6 +104,9 @@ int eigx_matdims_for_grid(int n, int x_procs, int y_procs, int m_forward, int m_
 
 /* replaces eigen_memory_internal src/eigen_libs0.F:1395-1549: bytes of device workspace a solve needs */
 int64_t eigx_memory_internal(int n, int lda, int ldz, int m_forward, int m_backward);
+/* bytes of device memory the library holds right now (pooled workspace + communication windows); the tests check it
+ * against eigx_memory_internal and that it scales like 1/P on several ranks.  -1 before eigx_init. */
+int64_t eigx_held_bytes(void);
 
 /* ---- index helpers (pure functions; 1-based like the reference, src/eigen_libs0.F:1744-2356) - */
 int eigx_loop_start(int istart, int nnod, int inod);

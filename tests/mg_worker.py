@@ -63,6 +63,19 @@ if route == "h":
     print(f"OK rank {rank}/{world} n={n} {route} nb={nb}: werr {werr:.2e} res {res:.3e} orth {orth:.3e}", flush=True)
     sys.exit(0)
 if nb == 0:
+    if n >= 200:
+        # a smaller solve first: every workspace buffer and peer window then has to GROW for the real one
+        n0 = n // 3
+        nx0, ny0 = ee.eigen_get_matdims(n0)
+        a0 = np.zeros((nx0, ny0), order="F")
+        r0_, c0_ = np.arange(px, n0, xp), np.arange(py, n0, yp)
+        a0[: len(r0_), : len(c0_)] = layout.random_symmetric(n0, rows=r0_, cols=c0_)
+        z0 = np.zeros((nx0, ny0), order="F")
+        w0 = np.zeros(n0)
+        (ee.eigen_sx if route == "sx" else ee.eigen_s)(n0, n0, a0, nx0, w0, z0, nx0, m_forward=32, mode="A")
+        assert api.last_status() == 0, api.last_status()
+        wr0 = np.linalg.eigvalsh(layout.random_symmetric(n0))
+        assert np.abs(w0 - wr0).max() / np.abs(wr0).max() < 1e-12
     nx, ny = ee.eigen_get_matdims(n)
     # fill the local cyclic block with the reference's index helpers (benchmark/main2.f style)
     a = np.zeros((nx, ny), order="F")
@@ -73,6 +86,12 @@ if nb == 0:
     w = np.zeros(n)
     (ee.eigen_sx if route == "sx" else ee.eigen_s)(n, n, a, nx, w, z, nx, m_forward=32, mode="A")
     assert api.last_status() == 0, api.last_status()
+    # per-rank device memory: what the library holds (workspace pool + peer windows, the outgrown ones of the first
+    # solve included) stays under eigen_memory_internal's figure, whose n^2 terms are all divided by the rank count
+    lib_ = api._lib.load()
+    held, est = lib_.eigx_held_bytes(), lib_.eigx_memory_internal(n, nx, nx, 32, 128)
+    assert 0 < held <= est, (held, est)
+    assert est <= 8 * (7 * n * n / world + 12 * 2048 * n + 4e6), (est, n, world)
     # gather the cyclic eigenvector blocks
     zl = np.zeros(((n + xp - 1) // xp, (n + yp - 1) // yp))
     zl[: len(rows), : len(cols)] = z[: len(rows), : len(cols)]
