@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="--gpus 1: skip the extra N=32768 solve")
     ap.add_argument("--cpu-n", type=int, default=2048)
+    ap.add_argument("--mf", type=int, default=128, help="m_forward (panel width) of the main line")
+    ap.add_argument("--extra-mf", type=int, default=256, help="m_forward of the extra N=32768 solve (K = 512 slabs for the trailing update)")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of the distributed solve")
     ap.add_argument("--weak", action="store_true", help="N>1: weak scaling, N = size*sqrt(P) (size defaults to 8192)")
     args = ap.parse_args()
@@ -79,6 +81,9 @@ def main():
     from eigenexa_amd import _lib, api, layout
 
     lib = _lib.load()
+    for kv in filter(None, os.environ.get("EIGX_TUNE", "").split(",")):   # lab hook: "key=value,..." -> eigx_tune (A/B runs)
+        k_, v_ = kv.split("=")
+        lib.eigx_tune(int(k_), int(v_))
     replicas = args.replicas or world == 1
     scaling = "weak"
     if world == 1 or args.replicas:
@@ -208,7 +213,7 @@ def main():
     w = torch.zeros(n, dtype=torch.float64, device=dev)
 
     def solve(a):
-        rc = fn(n, n, a.data_ptr(), nx, w.data_ptr(), z.data_ptr(), nx, 128, 128, b"A")
+        rc = fn(n, n, a.data_ptr(), nx, w.data_ptr(), z.data_ptr(), nx, args.mf, 128, b"A")
         _lib.check(rc, "eigen_" + args.route)
 
     torch.cuda.synchronize()
@@ -307,7 +312,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"N={n} random symmetric fp64 (counter-based R+R^T, seed 20240807), eigen_{args.route} "
-                            f"all eigenpairs, m_forward=128, m_backward=128",
+                            f"all eigenpairs, m_forward={args.mf}, m_backward=128",
                 "parallelism": par,
                 "stage_ms": {"reduction": round(tm[1] * 1e3, 2), "dc": round(tm[2] * 1e3, 2),
                              "backtransform": round(tm[3] * 1e3, 2)},
@@ -336,7 +341,8 @@ def main():
             lib.eigx_profile(8)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            _lib.check(lib.eigx_sx_dev(n2, n2, a2.data_ptr(), lda2, w2.data_ptr(), z2.data_ptr(), lda2, 128, 128, b"A"), "eigen_sx")
+            _lib.check(lib.eigx_sx_dev(n2, n2, a2.data_ptr(), lda2, w2.data_ptr(), z2.data_ptr(), lda2, args.extra_mf, 128, b"A"),
+                       "eigen_sx")
             torch.cuda.synchronize()
             dt2 = time.perf_counter() - t0
             prof2 = read_prof()
@@ -344,7 +350,7 @@ def main():
             tm2 = np.zeros(16)
             lib.eigx_get_timers(tm2.ctypes.data_as(C.POINTER(C.c_double)))
             fro_err = abs(float(torch.linalg.norm(w2).item()) - fro2 ** 0.5) / fro2 ** 0.5
-            ex = {"workload": "N=32768 random symmetric fp64, eigen_sx all eigenpairs, ONE solve on this GPU "
+            ex = {"workload": f"N=32768 random symmetric fp64, eigen_sx all eigenpairs, m_forward={args.extra_mf}, ONE solve on this GPU "
                               "(BASELINE.json configs[2]'s matrix; first call at this size: includes workspace allocation)",
                   "seconds": round(dt2, 3), "gflops": round(abs(float(tm2[12])) / dt2 / 1e9, 1),
                   "stage_ms": {"reduction": round(tm2[1] * 1e3, 1), "dc": round(tm2[2] * 1e3, 1),

@@ -22,7 +22,7 @@ Multi-rank runs (one process per GPU, launched by torch.distributed.run) take th
 its own 1x1 grid (the MPI_COMM_SELF case), ``-g <k>`` split the ranks into k groups of which group 0 solves and the
 others do not participate (the MPI_COMM_NULL case), ``-x Px Py`` an explicit Px x Py grid (Px <= Py).  The local
 2-D cyclic blocks are filled from the same matrix generators; the checks gather the eigenvector blocks onto rank 0.
-``EIGX_BENCH_BACKEND=gloo`` runs all ranks on GPU 0 over the host-staged transport (functional rehearsal only).
+``EIGX_BENCH_BACKEND=gloo`` runs all ranks on GPU 0 over the hipIpc peer-window transport (functional rehearsal only).
 """
 import argparse
 import sys

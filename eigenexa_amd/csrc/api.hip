@@ -313,6 +313,7 @@ int eigx_tune(int key, int value) {
   if (key == 3) return set_symv_threshold(0, value);
   if (key == 4) return set_symv_threshold(1, value);
   if (key == 5) return set_symv_threshold(2, value);
+  if (key == 6) return set_gemm_cstream(value);
   return -1;
 }
 

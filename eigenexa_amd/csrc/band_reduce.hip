@@ -199,6 +199,7 @@ struct KAArgs {
   int nt_prev, lgT_prev;  // SYMV tiling of the previous step: tiles per dimension, log2(tile edge)
   int par;                // multi-GPU: parity of the step messages that hold the previous step's SYMV partial sums
   int pan_c0;             // multi-GPU: first global column held by the gathered panel R.PAN
+  StepWait wait;          // multi-GPU: wait for the step messages here instead of in a wait kernel (wait.n = 0: no)
 };
 
 // multi-GPU: partial number t (0 <= t < Py + Px) of global row r in the step messages of parity `par`:
@@ -235,6 +236,25 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   const int r = blockIdx.x * KA_ROWS + rr;
   const bool rowok = r < S.rows;
   EIGX_STAMP_INIT
+  if (S.wait.n > 0) {
+    // several GPUs, one per rank: lane q of the first wave waits for rank q's step message (bounded spin; a time-out
+    // sets the sticky error word and the solver reports it), the workgroup barrier releases the other waves
+    if (tid < S.wait.n) {
+      const unsigned long long* f = S.wait.flag + (S.wait.epoch & 1) * EIGX_MAXP + tid;
+      const long long t0 = wall_clock64();
+      if (__hip_atomic_load(S.wait.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < S.wait.epoch) {
+          __builtin_amdgcn_s_sleep(1);
+          if (wall_clock64() - t0 > S.wait.limit_ticks) {
+            __hip_atomic_store(S.wait.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      if (blockIdx.x == 0 && tid == 0) atomicAdd(S.wait.ticks, (unsigned long long)(wall_clock64() - t0));
+    }
+    __syncthreads();
+  }
 
   // ============ phase 0: every load that depends on nothing computed in this kernel ==================
   // The kernel is a latency chain (a few hundred bytes per thread): ALL loads are issued first, in
@@ -1338,6 +1358,8 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   KAArgs S;
   S.has_prev = 0; S.iprev = 0; S.Lprev = 0; S.kprev = 0; S.nchunk_prev = 0; S.nt_prev = 0; S.lgT_prev = 7;
   S.par = 0; S.pan_c0 = 0;
+  S.wait.n = 0; S.wait.flag = nullptr; S.wait.err = nullptr; S.wait.ticks = nullptr; S.wait.limit_ticks = 0; S.wait.epoch = 0;
+  const bool fuse_wait = mg && comm_step_wait_fused(ctx);
   int k = 0;        // panel fill
   int i = n - 1;    // top column of the current block
   if (mg) {
@@ -1360,8 +1382,14 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     if (S.has_prev && S.iprev + 1 > S.rows) S.rows = S.iprev + 1;
     const int nb_ka = (S.rows + KA_ROWS - 1) / KA_ROWS;
     if (S.rows > 0 && (S.has_prev || ncols > 0)) {
-      if (mg && S.has_prev) comm_step_wait(ctx, epoch, st);      // the previous step's messages of every rank are in
+      // the previous step's messages of every rank must be in: a wait kernel, or the wait folded into K_A's prologue
+      S.wait.n = 0;
+      if (mg && S.has_prev) {
+        if (fuse_wait) S.wait = comm_step_wait_args(ctx, epoch);
+        else comm_step_wait(ctx, epoch, st);
+      }
       hipLaunchKernelGGL((ka_kernel<NB>), dim3(nb_ka), dim3(256), 0, st, R, S);
+      S.wait.n = 0;
     }
     if (!do_step) break;
     KBArgs B;
@@ -1436,7 +1464,11 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       // panel full and more reflectors to come: finish W, trailing update, start a new panel
       KAArgs F = S;
       F.ncols = 0; F.i = i; F.L = 0; F.k = k; F.rows = S.iprev + 1;
-      if (mg) comm_step_wait(ctx, epoch, st);
+      F.wait.n = 0;
+      if (mg) {
+        if (fuse_wait) F.wait = comm_step_wait_args(ctx, epoch);
+        else comm_step_wait(ctx, epoch, st);
+      }
       hipLaunchKernelGGL((ka_kernel<NB>), dim3((F.rows + KA_ROWS - 1) / KA_ROWS), dim3(256), 0, st, R, F);
       const int nr = i + 1;
       if (ctx.prof_stride > 0) ctx.prof_begin(1, 2.0 * (double)nr * nr * m / R.P, st);

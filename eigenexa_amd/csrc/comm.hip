@@ -741,6 +741,22 @@ unsigned long long comm_step_epoch_base(Context& ctx, unsigned long long nsteps)
   return base;
 }
 
+bool comm_step_wait_fused(const Context& ctx) {
+  const CommState* cs = ctx.comm;
+  if (!cs) return false;
+  const char* e = getenv("EIGX_FUSE_WAIT");
+  if (e) return atoi(e) != 0;
+  return !cs->shared_device;
+}
+StepWait comm_step_wait_args(Context& ctx, unsigned long long epoch) {
+  CommState* cs = ctx.comm;
+  StepWait w;
+  w.flag = (const u64*)cs->flags.local + flag_index(CH_STEP, 0, 0);
+  w.err = cs->err_dev; w.ticks = cs->ticks_dev; w.limit_ticks = limit_ticks(cs);
+  w.epoch = epoch; w.n = cs->P;
+  return w;
+}
+
 void comm_step_wait(Context& ctx, unsigned long long epoch, hipStream_t s) {
   CommState* cs = ctx.comm;
   WaitArgs W;

@@ -70,6 +70,19 @@ struct StepPeers {
 double* comm_step_window(Context& ctx, size_t msg_doubles, StepPeers* peers);
 // one-wave kernel on s: wait until every rank's message of step `epoch` (1-based) has arrived
 void comm_step_wait(Context& ctx, unsigned long long epoch, hipStream_t s);
+// The same wait folded into the consumer kernel's prologue (saves the wait kernel's launch): allowed when no two ranks
+// share a GPU -- on a shared card thousands of spinning consumer workgroups could keep the producers off the CUs --
+// or when EIGX_FUSE_WAIT=1 asks for it (tests at sizes whose grids leave room).  n = 0: nothing to wait for.
+struct StepWait {
+  const unsigned long long* flag;   // my flag block of the step channel: parity p, source q at flag[p * EIGX_MAXP + q]
+  int* err;
+  unsigned long long* ticks;
+  long long limit_ticks;
+  unsigned long long epoch;
+  int n;
+};
+bool comm_step_wait_fused(const Context& ctx);
+StepWait comm_step_wait_args(Context& ctx, unsigned long long epoch);
 // first epoch number of the next reduction (epochs are monotone over the life of the communicator)
 unsigned long long comm_step_epoch_base(Context& ctx, unsigned long long nsteps);
 

@@ -72,6 +72,8 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
 
 // tuning hook (eigx_tune key 0): 2 = LDS-DMA ring GEMM where supported, 1 = register-staged GEMM only
 int set_gemm_variant(int v);
+// tuning hook (eigx_tune key 6): 1 = the trailing update streams its C tiles with non-temporal loads / stores
+int set_gemm_cstream(int v);
 // tuning hook (eigx_tune key 1): target number of concurrent Sturm sweeps of the bisection
 int set_bisect_threads(int v);
 // tuning hook (eigx_tune key 2): super-block factor of the back-transformation (0 = automatic, 1, 2, 4)

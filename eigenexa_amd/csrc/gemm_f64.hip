@@ -54,7 +54,9 @@ struct GemmArgs {
   int ownP, ownp;      // tri mode, multi-GPU: this rank updates tile columns tn with tn % ownP == ownp
   int tri_gb;          // gemm2 tri mode: tile-block edge of the XCD-aware order
   int tn_lo, tn_hi;    // tri mode: only tile columns tn_lo <= tn < tn_hi are updated (look-ahead split of the trailing update)
+  int c_stream;        // gemm2: C tiles with non-temporal loads / stores (tuning hook, eigx_tune key 6)
 };
+typedef double d2s_t __attribute__((ext_vector_type(2)));
 
 // column indices (gather map) of the slab starting at k0 for this thread's NL elements
 template <int WT>
@@ -434,8 +436,12 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmArgs g) {
             const int m = m0 + wm * 64 + p * 32 + 2 * fm;
             double2 v = make_double2(0.0, 0.0);
             if (n < g.N) {
-              if (m + 1 < g.M) v = *reinterpret_cast<const double2*>(cp + m);
-              else if (m < g.M) v.x = cp[m];
+              if (m + 1 < g.M) {
+                // trailing update: every C tile is read once and written once per launch -- streamed past L2 so that it
+                // does not evict the operand panels the tile block shares there
+                if (g.c_stream) { const d2s_t t = __builtin_nontemporal_load(reinterpret_cast<const d2s_t*>(cp + m)); v = make_double2(t.x, t.y); }
+                else v = *reinterpret_cast<const double2*>(cp + m);
+              } else if (m < g.M) v.x = cp[m];
             }
             acc[2 * p][j][r] = cscale * v.x;
             acc[2 * p + 1][j][r] = cscale * v.y;
@@ -541,8 +547,10 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmArgs g) {
         for (int p = 0; p < 2; ++p) {
           const int m = m0 + wm * 64 + p * 32 + 2 * fm;
           const double2 v = make_double2(alpha * acc[2 * p][j][r], alpha * acc[2 * p + 1][j][r]);
-          if (m + 1 < g.M) *reinterpret_cast<double2*>(cp + m) = v;
-          else if (m < g.M) cp[m] = v.x;
+          if (m + 1 < g.M) {
+            if (g.c_stream) { d2s_t t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, reinterpret_cast<d2s_t*>(cp + m)); }
+            else *reinterpret_cast<double2*>(cp + m) = v;
+          } else if (m < g.M) cp[m] = v.x;
         }
       } else {
 #pragma unroll
@@ -555,6 +563,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmArgs g) {
   }
 }
 
+int g_gemm_cstream = 0;   // tuning hook (eigx_tune key 6): stream the C tiles of the trailing update past L2
 int g_gemm_variant = 2;   // 2 = gemm2 where supported and worthwhile, 3 = wherever supported (tests), 1 = never
 
 // gemm2 needs 16-byte aligned operand columns (even leading dimensions, aligned bases, even batch strides);
@@ -575,6 +584,7 @@ static bool gemm2_ok(const GemmArgs& g, bool a_kc, bool b_kc, int batch, int bat
 }  // namespace
 
 int set_gemm_variant(int v) { const int old = g_gemm_variant; g_gemm_variant = v; return old; }
+int set_gemm_cstream(int v) { const int old = g_gemm_cstream; g_gemm_cstream = v; return old; }
 
 void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, double alpha, const double* A,
                int lda, const double* B, int ldb, double beta, double* C, int ldc, int tri_mode,
@@ -593,6 +603,7 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
   g.sA2 = strideA2; g.sB2 = strideB2; g.sC2 = strideC2;
   g.ownP = ownP; g.ownp = ownp; g.tri_gb = 1;
   g.tn_lo = tn_lo; g.tn_hi = tn_hi;
+  g.c_stream = (tri_mode != 0 && g_gemm_cstream) ? 1 : 0;
   g.Px = grid ? grid->Px : 1; g.px = grid ? grid->px : 0;
   g.Py = grid ? grid->Py : 1; g.py = grid ? grid->py : 0;
   const bool a_kc = (opA == 'T' || opA == 't');   // op(A)(m,k) = A[k + m*lda]

@@ -333,21 +333,7 @@ def test_baseline_size_properties(gpu_lib, route):
     assert (w[1:] >= w[:-1]).all()                                             # ascending
 
 
-@pytest.mark.parametrize("world,n,route,nb,dims", [
-    (2, 300, "sx", 0, ""), (2, 301, "s", 0, "2x1"), (4, 517, "sx", 0, ""), (4, 300, "s", 0, ""), (3, 260, "sx", 0, ""),
-    (6, 700, "sx", 0, "2x3"), (6, 333, "s", 0, "3x2"), (4, 1111, "sx", 0, "1x4"), (4, 515, "s", 0, "4x1"),
-    (4, 517, "sx", 32, ""), (4, 301, "s", 7, ""), (2, 260, "sx", 64, ""),
-    (2, 97, "sx", 0, ""), (4, 129, "sx", 0, ""), (3, 65, "s", 0, ""), (4, 3, "sx", 0, ""), (4, 1, "s", 0, ""),
-    (2, 2, "sx", 0, ""), (4, 5, "s", 0, ""), (6, 7, "sx", 0, "2x3"),
-    (4, 200, "h", 0, ""), (3, 131, "h", 0, ""), (2, 1900, "sx", 0, ""), (4, 2500, "sx", 0, "")])
-def test_multi_rank_solver_on_one_gpu(world, n, route, nb, dims):
-    """the N>1 path -- 2-D cyclic ownership of A (nothing replicated), one peer-write exchange per reduction step,
-    panel gathers, local trailing update, streamed back-transformation -- with `world` ranks sharing the GPU over
-    the hipIpc peer-window transport (the device code that runs over xGMI on a multi-GPU node), on 1x2, 2x1, 2x2,
-    1x3, 2x3, 3x2, 1x4 and 4x1 grids, against LAPACK and the CPU oracle; nb > 0: ScaLAPACK-style block-cyclic local
-    blocks through eigen_sx_bc / eigen_s_bc (ragged last blocks, ranks without a last block).  The box admits six
-    processes on the card, so the 2x4 grid of the 8-GPU node is covered by the CPU tests of the index arithmetic
-    (tests/test_host.py) and by the 2x3 / 3x2 / 1x4 / 4x1 grids here."""
+def _run_multi_rank(world, n, route, nb, dims, env_extra=None):
     import socket
     import subprocess
     import sys
@@ -357,8 +343,9 @@ def test_multi_rank_solver_on_one_gpu(world, n, route, nb, dims):
     port = s.getsockname()[1]
     s.close()
     script = os.path.join(os.path.dirname(__file__), "mg_worker.py")
+    env = dict(os.environ, **(env_extra or {}))
     procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port), str(n), route, str(nb), dims or "-"],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
     outs = []
     for p in procs:
         try:
@@ -369,6 +356,32 @@ def test_multi_rank_solver_on_one_gpu(world, n, route, nb, dims):
             raise
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"OK rank {r}/{world}" in o, o[-3000:]
+
+
+@pytest.mark.parametrize("world,n,route,nb,dims", [
+    (2, 300, "sx", 0, ""), (2, 301, "s", 0, "2x1"), (4, 517, "sx", 0, ""), (4, 300, "s", 0, ""), (3, 260, "sx", 0, ""),
+    (5, 700, "sx", 0, "1x5"), (3, 333, "s", 0, "3x1"), (4, 1111, "sx", 0, "1x4"), (4, 515, "s", 0, "4x1"),
+    (4, 517, "sx", 32, ""), (4, 301, "s", 7, ""), (2, 260, "sx", 64, ""),
+    (2, 97, "sx", 0, ""), (4, 129, "sx", 0, ""), (3, 65, "s", 0, ""), (4, 3, "sx", 0, ""), (4, 1, "s", 0, ""),
+    (2, 2, "sx", 0, ""), (4, 5, "s", 0, ""), (5, 7, "sx", 0, "1x5"),
+    (4, 200, "h", 0, ""), (3, 131, "h", 0, ""), (2, 1900, "sx", 0, ""), (4, 2500, "sx", 0, "")])
+def test_multi_rank_solver_on_one_gpu(world, n, route, nb, dims):
+    """the N>1 path -- 2-D cyclic ownership of A (nothing replicated), one peer-write exchange per reduction step,
+    panel gathers, local trailing update, streamed back-transformation -- with `world` ranks sharing the GPU over
+    the hipIpc peer-window transport (the device code that runs over xGMI on a multi-GPU node), on 1x2, 2x1, 2x2,
+    1x3, 3x1, 1x4, 4x1 and 1x5 grids (Px | Py: closed-form tile numbering; 2x1, 3x1, 4x1: the counted form), against
+    LAPACK and the CPU oracle; nb > 0: ScaLAPACK-style block-cyclic local blocks through eigen_sx_bc / eigen_s_bc
+    (ragged last blocks, ranks without a last block).  The box admits six processes on the card, this test runner
+    included, so five ranks is the most; the 2x3, 3x2 and 2x4 grids (2x3 and 3x2 ran green by hand: gpurun_out
+    r2_mg2.log) are covered by the CPU test of the index arithmetic (tests/test_host.py)."""
+    _run_multi_rank(world, n, route, nb, dims)
+
+
+@pytest.mark.parametrize("world,n,route,dims", [(2, 300, "sx", ""), (4, 517, "s", ""), (4, 700, "sx", "1x4")])
+def test_multi_rank_wait_folded_into_consumer(world, n, route, dims):
+    """the per-step wait inside ka_kernel's prologue instead of a wait kernel -- the form used when every rank owns a GPU;
+    forced here (EIGX_FUSE_WAIT=1) at sizes whose grids leave the shared card room for the producers"""
+    _run_multi_rank(world, n, route, 0, dims, {"EIGX_FUSE_WAIT": "1"})
 
 
 def test_gemm_gather_vs_torch(gpu_lib):
@@ -610,7 +623,7 @@ def test_benchmark_driver_check_sweep(gpu_lib, tmp_path):
                                         (2, [])])
 def test_benchmark_driver_multi_rank_grid_options(gpu_lib, tmp_path, world, opts):
     """the reference driver's process-grid options (benchmark/main2.f:139-216) with `world` ranks on one GPU over the
-    host-staged gloo transport: -g R/C rank order, -x Px Py explicit grid, -g A every rank alone (MPI_COMM_SELF),
+    hipIpc peer-window transport (gloo only carries the session id): -g R/C rank order, -x Px Py explicit grid, -g A every rank alone (MPI_COMM_SELF),
     -g k split with non-participating ranks (MPI_COMM_NULL)"""
     import socket
     import subprocess
