@@ -215,7 +215,7 @@ __device__ __forceinline__ const double* mg_partial(const RedArgs& R, int par, i
   return R.MSG + ((size_t)par * R.P + src) * R.msg_stride + off;
 }
 
-template <int NB>
+template <int NB, bool MG>
 __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   __shared__ double red[64];
   __shared__ double kd[4][256];        // reduced panel-dot vectors: [UuA, WuA, UuB, WuB][kk]  (m <= 256)
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   double* Up = R.UW;
   double* Wp = R.UW + (size_t)ldp * m;
   const int nt = S.nt_prev, lgT = S.lgT_prev;      // SYMV tiling of the previous step (T = 1 << lgT)
-  const bool mg = R.P > 1;
+  constexpr bool mg = MG;   // several GPUs (a template parameter: a run-time branch here costs register copies and waits)
   const bool hp = S.has_prev != 0;
   const int kp = hp ? S.kprev : 0;
   const int kloop = hp ? S.kprev : S.k;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   const int r = blockIdx.x * KA_ROWS + rr;
   const bool rowok = r < S.rows;
   EIGX_STAMP_INIT
-  if (S.wait.n > 0) {
+  if (MG && S.wait.n > 0) {
     // several GPUs, one per rank: lane q of the first wave waits for rank q's step message (bounded spin; a time-out
     // sets the sticky error word and the solver reports it), the workgroup barrier releases the other waves
     if (tid < S.wait.n) {
@@ -284,120 +284,158 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
     for (int j = 0; j < CHB; ++j) kdl[q][j] = 0.0;
 #pragma unroll
   for (int j = 0; j < SPB; ++j) { spl[j][0] = 0.0; spl[j][1] = 0.0; spl[j][2] = 0.0; }
+  // Everything below is UNCONDITIONAL: no branch (not even a wave-uniform one), clamped addresses that are valid
+  // whatever the step, and no loaded value is touched before the marker at the end of the phase.  A select on a
+  // loaded value, a branch around a load (its result then has to be copied into the merged register before the
+  // branch closes) or a run-time index into a register array makes hipcc wait for the load on the spot: the compiled
+  // code of the previous version did ~20 such waits one after the other, 4.8 of the kernel's 9.9 us.  Entries that a
+  // lane or a step does not have are loaded from a clamped address and dropped by the masks of the consume phase.
+  double ru_raw[2], rw_raw[2];
+  double spr[SPB][3];
+  unsigned spok = 0;                     // bit j: spr[j] is a real entry of SP for this lane
   {
     const int rc = rowok ? r : 0;
 #pragma unroll
     for (int j = 0; j < KB; ++j) {
-      if (j * KA_SL < kloop && !(EIGX_ABL(8))) {            // uniform
-        const int kk = (ks + j * KA_SL < kloop) ? ks + j * KA_SL : 0;
-        tu[j] = Up[(size_t)kk * ldp + rc];
-        tw[j] = Wp[(size_t)kk * ldp + rc];
-      }
+      const int kk = (ks + j * KA_SL < kloop) ? ks + j * KA_SL : 0;
+      tu[j] = Up[(size_t)kk * ldp + rc];
+      tw[j] = Wp[(size_t)kk * ldp + rc];
     }
   }
-  if (S.ncols > 0) {
-    for (int cc = 0; cc < S.ncols; ++cc) {
-      const int c = S.i - cc;
-      if (tid < S.k && !(EIGX_ABL(32))) {
-        ru[cc] = Up[(size_t)tid * ldp + c];
-        rw[cc] = (tid < kold) ? Wp[(size_t)tid * ldp + c] : 0.0;
-      }
-    }
-    if (ks == 0 && r <= S.i) {
-      // column i of the (lazily updated) matrix: from A itself, or from the gathered panel on several GPUs
-      const double* ci = mg ? R.PAN + (size_t)(S.i - S.pan_c0) * R.ldpan : R.A + (size_t)S.i * R.lda;
-      const double* cm = mg ? R.PAN + (size_t)(S.i - 1 - S.pan_c0) * R.ldpan : R.A + (size_t)(S.i - 1) * R.lda;
-      a_i = ci[r];
-      if (S.ncols > 1 && r <= S.i - 1) a_im = cm[r];
-    }
+  {
+    const int kku = (tid < S.k) ? tid : 0;
+    const int ic0 = S.i, ic1 = (S.i > 0) ? S.i - 1 : 0;
+    // column i of the (lazily updated) matrix: from A itself, or from the gathered panel on several GPUs
+    const double* ci = mg ? R.PAN + (size_t)((ic0 > S.pan_c0 ? ic0 : S.pan_c0) - S.pan_c0) * R.ldpan : R.A + (size_t)ic0 * R.lda;
+    const double* cm = mg ? R.PAN + (size_t)((ic1 > S.pan_c0 ? ic1 : S.pan_c0) - S.pan_c0) * R.ldpan : R.A + (size_t)ic1 * R.lda;
+    ru_raw[0] = Up[(size_t)kku * ldp + ic0];
+    rw_raw[0] = Wp[(size_t)kku * ldp + ic0];
+    ru_raw[1] = Up[(size_t)kku * ldp + ic1];
+    rw_raw[1] = Wp[(size_t)kku * ldp + ic1];
+    a_i = ci[(r <= ic0) ? r : ic0];
+    a_im = cm[(r <= ic1) ? r : ic1];
   }
-  if (hp) {
-    bA = R.sc[SC_BETA_A];
-    if (NB == 2) bB = R.sc[SC_BETA_B];
-    if (ks == 0 && rowok) {
-      uA_r = Up[(size_t)kp * ldp + r];
-      if (NB == 2) uB_r = Up[(size_t)(kp + 1) * ldp + r];
-    }
-    // SYMV partial sums of my row: t-th partial, t in [0, nt]: t <= ty -> column result of tile row t
-    // (column r of tile (t, ty)); t > ty -> row result of tile column t-1 (row r of tile (ty, t-1))
-    if (!mg) {
-      const int rc = rowp ? r : 0;
-      const int ty = rc >> lgT;
+  bA = R.sc[SC_BETA_A];
+  bB = R.sc[SC_BETA_B];
+  {
+    const int rc = rowok ? r : 0;
+    uA_r = Up[(size_t)kp * ldp + rc];
+    uB_r = Up[(size_t)(kp + (NB == 2 ? 1 : 0)) * ldp + rc];
+  }
+  // SYMV partial sums of my row: t-th partial, t in [0, nt]: t <= ty -> column result of tile row t
+  // (column r of tile (t, ty)); t > ty -> row result of tile column t-1 (row r of tile (ty, t-1))
+  if (!mg) {   // (compile-time)
+    const int rc = rowp ? r : 0;
+    const int ty = rc >> lgT;
 #pragma unroll
-      for (int j = 0; j < RPB; ++j) {
-        if (j * KA_SL < nt + 1 && !(EIGX_ABL(4))) {          // uniform
-          const int tt = ks + j * KA_SL;
-          const int t = (tt < nt + 1) ? tt : 0;
-          const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
-          ta[j] = base[rc];
-          if (NB == 2) tb[j] = base[ldp + rc];
-        }
-      }
+    for (int j = 0; j < RPB; ++j) {
+      const int tt = ks + j * KA_SL;
+      const int t = (tt < nt + 1) ? tt : 0;
+      const bool isc = t <= ty;
+      const double* bb = isc ? R.YC : R.YR;
+      const size_t off = (size_t)(isc ? t : t - 1) * NB * ldp + rc;
+      ta[j] = bb[off];
+      tb[j] = bb[off + (NB == 2 ? ldp : 0)];
+    }
+  } else {
+    // several GPUs: slice ks < Py + Px takes one rank's contribution to this row from the step messages
+    const int rc = rowp ? r : 0;
+    const int t = (ks < R.Px + R.Py) ? ks : 0;
+    int stv;
+    const double* b = mg_partial<NB>(R, S.par, t, rc, stv);
+    ta[0] = ld_sys(b);
+    tb[0] = ld_sys(b + (NB == 2 ? stv : 0));
+  }
+  // panel dots: thread kk = tid (< kp <= 256) sums entry (kind, kk) over the K_P row chunks
+  {
+    const int kk = (tid < kp) ? tid : 0;
+#pragma unroll
+    for (int j = 0; j < CHB; ++j) {
+      const int jc = (j < S.nchunk_prev) ? j : 0;
+#pragma unroll
+      for (int q = 0; q < 2 * NB; ++q) kdl[q][j] = R.KD[((size_t)jc * 2 * NB + q) * m + kk];
+    }
+  }
+  // bilinear partials of the SYMV tiles, SP[ty][tx] with the fixed row stride maxseg, tx >= ty only.
+  // Folded rows: row f (nt - f tiles) and row nt-1-f (f + 1 tiles) together fill nt + 1 <= 64 lanes;
+  // wave w takes the folded rows f = w, w + 4, ...
+  if (!mg) {   // (compile-time)
+#pragma unroll
+    for (int j = 0; j < SPB; ++j) {
+      const int f = wave + 4 * j;
+      const int cnt = nt - f;          // tiles in row f
+      const int f2 = nt - 1 - f;       // partner row (== f for the middle row of an odd nt: skipped)
+      const bool first = lane < cnt;
+      const int ty = first ? f : f2;
+      const int tx = first ? f + lane : f2 + (lane - cnt);
+      const bool ok = hp && nt <= 63 && 2 * f < nt && (first || ((f2 > f) && tx < nt));
+      const double* sp = R.SP + ((size_t)(ok ? ty : 0) * R.maxseg + (ok ? tx : 0)) * 3;
+      spr[j][0] = sp[0];
+      spr[j][1] = sp[NB == 2 ? 1 : 0];
+      spr[j][2] = sp[NB == 2 ? 2 : 0];
+      spok |= ok ? (1u << j) : 0u;
+    }
+  } else {
+    // bilinear scalars: one message per rank
+    const double* b = R.MSG + ((size_t)S.par * R.P + (tid < R.P ? tid : 0)) * R.msg_stride + NB * (R.nxs + R.nys);
+    spr[0][0] = ld_sys(b);
+    spr[0][1] = ld_sys(b + (NB == 2 ? 1 : 0));
+    spr[0][2] = ld_sys(b + (NB == 2 ? 2 : 0));
+  }
+  abl = R.KD[R.kdab_off + (tid < S.nchunk_prev ? tid : 0)];
+  // P(c, a): rows c of the previous step's SYMV result for the new block columns
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    const int c = (S.i - cc > 0) ? S.i - cc : 0;
+    if (!mg) {   // (compile-time)
+      const int ty = c >> lgT;
+      const int t = (tid < nt + 1) ? tid : 0;
+      const bool isc = t <= ty;
+      const double* bb = isc ? R.YC : R.YR;
+      const size_t off = (size_t)(isc ? t : t - 1) * NB * ldp + c;
+      pcl[cc][0] = bb[off];
+      pcl[cc][1] = bb[off + (NB == 2 ? ldp : 0)];
     } else {
-      // several GPUs: slice ks < Py + Px takes one rank's contribution to this row from the step messages
-      const int rc = rowp ? r : 0;
-      const int t = (ks < R.Px + R.Py) ? ks : 0;
+      const int t = (tid < R.Px + R.Py) ? tid : 0;
       int stv;
-      const double* b = mg_partial<NB>(R, S.par, t, rc, stv);
-      ta[0] = ld_sys(b);
-      if (NB == 2) tb[0] = ld_sys(b + stv);
+      const double* b = mg_partial<NB>(R, S.par, t, c, stv);
+      pcl[cc][0] = ld_sys(b);
+      pcl[cc][1] = ld_sys(b + (NB == 2 ? stv : 0));
     }
-    // panel dots: thread kk = tid (< kp <= 256) sums entry (kind, kk) over the K_P row chunks
-    {
-      const int kk = (tid < kp) ? tid : 0;
+  }
+  asm volatile("" ::: "memory");   // ---- marker: every load of the phase has been issued
+  // ---- masks (consume side): drop what was loaded from clamped addresses for lanes / steps that have no such entry
+  {
 #pragma unroll
-      for (int j = 0; j < CHB; ++j) {
-        if (j < S.nchunk_prev && !(EIGX_ABL(2))) {           // uniform
+    for (int j = 0; j < KB; ++j) { if (!(j * KA_SL < kloop)) { tu[j] = 0.0; tw[j] = 0.0; } }
 #pragma unroll
-          for (int q = 0; q < 2 * NB; ++q) kdl[q][j] = R.KD[((size_t)j * 2 * NB + q) * m + kk];
-        }
-      }
+    for (int cc = 0; cc < 2; ++cc) {
+      const bool have = cc < S.ncols;
+      ru[cc] = (have && tid < S.k) ? ru_raw[cc] : 0.0;
+      rw[cc] = (have && tid < S.k && tid < kold) ? rw_raw[cc] : 0.0;
+      if (!(have && hp)) { pcl[cc][0] = 0.0; pcl[cc][1] = 0.0; }
     }
-    // bilinear partials of the SYMV tiles, SP[ty][tx] with the fixed row stride maxseg, tx >= ty only.
-    // Folded rows: row f (nt - f tiles) and row nt-1-f (f + 1 tiles) together fill nt + 1 <= 64 lanes;
-    // wave w takes the folded rows f = w, w + 4, ...
-    if (!mg && nt <= 63) {
+    if (!(S.ncols > 0 && ks == 0 && r <= S.i)) a_i = 0.0;
+    if (!(S.ncols > 1 && ks == 0 && r <= S.i - 1)) a_im = 0.0;
+    if (!hp) { bA = 0.0; bB = 0.0; abl = 0.0; }
+    if (NB == 1) bB = 0.0;
+    if (!(hp && ks == 0 && rowok)) { uA_r = 0.0; uB_r = 0.0; }
+    if (NB == 1) uB_r = 0.0;
 #pragma unroll
-      for (int j = 0; j < SPB; ++j) {
-        const int f = wave + 4 * j;
-        if (2 * f < nt && !(EIGX_ABL(1))) {                  // uniform per wave
-          const int cnt = nt - f;          // tiles in row f
-          const int f2 = nt - 1 - f;       // partner row (== f for the middle row of an odd nt: skipped)
-          int ty = f, tx = f + lane;
-          bool ok = lane < cnt;
-          if (!ok) { ty = f2; tx = f2 + (lane - cnt); ok = (f2 > f) && tx < nt; }
-          const double* sp = R.SP + ((size_t)(ok ? ty : 0) * R.maxseg + (ok ? tx : 0)) * 3;
-          const double s0 = sp[0];
-          spl[j][0] = ok ? s0 : 0.0;
-          if (NB == 2) { const double s1 = sp[1], s2 = sp[2]; spl[j][1] = ok ? s1 : 0.0; spl[j][2] = ok ? s2 : 0.0; }
-        }
+    for (int j = 0; j < RPB; ++j) { if (!hp || (!mg && !(j * KA_SL < nt + 1)) || (mg && j > 0)) { ta[j] = 0.0; tb[j] = 0.0; } }
+#pragma unroll
+    for (int j = 0; j < CHB; ++j) {
+      if (!(hp && j < S.nchunk_prev)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kdl[q][j] = 0.0;
       }
     }
-    if (NB == 2) abl = R.KD[R.kdab_off + (tid < S.nchunk_prev ? tid : 0)];
-    // P(c, a): rows c of the previous step's SYMV result for the new block columns
-    if (!mg && !(EIGX_ABL(64))) {
-      for (int cc = 0; cc < S.ncols; ++cc) {
-        const int c = S.i - cc;
-        const int ty = c >> lgT;
-        const int t = (tid < nt + 1) ? tid : 0;
-        const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
-        pcl[cc][0] = base[c];
-        if (NB == 2) pcl[cc][1] = base[ldp + c];
-      }
+#pragma unroll
+    for (int j = 0; j < SPB; ++j) {
+      const bool ok = (spok >> j) & 1u;
+      spl[j][0] = ok ? spr[j][0] : 0.0; spl[j][1] = ok ? spr[j][1] : 0.0; spl[j][2] = ok ? spr[j][2] : 0.0;
     }
-    if (mg) {
-      for (int cc = 0; cc < S.ncols; ++cc) {
-        const int t = (tid < R.Px + R.Py) ? tid : 0;
-        int stv;
-        const double* b = mg_partial<NB>(R, S.par, t, S.i - cc, stv);
-        pcl[cc][0] = ld_sys(b);
-        if (NB == 2) pcl[cc][1] = ld_sys(b + stv);
-      }
-      // bilinear scalars: one message per rank
-      const double* b = R.MSG + ((size_t)S.par * R.P + (tid < R.P ? tid : 0)) * R.msg_stride + NB * (R.nxs + R.nys);
-      spl[0][0] = ld_sys(b);
-      if (NB == 2) { spl[0][1] = ld_sys(b + 1); spl[0][2] = ld_sys(b + 2); }
-    }
+    if (mg) { spl[0][0] = hp ? spr[0][0] : 0.0; spl[0][1] = hp ? spr[0][1] : 0.0; spl[0][2] = hp ? spr[0][2] : 0.0; }
   }
   EIGX_STAMP(0);
   // ---- everything is in flight; now consume -----------------------------------------------------------
@@ -411,8 +449,9 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       const int npart = R.Px + R.Py;
       if (rowp && ks < npart) { prA = ta[0]; if (NB == 2) prB = tb[0]; }
       if (tid < R.P) { v[0] = spl[0][0]; if (NB == 2) { v[1] = spl[0][1]; v[2] = spl[0][2]; } }
-      for (int cc = 0; cc < S.ncols; ++cc) {
-        if (tid < npart) { v[7 + 2 * cc] += pcl[cc][0]; if (NB == 2) v[8 + 2 * cc] += pcl[cc][1]; }
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        if (cc < S.ncols && tid < npart) { v[7 + 2 * cc] += pcl[cc][0]; if (NB == 2) v[8 + 2 * cc] += pcl[cc][1]; }
       }
     } else {
 #pragma unroll
@@ -442,15 +481,18 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
             if (NB == 2) { v[1] += sp[1]; v[2] += sp[2]; }
           }
       }
-      for (int cc = 0; cc < S.ncols; ++cc) {
-        const bool ok = tid < nt + 1;
-        v[7 + 2 * cc] += ok ? pcl[cc][0] : 0.0;
-        if (NB == 2) v[8 + 2 * cc] += ok ? pcl[cc][1] : 0.0;
-        const int c = S.i - cc, ty = c >> lgT;
-        for (int t = tid + 256; t < nt + 1; t += 256) {
-          const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
-          v[7 + 2 * cc] += base[c];
-          if (NB == 2) v[8 + 2 * cc] += base[ldp + c];
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        if (cc < S.ncols) {
+          const bool ok = tid < nt + 1;
+          v[7 + 2 * cc] += ok ? pcl[cc][0] : 0.0;
+          if (NB == 2) v[8 + 2 * cc] += ok ? pcl[cc][1] : 0.0;
+          const int c = S.i - cc, ty = c >> lgT;
+          for (int t = tid + 256; t < nt + 1; t += 256) {
+            const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
+            v[7 + 2 * cc] += base[c];
+            if (NB == 2) v[8 + 2 * cc] += base[ldp + c];
+          }
         }
       }
     }
@@ -475,7 +517,9 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
     }
   }
   if (S.ncols > 0 && tid < S.k) {
-    for (int cc = 0; cc < S.ncols; ++cc) { rowU[cc][tid] = ru[cc]; rowW[cc][tid] = rw[cc]; }
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+      if (cc < S.ncols) { rowU[cc][tid] = ru[cc]; rowW[cc][tid] = rw[cc]; }
   }
   // ============ phase 2: one block reduction for all replicated scalars ================================
   // thread kk = tid holds kd(:, kk) in registers: the corrections need no LDS round trip
@@ -488,9 +532,12 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
         v[4] += kdr[0] * kdr[3] + kdr[1] * kdr[2];
         v[5] += 2.0 * kdr[2] * kdr[3];
       }
-      for (int cc = 0; cc < S.ncols; ++cc) {
-        v[7 + 2 * cc] -= ru[cc] * kdr[1] + rw[cc] * kdr[0];
-        if (NB == 2) v[8 + 2 * cc] -= ru[cc] * kdr[3] + rw[cc] * kdr[2];
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        if (cc < S.ncols) {
+          v[7 + 2 * cc] -= ru[cc] * kdr[1] + rw[cc] * kdr[0];
+          if (NB == 2) v[8 + 2 * cc] -= ru[cc] * kdr[3] + rw[cc] * kdr[2];
+        }
       }
     }
     // G = (bilinear partials) - (panel corrections) needs only the differences: 8 values to reduce, not 11
@@ -509,12 +556,15 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
     tm[5] = tAB * gt11 + tBB * gt21;  // m21
     tm[6] = tAB * gt12 + tBB * gt22;  // m22
     // W(c, new slots) = row c of the previous step's W (same formula as the row loop below)
-    for (int cc = 0; cc < S.ncols; ++cc) {
-      const double pA = v[7 + 2 * cc], pB = v[8 + 2 * cc];
-      const double uA = rowU[cc][kp], uB = (NB == 2) ? rowU[cc][kp + 1] : 0.0;
-      const double yA = tm[0] * pA, yB = tm[1] * pA + tm[2] * pB;
-      wnew[cc][0] = yA - 0.5 * (uA * tm[3] + uB * tm[5]);
-      if (NB == 2) wnew[cc][1] = yB - 0.5 * (uA * tm[4] + uB * tm[6]);
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      if (cc < S.ncols) {
+        const double pA = v[7 + 2 * cc], pB = v[8 + 2 * cc];
+        const double uA = rowU[cc][kp], uB = (NB == 2) ? rowU[cc][kp + 1] : 0.0;
+        const double yA = tm[0] * pA, yB = tm[1] * pA + tm[2] * pB;
+        wnew[cc][0] = yA - 0.5 * (uA * tm[3] + uB * tm[5]);
+        if (NB == 2) wnew[cc][1] = yB - 0.5 * (uA * tm[4] + uB * tm[6]);
+      }
     }
   } else {
     __syncthreads();
@@ -1388,7 +1438,8 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
         if (fuse_wait) S.wait = comm_step_wait_args(ctx, epoch);
         else comm_step_wait(ctx, epoch, st);
       }
-      hipLaunchKernelGGL((ka_kernel<NB>), dim3(nb_ka), dim3(256), 0, st, R, S);
+      if (mg) hipLaunchKernelGGL((ka_kernel<NB, true>), dim3(nb_ka), dim3(256), 0, st, R, S);
+      else hipLaunchKernelGGL((ka_kernel<NB, false>), dim3(nb_ka), dim3(256), 0, st, R, S);
       S.wait.n = 0;
     }
     if (!do_step) break;
@@ -1469,7 +1520,8 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
         if (fuse_wait) F.wait = comm_step_wait_args(ctx, epoch);
         else comm_step_wait(ctx, epoch, st);
       }
-      hipLaunchKernelGGL((ka_kernel<NB>), dim3((F.rows + KA_ROWS - 1) / KA_ROWS), dim3(256), 0, st, R, F);
+      if (mg) hipLaunchKernelGGL((ka_kernel<NB, true>), dim3((F.rows + KA_ROWS - 1) / KA_ROWS), dim3(256), 0, st, R, F);
+      else hipLaunchKernelGGL((ka_kernel<NB, false>), dim3((F.rows + KA_ROWS - 1) / KA_ROWS), dim3(256), 0, st, R, F);
       const int nr = i + 1;
       if (ctx.prof_stride > 0) ctx.prof_begin(1, 2.0 * (double)nr * nr * m / R.P, st);
       if (!mg) {
