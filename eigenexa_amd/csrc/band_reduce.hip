@@ -293,13 +293,20 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   double ru_raw[2], rw_raw[2];
   double spr[SPB][3];
   unsigned spok = 0;                     // bit j: spr[j] is a real entry of SP for this lane
+  // Addresses = wave-uniform base (SGPR pair, one scalar add per load) + ONE 32-bit lane offset per family: the
+  // kernel's instruction issue is as long as its memory wait (PMC: SQ_ACTIVE_INST_ANY = SQ_WAIT_INST_ANY), and 64-bit
+  // per-lane address arithmetic with clamps was most of it.  The buffers are padded so that unclamped slots stay
+  // inside the allocation (band_reduce_impl).
   {
-    const int rc = rowok ? r : 0;
+    const unsigned voff = (unsigned)ks * (unsigned)ldp + (unsigned)(rowok ? r : 0);
 #pragma unroll
     for (int j = 0; j < KB; ++j) {
-      const int kk = (ks + j * KA_SL < kloop) ? ks + j * KA_SL : 0;
-      tu[j] = Up[(size_t)kk * ldp + rc];
-      tw[j] = Wp[(size_t)kk * ldp + rc];
+      // uniform; batches beyond the panel fill re-read batch 0 (same cache lines) instead of touching new memory
+      const int jb = (j * KA_SL < kloop) ? j * KA_SL : 0;
+      const double* bu = Up + (size_t)jb * ldp;
+      const double* bw = Wp + (size_t)jb * ldp;
+      tu[j] = bu[voff];
+      tw[j] = bw[voff];
     }
   }
   {
@@ -324,18 +331,14 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   }
   // SYMV partial sums of my row: t-th partial, t in [0, nt]: t <= ty -> column result of tile row t
   // (column r of tile (t, ty)); t > ty -> row result of tile column t-1 (row r of tile (ty, t-1))
-  if (!mg) {   // (compile-time)
-    const int rc = rowp ? r : 0;
-    const int ty = rc >> lgT;
+  if (!mg) {   // (compile-time)  one GPU: slot t of the unified array Y = YC (see band_reduce_impl)
+    const unsigned voff = (unsigned)ks * (unsigned)(NB * ldp) + (unsigned)(rowp ? r : 0);
 #pragma unroll
     for (int j = 0; j < RPB; ++j) {
-      const int tt = ks + j * KA_SL;
-      const int t = (tt < nt + 1) ? tt : 0;
-      const bool isc = t <= ty;
-      const double* bb = isc ? R.YC : R.YR;
-      const size_t off = (size_t)(isc ? t : t - 1) * NB * ldp + rc;
-      ta[j] = bb[off];
-      tb[j] = bb[off + (NB == 2 ? ldp : 0)];
+      const int jb = (j * KA_SL < nt + 1) ? j * KA_SL : 0;        // uniform; unused batches re-read batch 0
+      const double* by = R.YC + (size_t)jb * NB * ldp;
+      ta[j] = by[voff];
+      tb[j] = by[voff + (NB == 2 ? (unsigned)ldp : 0u)];
     }
   } else {
     // several GPUs: slice ks < Py + Px takes one rank's contribution to this row from the step messages
@@ -348,12 +351,13 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   }
   // panel dots: thread kk = tid (< kp <= 256) sums entry (kind, kk) over the K_P row chunks
   {
-    const int kk = (tid < kp) ? tid : 0;
 #pragma unroll
     for (int j = 0; j < CHB; ++j) {
-      const int jc = (j < S.nchunk_prev) ? j : 0;
 #pragma unroll
-      for (int q = 0; q < 2 * NB; ++q) kdl[q][j] = R.KD[((size_t)jc * 2 * NB + q) * m + kk];
+      for (int q = 0; q < 2 * NB; ++q) {
+        const double* bk = R.KD + (size_t)((j < S.nchunk_prev ? j : 0) * 2 * NB + q) * m;   // uniform
+        kdl[q][j] = bk[(unsigned)tid];
+      }
     }
   }
   // bilinear partials of the SYMV tiles, SP[ty][tx] with the fixed row stride maxseg, tx >= ty only.
@@ -388,13 +392,10 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   for (int cc = 0; cc < 2; ++cc) {
     const int c = (S.i - cc > 0) ? S.i - cc : 0;
     if (!mg) {   // (compile-time)
-      const int ty = c >> lgT;
-      const int t = (tid < nt + 1) ? tid : 0;
-      const bool isc = t <= ty;
-      const double* bb = isc ? R.YC : R.YR;
-      const size_t off = (size_t)(isc ? t : t - 1) * NB * ldp + c;
-      pcl[cc][0] = bb[off];
-      pcl[cc][1] = bb[off + (NB == 2 ? ldp : 0)];
+      const unsigned t = (tid < nt + 1) ? (unsigned)tid : 0u;
+      const double* bc = R.YC + c;                                  // uniform
+      pcl[cc][0] = bc[t * (unsigned)(NB * ldp)];
+      pcl[cc][1] = bc[t * (unsigned)(NB * ldp) + (NB == 2 ? (unsigned)ldp : 0u)];
     } else {
       const int t = (tid < R.Px + R.Py) ? tid : 0;
       int stv;
@@ -406,8 +407,6 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   asm volatile("" ::: "memory");   // ---- marker: every load of the phase has been issued
   // ---- masks (consume side): drop what was loaded from clamped addresses for lanes / steps that have no such entry
   {
-#pragma unroll
-    for (int j = 0; j < KB; ++j) { if (!(j * KA_SL < kloop)) { tu[j] = 0.0; tw[j] = 0.0; } }
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
       const bool have = cc < S.ncols;
@@ -1343,12 +1342,24 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   R.maxseg = maxseg;
   R.maxrs = maxseg;
   R.maxchunk = 4 + 1;
-  R.UW = ctx.pool.get_t<double>("red.UW", (size_t)ldp * m * 3);
+  // + 128 columns: K_A loads panel columns kk < 128 of the U and of the W region without clamping kk (masked afterwards)
+  R.UW = ctx.pool.get_t<double>("red.UW", (size_t)ldp * (m * 3 + 128));
   R.X = ctx.pool.get_t<double>("red.X", (size_t)ldp * 3);
-  R.YR = ctx.pool.get_t<double>("red.YR", (size_t)maxseg * NB * ldp);
-  R.YC = ctx.pool.get_t<double>("red.YC", (size_t)R.maxrs * NB * ldp);
+  if (!mg) {
+    // One GPU: tile (ty, tx), tx >= ty, writes its column sums to slot ty and its row sums to slot tx + 1 of ONE array
+    // Y[slot][vector][ldp] (YR = YC + one slot): the partial sums of a row r in tile row ty(r) are then simply the
+    // slots 0 .. nt -- slots t <= ty(r) hold column results of tiles (t, ty), slots t > ty(r) row results of tiles
+    // (ty, t-1), each written by exactly one tile -- and K_A addresses them with one uniform stride, no select.
+    // 161 slots at least: K_A's first batch loads slots < RPB * KA_SL = 160 unclamped.
+    const int nslot = (maxseg + 2 > 162) ? maxseg + 2 : 162;
+    R.YC = ctx.pool.get_t<double>("red.Y", (size_t)nslot * NB * ldp);
+    R.YR = R.YC + (size_t)NB * ldp;
+  } else {
+    R.YR = ctx.pool.get_t<double>("red.YR", (size_t)maxseg * NB * ldp);
+    R.YC = ctx.pool.get_t<double>("red.YC", (size_t)R.maxrs * NB * ldp);
+  }
   R.kdab_off = R.maxchunk * 2 * NB * m;
-  R.KD = ctx.pool.get_t<double>("red.KD", (size_t)R.kdab_off + R.maxchunk + 8);
+  R.KD = ctx.pool.get_t<double>("red.KD", (size_t)R.kdab_off + R.maxchunk + 8 + 512);   // + slack: K_A loads kk < 256 unclamped
   R.SP = ctx.pool.get_t<double>("red.SP", (size_t)(maxseg * maxseg) * 3 + 8);
   const int maxgp = (n + KA_ROWS - 1) / KA_ROWS + 2;
   R.gp2_off = 0;
