@@ -128,7 +128,9 @@ int eigx_sx(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, 
 int eigx_s(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int m_forward,
            int m_backward, char mode);
 
-/* Same solvers on device-resident arrays (a_dev, w_dev, z_dev are HBM pointers of this rank's GPU). */
+/* Same solvers on device-resident arrays (a_dev, w_dev, z_dev are HBM pointers of this rank's GPU).  lda >= the local
+ * row count (any parity: an odd lda or a base that is not 16-byte aligned is served from an internal padded copy); like
+ * the reference `a` is destroyed, and its padding rows (local rows beyond the matrix, up to lda) are scratch as well. */
 int eigx_sx_dev(int n, int nvec, double* a_dev, int lda, double* w_dev, double* z_dev, int ldz,
                 int m_forward, int m_backward, char mode);
 int eigx_s_dev(int n, int nvec, double* a_dev, int lda, double* w_dev, double* z_dev, int ldz,
