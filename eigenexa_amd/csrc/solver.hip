@@ -10,6 +10,8 @@
 #include <chrono>
 #include <cfloat>
 #include <limits>
+#include <vector>
+#include <cstring>
 
 namespace eigx {
 
@@ -83,38 +85,6 @@ __global__ void fill_vec_kernel(double* __restrict__ w, int n, double v) {
 // local index l of process p (of P) -> global index, blocks of nb (nb = 1: cyclic, l*P + p)
 __device__ __forceinline__ int bc_l2g(int l, int nb, int P, int p) { return ((l / nb) * P + p) * nb + l % nb; }
 
-// recv = [rank q][li + lj*bx] : local (block-)cyclic blocks of all ranks -> full matrix F(gi, gj)
-__global__ void cyclic_to_full_kernel(const double* __restrict__ recv, int bx, int by, int Px, int Py, int order_r,
-                                      int n, int nb, double* __restrict__ F, int ldf) {
-  const int q = blockIdx.z;
-  const int qx = order_r ? q / Py : q % Px, qy = order_r ? q % Py : q / Px;
-  const int lj = blockIdx.y;
-  const int gj = bc_l2g(lj, nb, Py, qy);
-  if (gj >= n) return;
-  const double* src = recv + (size_t)q * bx * by + (size_t)lj * bx;
-  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < bx; li += gridDim.x * blockDim.x) {
-    const int gi = bc_l2g(li, nb, Px, qx);
-    if (gi < n) F[(size_t)gj * ldf + gi] = src[li];
-  }
-}
-
-// local (nloc_r x nloc_c) block of the full matrix: dst(li, lj) = F(l2g(li), l2g(lj))
-__global__ void full_to_cyclic_kernel(const double* __restrict__ F, int ldf, int nloc_r, int ncols, int nb, int Px,
-                                      int px, int Py, int py, double* __restrict__ dst, int ldd) {
-  const int lj = blockIdx.y;
-  const int gj = bc_l2g(lj, nb, Py, py);
-  if (gj >= ncols) return;
-  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < nloc_r; li += gridDim.x * blockDim.x)
-    dst[(size_t)lj * ldd + li] = F[(size_t)gj * ldf + bc_l2g(li, nb, Px, px)];
-}
-
-__global__ void pack_block_kernel(const double* __restrict__ a, int lda, int nr, int nc, double* __restrict__ out,
-                                  int bx, int by) {
-  const int lj = blockIdx.y;
-  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < bx; li += gridDim.x * blockDim.x)
-    out[(size_t)lj * bx + li] = (li < nr && lj < nc) ? a[(size_t)lj * lda + li] : 0.0;
-}
-
 double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -170,19 +140,99 @@ __global__ void unpack_z_pieces_kernel(const double* __restrict__ recv, size_t p
     col[li] = __hip_atomic_load(src + li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// local blocks of every rank (2-D block-cyclic, block size nb; nb = 1: cyclic) -> replicated full matrix F(ldf, ncols)
-static void gather_full(Context& ctx, const double* a, int lda, int nrows, int ncols, int nb, double* F, int ldf,
-                        hipStream_t st) {
+// ---- block-cyclic (nb x nb blocks, a ScaLAPACK descriptor's layout) -> cyclic, as one all-to-all ---------------------
+// The element a rank holds at local (li, lj) is global (gi, gj) = (l2g(li), l2g(lj)); in the cyclic layout it belongs to
+// rank (gi mod Px, gj mod Py) at local (gi div Px, gj div Py).  The piece for a destination is addressed by the RANK of
+// the row / column among the sender's rows / columns that go to that destination: rrank[li], crank[lj] (host tables,
+// O(n / P) integers); the receiver holds, for each of its cyclic rows / columns, the sender's grid coordinate and that
+// rank (srcx / posr, srcy / posc).  This is what pdgemr2d does for the reference's callers (manual 3.4).
+__global__ void bc_pack_kernel(const double* __restrict__ a, int lda, int nr, int nc, int nb, int Px, int px, int Py, int py,
+                               int row_major, const int* __restrict__ rrank, const int* __restrict__ crank, int nrp,
+                               size_t piece, double* __restrict__ send) {
+  const int lj = blockIdx.y;
+  if (lj >= nc) return;
+  const int gj = bc_l2g(lj, nb, Py, py);
+  const int qy = gj % Py;
+  const int pc = crank[lj];
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < nr; li += gridDim.x * blockDim.x) {
+    const int gi = bc_l2g(li, nb, Px, px);
+    const int qx = gi % Px;
+    const int dst = row_major ? qx * Py + qy : qx + qy * Px;
+    send[(size_t)dst * piece + (size_t)pc * nrp + rrank[li]] = a[(size_t)lj * lda + li];
+  }
+}
+__global__ void bc_unpack_kernel(const double* __restrict__ recv, size_t piece, int nrp, int clr, int clc, int Px, int Py,
+                                 int row_major, const int* __restrict__ srcx, const int* __restrict__ posr,
+                                 const int* __restrict__ srcy, const int* __restrict__ posc, double* __restrict__ out, int ldo) {
+  const int lj = blockIdx.y;
+  if (lj >= clc) return;
+  const int sy = srcy[lj], pc = posc[lj];
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < clr; li += gridDim.x * blockDim.x) {
+    const int sx = srcx[li];
+    const int src = row_major ? sx * Py + sy : sx + sy * Px;
+    out[(size_t)lj * ldo + li] = __hip_atomic_load(recv + (size_t)src * piece + (size_t)pc * nrp + posr[li], __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// one dimension of the index tables: n indices dealt in blocks of nb to P processes (me = p) -> cyclic over the same P
+static void bc_tables_1d(int n, int nb, int P, int p, std::vector<int>& rank_of_local, std::vector<int>& src_of_cyc,
+                         std::vector<int>& pos_of_cyc, int& max_piece) {
+  const int nl = numroc(n, nb, p, P);
+  rank_of_local.assign(nl > 0 ? nl : 1, 0);
+  std::vector<int> cnt(P, 0);
+  for (int l = 0; l < nl; ++l) {                       // my block-cyclic indices in ascending local order
+    const int g = ((l / nb) * P + p) * nb + l % nb;
+    rank_of_local[l] = cnt[g % P]++;
+  }
+  // what I receive as cyclic owner p: my cyclic index c is global g = c*P + p, held by block-cyclic process (g/nb) % P
+  // at the rank it has among THAT process's indices going to me
+  const int nc = local_count(n, P, p);
+  src_of_cyc.assign(nc > 0 ? nc : 1, 0);
+  pos_of_cyc.assign(nc > 0 ? nc : 1, 0);
+  std::vector<int> seen(P, 0);
+  for (int c = 0; c < nc; ++c) {                       // ascending global order = ascending local order on every sender
+    const int g = c * P + p;
+    const int s = (g / nb) % P;
+    src_of_cyc[c] = s;
+    pos_of_cyc[c] = seen[s]++;
+  }
+  max_piece = 0;
+  for (int q = 0; q < P; ++q) { if (cnt[q] > max_piece) max_piece = cnt[q]; if (seen[q] > max_piece) max_piece = seen[q]; }
+}
+
+static void bc_to_cyclic(Context& ctx, const double* a, int lda, int n, int nb, double* out, int ldo, hipStream_t st) {
   const Grid& G = ctx.grid;
   const int P = G.nranks;
-  const int bx = numroc(nrows, nb, 0, G.Px), by = numroc(ncols, nb, 0, G.Py);   // process 0 holds the largest block
-  const int nr = numroc(nrows, nb, G.px, G.Px), nc = numroc(ncols, nb, G.py, G.Py);
-  double* sendb = ctx.pool.get_t<double>("mg.send", (size_t)bx * by);
-  double* recvb = ctx.pool.get_t<double>("mg.recv", (size_t)bx * by * P);
-  hipLaunchKernelGGL(pack_block_kernel, dim3(8, by), dim3(256), 0, st, a, lda, nr, nc, sendb, bx, by);
-  comm_allgather(ctx, COMM_WORLD, sendb, recvb, (size_t)bx * by, st);
-  hipLaunchKernelGGL(cyclic_to_full_kernel, dim3(8, by, P), dim3(256), 0, st, recvb, bx, by, G.Px, G.Py, G.row_major,
-                     nrows > ncols ? nrows : ncols, nb, F, ldf);
+  std::vector<int> rrank, srcx, posr, crank, srcy, posc;
+  int mr = 0, mc = 0;
+  bc_tables_1d(n, nb, G.Px, G.px, rrank, srcx, posr, mr);
+  bc_tables_1d(n, nb, G.Py, G.py, crank, srcy, posc, mc);
+  // the piece extents must agree on every rank: an upper bound that depends on (n, nb, grid) only
+  // (every block of a sender starts at the same residue mod P, so one destination can get ceil(nb/P) rows of EVERY block)
+  const int nrp = (numroc(n, nb, 0, G.Px) / nb + 1) * ceil_div(nb, G.Px), ncp = (numroc(n, nb, 0, G.Py) / nb + 1) * ceil_div(nb, G.Py);
+  if (mr > nrp || mc > ncp) { fprintf(stderr, "[eigx] internal: block-cyclic piece bound violated (%d > %d or %d > %d)\n", mr, nrp, mc, ncp); abort(); }
+  const size_t piece = (size_t)nrp * ncp;
+  const int nr = numroc(n, nb, G.px, G.Px), nc = numroc(n, nb, G.py, G.Py);
+  const int clr = local_count(n, G.Px, G.px), clc = local_count(n, G.Py, G.py);
+  const size_t nt = rrank.size() + srcx.size() + posr.size() + crank.size() + srcy.size() + posc.size();
+  int* tab = ctx.pool.get_t<int>("mg.bctab", nt);
+  int* htab = (int*)ctx.pool.get_host("mg.bctab", nt * sizeof(int));
+  size_t o = 0;
+  auto put = [&](const std::vector<int>& v) { int* d = tab + o; memcpy(htab + o, v.data(), v.size() * sizeof(int)); o += v.size(); return d; };
+  const int* d_rrank = put(rrank); const int* d_srcx = put(srcx); const int* d_posr = put(posr);
+  const int* d_crank = put(crank); const int* d_srcy = put(srcy); const int* d_posc = put(posc);
+  EIGX_HIP_CHECK(hipMemcpyAsync(tab, htab, nt * sizeof(int), hipMemcpyHostToDevice, st));
+  double* sendb = ctx.pool.get_t<double>("mg.xsend", piece * P);
+  PeerBuf* recvb = comm_buffer(ctx, "mg.xrecv", piece * P * sizeof(double));
+  if (nr > 0 && nc > 0)
+    hipLaunchKernelGGL(bc_pack_kernel, dim3(8, nc), dim3(256), 0, st, a, lda, nr, nc, nb, G.Px, G.px, G.Py, G.py, G.row_major,
+                       d_rrank, d_crank, nrp, piece, sendb);
+  comm_exchange(ctx, COMM_WORLD, sendb, piece, recvb, 0, piece, st, CH_BULK);
+  if (clr > 0 && clc > 0)
+    hipLaunchKernelGGL(bc_unpack_kernel, dim3(8, clc), dim3(256), 0, st, (const double*)recvb->local, piece, nrp, clr, clc, G.Px,
+                       G.Py, G.row_major, d_srcx, d_posr, d_srcy, d_posc, out, ldo);
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));   // the pinned table staging buffer is reused by the next call
 }
 
 // nb = block size of the 2-D block-cyclic layout of a and z over the process grid (1 = the cyclic layout of the
@@ -221,18 +271,13 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   // The kernels read columns in 16-byte pieces: an odd leading dimension (eigen_get_matdims mode 'M' with an odd
   // ceil(n/Px) produces one) is served from an internal padded copy; `a` is destroyed by contract anyway.
   // Several GPUs: the cyclic block a(lda, *) is used IN PLACE -- nothing of A is replicated; a block-cyclic caller
-  // (nb > 1, the ScaLAPACK interop entry) is converted to the cyclic layout through a gathered copy first.
+  // (nb > 1, the ScaLAPACK interop entry) is converted to the cyclic layout by one all-to-all first.
   const int clr = local_count(n, G.Px, G.px), clc = local_count(n, G.Py, G.py);   // cyclic local extents
   if ((lda & 1) || ((uintptr_t)a & 15) || (P > 1 && nb > 1)) {
     const int ldi = pad_ld(clr + 2);
     double* ai = ctx.pool.get_t<double>("sol.apad", (size_t)ldi * (clc > 0 ? clc : 1));
     if (P > 1 && nb > 1) {
-      const int ldf = pad_ld(n);
-      double* F = ctx.pool.get_t<double>("mg.F", (size_t)ldf * n);
-      gather_full(ctx, a, lda, n, n, nb, F, ldf, st);
-      if (clr > 0 && clc > 0)
-        hipLaunchKernelGGL(full_to_cyclic_kernel, dim3(8, clc), dim3(256), 0, st, F, ldf, clr, n, 1, G.Px, G.px, G.Py, G.py,
-                           ai, ldi);
+      bc_to_cyclic(ctx, a, lda, n, nb, ai, ldi, st);     // one all-to-all: nothing is replicated
     } else if (clr > 0 && clc > 0) {
       EIGX_HIP_CHECK(hipMemcpy2DAsync(ai, (size_t)ldi * 8, a, (size_t)lda * 8, (size_t)clr * 8, (size_t)clc,
                                       hipMemcpyDeviceToDevice, st));

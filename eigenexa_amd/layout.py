@@ -89,13 +89,16 @@ def scatter_block_cyclic(a_global, nb, nranks, rank, order="C"):
     return np.asfortranarray(a_global[np.ix_(rows, cols)])
 
 
-def gather_block_cyclic(blocks, n0, n1, nb, order="C"):
-    """inverse of scatter_block_cyclic: blocks[rank] -> global (n0, n1) matrix"""
+def gather_block_cyclic(blocks, n0, n1, nb, order="C", dims=None):
+    """inverse of scatter_block_cyclic: blocks[rank] -> global (n0, n1) matrix; dims = explicit (Px, Py) grid"""
     nranks = len(blocks)
-    Px, Py = grid_shape(nranks)
+    Px, Py = dims or grid_shape(nranks)
     out = np.zeros((n0, n1), dtype=blocks[0].dtype)
     for rank, b in enumerate(blocks):
-        px, py = rank_coords(rank, nranks, order)
+        if dims:
+            px, py = (rank // Py, rank % Py) if order in ("R", "r") else (rank % Px, rank // Px)
+        else:
+            px, py = rank_coords(rank, nranks, order)
         rows = block_cyclic_indices(n0, nb, px, Px)
         cols = block_cyclic_indices(n1, nb, py, Py)
         out[np.ix_(rows, cols)] = b[: len(rows), : len(cols)]

@@ -115,7 +115,7 @@ else:
     zl[: len(rows), : len(cols)] = z[: len(rows), : len(cols)]
     blocks = [torch.zeros(zl.shape, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(blocks, torch.from_numpy(np.ascontiguousarray(zl)))
-    Z = layout.gather_block_cyclic([b.numpy() for b in blocks], n, n, nb)
+    Z = layout.gather_block_cyclic([b.numpy() for b in blocks], n, n, nb, dims=dims)
 wr = np.linalg.eigvalsh(A)
 werr = np.abs(w - wr).max() / np.abs(wr).max()
 res, orth = layout.accuracy_metrics(A, w, Z)

@@ -361,7 +361,7 @@ def _run_multi_rank(world, n, route, nb, dims, env_extra=None):
 @pytest.mark.parametrize("world,n,route,nb,dims", [
     (2, 300, "sx", 0, ""), (2, 301, "s", 0, "2x1"), (4, 517, "sx", 0, ""), (4, 300, "s", 0, ""), (3, 260, "sx", 0, ""),
     (5, 700, "sx", 0, "1x5"), (3, 333, "s", 0, "3x1"), (4, 1111, "sx", 0, "1x4"), (4, 515, "s", 0, "4x1"),
-    (4, 517, "sx", 32, ""), (4, 301, "s", 7, ""), (2, 260, "sx", 64, ""),
+    (4, 517, "sx", 32, ""), (4, 301, "s", 7, ""), (2, 260, "sx", 64, ""), (3, 200, "sx", 5, "3x1"), (4, 131, "s", 3, "1x4"),
     (2, 97, "sx", 0, ""), (4, 129, "sx", 0, ""), (3, 65, "s", 0, ""), (4, 3, "sx", 0, ""), (4, 1, "s", 0, ""),
     (2, 2, "sx", 0, ""), (4, 5, "s", 0, ""), (5, 7, "sx", 0, "1x5"),
     (4, 200, "h", 0, ""), (3, 131, "h", 0, ""), (2, 1900, "sx", 0, ""), (4, 2500, "sx", 0, "")])
