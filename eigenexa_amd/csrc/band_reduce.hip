@@ -95,6 +95,7 @@ struct SymvGeom { int L, T, nt; };
 // non-temporal loads (its 512 MB matrix still profits from the 256 MB Infinity Cache).  Re-swept after the 1-D
 // triangular grid: N=32768 5131 ms (256 tile throughout) -> 5005 ms with the 512 tile for L > 20000; N=16384 prefers
 // the 256 tile everywhere (797 vs 818 ms with a threshold of 12000).
+int g_ka_wgs = 256;   // K_A (eigx_tune key 7): beyond 2 * this many row groups a workgroup takes several of them, ~this many workgroups
 int g_symv_t128 = 4500, g_symv_t256 = 20000;
 int g_symv_nt = 9000;
 
@@ -200,6 +201,8 @@ struct KAArgs {
   int par;                // multi-GPU: parity of the step messages that hold the previous step's SYMV partial sums
   int pan_c0;             // multi-GPU: first global column held by the gathered panel R.PAN
   StepWait wait;          // multi-GPU: wait for the step messages here instead of in a wait kernel (wait.n = 0: no)
+  int G;                  // row groups (of KA_ROWS rows) per workgroup: the scalar work of a workgroup is done once, then
+                          // its G row groups follow in a loop (the next group's loads in flight behind the current one)
 };
 
 // multi-GPU: partial number t (0 <= t < Py + Px) of global row r in the step messages of parity `par`:
@@ -215,7 +218,7 @@ __device__ __forceinline__ const double* mg_partial(const RedArgs& R, int par, i
   return R.MSG + ((size_t)par * R.P + src) * R.msg_stride + off;
 }
 
-template <int NB, bool MG>
+template <int NB, bool MG, bool LG>
 __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   __shared__ double red[64];
   __shared__ double kd[4][256];        // reduced panel-dot vectors: [UuA, WuA, UuB, WuB][kk]  (m <= 256)
@@ -233,7 +236,15 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   const int kp = hp ? S.kprev : 0;
   const int kloop = hp ? S.kprev : S.k;
   const int kold = hp ? S.kprev : S.k;  // panel slots that are final in memory
-  const int r = blockIdx.x * KA_ROWS + rr;
+  // The workgroup owns the row groups blockIdx.x * G + g, g = 0 .. G-1 (KA_ROWS rows each).  Everything that does not
+  // depend on the row -- ~85 % of the kernel's instructions: the re-reduction of the tile / panel partial sums, the 2x2
+  // algebra, the LDS tables -- is done ONCE per workgroup; with one row group per workgroup the chip ran that overhead
+  // 2 (N = 8192) to 8 (N = 32768) times per SIMD, and the PMC counters show the kernel issue-bound there.
+  // LG = false: exactly one group per workgroup (the second register set of the loop form disappears: 195 instead of 255
+  // VGPRs, two waves per SIMD) -- faster up to 512 groups (N = 8192: 143.7 against 146.8 ms per reduction); LG = true beyond
+  // (N = 32768: 5.15 against 5.48 s).
+  const int G = LG ? S.G : 1;
+  const int r = (blockIdx.x * G) * KA_ROWS + rr;      // row of group 0
   const bool rowok = r < S.rows;
   EIGX_STAMP_INIT
   if (MG && S.wait.n > 0) {
@@ -265,19 +276,13 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   constexpr int RPB = 10;               // SYMV partials per slice in the first batch (10 * KA_SL = 160)
   constexpr int CHB = 4;                // K_P row chunks (pd_rows_for() never makes more)
   constexpr int SPB = 8;                // folded SP rows per wave in the first batch (covers nt <= 64)
-  double tu[KB], tw[KB];
-  double ta[RPB], tb[RPB];
+  struct RowRegs { double tu[KB], tw[KB], ta[RPB], tb[RPB], uA, uB, ai, aim; };   // what a thread loads for its row of a group
+  RowRegs cur, nxt;
   double kdl[4][CHB];
   double spl[SPB][3];
   double abl = 0.0, pcl[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
   double bA = 0.0, bB = 0.0;
   double ru[2] = {0.0, 0.0}, rw[2] = {0.0, 0.0};
-  double uA_r = 0.0, uB_r = 0.0, a_i = 0.0, a_im = 0.0;
-  const bool rowp = hp && rowok && r < S.Lprev;
-#pragma unroll
-  for (int j = 0; j < KB; ++j) { tu[j] = 0.0; tw[j] = 0.0; }
-#pragma unroll
-  for (int j = 0; j < RPB; ++j) { ta[j] = 0.0; tb[j] = 0.0; }
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -297,58 +302,77 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   // kernel's instruction issue is as long as its memory wait (PMC: SQ_ACTIVE_INST_ANY = SQ_WAIT_INST_ANY), and 64-bit
   // per-lane address arithmetic with clamps was most of it.  The buffers are padded so that unclamped slots stay
   // inside the allocation (band_reduce_impl).
-  {
-    const unsigned voff = (unsigned)ks * (unsigned)ldp + (unsigned)(rowok ? r : 0);
+  // row loads of one row group (this thread's row rg of it): unconditional, clamped / padded addresses
+  auto load_rows = [&](int rg, RowRegs& Q) {
+    const bool ok = rg < S.rows;
+    const bool okp = hp && ok && rg < S.Lprev;
+    {
+      const unsigned voff = (unsigned)ks * (unsigned)ldp + (unsigned)(ok ? rg : 0);
 #pragma unroll
-    for (int j = 0; j < KB; ++j) {
-      // uniform; batches beyond the panel fill re-read batch 0 (same cache lines) instead of touching new memory
-      const int jb = (j * KA_SL < kloop) ? j * KA_SL : 0;
-      const double* bu = Up + (size_t)jb * ldp;
-      const double* bw = Wp + (size_t)jb * ldp;
-      tu[j] = bu[voff];
-      tw[j] = bw[voff];
+      for (int j = 0; j < KB; ++j) {
+        // uniform; batches beyond the panel fill re-read batch 0 (same cache lines) instead of touching new memory
+        const int jb = (j * KA_SL < kloop) ? j * KA_SL : 0;
+        const double* bu = Up + (size_t)jb * ldp;
+        const double* bw = Wp + (size_t)jb * ldp;
+        Q.tu[j] = bu[voff];
+        Q.tw[j] = bw[voff];
+      }
     }
-  }
+    {
+      const int ic0 = S.i, ic1 = (S.i > 0) ? S.i - 1 : 0;
+      // column i of the (lazily updated) matrix: from A itself, or from the gathered panel on several GPUs
+      const double* ci = mg ? R.PAN + (size_t)((ic0 > S.pan_c0 ? ic0 : S.pan_c0) - S.pan_c0) * R.ldpan : R.A + (size_t)ic0 * R.lda;
+      const double* cm = mg ? R.PAN + (size_t)((ic1 > S.pan_c0 ? ic1 : S.pan_c0) - S.pan_c0) * R.ldpan : R.A + (size_t)ic1 * R.lda;
+      Q.ai = ci[(rg <= ic0) ? rg : ic0];
+      Q.aim = cm[(rg <= ic1) ? rg : ic1];
+      const int rc = ok ? rg : 0;
+      Q.uA = Up[(size_t)kp * ldp + rc];
+      Q.uB = Up[(size_t)(kp + (NB == 2 ? 1 : 0)) * ldp + rc];
+    }
+    // SYMV partial sums of the row: t-th partial, t in [0, nt]: t <= ty -> column result of tile row t
+    // (column r of tile (t, ty)); t > ty -> row result of tile column t-1 (row r of tile (ty, t-1))
+    if (!mg) {   // (compile-time)  one GPU: slot t of the unified array Y = YC (see band_reduce_impl)
+      const unsigned voff = (unsigned)ks * (unsigned)(NB * ldp) + (unsigned)(okp ? rg : 0);
+#pragma unroll
+      for (int j = 0; j < RPB; ++j) {
+        const int jb = (j * KA_SL < nt + 1) ? j * KA_SL : 0;        // uniform; unused batches re-read batch 0
+        const double* by = R.YC + (size_t)jb * NB * ldp;
+        Q.ta[j] = by[voff];
+        Q.tb[j] = by[voff + (NB == 2 ? (unsigned)ldp : 0u)];
+      }
+    } else {
+      // several GPUs: slice ks < Py + Px takes one rank's contribution to this row from the step messages
+      const int rc = okp ? rg : 0;
+      const int t = (ks < R.Px + R.Py) ? ks : 0;
+      int stv;
+      const double* b = mg_partial<NB>(R, S.par, t, rc, stv);
+      Q.ta[0] = ld_sys(b);
+      Q.tb[0] = ld_sys(b + (NB == 2 ? stv : 0));
+#pragma unroll
+      for (int j = 1; j < RPB; ++j) { Q.ta[j] = 0.0; Q.tb[j] = 0.0; }
+    }
+  };
+  // masks of the row data (consume side): entries loaded from clamped addresses for rows / steps that have none
+  auto mask_rows = [&](int rg, RowRegs& Q) {
+    const bool ok = rg < S.rows;
+    if (!(S.ncols > 0 && ks == 0 && rg <= S.i)) Q.ai = 0.0;
+    if (!(S.ncols > 1 && ks == 0 && rg <= S.i - 1)) Q.aim = 0.0;
+    if (!(hp && ks == 0 && ok)) { Q.uA = 0.0; Q.uB = 0.0; }
+    if (NB == 1) Q.uB = 0.0;
+#pragma unroll
+    for (int j = 0; j < RPB; ++j) { if (!hp || (!mg && !(j * KA_SL < nt + 1)) || (mg && j > 0)) { Q.ta[j] = 0.0; Q.tb[j] = 0.0; } }
+  };
+  load_rows(r, cur);
   {
     const int kku = (tid < S.k) ? tid : 0;
     const int ic0 = S.i, ic1 = (S.i > 0) ? S.i - 1 : 0;
-    // column i of the (lazily updated) matrix: from A itself, or from the gathered panel on several GPUs
-    const double* ci = mg ? R.PAN + (size_t)((ic0 > S.pan_c0 ? ic0 : S.pan_c0) - S.pan_c0) * R.ldpan : R.A + (size_t)ic0 * R.lda;
-    const double* cm = mg ? R.PAN + (size_t)((ic1 > S.pan_c0 ? ic1 : S.pan_c0) - S.pan_c0) * R.ldpan : R.A + (size_t)ic1 * R.lda;
     ru_raw[0] = Up[(size_t)kku * ldp + ic0];
     rw_raw[0] = Wp[(size_t)kku * ldp + ic0];
     ru_raw[1] = Up[(size_t)kku * ldp + ic1];
     rw_raw[1] = Wp[(size_t)kku * ldp + ic1];
-    a_i = ci[(r <= ic0) ? r : ic0];
-    a_im = cm[(r <= ic1) ? r : ic1];
   }
   bA = R.sc[SC_BETA_A];
   bB = R.sc[SC_BETA_B];
-  {
-    const int rc = rowok ? r : 0;
-    uA_r = Up[(size_t)kp * ldp + rc];
-    uB_r = Up[(size_t)(kp + (NB == 2 ? 1 : 0)) * ldp + rc];
-  }
-  // SYMV partial sums of my row: t-th partial, t in [0, nt]: t <= ty -> column result of tile row t
-  // (column r of tile (t, ty)); t > ty -> row result of tile column t-1 (row r of tile (ty, t-1))
-  if (!mg) {   // (compile-time)  one GPU: slot t of the unified array Y = YC (see band_reduce_impl)
-    const unsigned voff = (unsigned)ks * (unsigned)(NB * ldp) + (unsigned)(rowp ? r : 0);
-#pragma unroll
-    for (int j = 0; j < RPB; ++j) {
-      const int jb = (j * KA_SL < nt + 1) ? j * KA_SL : 0;        // uniform; unused batches re-read batch 0
-      const double* by = R.YC + (size_t)jb * NB * ldp;
-      ta[j] = by[voff];
-      tb[j] = by[voff + (NB == 2 ? (unsigned)ldp : 0u)];
-    }
-  } else {
-    // several GPUs: slice ks < Py + Px takes one rank's contribution to this row from the step messages
-    const int rc = rowp ? r : 0;
-    const int t = (ks < R.Px + R.Py) ? ks : 0;
-    int stv;
-    const double* b = mg_partial<NB>(R, S.par, t, rc, stv);
-    ta[0] = ld_sys(b);
-    tb[0] = ld_sys(b + (NB == 2 ? stv : 0));
-  }
   // panel dots: thread kk = tid (< kp <= 256) sums entry (kind, kk) over the K_P row chunks
   {
 #pragma unroll
@@ -414,14 +438,9 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       rw[cc] = (have && tid < S.k && tid < kold) ? rw_raw[cc] : 0.0;
       if (!(have && hp)) { pcl[cc][0] = 0.0; pcl[cc][1] = 0.0; }
     }
-    if (!(S.ncols > 0 && ks == 0 && r <= S.i)) a_i = 0.0;
-    if (!(S.ncols > 1 && ks == 0 && r <= S.i - 1)) a_im = 0.0;
     if (!hp) { bA = 0.0; bB = 0.0; abl = 0.0; }
     if (NB == 1) bB = 0.0;
-    if (!(hp && ks == 0 && rowok)) { uA_r = 0.0; uB_r = 0.0; }
-    if (NB == 1) uB_r = 0.0;
-#pragma unroll
-    for (int j = 0; j < RPB; ++j) { if (!hp || (!mg && !(j * KA_SL < nt + 1)) || (mg && j > 0)) { ta[j] = 0.0; tb[j] = 0.0; } }
+    mask_rows(r, cur);
 #pragma unroll
     for (int j = 0; j < CHB; ++j) {
       if (!(hp && j < S.nchunk_prev)) {
@@ -439,34 +458,18 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   EIGX_STAMP(0);
   // ---- everything is in flight; now consume -----------------------------------------------------------
   double v[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [0..2] SP, [3..5] corrections, [6] uA.uB, [7..10] P(c,a)
-  double prA = 0.0, prB = 0.0;                   // my share of this row's SYMV partial sums
   // the two reciprocals of the 2x2 algebra only need the betas: start them here, off the post-reduction chain
   const double tAA = (hp && bA != 0.0) ? 1.0 / bA : 0.0;
   const double tBB = (hp && bB != 0.0) ? 1.0 / bB : 0.0;
   if (hp) {
     if (mg) {
       const int npart = R.Px + R.Py;
-      if (rowp && ks < npart) { prA = ta[0]; if (NB == 2) prB = tb[0]; }
       if (tid < R.P) { v[0] = spl[0][0]; if (NB == 2) { v[1] = spl[0][1]; v[2] = spl[0][2]; } }
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
         if (cc < S.ncols && tid < npart) { v[7 + 2 * cc] += pcl[cc][0]; if (NB == 2) v[8 + 2 * cc] += pcl[cc][1]; }
       }
     } else {
-#pragma unroll
-      for (int j = 0; j < RPB; ++j) {
-        const bool ok = rowp && (ks + j * KA_SL < nt + 1);
-        prA += ok ? ta[j] : 0.0;
-        if (NB == 2) prB += ok ? tb[j] : 0.0;
-      }
-      if (rowp) {   // more than RPB * KA_SL = 160 partials per row: not reached by symv_geom below N ~ 80000
-        const int ty = r >> lgT;
-        for (int t = ks + RPB * KA_SL; t < nt + 1; t += KA_SL) {
-          const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
-          prA += base[r];
-          if (NB == 2) prB += base[ldp + r];
-        }
-      }
 #pragma unroll
       for (int j = 0; j < SPB; ++j) {
         v[0] += spl[j][0];
@@ -570,92 +573,127 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   }
   EIGX_STAMP(2);
 
-  // ============ phase 3: row loop: slice partial sums ================================================
-  {
-    double pA = prA, pB = prB, x0 = 0.0, x1 = 0.0;
-    auto accum = [&](int kk, double u, double w) {
+  // ============ phase 3: the row groups of this workgroup ===============================================
+  double gg[3] = {0.0, 0.0, 0.0};
+  for (int g = 0; g < G; ++g) {
+    const int rg = r + g * KA_ROWS;
+    const bool okg = rg < S.rows;
+    const bool more = LG && (g + 1 < G);
+    if (more) load_rows(rg + KA_ROWS, nxt);        // the next group's loads travel behind this group's work
+    // my share of this row's SYMV partial sums
+    double prA = 0.0, prB = 0.0;
+    {
+      const bool okp = hp && okg && rg < S.Lprev;
       if (hp) {
-        pA -= u * kd[1][kk] + w * kd[0][kk];
-        if (NB == 2) pB -= u * kd[3][kk] + w * kd[2][kk];
-      }
-      if (S.ncols > 0) {
-        x0 += u * rowW[0][kk] + w * rowU[0][kk];
-        if (S.ncols > 1) x1 += u * rowW[1][kk] + w * rowU[1][kk];
-      }
-    };
-    if (rowok) {
+        if (mg) {
+          if (okp && ks < R.Px + R.Py) { prA = cur.ta[0]; if (NB == 2) prB = cur.tb[0]; }
+        } else {
 #pragma unroll
-      for (int j = 0; j < KB; ++j) {
-        const int kk = ks + j * KA_SL;
-        if (kk < kloop) accum(kk, tu[j], tw[j]);
+          for (int j = 0; j < RPB; ++j) {
+            const bool ok = okp && (ks + j * KA_SL < nt + 1);
+            prA += ok ? cur.ta[j] : 0.0;
+            if (NB == 2) prB += ok ? cur.tb[j] : 0.0;
+          }
+          if (okp) {   // more than RPB * KA_SL = 160 partials per row: not reached by symv_geom below N ~ 80000
+            for (int t = ks + RPB * KA_SL; t < nt + 1; t += KA_SL) {
+              const double* base = R.YC + (size_t)t * NB * ldp;
+              prA += base[rg];
+              if (NB == 2) prB += base[ldp + rg];
+            }
+          }
+        }
       }
-      for (int k0 = ks + KB * KA_SL; k0 < kloop; k0 += KB * KA_SL) {   // m > 128 only
-        double xu[KB], xw[KB];
+    }
+    {
+      double pA = prA, pB = prB, x0 = 0.0, x1 = 0.0;
+      auto accum = [&](int kk, double u, double w) {
+        if (hp) {
+          pA -= u * kd[1][kk] + w * kd[0][kk];
+          if (NB == 2) pB -= u * kd[3][kk] + w * kd[2][kk];
+        }
+        if (S.ncols > 0) {
+          x0 += u * rowW[0][kk] + w * rowU[0][kk];
+          if (S.ncols > 1) x1 += u * rowW[1][kk] + w * rowU[1][kk];
+        }
+      };
+      if (okg) {
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
-          const int kk = (k0 + j * KA_SL < kloop) ? k0 + j * KA_SL : 0;
-          xu[j] = Up[(size_t)kk * ldp + r];
-          xw[j] = Wp[(size_t)kk * ldp + r];
+          const int kk = ks + j * KA_SL;
+          if (kk < kloop) accum(kk, cur.tu[j], cur.tw[j]);
         }
+        for (int k0 = ks + KB * KA_SL; k0 < kloop; k0 += KB * KA_SL) {   // m > 128 only
+          double xu[KB], xw[KB];
 #pragma unroll
-        for (int j = 0; j < KB; ++j)
-          if (k0 + j * KA_SL < kloop) accum(k0 + j * KA_SL, xu[j], xw[j]);
-      }
-    }
-    // the wave's 4 slices (lane >> 4) of each row are combined with two shuffles, the 4 waves through LDS
-    double q4[4] = {pA, pB, x0, x1};
+          for (int j = 0; j < KB; ++j) {
+            const int kk = (k0 + j * KA_SL < kloop) ? k0 + j * KA_SL : 0;
+            xu[j] = Up[(size_t)kk * ldp + rg];
+            xw[j] = Wp[(size_t)kk * ldp + rg];
+          }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      q4[q] += __shfl_xor(q4[q], 16, 64);
-      q4[q] += __shfl_xor(q4[q], 32, 64);
-    }
-    if (lane < KA_ROWS) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) slice[wave][lane][q] = q4[q];
-    }
-  }
-  __syncthreads();
-  EIGX_STAMP(3);
-  double gg[3] = {0.0, 0.0, 0.0};
-  if (ks == 0 && rowok) {
-    double pA = 0.0, pB = 0.0, x0 = 0.0, x1 = 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      pA += slice[q][rr][0]; pB += slice[q][rr][1]; x0 += slice[q][rr][2]; x1 += slice[q][rr][3];
-    }
-    if (hp) {
-      const double uA = uA_r, uB = uB_r;
-      const double yA = tm[0] * pA, yB = tm[1] * pA + tm[2] * pB;
-      double wA = yA - 0.5 * (uA * tm[3] + uB * tm[5]);
-      double wB = (NB == 2) ? yB - 0.5 * (uA * tm[4] + uB * tm[6]) : 0.0;
-      if (r >= S.Lprev) { wA = 0.0; wB = 0.0; }
-      Wp[(size_t)kp * ldp + r] = wA;
-      if (NB == 2) Wp[(size_t)(kp + 1) * ldp + r] = wB;
-      if (S.ncols > 0) {
-        x0 += uA * wnew[0][0] + wA * rowU[0][kp];
-        if (NB == 2) x0 += uB * wnew[0][1] + wB * rowU[0][kp + 1];
-        if (S.ncols > 1) {
-          x1 += uA * wnew[1][0] + wA * rowU[1][kp];
-          if (NB == 2) x1 += uB * wnew[1][1] + wB * rowU[1][kp + 1];
+          for (int j = 0; j < KB; ++j)
+            if (k0 + j * KA_SL < kloop) accum(k0 + j * KA_SL, xu[j], xw[j]);
         }
       }
-    }
-    if (S.ncols > 0 && r <= S.i) {
-      const double xi = a_i - x0;
-      R.X[r] = xi;
-      double xim = 0.0;
-      if (S.ncols > 1 && r <= S.i - 1) {
-        xim = a_im - x1;
-        R.X[ldp + r] = xim;
+      // the wave's 4 slices (lane >> 4) of each row are combined with two shuffles, the 4 waves through LDS
+      double q4[4] = {pA, pB, x0, x1};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        q4[q] += __shfl_xor(q4[q], 16, 64);
+        q4[q] += __shfl_xor(q4[q], 32, 64);
       }
-      if (r < S.L) { gg[0] = xi * xi; gg[1] = xi * xim; gg[2] = xim * xim; }
-      if (r == S.i) R.d[S.i] = xi;
-      if (S.ncols > 1 && r == S.i - 1) { R.e[S.i] = xi; R.d[S.i - 1] = xim; }  // e(i,1) = A_eff(i-1,i)
+      if (lane < KA_ROWS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) slice[wave][lane][q] = q4[q];
+      }
+    }
+    __syncthreads();
+    EIGX_STAMP(3);
+    if (ks == 0 && okg) {
+      double pA = 0.0, pB = 0.0, x0 = 0.0, x1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        pA += slice[q][rr][0]; pB += slice[q][rr][1]; x0 += slice[q][rr][2]; x1 += slice[q][rr][3];
+      }
+      if (hp) {
+        const double uA = cur.uA, uB = cur.uB;
+        const double yA = tm[0] * pA, yB = tm[1] * pA + tm[2] * pB;
+        double wA = yA - 0.5 * (uA * tm[3] + uB * tm[5]);
+        double wB = (NB == 2) ? yB - 0.5 * (uA * tm[4] + uB * tm[6]) : 0.0;
+        if (rg >= S.Lprev) { wA = 0.0; wB = 0.0; }
+        Wp[(size_t)kp * ldp + rg] = wA;
+        if (NB == 2) Wp[(size_t)(kp + 1) * ldp + rg] = wB;
+        if (S.ncols > 0) {
+          x0 += uA * wnew[0][0] + wA * rowU[0][kp];
+          if (NB == 2) x0 += uB * wnew[0][1] + wB * rowU[0][kp + 1];
+          if (S.ncols > 1) {
+            x1 += uA * wnew[1][0] + wA * rowU[1][kp];
+            if (NB == 2) x1 += uB * wnew[1][1] + wB * rowU[1][kp + 1];
+          }
+        }
+      }
+      if (S.ncols > 0 && rg <= S.i) {
+        const double xi = cur.ai - x0;
+        R.X[rg] = xi;
+        double xim = 0.0;
+        if (S.ncols > 1 && rg <= S.i - 1) {
+          xim = cur.aim - x1;
+          R.X[ldp + rg] = xim;
+        }
+        if (rg < S.L) { gg[0] += xi * xi; gg[1] += xi * xim; gg[2] += xim * xim; }
+        if (rg == S.i) R.d[S.i] = xi;
+        if (S.ncols > 1 && rg == S.i - 1) { R.e[S.i] = xi; R.d[S.i - 1] = xim; }  // e(i,1) = A_eff(i-1,i)
+      }
+    }
+    if (more) {
+      __syncthreads();                 // slice[] is written again by the next group
+      mask_rows(rg + KA_ROWS, nxt);
+      cur = nxt;
     }
   }
   if (S.ncols > 0 && wave == 0) {
-    // Gram partials of the new columns over the rows above the block: x_i.x_i, x_i.x_{i-1}, x_{i-1}.x_{i-1}
-    // (the 16 row threads are lanes 0..15 of wave 0: no block reduction needed)
+    // Gram partials of the new columns over the rows above the block: x_i.x_i, x_i.x_{i-1}, x_{i-1}.x_{i-1}: one entry
+    // per workgroup (the row threads of every group are lanes 0..15 of wave 0: no block reduction needed)
 #pragma unroll
     for (int q = 0; q < 3; ++q) gg[q] = wave_sum(gg[q]);
     if (lane == 0) { R.GP[blockIdx.x * 3 + 0] = gg[0]; R.GP[blockIdx.x * 3 + 1] = gg[1]; R.GP[blockIdx.x * 3 + 2] = gg[2]; }
@@ -1418,7 +1456,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   KAArgs S;
   S.has_prev = 0; S.iprev = 0; S.Lprev = 0; S.kprev = 0; S.nchunk_prev = 0; S.nt_prev = 0; S.lgT_prev = 7;
-  S.par = 0; S.pan_c0 = 0;
+  S.par = 0; S.pan_c0 = 0; S.G = 1;
   S.wait.n = 0; S.wait.flag = nullptr; S.wait.err = nullptr; S.wait.ticks = nullptr; S.wait.limit_ticks = 0; S.wait.epoch = 0;
   const bool fuse_wait = mg && comm_step_wait_fused(ctx);
   int k = 0;        // panel fill
@@ -1441,7 +1479,11 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     S.k = k;
     S.rows = i + 1;
     if (S.has_prev && S.iprev + 1 > S.rows) S.rows = S.iprev + 1;
-    const int nb_ka = (S.rows + KA_ROWS - 1) / KA_ROWS;
+    // row groups per workgroup: one wave per SIMD at most (1024 SIMDs = 256 workgroups of 4 waves); the scalar work
+    // of a workgroup is done once for all its groups
+    const int ngroups = (S.rows + KA_ROWS - 1) / KA_ROWS;
+    S.G = (ngroups > 2 * g_ka_wgs) ? (ngroups + g_ka_wgs - 1) / g_ka_wgs : 1;
+    const int nb_ka = (ngroups + S.G - 1) / S.G;
     if (S.rows > 0 && (S.has_prev || ncols > 0)) {
       // the previous step's messages of every rank must be in: a wait kernel, or the wait folded into K_A's prologue
       S.wait.n = 0;
@@ -1449,8 +1491,13 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
         if (fuse_wait) S.wait = comm_step_wait_args(ctx, epoch);
         else comm_step_wait(ctx, epoch, st);
       }
-      if (mg) hipLaunchKernelGGL((ka_kernel<NB, true>), dim3(nb_ka), dim3(256), 0, st, R, S);
-      else hipLaunchKernelGGL((ka_kernel<NB, false>), dim3(nb_ka), dim3(256), 0, st, R, S);
+      if (mg) {
+        if (S.G > 1) hipLaunchKernelGGL((ka_kernel<NB, true, true>), dim3(nb_ka), dim3(256), 0, st, R, S);
+        else hipLaunchKernelGGL((ka_kernel<NB, true, false>), dim3(nb_ka), dim3(256), 0, st, R, S);
+      } else {
+        if (S.G > 1) hipLaunchKernelGGL((ka_kernel<NB, false, true>), dim3(nb_ka), dim3(256), 0, st, R, S);
+        else hipLaunchKernelGGL((ka_kernel<NB, false, false>), dim3(nb_ka), dim3(256), 0, st, R, S);
+      }
       S.wait.n = 0;
     }
     if (!do_step) break;
@@ -1526,13 +1573,21 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       // panel full and more reflectors to come: finish W, trailing update, start a new panel
       KAArgs F = S;
       F.ncols = 0; F.i = i; F.L = 0; F.k = k; F.rows = S.iprev + 1;
+      const int fgroups = (F.rows + KA_ROWS - 1) / KA_ROWS;
+      F.G = (fgroups > 2 * g_ka_wgs) ? (fgroups + g_ka_wgs - 1) / g_ka_wgs : 1;
+      const int nb_kf = (fgroups + F.G - 1) / F.G;
       F.wait.n = 0;
       if (mg) {
         if (fuse_wait) F.wait = comm_step_wait_args(ctx, epoch);
         else comm_step_wait(ctx, epoch, st);
       }
-      if (mg) hipLaunchKernelGGL((ka_kernel<NB, true>), dim3((F.rows + KA_ROWS - 1) / KA_ROWS), dim3(256), 0, st, R, F);
-      else hipLaunchKernelGGL((ka_kernel<NB, false>), dim3((F.rows + KA_ROWS - 1) / KA_ROWS), dim3(256), 0, st, R, F);
+      if (mg) {
+        if (F.G > 1) hipLaunchKernelGGL((ka_kernel<NB, true, true>), dim3(nb_kf), dim3(256), 0, st, R, F);
+        else hipLaunchKernelGGL((ka_kernel<NB, true, false>), dim3(nb_kf), dim3(256), 0, st, R, F);
+      } else {
+        if (F.G > 1) hipLaunchKernelGGL((ka_kernel<NB, false, true>), dim3(nb_kf), dim3(256), 0, st, R, F);
+        else hipLaunchKernelGGL((ka_kernel<NB, false, false>), dim3(nb_kf), dim3(256), 0, st, R, F);
+      }
       const int nr = i + 1;
       if (ctx.prof_stride > 0) ctx.prof_begin(1, 2.0 * (double)nr * nr * m / R.P, st);
       if (!mg) {
@@ -1599,7 +1654,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
 }  // namespace
 
 int set_symv_threshold(int which, int v) {
-  int& t = (which == 2) ? g_symv_nt : (which ? g_symv_t256 : g_symv_t128);
+  int& t = (which == 3) ? g_ka_wgs : (which == 2) ? g_symv_nt : (which ? g_symv_t256 : g_symv_t128);
   const int old = t; t = v; return old;
 }
 

@@ -1048,9 +1048,11 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
       if (trace) {
         long sumK = 0, sumN = 0;
         for (const MergeDev& M : mds) { sumK += M.K; sumN += M.nm; }
-        fprintf(stderr, "[eigx dc] height %d pass %d: %zu merges (non-deflated %ld of %ld), z gather + D2H %.3f ms, host deflation %.3f ms, "
-                "device part %.3f ms (GEMM enqueue %.3f ms)\n", h, k, ids.size(), sumK, sumN, (tt1 - tt0) * 1e3, (tt2 - tt1) * 1e3,
-                (now_s() - tt2) * 1e3, t_gemm_enq * 1e3);
+        long mine = 0;   // secular roots this rank solved (several GPUs: K (r+1)/P - K r/P of every merge)
+        for (const MergeDev& M : mds) mine += (P > 1) ? (long)((long)M.K * (ctx.grid.rank + 1) / P - (long)M.K * ctx.grid.rank / P) : M.K;
+        fprintf(stderr, "[eigx dc] rank %d/%d height %d pass %d: %zu merges (non-deflated %ld of %ld; secular roots solved here %ld), "
+                "z gather + D2H %.3f ms, host deflation %.3f ms, device part %.3f ms (GEMM enqueue %.3f ms)\n", ctx.grid.rank, P, h, k,
+                ids.size(), sumK, sumN, mine, (tt1 - tt0) * 1e3, (tt2 - tt1) * 1e3, (now_s() - tt2) * 1e3, t_gemm_enq * 1e3);
       }
     }
   }

@@ -184,9 +184,9 @@ if mode == "pmc":
 if mode == "pmc_k1":
     # one ring-kernel launch per trailing-update shape for the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     lib.eigx_tune(0, 2)
-    for nn in (8192, 16384, 32768):
-        A, lda = mk(nn, 256, 32); B, ldb = mk(nn, 256, 32); C, ldc = mk(nn, nn, 32)
+    for nn, kk in ((8192, 256), (16384, 256), (32768, 256), (32768, 512)):
+        A, lda = mk(nn, kk, 32); B, ldb = mk(nn, kk, 32); C, ldc = mk(nn, nn, 32)
         torch.cuda.synchronize()
-        call("N", "T", nn, nn, 256, -1.0, A, lda, B, ldb, 1.0, C, ldc, 1)
+        call("N", "T", nn, nn, kk, -1.0, A, lda, B, ldb, 1.0, C, ldc, 1)
         torch.cuda.synchronize()
         del A, B, C
