@@ -27,6 +27,65 @@ idn, xi, yi = ee.eigen_get_id()
 assert (xp, yp) == (dims or layout.grid_shape(world)) and idn == rank + 1
 px, py = xi - 1, yi - 1
 A = layout.random_symmetric(n)
+if route.startswith("modes-"):
+    # every mode of src/eigen_sx.F:200-240 and a partial eigenvector set on the process grid, against the CPU oracle run in
+    # the same mode (rank 0) and LAPACK
+    rt = route.split("-")[1]
+    band = 2 if rt == "sx" else 1
+    fn = ee.eigen_sx if rt == "sx" else ee.eigen_s
+    A = layout.random_symmetric(n, seed=21)
+    wr = np.linalg.eigvalsh(A)
+    rows = np.arange(px, n, xp)
+    cols = np.arange(py, n, yp)
+    nx, ny = ee.eigen_get_matdims(n)
+
+    def solve(mode, nvec):
+        a = np.zeros((nx, ny), order="F")
+        a[: len(rows), : len(cols)] = A[np.ix_(rows, cols)]
+        z = np.full((nx, ny), 7.0, order="F")
+        w = np.zeros(n)
+        fn(n, nvec, a, nx, w, z, nx, m_forward=32, m_backward=64, mode=mode)
+        assert api.last_status() == 0, (mode, api.last_status())
+        zl = np.zeros(((n + xp - 1) // xp, (n + yp - 1) // yp))
+        zl[: len(rows), : len(cols)] = z[: len(rows), : len(cols)]
+        blocks = [torch.zeros(zl.shape, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(blocks, torch.from_numpy(np.ascontiguousarray(zl)))
+        return w, layout.gather_cyclic([b.numpy() for b in blocks], n, n, dims=dims), z
+
+    for mode in "NXSCTR":
+        w, Z, zraw = solve(mode, n)
+        assert np.abs(w - wr).max() < 1e-12 * np.abs(wr).max(), mode
+        if rank == 0:
+            from oracle import orc
+
+            wo = orc.eigen(A, rt, mode)[0]
+            assert np.abs(w - wo).max() < 1e-12 * np.abs(wr).max(), mode
+        if mode == "N":
+            assert (zraw == 7.0).all()
+        if mode == "X":
+            res, orth = layout.accuracy_metrics(A, w, Z)
+            assert res < 768 and orth < 8, (res, orth)
+        if mode == "S":
+            B = Z.T @ A @ Z
+            assert np.abs(Z.T @ Z - np.eye(n)).max() < 1e-13
+            assert np.abs(np.triu(B, band + 1)).max() < 1e-12 * np.abs(A).max() * n
+        if mode == "C":
+            assert np.array_equal(Z, np.eye(n))
+        if mode in "TR":
+            assert np.abs(Z.T @ Z - np.eye(n)).max() < 1e-12
+    # partial spectrum: the first nvec eigenvectors only (src/eigen_sx.F:108-130)
+    nv = n // 3 + 1
+    w, Z, _ = solve("A", nv)
+    assert np.abs(w - wr).max() < 1e-12 * np.abs(wr).max()
+    Zp = Z[:, :nv]
+    r_ = np.linalg.norm(A @ Zp - Zp * w[None, :nv]) / (n * np.finfo(float).eps * np.linalg.norm(A))
+    o_ = np.linalg.norm(Zp.T @ Zp - np.eye(nv)) / (n * np.finfo(float).eps)
+    assert r_ < 768 and o_ < 8, (r_, o_)
+    ee.eigen_free()
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"OK rank {rank}/{world} n={n} {route} nb={nb}: all modes + nvec={nv}", flush=True)
+    sys.exit(0)
 if route == "h":
     # complex Hermitian route: every rank fills its 2-D cyclic block of the same Hermitian matrix
     rng = np.random.default_rng(4242)

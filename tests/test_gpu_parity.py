@@ -377,6 +377,13 @@ def test_multi_rank_solver_on_one_gpu(world, n, route, nb, dims):
     _run_multi_rank(world, n, route, nb, dims)
 
 
+@pytest.mark.parametrize("world,n,route,dims", [(4, 230, "modes-sx", ""), (3, 190, "modes-s", ""), (2, 150, "modes-sx", "2x1")])
+def test_multi_rank_modes_and_partial_spectrum(world, n, route, dims):
+    """modes N / X / S / C / T / R (src/eigen_sx.F:200-240) and nvec < n on the process grid: the distributed D&C delivers
+    column blocks, the identity of modes S / C is built per column block, the final all-to-all deals nvec columns"""
+    _run_multi_rank(world, n, route, 0, dims)
+
+
 @pytest.mark.parametrize("world,n,route,dims", [(2, 300, "sx", ""), (4, 517, "s", ""), (4, 700, "sx", "1x4")])
 def test_multi_rank_wait_folded_into_consumer(world, n, route, dims):
     """the per-step wait inside ka_kernel's prologue instead of a wait kernel -- the form used when every rank owns a GPU;
