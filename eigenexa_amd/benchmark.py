@@ -45,6 +45,7 @@ MATRIX_TEXT = {
     0: "(Frank matrix)", 1: "(Toeplitz matrix)", 2: "(Random matrix)", 3: "(Frank matrix 2)",
     4: "(W: 0, 1, ..., n-1)", 5: "(W: sin(PAI*5*i/(n-1)+EPS^1/4)^3)", 6: "(W: MOD(i,5)+MOD(i,2))",
     7: "(W: same as Frank matrix)", 8: "(W: Uniform Distribution, [0,1))", 9: "(W: Gauss Distribution, m=0,s=1)",
+    -1: "(Read from the data file 'A.mtx')", -2: "(Read from the data file 'B.mtx')",
 }
 EPS = np.finfo(np.float64).eps
 EPS2 = np.sqrt(EPS)
@@ -113,6 +114,8 @@ def run_case(case, check_default=None, out=print, mr=None):
     import torch
 
     n, nvec, bx, by, imode, mtype, solver, merror = case
+    if mtype < 0:   # the file decides the order (mat_dim_get, benchmark/main2.f:366-374)
+        n = layout.matrix_market_dim("A.mtx" if mtype == -1 else "B.mtx")
     nvec = min(nvec, n)
     mode = MODES.get(imode, "A")
     check = (merror == 1) if check_default is None else check_default

@@ -187,9 +187,52 @@ def helmert_spectrum_matrix(n, mtype, seed=7):
     return 0.5 * (A + A.T), np.sort(w)
 
 
+def matrix_market_dim(path):
+    """order of the matrix in a Matrix-Market coordinate file (mat_dim_get, benchmark/mat_set.f:461-533): the first line
+    that does not start with '%' holds "rows cols entries"; returns n or raises ValueError on a non-square size"""
+    with open(path) as f:
+        for line in f:
+            if not line.startswith("%"):
+                n1, n2, _ = (int(v) for v in line.split()[:3])
+                if n1 != n2:
+                    raise ValueError("Matrix size inconsistency has been found.")
+                return n1
+    raise ValueError(f"no size line in {path}")
+
+
+def read_matrix_market(path, n):
+    """symmetric matrix from a Matrix-Market coordinate file, as the reference driver reads it for matrix types -1
+    ('A.mtx') and -2 ('B.mtx') (benchmark/mat_set.f:218-330): "i j value" triples, 1-based, every entry set at (i, j)
+    and (j, i); entries that are not listed are zero"""
+    A = np.zeros((n, n))
+    with open(path) as f:
+        for line in f:
+            if not line.startswith("%"):
+                n1, n2, ne = (int(v) for v in line.split()[:3])
+                break
+        else:
+            raise ValueError(f"no size line in {path}")
+        if n1 != n or n2 != n:
+            raise ValueError("Matrix size inconsistency has been found.")
+        k = 0
+        for line in f:
+            t = line.split()
+            if len(t) < 3:
+                continue
+            i, j, v = int(t[0]) - 1, int(t[1]) - 1, float(t[2].replace("D", "E").replace("d", "e"))
+            A[i, j] = v
+            A[j, i] = v
+            k += 1
+            if k == ne:
+                break
+    return A
+
+
 def reference_matrix(n, mtype, seed=7):
     """the reference benchmark's matrix families by its type number (benchmark/mat_set.f:566-595);
-    returns (A, known ascending eigenvalues or None)."""
+    returns (A, known ascending eigenvalues or None).  Types -1 / -2 read 'A.mtx' / 'B.mtx' from the working directory."""
+    if mtype in (-1, -2):
+        return read_matrix_market("A.mtx" if mtype == -1 else "B.mtx", n), None
     if mtype == 0:
         return frank(n), frank_eigenvalues(n)
     if mtype == 1:

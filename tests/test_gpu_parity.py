@@ -600,6 +600,32 @@ def test_all_modes(gpu_lib, orc, route):
             assert np.abs(z.T @ z - np.eye(n)).max() < 1e-12
 
 
+def test_benchmark_driver_matrix_market_input(gpu_lib, tmp_path, monkeypatch):
+    """matrix type -1 of the reference driver: 'A.mtx' in the working directory decides the order and the entries
+    (benchmark/main2.f:366-374, benchmark/mat_set.f:218-330)"""
+    from eigenexa_amd import benchmark, layout
+
+    n = 150
+    A = layout.random_symmetric(n, seed=3)
+    A[np.abs(A) < 0.6] = 0.0                        # sparse: entries that are not listed are zero
+    lines = ["%%MatrixMarket matrix coordinate real symmetric", f"{n} {n} {int((np.triu(A) != 0).sum())}"]
+    for i in range(n):
+        for j in range(i, n):
+            if A[i, j] != 0.0:
+                lines.append(f"{j + 1} {i + 1} {A[i, j]!r}")
+    (tmp_path / "A.mtx").write_text("\n".join(lines) + "\n")
+    monkeypatch.chdir(tmp_path)
+    import eigenexa_amd as ee
+
+    ee.eigen_init()
+    msgs = []
+    res = benchmark.run_case((999, 999, 48, 128, 1, -1, 0, 1), out=msgs.append)     # N of the input line is overridden by the file
+    ee.eigen_free()
+    assert res["n"] == n and res["ok"], msgs
+    assert any("Read from the data file 'A.mtx'" in m for m in msgs)
+    assert any("Residual Error Test ***   : PASSED" in m for m in msgs)
+
+
 # ------------------------------------------------------------------ the reference's benchmark driver inputs
 def test_benchmark_driver_check_sweep(gpu_lib, tmp_path):
     """benchmark/check.sh: every N (here a subset of 3..256 plus 511..1025) x {Frank, random} x {eigen_sx, eigen_s}

@@ -379,3 +379,18 @@ def test_step_partition_covers_the_upper_triangle(Px, Py):
             for qx in range(Px):
                 y[r] += yc[(qx, r % Py)][r // Py]
         assert np.allclose(y, A @ u, rtol=1e-12, atol=1e-12)
+
+
+def test_matrix_market_reader(tmp_path):
+    """matrix types -1 / -2 of the reference driver (benchmark/mat_set.f:218-330, mat_dim_get :461-533): coordinate
+    triples of a symmetric matrix, comment lines, Fortran D exponents"""
+    from eigenexa_amd import layout
+
+    p = tmp_path / "A.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real symmetric\n% a comment\n4 4 5\n1 1 2.0\n2 1 -1.0\n3 3 1.5D0\n4 2 0.25\n4 4 3\n")
+    assert layout.matrix_market_dim(str(p)) == 4
+    A = layout.read_matrix_market(str(p), 4)
+    ref = np.array([[2, -1, 0, 0], [-1, 0, 0, 0.25], [0, 0, 1.5, 0], [0, 0.25, 0, 3.0]])
+    assert np.array_equal(A, ref)
+    with pytest.raises(ValueError):
+        layout.read_matrix_market(str(p), 5)
