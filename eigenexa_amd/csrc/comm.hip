@@ -432,7 +432,7 @@ int comm_init(Context& ctx, const void* uid) {
       if (now_s() - t0 > cs->timeout_s) {
         fprintf(stderr, "[eigx] rank %d: only %u of %d ranks reached eigx_init_multi\n", cs->me, cs->board->attached.load(), cs->P);
         shm_unlink(name);
-        munmap(mp, sizeof(Board)); delete cs; return EIGX_ERR_INTERNAL;
+        munmap(mp, sizeof(Board)); cs->board = nullptr; delete cs; return EIGX_ERR_INTERNAL;
       }
       usleep(100);
     }
@@ -459,10 +459,17 @@ int comm_init(Context& ctx, const void* uid) {
   }
   if (getenv("EIGX_NO_IPC")) mine.ipc_ok = 0;
   unsigned char all[EIGX_MAXP][128];
-  if (!board_exchange(cs, &mine, sizeof(mine), all)) {
-    fprintf(stderr, "[eigx] rank %d: bootstrap exchange timed out\n", cs->me);
-    delete cs; return EIGX_ERR_INTERNAL;
-  }
+  auto give_up = [&](const char* why) {   // nothing of a rejected init stays behind
+    fprintf(stderr, "[eigx] rank %d: %s\n", cs->me, why);
+    if (cs->me == 0) shm_unlink(name);
+    Board* b = cs->board;
+    cs->board = nullptr;                  // no farewell exchange in comm_free: the peers may be gone
+    ctx.comm = cs;
+    comm_free(ctx);
+    if (b) munmap(b, sizeof(Board));
+    return EIGX_ERR_INTERNAL;
+  };
+  if (!board_exchange(cs, &mine, sizeof(mine), all)) return give_up("bootstrap exchange timed out");
   if (cs->me == 0) shm_unlink(name);   // everybody has it mapped: the name can go (the memory lives until the last munmap)
   bool all_ipc = true;
   for (int q = 0; q < cs->P; ++q) {
@@ -489,7 +496,7 @@ int comm_init(Context& ctx, const void* uid) {
   }
   {  // the decision must be the same everywhere
     unsigned char ok_all[EIGX_MAXP][128];
-    if (!board_exchange(cs, &map_ok, sizeof(map_ok), ok_all)) { delete cs; return EIGX_ERR_INTERNAL; }
+    if (!board_exchange(cs, &map_ok, sizeof(map_ok), ok_all)) return give_up("bootstrap exchange timed out");
     for (int q = 0; q < cs->P; ++q) { int v; memcpy(&v, ok_all[q], sizeof(v)); if (!v) map_ok = 0; }
   }
   cs->ipc = map_ok != 0;
@@ -515,7 +522,7 @@ int comm_init(Context& ctx, const void* uid) {
   }
   {
     unsigned char ok_all[EIGX_MAXP][128];
-    if (!board_exchange(cs, &rccl_ok, sizeof(rccl_ok), ok_all)) { delete cs; return EIGX_ERR_INTERNAL; }
+    if (!board_exchange(cs, &rccl_ok, sizeof(rccl_ok), ok_all)) return give_up("bootstrap exchange timed out");
     for (int q = 0; q < cs->P; ++q) { int v; memcpy(&v, ok_all[q], sizeof(v)); if (!v) rccl_ok = 0; }
   }
   cs->rccl = rccl_ok != 0;

@@ -201,7 +201,7 @@ static void bc_tables_1d(int n, int nb, int P, int p, std::vector<int>& rank_of_
   for (int q = 0; q < P; ++q) { if (cnt[q] > max_piece) max_piece = cnt[q]; if (seen[q] > max_piece) max_piece = seen[q]; }
 }
 
-static void bc_to_cyclic(Context& ctx, const double* a, int lda, int n, int nb, double* out, int ldo, hipStream_t st) {
+static int bc_to_cyclic(Context& ctx, const double* a, int lda, int n, int nb, double* out, int ldo, hipStream_t st) {
   const Grid& G = ctx.grid;
   const int P = G.nranks;
   std::vector<int> rrank, srcx, posr, crank, srcy, posc;
@@ -211,7 +211,10 @@ static void bc_to_cyclic(Context& ctx, const double* a, int lda, int n, int nb, 
   // the piece extents must agree on every rank: an upper bound that depends on (n, nb, grid) only
   // (every block of a sender starts at the same residue mod P, so one destination can get ceil(nb/P) rows of EVERY block)
   const int nrp = (numroc(n, nb, 0, G.Px) / nb + 1) * ceil_div(nb, G.Px), ncp = (numroc(n, nb, 0, G.Py) / nb + 1) * ceil_div(nb, G.Py);
-  if (mr > nrp || mc > ncp) { fprintf(stderr, "[eigx] internal: block-cyclic piece bound violated (%d > %d or %d > %d)\n", mr, nrp, mc, ncp); abort(); }
+  if (mr > nrp || mc > ncp) {   // cannot happen (see the bound above); refuse rather than write past a piece
+    fprintf(stderr, "[eigx] internal: block-cyclic piece bound violated (%d > %d or %d > %d)\n", mr, nrp, mc, ncp);
+    return EIGX_ERR_INTERNAL;
+  }
   const size_t piece = (size_t)nrp * ncp;
   const int nr = numroc(n, nb, G.px, G.Px), nc = numroc(n, nb, G.py, G.Py);
   const int clr = local_count(n, G.Px, G.px), clc = local_count(n, G.Py, G.py);
@@ -233,6 +236,7 @@ static void bc_to_cyclic(Context& ctx, const double* a, int lda, int n, int nb, 
     hipLaunchKernelGGL(bc_unpack_kernel, dim3(8, clc), dim3(256), 0, st, (const double*)recvb->local, piece, nrp, clr, clc, G.Px,
                        G.Py, G.row_major, d_srcx, d_posr, d_srcy, d_posc, out, ldo);
   EIGX_HIP_CHECK(hipStreamSynchronize(st));   // the pinned table staging buffer is reused by the next call
+  return EIGX_OK;
 }
 
 // nb = block size of the 2-D block-cyclic layout of a and z over the process grid (1 = the cyclic layout of the
@@ -277,7 +281,8 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
     const int ldi = pad_ld(clr + 2);
     double* ai = ctx.pool.get_t<double>("sol.apad", (size_t)ldi * (clc > 0 ? clc : 1));
     if (P > 1 && nb > 1) {
-      bc_to_cyclic(ctx, a, lda, n, nb, ai, ldi, st);     // one all-to-all: nothing is replicated
+      const int rc_bc = bc_to_cyclic(ctx, a, lda, n, nb, ai, ldi, st);     // one all-to-all: nothing is replicated
+      if (rc_bc != EIGX_OK) return rc_bc;
     } else if (clr > 0 && clc > 0) {
       EIGX_HIP_CHECK(hipMemcpy2DAsync(ai, (size_t)ldi * 8, a, (size_t)lda * 8, (size_t)clr * 8, (size_t)clc,
                                       hipMemcpyDeviceToDevice, st));

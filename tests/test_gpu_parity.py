@@ -612,7 +612,7 @@ def test_benchmark_driver_matrix_market_input(gpu_lib, tmp_path, monkeypatch):
     for i in range(n):
         for j in range(i, n):
             if A[i, j] != 0.0:
-                lines.append(f"{j + 1} {i + 1} {A[i, j]!r}")
+                lines.append(f"{j + 1} {i + 1} {float(A[i, j])!r}")
     (tmp_path / "A.mtx").write_text("\n".join(lines) + "\n")
     monkeypatch.chdir(tmp_path)
     import eigenexa_amd as ee

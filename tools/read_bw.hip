@@ -61,6 +61,21 @@ int main() {
     }
   time("linear read, 8192 WGs, 16 loads in flight, nt", [&] { hipLaunchKernelGGL((rd<16, true>), dim3(8192), dim3(256), 0, 0, p, n2, out); }, (double)bytes);
   time("linear read, 8192 WGs, 4 loads in flight, nt", [&] { hipLaunchKernelGGL((rd<4, true>), dim3(8192), dim3(256), 0, 0, p, n2, out); }, (double)bytes);
+  // Infinity-Cache-resident sizes (the upper triangle of N = 8192 is 268 MB and shrinks): repeated reads of one buffer
+  for (size_t mb : {64, 128, 192, 256, 512}) {
+    char nm[96];
+    snprintf(nm, 96, "linear read of the same %zu MB, 8192 WGs, repeated", mb);
+    const size_t m2 = (mb << 20) / 16;
+    time(nm, [&] { hipLaunchKernelGGL((rd<8, false>), dim3(8192), dim3(256), 0, 0, p, m2, out); }, (double)(mb << 20));
+    snprintf(nm, 96, "linear read of the same %zu MB, 2048 WGs, repeated", mb);
+    time(nm, [&] { hipLaunchKernelGGL((rd<8, false>), dim3(2048), dim3(256), 0, 0, p, m2, out); }, (double)(mb << 20));
+  }
+  {
+    const int n = 8192 - 1024, ld = 8192 + 34, nt = n / 128;   // N = 8192-sized matrix (411 MB square, repeated)
+    time("128x128 tiles of a 7168^2 block, ld=8226, repeated", [&] { hipLaunchKernelGGL((rd_tiles<false>), dim3(nt * nt), dim3(256), 0, 0, (const double*)p, ld, nt, out); }, 8.0 * n * n);
+    const int n2 = 4096, nt2 = n2 / 128;                        // 134 MB square
+    time("128x128 tiles of a 4096^2 block, ld=8226, repeated", [&] { hipLaunchKernelGGL((rd_tiles<false>), dim3(nt2 * nt2), dim3(256), 0, 0, (const double*)p, ld, nt2, out); }, 8.0 * n2 * n2);
+  }
   {
     const int n = 32768 - 2048, ld = 32768 + 34, nt = n / 128;   // column-major matrix, SYMV-like tiles
     time("128x128 tiles, 8 cols x 1 KiB per wave, ld=32802", [&] { hipLaunchKernelGGL((rd_tiles<false>), dim3(nt * nt), dim3(256), 0, 0, (const double*)p, ld, nt, out); }, 8.0 * n * n);
