@@ -22,6 +22,8 @@ import eigenexa_amd as ee
 from eigenexa_amd import api, layout
 
 ee.eigen_init(comm=True, device=0, dims=dims)
+for kv in filter(None, os.environ.get("EIGX_TEST_TUNE", "").split(",")):   # e.g. "7=4": K_A's row-group loop at small sizes
+    api._lib.load().eigx_tune(int(kv.split("=")[0]), int(kv.split("=")[1]))
 procs, xp, yp = ee.eigen_get_procs()
 idn, xi, yi = ee.eigen_get_id()
 assert (xp, yp) == (dims or layout.grid_shape(world)) and idn == rank + 1
@@ -85,6 +87,49 @@ if route.startswith("modes-"):
     dist.barrier()
     dist.destroy_process_group()
     print(f"OK rank {rank}/{world} n={n} {route} nb={nb}: all modes + nvec={nv}", flush=True)
+    sys.exit(0)
+if route.startswith("edge-"):
+    # error behaviour and scaling on the process grid: NaN / Inf anywhere in the upper triangle -> w = NaN on every rank
+    # (src/eigen_sx.F:151-155, the flag travels through the MAX allreduce of eigen_scaling); matrices scaled by 1e+-200
+    # are solved as accurately as the unscaled one (src/eigen_scaling.F:127-147)
+    rt = route.split("-")[1]
+    fn = ee.eigen_sx if rt == "sx" else ee.eigen_s
+    A = layout.random_symmetric(n, seed=5)
+    wr = np.linalg.eigvalsh(A)
+    rows = np.arange(px, n, xp)
+    cols = np.arange(py, n, yp)
+    nx, ny = ee.eigen_get_matdims(n)
+    for scale in (1e200, 1e-200, 1.0):
+        a = np.zeros((nx, ny), order="F")
+        a[: len(rows), : len(cols)] = A[np.ix_(rows, cols)] * scale
+        z = np.zeros((nx, ny), order="F")
+        w = np.zeros(n)
+        fn(n, n, a, nx, w, z, nx, m_forward=32, mode="A")
+        assert api.last_status() == 0
+        assert np.abs(w / scale - wr).max() < 1e-12 * np.abs(wr).max(), scale
+    for bad in (np.nan, np.inf):
+        a = np.zeros((nx, ny), order="F")
+        a[: len(rows), : len(cols)] = A[np.ix_(rows, cols)]
+        gi, gj = n // 3, n // 2          # one entry of the upper triangle, on whichever rank owns it
+        if gi % xp == px and gj % yp == py:
+            a[gi // xp, gj // yp] = bad
+        z = np.zeros((nx, ny), order="F")
+        w = np.zeros(n)
+        fn(n, n, a, nx, w, z, nx, m_forward=32, mode="A")
+        assert api.last_status() == -5 and np.isnan(w).all(), (api.last_status(), w[:3])
+    # the strict lower triangle is never read: poison it on every rank
+    a = np.zeros((nx, ny), order="F")
+    blk = A[np.ix_(rows, cols)].copy()
+    blk[rows[:, None] > cols[None, :]] = np.nan
+    a[: len(rows), : len(cols)] = blk
+    z = np.zeros((nx, ny), order="F")
+    w = np.zeros(n)
+    fn(n, n, a, nx, w, z, nx, m_forward=32, mode="A")
+    assert api.last_status() == 0 and np.abs(w - wr).max() < 1e-12 * np.abs(wr).max()
+    ee.eigen_free()
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"OK rank {rank}/{world} n={n} {route} nb={nb}: scaling, NaN / Inf, poisoned lower triangle", flush=True)
     sys.exit(0)
 if route == "h":
     # complex Hermitian route: every rank fills its 2-D cyclic block of the same Hermitian matrix

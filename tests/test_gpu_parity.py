@@ -384,6 +384,44 @@ def test_multi_rank_modes_and_partial_spectrum(world, n, route, dims):
     _run_multi_rank(world, n, route, 0, dims)
 
 
+@pytest.mark.parametrize("world,n,route,dims", [(2, 700, "sx", ""), (4, 900, "s", "")])
+def test_multi_rank_row_group_loop(world, n, route, dims):
+    """ka_kernel's loop form (one workgroup, several row groups: what runs beyond 512 row groups, i.e. N > 8192) forced
+    at a small size on the process grid (eigx_tune key 7 = 4 workgroups), with the wait folded into the kernel"""
+    _run_multi_rank(world, n, route, 0, dims, {"EIGX_TEST_TUNE": "7=4", "EIGX_FUSE_WAIT": "1"})
+
+
+@pytest.mark.parametrize("band", [1, 2])
+def test_row_group_loop_matches_oracle(gpu_lib, orc, band):
+    """the same loop form on one GPU against the oracle: tridiagonal (d, |e|) element-wise, pentadiagonal spectrum"""
+    import torch
+    from eigenexa_amd import layout
+
+    n, m = 700, 48
+    A = layout.random_symmetric(n, seed=11)
+    old = gpu_lib.eigx_tune(7, 4)
+    try:
+        a, lda = _to_colmajor(A)
+        d = torch.zeros(n, dtype=torch.float64, device=_dev())
+        e = torch.zeros(2 * n, dtype=torch.float64, device=_dev())
+        assert gpu_lib.eigx_band_reduce_dev(n, a.data_ptr(), lda, d.data_ptr(), e.data_ptr(), n, m, band) == 0
+    finally:
+        gpu_lib.eigx_tune(7, old)
+    dg, eg = d.cpu().numpy(), e.cpu().numpy().reshape(2, n)
+    wr = np.linalg.eigvalsh(A)
+    assert np.abs(np.linalg.eigvalsh(_band_matrix(dg, eg[:band], band)) - wr).max() < 1e-13 * n * np.abs(wr).max()
+    if band == 1:
+        do, eo, _ = orc.band_reduce(A, 1)
+        scale = np.abs(A).max() * n
+        assert np.abs(dg - do).max() < 1e-9 * scale and np.abs(np.abs(eg[0]) - np.abs(eo[0])).max() < 1e-9 * scale
+
+
+@pytest.mark.parametrize("world,n,route,dims", [(4, 210, "edge-sx", ""), (2, 170, "edge-s", "2x1")])
+def test_multi_rank_error_behaviour_and_scaling(world, n, route, dims):
+    """NaN / Inf input, matrices scaled by 1e+-200 and a NaN-poisoned strict lower triangle on the process grid"""
+    _run_multi_rank(world, n, route, 0, dims)
+
+
 @pytest.mark.parametrize("world,n,route,dims", [(2, 300, "sx", ""), (4, 517, "s", ""), (4, 700, "sx", "1x4")])
 def test_multi_rank_wait_folded_into_consumer(world, n, route, dims):
     """the per-step wait inside ka_kernel's prologue instead of a wait kernel -- the form used when every rank owns a GPU;
@@ -615,12 +653,8 @@ def test_benchmark_driver_matrix_market_input(gpu_lib, tmp_path, monkeypatch):
                 lines.append(f"{j + 1} {i + 1} {float(A[i, j])!r}")
     (tmp_path / "A.mtx").write_text("\n".join(lines) + "\n")
     monkeypatch.chdir(tmp_path)
-    import eigenexa_amd as ee
-
-    ee.eigen_init()
     msgs = []
     res = benchmark.run_case((999, 999, 48, 128, 1, -1, 0, 1), out=msgs.append)     # N of the input line is overridden by the file
-    ee.eigen_free()
     assert res["n"] == n and res["ok"], msgs
     assert any("Read from the data file 'A.mtx'" in m for m in msgs)
     assert any("Residual Error Test ***   : PASSED" in m for m in msgs)
