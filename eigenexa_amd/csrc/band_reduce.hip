@@ -85,18 +85,23 @@ struct RedArgs {
 };
 
 // SYMV tiling: square tiles of T = 128*RB rows/cols (RB = 1,2,4); tile (ty,tx) with tx >= ty is one
-// workgroup.  Small triangles get small tiles so that >= ~400 workgroups exist; the 512 tile takes over beyond
-// L = 20000 (fewer partial sums per row, 2.5 % faster there).
+// workgroup.  Small triangles get small tiles so that enough workgroups exist.
 struct SymvGeom { int L, T, nt; };
 
 // Tile-size thresholds and the active size above which the matrix is streamed with non-temporal loads
-// (eigx_tune keys 3, 4, 5).  A/B on one MI355X (tools/gpu_reduce_time.py): N=16384 972 -> 833 ms and N=32768
-// 6008 -> 5347 ms with the 256 tile + non-temporal loads instead of the 512 tile; N=8192 loses 1 % with
-// non-temporal loads (its 512 MB matrix still profits from the 256 MB Infinity Cache).  Re-swept after the 1-D
-// triangular grid: N=32768 5131 ms (256 tile throughout) -> 5005 ms with the 512 tile for L > 20000; N=16384 prefers
-// the 256 tile everywhere (797 vs 818 ms with a threshold of 12000).
+// (eigx_tune keys 3, 4, 5).  History of the A/B runs on one MI355X (tools/gpu_reduce_time.py): the 256 tile + non-temporal
+// loads took N=16384 from 972 to 833 ms and N=32768 from 6008 to 5347 ms against the 512 tile; N=8192 loses 1 % with
+// non-temporal loads (its 512 MB matrix still profits from the 256 MB Infinity Cache).  Round 2, same box, same call:
+// N=32768 4871 ms (512 tile beyond L = 20000) / 4807 (beyond 26000) / 4732 (256 tile throughout) -- the 512 tile's 172
+// VGPRs leave two workgroups per CU and its 2080 tiles two "generations" -- so the 512 tile now starts at L = 40000
+// (beyond that the 256 tile would give a row more than the 160 partial sums K_A loads in its first batch); and the
+// 128 tile up to L = 9000 instead of 4500: N=8192 141.7 -> 140.9 ms (below ~8000 the 256 tile leaves fewer than two
+// workgroups per CU), N=32768 unchanged.  tools/symv_stream.hip (the kernel's load loop alone, same tiles and order)
+// reads 6.5-6.9 TB/s; adding the tile's partial-sum stores (1.6 % of the bytes) costs 10-17 % of that on their own,
+// and nothing when they stay inside L2.  Walking the triangle tile column by tile column instead
+// of row by row changes nothing (A/B on one buffer).
 int g_ka_wgs = 256;   // K_A (eigx_tune key 7): beyond 2 * this many row groups a workgroup takes several of them, ~this many workgroups
-int g_symv_t128 = 4500, g_symv_t256 = 20000;
+int g_symv_t128 = 9000, g_symv_t256 = 40000;
 int g_symv_nt = 9000;
 
 inline SymvGeom symv_geom(int L) {
@@ -981,7 +986,15 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
       gv[0] += R.GP[3 * q];
       if (NV == 2) { gv[1] += R.GP[3 * q + 1]; gv[2] += R.GP[3 * q + 2]; }
     }
-    block_sum_multi<3>(gv, red);
+    if (EIGX_ABL(128)) { gv[0] = 1.0; gv[1] = 0.1; gv[2] = 1.0; }   // diagnostic build: no scalar reduction
+    else block_sum_multi<3>(gv, red);
+    if (EIGX_ABL(2048)) {   // diagnostic build: the scalar reduction a second time (what one such phase costs)
+      double g2[3] = {gv[0] + tid, gv[1], gv[2]};
+      __syncthreads();
+      block_sum_multi<3>(g2, red);
+      if (g2[0] == 1.2345678) gv[0] = g2[1];
+      __syncthreads();
+    }
     if (gv[0] > 0.0) { sA = -sign_of(sqrt(gv[0]), x0L); betaA = gv[0] - sA * x0L; }
     else { sA = x0L; betaA = 0.0; }
     if (NV == 2) {
@@ -1171,6 +1184,11 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) yc[a][j] = 0.0;
     }
+    if (EIGX_ABL(64)) {   // diagnostic build: loads only (what the load loop alone sustains)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) yr[0][rb][0] += av[j].x + av[j].y;
+      return;
+    }
     if (!diag) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -1271,6 +1289,10 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   }
 
   EIGX_STAMP(10);
+  if (EIGX_ABL(256)) {   // diagnostic build: no epilogue
+    if (yr[0][0][0] == 1.2345678) R.SP[0] = yr[0][0][1] + yr[NV - 1][RB - 1][0];
+    return;
+  }
   // ---- row sums: combine the 4 waves through LDS; bilinear row part ----------------------------------
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
@@ -1287,6 +1309,20 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
     }
   }
   __syncthreads();
+  for (int rep_ = 0; rep_ < (EIGX_ABL(4096) ? 2 : 1); ++rep_) {   // diagnostic build: the combine + stores twice
+  if (rep_) {
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int a = 0; a < NV; ++a) {
+        double* dst = yrs + ((size_t)wave * NV + a) * T + rb * 128 + lane * 2;
+        dst[0] = yr[a][rb][0];
+        dst[1] = yr[a][rb][1];
+      }
+    __syncthreads();
+  }
+  if (!EIGX_ABL(1024))
   for (int t = tid; t < T; t += 256) {
     const int r = row0 + t;
     if (r < Lr) {
@@ -1298,7 +1334,14 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
       }
     }
   }
-  block_sum_multi<3>(sp, red);
+  }
+  if (EIGX_ABL(8192)) {   // diagnostic build: the block reduction twice
+    double s2[3] = {sp[0], sp[1], sp[2]};
+    block_sum_multi<3>(s2, red);
+    __syncthreads();
+    if (s2[0] == 1.2345678) sp[0] = s2[1];
+  }
+  if (!EIGX_ABL(512)) block_sum_multi<3>(sp, red);
   if (tid == 0) {
     const size_t w = (size_t)ty * R.maxseg + tx;
     R.SP[w * 3 + 0] = sp[0]; R.SP[w * 3 + 1] = sp[1]; R.SP[w * 3 + 2] = sp[2];

@@ -416,6 +416,34 @@ def test_row_group_loop_matches_oracle(gpu_lib, orc, band):
         assert np.abs(dg - do).max() < 1e-9 * scale and np.abs(np.abs(eg[0]) - np.abs(eo[0])).max() < 1e-9 * scale
 
 
+@pytest.mark.parametrize("band", [1, 2])
+def test_symv_tile_sizes_forced_small(gpu_lib, orc, band):
+    """every tile size of the fused mat-vec (128 / 256 / 512, the latter two with non-temporal loads) at a size the
+    oracle handles: eigx_tune keys 3 / 4 / 5 move the thresholds down to L = 200 / 450 / 300, so one reduction of
+    n = 900 passes through all of them"""
+    import torch
+    from eigenexa_amd import layout
+
+    n, m = 900, 64
+    A = layout.random_symmetric(n, seed=13)
+    old = [gpu_lib.eigx_tune(3, 200), gpu_lib.eigx_tune(4, 450), gpu_lib.eigx_tune(5, 300)]
+    try:
+        a, lda = _to_colmajor(A)
+        d = torch.zeros(n, dtype=torch.float64, device=_dev())
+        e = torch.zeros(2 * n, dtype=torch.float64, device=_dev())
+        assert gpu_lib.eigx_band_reduce_dev(n, a.data_ptr(), lda, d.data_ptr(), e.data_ptr(), n, m, band) == 0
+    finally:
+        for key, v in zip((3, 4, 5), old):
+            gpu_lib.eigx_tune(key, v)
+    dg, eg = d.cpu().numpy(), e.cpu().numpy().reshape(2, n)
+    wr = np.linalg.eigvalsh(A)
+    assert np.abs(np.linalg.eigvalsh(_band_matrix(dg, eg[:band], band)) - wr).max() < 1e-13 * n * np.abs(wr).max()
+    if band == 1:
+        do, eo, _ = orc.band_reduce(A, 1)
+        scale = np.abs(A).max() * n
+        assert np.abs(dg - do).max() < 1e-9 * scale and np.abs(np.abs(eg[0]) - np.abs(eo[0])).max() < 1e-9 * scale
+
+
 @pytest.mark.parametrize("world,n,route,dims", [(4, 210, "edge-sx", ""), (2, 170, "edge-s", "2x1")])
 def test_multi_rank_error_behaviour_and_scaling(world, n, route, dims):
     """NaN / Inf input, matrices scaled by 1e+-200 and a NaN-poisoned strict lower triangle on the process grid"""

@@ -17,8 +17,26 @@ lda = n + (n & 1) + 2 + 30   # even, not a multiple of a large power of two
 R = torch.rand(n, lda, dtype=torch.float64, device=dev)
 d = torch.zeros(n, dtype=torch.float64, device=dev)
 e = torch.zeros(band * n, dtype=torch.float64, device=dev)
+# EIGX_VARIANTS="3=9000,4=40000;3=40000;8=1;..." : one eigx_tune setting list per rep, cycled, all on the SAME buffer
+# (the time of a reduction depends on the buffer it runs on -- see DESIGN.md -- so A/B runs must not change buffers)
+variants = [v for v in os.environ.get("EIGX_VARIANTS", "").split(";") if v]
+defaults = {}
+a_fixed = torch.empty_like(R) if variants else None
 for rep in range(reps + 1):
-    a = R.clone()
+    if variants:
+        a = a_fixed
+        a.copy_(R)
+        for k_, v_ in defaults.items():
+            lib.eigx_tune(k_, v_)
+        cur = variants[rep % len(variants)]
+        for kv in cur.split(","):
+            if "=" in kv:
+                k_, v_ = (int(t) for t in kv.split("="))
+                old = lib.eigx_tune(k_, v_)
+                defaults.setdefault(k_, old)
+        os.environ["EIGX_LIB"] = "variant[" + cur + "]"
+    else:
+        a = R.clone()
     a[:, :n] = a[:, :n] + a[:, :n].T
     torch.cuda.synchronize()
     t0 = time.perf_counter()
