@@ -315,6 +315,7 @@ int eigx_tune(int key, int value) {
   if (key == 5) return set_symv_threshold(2, value);
   if (key == 6) return set_gemm_cstream(value);
   if (key == 7) return value > 0 ? set_symv_threshold(3, value) : -1;
+  if (key == 8) return set_dc_chunk(value);
   return -1;
 }
 

@@ -639,6 +639,15 @@ struct DeflOut {
 
 }  // namespace
 
+// several GPUs: width of the chunk buffer in which eigenvector rows are regenerated (eigx_tune key 8; the tests lower it so
+// that the chunk-by-chunk path of the big merges runs at sizes the oracle handles)
+int g_dc_chunk = 2048;
+int set_dc_chunk(int v) {
+  const int old = g_dc_chunk;
+  if (v >= 64 && v <= 2048 && v % 64 == 0) g_dc_chunk = v;
+  return old;
+}
+
 // The two Q buffers must be zero outside the diagonal blocks before the leaves are written: 2 n^2 doubles of memset
 // that depend on nothing.  The solver calls this before the reduction; the fills run on the side stream underneath it.
 void band_dc_prepare(Context& ctx, int n) {
@@ -705,7 +714,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   double* Qb = Qb_base - r0;
   // eigenvector rows of the rank-one updates.  One GPU: block diagonal K x K blocks in an n x n array.  Several GPUs:
   // a chunk buffer of n x SCW doubles (all merges of a low height side by side, or one chunk of roots of a big merge)
-  constexpr int SCW = 2048;
+  const int SCW = g_dc_chunk;
   const int lds_mg = SCW;
   double* S = ctx.pool.get_t<double>("dc.S", (P > 1) ? (size_t)n * SCW + 64 : (size_t)ldq * n);
   double* sec = (P > 1) ? ctx.pool.get_t<double>("dc.sec", (size_t)3 * n) : nullptr;
@@ -959,7 +968,9 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
         }
         // the merges of one height are independent: when there are several, spread their GEMMs over the aux
         // streams so that small products run side by side instead of one after another
-        const bool fan = mds.size() > 1;
+        // (not in chunked mode: there the chunk buffer S is reused from chunk to chunk and from merge to merge, and only
+        // the order of ONE stream keeps a chunk's generation behind the GEMMs that still read the previous one)
+        const bool fan = mds.size() > 1 && !(mg && !compact);
         if (fan) {
           EIGX_HIP_CHECK(hipEventRecord(ctx.aux_ev[Context::kAux], st));
           for (int q = 0; q < Context::kAux; ++q) EIGX_HIP_CHECK(hipStreamWaitEvent(ctx.aux[q], ctx.aux_ev[Context::kAux], 0));

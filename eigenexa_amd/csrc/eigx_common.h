@@ -80,5 +80,7 @@ int set_bisect_threads(int v);
 int set_bt_q(int v);
 // tuning hook (eigx_tune keys 3, 4): largest L that uses the 128 / 256 SYMV tile
 int set_symv_threshold(int which, int v);
+// tuning hook (eigx_tune key 8): chunk width (roots) of the multi-rank D&C's eigenvector-row buffer, 64 .. 2048
+int set_dc_chunk(int v);
 
 }  // namespace eigx

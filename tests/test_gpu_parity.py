@@ -391,6 +391,15 @@ def test_multi_rank_row_group_loop(world, n, route, dims):
     _run_multi_rank(world, n, route, 0, dims, {"EIGX_TEST_TUNE": "7=4", "EIGX_FUSE_WAIT": "1"})
 
 
+@pytest.mark.parametrize("world,n,route,dims,chunk", [(2, 333, "sx", "", 64), (4, 517, "s", "", 64), (3, 260, "sx", "", 128),
+                                                       (4, 700, "sx", "2x2", 128)])
+def test_multi_rank_dc_chunk_by_chunk(world, n, route, dims, chunk):
+    """the chunk-by-chunk form of the distributed D&C (eigenvector rows of a big merge regenerated a chunk of roots at a
+    time into ONE reused buffer: what every merge above 2048 columns does, i.e. N > 4096) forced at small sizes through
+    eigx_tune key 8 -- several chunked merges at one height included, whose GEMMs must not be spread over streams"""
+    _run_multi_rank(world, n, route, 0, dims, {"EIGX_TEST_TUNE": f"8={chunk}"})
+
+
 @pytest.mark.parametrize("band", [1, 2])
 def test_row_group_loop_matches_oracle(gpu_lib, orc, band):
     """the same loop form on one GPU against the oracle: tridiagonal (d, |e|) element-wise, pentadiagonal spectrum"""
