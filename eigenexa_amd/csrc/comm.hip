@@ -310,6 +310,8 @@ __global__ void copy_sys_kernel(const double* __restrict__ in, size_t count, dou
     out[i] = __hip_atomic_load(in + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+long long g_comm_bounce = (long long)32 << 20;   // doubles per slice of comm_alltoall_big's bounce window (eigx_tune key 9)
+
 long long limit_ticks(const CommState* cs) { return (long long)(cs->timeout_s * 1e8); }   // wall_clock64: 100 MHz
 
 void* pick(const CommState* cs, CommGroup grp) { return grp == COMM_X ? cs->x : grp == COMM_Y ? cs->y : cs->world; }
@@ -576,24 +578,33 @@ PeerBuf* comm_buffer(Context& ctx, const std::string& name, size_t bytes) {
   // A buffer that has to grow is RETIRED, not freed: its mappings stay valid on every peer until comm_free, so no
   // rank can ever store through a stale pointer and no IPC handle is closed and re-opened in the life of the
   // communicator (sizes grow geometrically, so the retired copies add up to less than the live one).
+  stage_trace(cs->me, name.c_str(), (long)bytes);
   EIGX_HIP_CHECK(hipDeviceSynchronize());
+  stage_trace(cs->me, "  device idle");
   if (b.local) {
     cs->retired.push_back(b);
     b = PeerBuf();
   }
-  const size_t want = bytes + bytes / 2 + 256;
-  b.local = cs->ipc ? alloc_window(want) : nullptr;
+  // head room only for the small windows (they grow with the panel width and the like); the big ones are sized by N
+  const size_t want = (bytes < ((size_t)64 << 20)) ? bytes + bytes / 2 + 256 : bytes + 256;
+  // only what kernels store into needs a peer mapping: everything when the peer windows carry the bulk collectives too
+  // (ranks sharing a card), otherwise just the per-step window -- RCCL takes plain device pointers
+  const bool map = cs->ipc && (!cs->rccl || name == "comm.step");
+  b.local = map ? alloc_window(want) : nullptr;
   if (!b.local) EIGX_HIP_CHECK(hipMalloc((void**)&b.local, want));
+  stage_trace(cs->me, "  allocated");
   b.bytes = want;
   b.peer[cs->me] = b.local;
-  if (cs->ipc) {
+  if (map) {
     BufBlob mine; memset(&mine, 0, sizeof(mine));
     mine.bytes = want;
     hipError_t e1 = hipIpcGetMemHandle(&mine.handle, b.local);
     mine.ok = (e1 == hipSuccess) ? 1 : 0;
     if (!mine.ok) { fprintf(stderr, "[eigx] rank %d: hipIpcGetMemHandle(%s, %zu bytes): %s\n", cs->me, name.c_str(), want, hipGetErrorString(e1)); (void)hipGetLastError(); }
     unsigned char all[EIGX_MAXP][128];
+    stage_trace(cs->me, "  handle exported");
     if (!board_exchange(cs, &mine, sizeof(mine), all)) { comm_fail(cs, "buffer exchange timed out"); return &b; }
+    stage_trace(cs->me, "  handles exchanged");
     bool ok = true;
     for (int q = 0; q < cs->P && ok; ++q) {
       BufBlob o; memcpy(&o, all[q], sizeof(o));
@@ -601,23 +612,39 @@ PeerBuf* comm_buffer(Context& ctx, const std::string& name, size_t bytes) {
         fprintf(stderr, "[eigx] rank %d: buffer %s: rank %d offers %llu bytes (ok %d), expected %zu\n", cs->me, name.c_str(), q,
                 (unsigned long long)o.bytes, o.ok, want);
         ok = false;
-        break;
       }
-      if (q == cs->me) continue;
-      void* p = nullptr;
-      hipError_t e2 = hipIpcOpenMemHandle(&p, o.handle, hipIpcMemLazyEnablePeerAccess);
-      if (e2 != hipSuccess) {
-        fprintf(stderr, "[eigx] rank %d: hipIpcOpenMemHandle(%s of rank %d, %zu bytes): %s\n", cs->me, name.c_str(), q, want,
-                hipGetErrorString(e2));
-        (void)hipGetLastError();
-        ok = false;
-        break;
+    }
+    // The ranks import one after the other (a turn per rank, a board round between the turns), so that a failure is
+    // attributed to one rank and agreed on by all.  Known limit of this driver: importing 3-GiB windows of three other
+    // processes on the same card never returns from hipIpcOpenMemHandle (N = 32768 on a 2 x 2 grid sharing one GPU;
+    // 1.6-GiB windows are fine, and so are 6-GiB ones between two bare processes: tools/ipc_big.hip).  A node with one
+    // rank per GPU never maps windows of that size (RCCL carries the bulk collectives there, see `map` above).
+    for (int turn = 0; turn < cs->P; ++turn) {
+      if (turn == cs->me && ok) {
+        for (int q = 0; q < cs->P && ok; ++q) {
+          if (q == cs->me) continue;
+          BufBlob o; memcpy(&o, all[q], sizeof(o));
+          void* p = nullptr;
+          hipError_t e2 = hipIpcOpenMemHandle(&p, o.handle, hipIpcMemLazyEnablePeerAccess);
+          if (e2 != hipSuccess) {
+            fprintf(stderr, "[eigx] rank %d: hipIpcOpenMemHandle(%s of rank %d, %zu bytes): %s\n", cs->me, name.c_str(), q, want,
+                    hipGetErrorString(e2));
+            (void)hipGetLastError();
+            ok = false;
+            break;
+          }
+          b.peer[q] = (double*)p;
+        }
+        stage_trace(cs->me, "  peers imported");
       }
-      b.peer[q] = (double*)p;
+      unsigned char okb = ok ? 1 : 0, oks[EIGX_MAXP][128];
+      if (!board_exchange(cs, &okb, 1, oks)) { comm_fail(cs, "buffer exchange timed out"); return &b; }
+      for (int q = 0; q < cs->P; ++q) if (!oks[q][0]) ok = false;   // a failure anywhere ends the turns on every rank alike
     }
     if (!ok) comm_fail(cs, "mapping a peer buffer failed");
     b.mapped = ok;
   }
+  stage_trace(cs->me, "window mapped");
   return &b;
 }
 
@@ -724,6 +751,73 @@ void comm_allgather(Context& ctx, CommGroup grp, const double* send, double* rec
   hipLaunchKernelGGL(copy_sys_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w->local, (size_t)n * count, recv);
 }
 
+// All-to-all of LARGE pieces (the eigenvector redistributions: N^2 / P doubles per rank) into a plain local buffer:
+//   recv[r * count + i] = send_r[(my index) * count + i]   for every member r of the group.
+// RCCL: one grouped send / receive, no window at all.  Peer windows: pairwise rounds (round k: send to member me + k,
+// receive from member me - k) through ONE bounce window of at most BOUNCE doubles, slice by slice -- every slice is a
+// ready / push / wait round of its own and is copied out of the window before the next one is admitted -- so the
+// hipIpc-mapped memory stays bounded whatever N is (windows of 2-3 GiB could not be imported on a shared card).
+void comm_alltoall_big(Context& ctx, CommGroup grp, const double* send, double* recv, size_t count, hipStream_t s) {
+  CommState* cs = ctx.comm;
+  int members[EIGX_MAXP], mine = 0;
+  const int n = comm_group(ctx, grp, members, &mine);
+  if (count == 0) return;
+  if (n == 1) {
+    if (send != recv) EIGX_HIP_CHECK(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
+    return;
+  }
+  if (cs->failed) return;
+  if (cs->rccl) {
+    rccl_time_begin(cs, s);
+    EIGX_NCCL_TRY(cs, api.GroupStart());
+    for (int r = 0; r < n; ++r) {
+      EIGX_NCCL_TRY(cs, api.Send(send + (size_t)r * count, count, kNcclFloat64, r, pick(cs, grp), s));
+      EIGX_NCCL_TRY(cs, api.Recv(recv + (size_t)r * count, count, kNcclFloat64, r, pick(cs, grp), s));
+    }
+    EIGX_NCCL_TRY(cs, api.GroupEnd());
+    rccl_time_end(cs, s);
+    return;
+  }
+  const size_t BOUNCE = (size_t)g_comm_bounce;
+  const size_t slice = count < BOUNCE ? count : BOUNCE;
+  PeerBuf* w = comm_buffer(ctx, "comm.bounce", slice * sizeof(double));
+  if (!w->mapped) { comm_fail(cs, "exchange through an unmapped window"); return; }
+  EIGX_HIP_CHECK(hipMemcpyAsync(recv + (size_t)mine * count, send + (size_t)mine * count, count * sizeof(double),
+                                hipMemcpyDeviceToDevice, s));
+  const CommChannel ch = CH_BULK;
+  for (int k = 1; k < n; ++k) {
+    const int di = (mine + k) % n, si = (mine - k + n) % n;     // group indices of this round's destination / source
+    const int dq = members[di], sq = members[si];               // ... and their world ranks
+    for (size_t off = 0; off < count; off += slice) {
+      const size_t c = (count - off < slice) ? count - off : slice;
+      const u64 epoch = ++cs->epoch[ch];
+      ReadyArgs R;
+      WaitArgs W;
+      PushArgs A;
+      R.n = W.n = A.n = 1;
+      R.epoch = W.epoch = A.epoch = epoch;
+      R.err = W.err = cs->err_dev;
+      R.ticks = W.ticks = A.ticks = cs->ticks_dev;
+      R.limit_ticks = W.limit_ticks = limit_ticks(cs);
+      R.remote[0] = flag_word(cs->flags.peer[sq], ch, 1, cs->me);   // "my window is free" goes to the rank that fills it
+      R.local[0] = flag_word(cs->flags.local, ch, 1, dq);           // ... and I wait for the same word of my destination
+      A.src = send + (size_t)di * count + off; A.src_stride = 0; A.count = c; A.counter = cs->counters + ch;
+      A.dst[0] = w->peer[dq];
+      A.flag[0] = flag_word(cs->flags.peer[dq], ch, 0, cs->me);
+      W.flag[0] = flag_word(cs->flags.local, ch, 0, sq);
+      hipLaunchKernelGGL(ready_kernel, dim3(1), dim3(64), 0, s, R);
+      size_t blocks = (c + 4095) / 4096;
+      if (blocks > 512) blocks = 512;
+      hipLaunchKernelGGL(push_kernel, dim3((unsigned)blocks), dim3(256), 0, s, A);
+      hipLaunchKernelGGL(wait_kernel, dim3(1), dim3(64), 0, s, W);
+      size_t cb = (c + 255) / 256;
+      if (cb > 2048) cb = 2048;
+      hipLaunchKernelGGL(copy_sys_kernel, dim3((unsigned)cb), dim3(256), 0, s, (const double*)w->local, c,
+                         recv + (size_t)si * count + off);
+    }
+  }
+}
+
 // ---- per-step exchange ---------------------------------------------------------------------------------------
 double* comm_step_window(Context& ctx, size_t msg_doubles, StepPeers* peers) {
   CommState* cs = ctx.comm;
@@ -771,6 +865,12 @@ void comm_step_wait(Context& ctx, unsigned long long epoch, hipStream_t s) {
   const int kind = (int)(epoch & 1);
   for (int q = 0; q < cs->P; ++q) W.flag[q] = flag_word(cs->flags.local, CH_STEP, kind, q);
   hipLaunchKernelGGL(wait_kernel, dim3(1), dim3(64), 0, s, W);
+}
+
+int comm_set_bounce(int doubles) {
+  const int old = (int)g_comm_bounce;
+  if (doubles >= 1024) g_comm_bounce = doubles;
+  return old;
 }
 
 }  // namespace eigx

@@ -640,7 +640,7 @@ struct DeflOut {
 }  // namespace
 
 // several GPUs: width of the chunk buffer in which eigenvector rows are regenerated (eigx_tune key 8; the tests lower it so
-// that the chunk-by-chunk path of the big merges runs at sizes the oracle handles)
+// that the chunk-by-chunk path of the big merges runs at small sizes)
 int g_dc_chunk = 2048;
 int set_dc_chunk(int v) {
   const int old = g_dc_chunk;
@@ -1069,6 +1069,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   }
 
   // ---- final sort + copy-out ----------------------------------------------------------------------------
+  stage_trace(ctx.grid.rank, "D&C merges done");
   EIGX_HIP_CHECK(hipMemcpyAsync(Dh, Dcur, (size_t)n * 8, hipMemcpyDeviceToHost, st));
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
   ord.resize(n);
@@ -1087,13 +1088,15 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
     const int zc = (nvec + P - 1) / P;
     const size_t piece = (size_t)rp * zc;
     double* sendb = ctx.pool.get_t<double>("mg.xsend", piece * P);
-    PeerBuf* recvb = comm_buffer(ctx, "mg.xrecv", piece * P * sizeof(double));
+    double* recvb = ctx.pool.get_t<double>("mg.xrecv", piece * P);
     hipLaunchKernelGGL(pack_q_for_cols_kernel, dim3(8, zc, P), dim3(256), 0, st, perm_dev, Qa, ldq, r0, r1 - r0, rp, zc, nvec,
                        sendb);
-    comm_exchange(ctx, COMM_WORLD, sendb, piece, recvb, 0, piece, st, CH_BULK);
-    hipLaunchKernelGGL(unpack_cols_kernel, dim3(8, zc, P), dim3(256), 0, st, (const double*)recvb->local, rp, zc, n, z_dev, ldz);
+    stage_trace(ctx.grid.rank, "D&C all-to-all: doubles per piece", (long)piece);
+    comm_alltoall_big(ctx, COMM_WORLD, sendb, recvb, piece, st);
+    hipLaunchKernelGGL(unpack_cols_kernel, dim3(8, zc, P), dim3(256), 0, st, (const double*)recvb, rp, zc, n, z_dev, ldz);
   }
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  stage_trace(ctx.grid.rank, "D&C done");
   EIGX_HIP_CHECK(hipGetLastError());
   ctx.timers[11] = gemm_flops;
 }

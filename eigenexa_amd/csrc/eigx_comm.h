@@ -55,6 +55,11 @@ void comm_allreduce_max(Context& ctx, CommGroup grp, double* buf, size_t count, 
 void comm_allgather(Context& ctx, CommGroup grp, const double* send, double* recv, size_t count, hipStream_t s,
                     CommChannel ch = CH_BULK);
 
+// all-to-all of large pieces into a plain local buffer: recv[r * count + i] = (member r's send)[(my index) * count + i];
+// bounded hipIpc footprint (a bounce window of at most `bounce` doubles, eigx_tune key 9), RCCL send / receive on a node
+void comm_alltoall_big(Context& ctx, CommGroup grp, const double* send, double* recv, size_t count, hipStream_t s);
+int comm_set_bounce(int doubles);
+
 // ---- per-step exchange of the reduction (channel CH_STEP, double-buffered by step parity) ---------------------
 // View handed to the producer kernel (band_reduce.hip kl_kernel): where rank `me`'s message of the given parity lives
 // in every rank's window, and which flag word announces it.

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cmath>
 #include <vector>
+#include <ctime>
 
 #define EIGX_HIP_CHECK(expr)                                                        \
   do {                                                                              \
@@ -69,6 +70,18 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
                const int* cmapC = nullptr, int batch = 1, long strideA = 0, long strideB = 0, long strideC = 0,
                int batch2 = 1, long strideA2 = 0, long strideB2 = 0, long strideC2 = 0, int ownP = 1,
                int ownp = 0, const int* kmapB = nullptr, int tn_lo = 0, int tn_hi = 0x7fffffff);
+
+// EIGX_TRACE_STAGES=1: one stderr line per stage boundary of a solve (rank, wall clock), for locating a stall on a
+// process grid; costs one getenv per process
+inline void stage_trace(int rank, const char* what, long detail = -1) {
+  static const bool on = getenv("EIGX_TRACE_STAGES") != nullptr;
+  if (!on) return;
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  if (detail >= 0) fprintf(stderr, "[eigx stage] rank %d t=%.3f %s %ld\n", rank, ts.tv_sec % 100000 + ts.tv_nsec * 1e-9, what, detail);
+  else fprintf(stderr, "[eigx stage] rank %d t=%.3f %s\n", rank, ts.tv_sec % 100000 + ts.tv_nsec * 1e-9, what);
+  fflush(stderr);
+}
 
 // tuning hook (eigx_tune key 0): 2 = LDS-DMA ring GEMM where supported, 1 = register-staged GEMM only
 int set_gemm_variant(int v);

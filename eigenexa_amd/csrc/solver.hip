@@ -227,13 +227,13 @@ static int bc_to_cyclic(Context& ctx, const double* a, int lda, int n, int nb, d
   const int* d_crank = put(crank); const int* d_srcy = put(srcy); const int* d_posc = put(posc);
   EIGX_HIP_CHECK(hipMemcpyAsync(tab, htab, nt * sizeof(int), hipMemcpyHostToDevice, st));
   double* sendb = ctx.pool.get_t<double>("mg.xsend", piece * P);
-  PeerBuf* recvb = comm_buffer(ctx, "mg.xrecv", piece * P * sizeof(double));
+  double* recvb = ctx.pool.get_t<double>("mg.xrecv", piece * P);
   if (nr > 0 && nc > 0)
     hipLaunchKernelGGL(bc_pack_kernel, dim3(8, nc), dim3(256), 0, st, a, lda, nr, nc, nb, G.Px, G.px, G.Py, G.py, G.row_major,
                        d_rrank, d_crank, nrp, piece, sendb);
-  comm_exchange(ctx, COMM_WORLD, sendb, piece, recvb, 0, piece, st, CH_BULK);
+  comm_alltoall_big(ctx, COMM_WORLD, sendb, recvb, piece, st);
   if (clr > 0 && clc > 0)
-    hipLaunchKernelGGL(bc_unpack_kernel, dim3(8, clc), dim3(256), 0, st, (const double*)recvb->local, piece, nrp, clr, clc, G.Px,
+    hipLaunchKernelGGL(bc_unpack_kernel, dim3(8, clc), dim3(256), 0, st, (const double*)recvb, piece, nrp, clr, clc, G.Px,
                        G.Py, G.row_major, d_srcx, d_posr, d_srcy, d_posc, out, ldo);
   EIGX_HIP_CHECK(hipStreamSynchronize(st));   // the pinned table staging buffer is reused by the next call
   return EIGX_OK;
@@ -346,6 +346,7 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
   if (P > 1 && comm_failed(ctx)) return EIGX_ERR_INTERNAL;
   const double t2 = now_s();
+  stage_trace(G.rank, "reduction done");
 
   // ---- divide and conquer --------------------------------------------------------------------------
   // modes (src/eigen_sx.F:200-222): A/X/T/R divide and conquer (X: eigenvalues then re-done by bisection),
@@ -366,6 +367,7 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
     if (mode == 'X') band_bisect_dev(ctx, n, d, e, lde, band, w);
   }
   const double t3 = now_s();
+  stage_trace(G.rank, "eigenvalue stage done");
 
   // ---- back-transformation ---------------------------------------------------------------------------
   if (do_bt) {
@@ -377,19 +379,20 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
       trbak_mg_dev(ctx, n, zcnt, a, lda, z, ldz, e, lde, mb, band);
     }
   }
+  stage_trace(G.rank, "back-transformation enqueued");
   if (P > 1 && want_vec) {
     // column blocks -> the caller's 2-D (block-)cyclic blocks: one all-to-all of (rows of qx) x (my columns of qy) pieces
     const int nrmax = numroc(n, nb, 0, G.Px);
     const int ncmax = (zcols_per_rank / (nb * G.Py) + 2) * nb;
     const size_t piece = (size_t)nrmax * ncmax;
     double* sendb = ctx.pool.get_t<double>("mg.xsend", piece * P);
-    PeerBuf* recvb = comm_buffer(ctx, "mg.xrecv", piece * P * sizeof(double));
+    double* recvb = ctx.pool.get_t<double>("mg.xrecv", piece * P);
     if (zcnt > 0)
       hipLaunchKernelGGL(pack_z_pieces_kernel, dim3(8, zcnt, G.Px), dim3(256), 0, st, (const double*)z, ldz, n, zc0, zcnt, nb, G.Px,
                          G.Py, G.row_major, nrmax, piece, sendb);
-    comm_exchange(ctx, COMM_WORLD, sendb, piece, recvb, 0, piece, st, CH_BULK);
+    comm_alltoall_big(ctx, COMM_WORLD, sendb, recvb, piece, st);
     if (nloc_r > 0)
-      hipLaunchKernelGGL(unpack_z_pieces_kernel, dim3(8, ncmax, P), dim3(256), 0, st, (const double*)recvb->local, piece, nrmax,
+      hipLaunchKernelGGL(unpack_z_pieces_kernel, dim3(8, ncmax, P), dim3(256), 0, st, (const double*)recvb, piece, nrmax,
                          nvec, zcols_per_rank, nb, G.py, G.Py, nloc_r, z_user, ldz_user);
   } else if (want_vec && z != z_user) {
     EIGX_HIP_CHECK(hipMemcpy2DAsync(z_user, (size_t)ldz_user * 8, z, (size_t)ldz * 8, (size_t)n * 8, (size_t)nvec,
@@ -397,7 +400,9 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   }
   if (sigma != 1.0 && sigma != 0.0)
     hipLaunchKernelGGL(scale_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, n, 1.0 / sigma);
+  stage_trace(G.rank, "exit redistribution enqueued");
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  stage_trace(G.rank, "stream drained");
   if (P > 1 && comm_failed(ctx)) return EIGX_ERR_INTERNAL;
   const double t4 = now_s();
 
@@ -556,6 +561,7 @@ int64_t solver_workspace_bytes(const Context& ctx, int n, int lda, int ldz, int 
   int64_t w = 0;
   w += 2 * (int64_t)pad_ld((int)rp + 2) * n + (int64_t)n * 2048 + ldn * zc;              // D&C + Z block
   w += (int64_t)(2.6 * (double)((nxs + 8) * ((zc / ctx.grid.Py) + 2) * P)) + 3 * rp * zc;     // the two all-to-alls
+  w += (int64_t)(1.5 * (double)(rp * zc < ((int64_t)32 << 20) ? rp * zc : ((int64_t)32 << 20))) + 64;   // their bounce window
   w += ldp * (4 * mf + 2) + 2 * maxseg * 2 * ldp + 3 * ldp + (nxs + nys + 128) * 2 * mf;   // reduction panels / partials
   w += (int64_t)(1.5 * (double)(2 * P * (2 * (nxs + nys) + 8))) + (int64_t)(2.5 * (double)(P + 1) * (mf / ctx.grid.Py + 3) * nxs);
   w += (int64_t)pad_ld(n + 1024) * 2048 + (int64_t)(2.5 * (double)(P + 1) * (2048 / ctx.grid.Py + 2) * nxs);   // reflector groups

@@ -322,6 +322,7 @@ void trbak_mg_dev(Context& ctx, int n, int nvec, const double* Aloc, int lda, do
   double* send = ctx.pool.get_t<double>("bt.send", (size_t)mloc_max * nxs);
   auto run_group = [&](int j0, int j1, int q) {
     if (j1 <= j0) return;
+    stage_trace(G.rank, "back-transformation: reflector group starting at column", j0);
     const int toprows = j1 - band;                      // longest reflector of the group
     const int nxc = (ceil_div(toprows, G.Px) + 7) / 8 * 8;
     const size_t cnt = (size_t)(ceil_div(j1 - j0, G.Py) + 1) * nxc;

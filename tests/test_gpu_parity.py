@@ -400,6 +400,16 @@ def test_multi_rank_dc_chunk_by_chunk(world, n, route, dims, chunk):
     _run_multi_rank(world, n, route, 0, dims, {"EIGX_TEST_TUNE": f"8={chunk}"})
 
 
+@pytest.mark.parametrize("world,n,route,nb,dims", [(4, 517, "sx", 0, "2x2"), (3, 400, "s", 0, ""), (4, 301, "sx", 32, "2x2"),
+                                                    (2, 333, "s", 7, "")])
+def test_multi_rank_redistributions_through_small_bounce_window(world, n, route, nb, dims):
+    """the eigenvector redistributions (row blocks -> column blocks after the D&C, column blocks -> the caller's
+    (block-)cyclic z at the exit, block-cyclic -> cyclic at the entry) go through ONE bounded bounce window in pairwise
+    rounds, slice by slice (what keeps the hipIpc footprint bounded at N = 32768); eigx_tune key 9 shrinks the window to
+    1024 doubles so that every piece of these small cases takes several slices"""
+    _run_multi_rank(world, n, route, nb, dims, {"EIGX_TEST_TUNE": "9=1024"})
+
+
 @pytest.mark.parametrize("band", [1, 2])
 def test_row_group_loop_matches_oracle(gpu_lib, orc, band):
     """the same loop form on one GPU against the oracle: tridiagonal (d, |e|) element-wise, pentadiagonal spectrum"""

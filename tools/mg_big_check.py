@@ -40,6 +40,7 @@ w = torch.zeros(n, dtype=torch.float64, device=dev)
 fn = lib.eigx_sx_dev if route == "sx" else lib.eigx_s_dev
 torch.cuda.synchronize()
 dist.barrier()
+print(f"[rank {rank}] solving n={n} on {Px}x{Py} ...", flush=True)
 t0 = time.perf_counter()
 rc = fn(n, n, a.data_ptr(), nx, w.data_ptr(), z.data_ptr(), nx, mf, 128, b"A")
 torch.cuda.synchronize()
