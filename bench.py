@@ -276,7 +276,28 @@ def main():
         znorm_full[cc] = zn
         zc = znorm_full.cpu() if cpu_coll else znorm_full
         dist.all_reduce(zc)
-        acc = {"trace_error_over_anorm": abs(float(w.sum().item()) - float(trc[0].item())) / anorm,
+        # randomised residual: || A X - Z W Z^T X ||_F / (||A||_F ||X||_F) for 4 random vectors X -- three block mat-vecs
+        # and three allreduces of n x 4 numbers on the 2-D cyclic blocks; a wrong or non-orthogonal Z shows up here
+        def allsum(t):
+            tc = t.cpu() if cpu_coll else t
+            dist.all_reduce(tc)
+            return tc.to(dev)
+
+        gx = torch.Generator(device="cpu").manual_seed(7)
+        X = torch.randn(n, 4, dtype=torch.float64, generator=gx).to(dev)
+        Zb = zl.T                                            # [local row, local col]
+        t1 = torch.zeros(n, 4, dtype=torch.float64, device=dev)
+        t1[cc] = Zb.T @ X[rr]
+        t1 = allsum(t1) * w[:, None]
+        y2 = torch.zeros(n, 4, dtype=torch.float64, device=dev)
+        y2[rr] = Zb @ t1[cc]
+        y2 = allsum(y2)
+        y1 = torch.zeros(n, 4, dtype=torch.float64, device=dev)
+        y1[rr] = Aloc @ X[cc]
+        y1 = allsum(y1)
+        probe = float(torch.linalg.norm(y1 - y2).item()) / (anorm * float(torch.linalg.norm(X).item()))
+        acc = {"probe_residual_over_anorm": probe,
+               "trace_error_over_anorm": abs(float(w.sum().item()) - float(trc[0].item())) / anorm,
                "frobenius_error_over_anorm": abs(float(torch.linalg.norm(w).item()) - anorm) / anorm,
                "max_abs_znorm2_minus_1": float((zc - 1.0).abs().max().item()),
                "comm_seconds_per_solve_max_over_ranks": round(comm_max, 4),
