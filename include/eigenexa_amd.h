@@ -223,9 +223,12 @@ int eigx_profile_read(double* out6);
  * applies [default], 1 = register-staged kernel everywhere); key 1 = target number of concurrent Sturm
  * sweeps of the bisection (default 65536); key 2 = super-block factor of the back-transformation (0 = automatic);
  * keys 3 / 4 = largest active size L that uses the 128 / 256 tile of the fused symmetric mat-vec, key 5 = active
- * size above which it streams the matrix with non-temporal loads.
- * Returns the previous value, or -1 for an
- * unknown key.  Not part of the reference's interface. */
+ * size above which it streams the matrix with non-temporal loads; key 6 = 1: the trailing update streams its C tiles
+ * past L2; key 7 = workgroups of the column-formation kernel beyond which a workgroup loops over row groups;
+ * key 8 = chunk width (roots, 64 .. 2048) of the multi-rank D&C's eigenvector-row buffer; key 9 = doubles per slice of
+ * the bounce window of the multi-rank eigenvector redistributions (keys 7-9 exist so that the tests reach the
+ * large-N code paths at small sizes).  Returns the previous value, or -1 for an unknown key.  Not part of the
+ * reference's interface. */
 int eigx_tune(int key, int value);
 
 /* device synchronisation helper for hosts without a HIP binding */

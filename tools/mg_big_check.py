@@ -1,7 +1,8 @@
 """Lab tool: the multi-rank solver at BASELINE-like sizes with `world` processes sharing GPU 0 (peer-window transport, the
 device code that runs over xGMI on a node) and a full check on rank 0: residual ||A Z - Z W||_F / (N eps ||A||_F) < 768,
 orthogonality ||Z^T Z - I||_F / (N eps) < 8 through GPU matmuls, w bit-identical on every rank.
-argv: rank world port n route(sx|s) [PxxPy] [m_forward]
+argv: rank world port n route(sx|s) [PxxPy] [m_forward] [mode A|N]   (mode N: eigenvalues only, checked through
+sum(w) = tr(A), sum(w^2) = ||A||_F^2 and sortedness -- the invariants of test_baseline_config_n65536_eigenvalues_only)
 launcher: tools/mg_big_check.sh"""
 import os
 import sys
@@ -17,6 +18,7 @@ import torch.distributed as dist
 rank, world, port, n, route = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
 dims = tuple(int(v) for v in sys.argv[6].split("x")) if len(sys.argv) > 6 and "x" in sys.argv[6] else None
 mf = int(sys.argv[7]) if len(sys.argv) > 7 else 128
+mode = sys.argv[8] if len(sys.argv) > 8 else "A"
 os.environ.setdefault("EIGX_COMM_TIMEOUT_S", "300")
 dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
 import eigenexa_amd as ee
@@ -34,15 +36,20 @@ nx, ny = ee.eigen_get_matdims(n)
 loc = layout.random_symmetric_torch(n, dev, rows=rows, cols=cols)
 a = torch.zeros(ny, nx, dtype=torch.float64, device=dev)
 a[: len(cols), : len(rows)] = loc.T
+inv = torch.zeros(2, dtype=torch.float64)
+rr_, cc_ = torch.from_numpy(rows).to(dev), torch.from_numpy(cols).to(dev)
+inv[0] = (loc * (rr_[:, None] == cc_[None, :])).sum().item()      # my share of tr(A)
+inv[1] = (loc * loc).sum().item()                                 # ... and of ||A||_F^2
+dist.all_reduce(inv)
 del loc
-z = torch.zeros(ny, nx, dtype=torch.float64, device=dev)
+z = torch.zeros(ny, nx, dtype=torch.float64, device=dev) if mode == "A" else torch.zeros(8, dtype=torch.float64, device=dev)
 w = torch.zeros(n, dtype=torch.float64, device=dev)
 fn = lib.eigx_sx_dev if route == "sx" else lib.eigx_s_dev
 torch.cuda.synchronize()
 dist.barrier()
 print(f"[rank {rank}] solving n={n} on {Px}x{Py} ...", flush=True)
 t0 = time.perf_counter()
-rc = fn(n, n, a.data_ptr(), nx, w.data_ptr(), z.data_ptr(), nx, mf, 128, b"A")
+rc = fn(n, n if mode == "A" else 0, a.data_ptr(), nx, w.data_ptr(), z.data_ptr(), nx, mf, 128, mode.encode())
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 assert rc == 0, f"rank {rank}: status {rc}"
@@ -57,6 +64,21 @@ wl = [torch.zeros(n, dtype=torch.float64) for _ in range(world)]
 dist.all_gather(wl, w.cpu())
 for q in range(world):
     assert torch.equal(wl[q], wl[0]), f"w differs between rank 0 and rank {q}"
+
+anorm_ = float(inv[1].sqrt())
+tr_err = abs(float(w.sum().item()) - float(inv[0])) / anorm_
+fro_err = abs(float(torch.linalg.norm(w).item()) - anorm_) / anorm_
+srt = bool((w[1:] >= w[:-1]).all().item())
+print(f"[rank {rank}] trace error / ||A|| {tr_err:.2e}, Frobenius error / ||A|| {fro_err:.2e}, ascending {srt} "
+      f"(sum w {float(w.sum().item())!r}, tr A {float(inv[0])!r}, ||w|| {float(torch.linalg.norm(w).item())!r}, ||A|| {anorm_!r}, "
+      f"w[0] {float(w[0])!r}, w[-1] {float(w[-1])!r})", flush=True)
+assert tr_err < 1e-12 and fro_err < 1e-12 and srt
+if mode != "A":
+    dist.barrier()
+    ee.eigen_free()
+    dist.destroy_process_group()
+    print(f"OK rank {rank}/{world}", flush=True)
+    sys.exit(0)
 
 # gather the blocks of z on rank 0 (one block at a time: bounded host memory)
 mr, mc = (n + Px - 1) // Px, (n + Py - 1) // Py
