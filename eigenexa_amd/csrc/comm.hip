@@ -310,7 +310,7 @@ __global__ void copy_sys_kernel(const double* __restrict__ in, size_t count, dou
     out[i] = __hip_atomic_load(in + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-long long g_comm_bounce = (long long)32 << 20;   // doubles per slice of comm_alltoall_big's bounce window (eigx_tune key 9)
+long long g_comm_bounce = (long long)32 << 20;   // doubles per slice of comm_exchange_big's bounce window (eigx_tune key 9)
 
 long long limit_ticks(const CommState* cs) { return (long long)(cs->timeout_s * 1e8); }   // wall_clock64: 100 MHz
 
@@ -744,6 +744,10 @@ void comm_allgather(Context& ctx, CommGroup grp, const double* send, double* rec
     rccl_time_end(cs, s);
     return;
   }
+  if (ch == CH_BULK && (size_t)n * count > (size_t)g_comm_bounce) {   // large (eigen_h's matrix gather): bounded window
+    comm_exchange_big(ctx, grp, send, 0, recv, count, s);
+    return;
+  }
   PeerBuf* w = comm_buffer(ctx, ch == CH_SIDE ? "comm.ag.side" : "comm.ag", (size_t)n * count * sizeof(double));
   comm_exchange(ctx, grp, send, 0, w, 0, count, s, ch);
   size_t blocks = ((size_t)n * count + 255) / 256;
@@ -752,12 +756,13 @@ void comm_allgather(Context& ctx, CommGroup grp, const double* send, double* rec
 }
 
 // All-to-all of LARGE pieces (the eigenvector redistributions: N^2 / P doubles per rank) into a plain local buffer:
-//   recv[r * count + i] = send_r[(my index) * count + i]   for every member r of the group.
-// RCCL: one grouped send / receive, no window at all.  Peer windows: pairwise rounds (round k: send to member me + k,
+//   recv[r * count + i] = send_r[(my index) * send_stride + i]   for every member r of the group
+// (send_stride = count: all-to-all; 0: allgather).  RCCL: one collective / grouped send + receive, no window at all.  Peer windows: pairwise rounds (round k: send to member me + k,
 // receive from member me - k) through ONE bounce window of at most BOUNCE doubles, slice by slice -- every slice is a
 // ready / push / wait round of its own and is copied out of the window before the next one is admitted -- so the
 // hipIpc-mapped memory stays bounded whatever N is (windows of 2-3 GiB could not be imported on a shared card).
-void comm_alltoall_big(Context& ctx, CommGroup grp, const double* send, double* recv, size_t count, hipStream_t s) {
+void comm_exchange_big(Context& ctx, CommGroup grp, const double* send, size_t send_stride, double* recv, size_t count,
+                       hipStream_t s) {
   CommState* cs = ctx.comm;
   int members[EIGX_MAXP], mine = 0;
   const int n = comm_group(ctx, grp, members, &mine);
@@ -769,12 +774,16 @@ void comm_alltoall_big(Context& ctx, CommGroup grp, const double* send, double* 
   if (cs->failed) return;
   if (cs->rccl) {
     rccl_time_begin(cs, s);
-    EIGX_NCCL_TRY(cs, api.GroupStart());
-    for (int r = 0; r < n; ++r) {
-      EIGX_NCCL_TRY(cs, api.Send(send + (size_t)r * count, count, kNcclFloat64, r, pick(cs, grp), s));
-      EIGX_NCCL_TRY(cs, api.Recv(recv + (size_t)r * count, count, kNcclFloat64, r, pick(cs, grp), s));
+    if (send_stride == 0) {
+      EIGX_NCCL_TRY(cs, api.AllGather(send, recv, count, kNcclFloat64, pick(cs, grp), s));
+    } else {
+      EIGX_NCCL_TRY(cs, api.GroupStart());
+      for (int r = 0; r < n; ++r) {
+        EIGX_NCCL_TRY(cs, api.Send(send + (size_t)r * send_stride, count, kNcclFloat64, r, pick(cs, grp), s));
+        EIGX_NCCL_TRY(cs, api.Recv(recv + (size_t)r * count, count, kNcclFloat64, r, pick(cs, grp), s));
+      }
+      EIGX_NCCL_TRY(cs, api.GroupEnd());
     }
-    EIGX_NCCL_TRY(cs, api.GroupEnd());
     rccl_time_end(cs, s);
     return;
   }
@@ -782,7 +791,7 @@ void comm_alltoall_big(Context& ctx, CommGroup grp, const double* send, double* 
   const size_t slice = count < BOUNCE ? count : BOUNCE;
   PeerBuf* w = comm_buffer(ctx, "comm.bounce", slice * sizeof(double));
   if (!w->mapped) { comm_fail(cs, "exchange through an unmapped window"); return; }
-  EIGX_HIP_CHECK(hipMemcpyAsync(recv + (size_t)mine * count, send + (size_t)mine * count, count * sizeof(double),
+  EIGX_HIP_CHECK(hipMemcpyAsync(recv + (size_t)mine * count, send + (size_t)mine * send_stride, count * sizeof(double),
                                 hipMemcpyDeviceToDevice, s));
   const CommChannel ch = CH_BULK;
   for (int k = 1; k < n; ++k) {
@@ -801,7 +810,7 @@ void comm_alltoall_big(Context& ctx, CommGroup grp, const double* send, double* 
       R.limit_ticks = W.limit_ticks = limit_ticks(cs);
       R.remote[0] = flag_word(cs->flags.peer[sq], ch, 1, cs->me);   // "my window is free" goes to the rank that fills it
       R.local[0] = flag_word(cs->flags.local, ch, 1, dq);           // ... and I wait for the same word of my destination
-      A.src = send + (size_t)di * count + off; A.src_stride = 0; A.count = c; A.counter = cs->counters + ch;
+      A.src = send + (size_t)di * send_stride + off; A.src_stride = 0; A.count = c; A.counter = cs->counters + ch;
       A.dst[0] = w->peer[dq];
       A.flag[0] = flag_word(cs->flags.peer[dq], ch, 0, cs->me);
       W.flag[0] = flag_word(cs->flags.local, ch, 0, sq);

@@ -1092,7 +1092,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
     hipLaunchKernelGGL(pack_q_for_cols_kernel, dim3(8, zc, P), dim3(256), 0, st, perm_dev, Qa, ldq, r0, r1 - r0, rp, zc, nvec,
                        sendb);
     stage_trace(ctx.grid.rank, "D&C all-to-all: doubles per piece", (long)piece);
-    comm_alltoall_big(ctx, COMM_WORLD, sendb, recvb, piece, st);
+    comm_exchange_big(ctx, COMM_WORLD, sendb, piece, recvb, piece, st);
     hipLaunchKernelGGL(unpack_cols_kernel, dim3(8, zc, P), dim3(256), 0, st, (const double*)recvb, rp, zc, n, z_dev, ldz);
   }
   EIGX_HIP_CHECK(hipStreamSynchronize(st));

@@ -55,9 +55,11 @@ void comm_allreduce_max(Context& ctx, CommGroup grp, double* buf, size_t count, 
 void comm_allgather(Context& ctx, CommGroup grp, const double* send, double* recv, size_t count, hipStream_t s,
                     CommChannel ch = CH_BULK);
 
-// all-to-all of large pieces into a plain local buffer: recv[r * count + i] = (member r's send)[(my index) * count + i];
-// bounded hipIpc footprint (a bounce window of at most `bounce` doubles, eigx_tune key 9), RCCL send / receive on a node
-void comm_alltoall_big(Context& ctx, CommGroup grp, const double* send, double* recv, size_t count, hipStream_t s);
+// exchange of large pieces into a plain local buffer: recv[r * count + i] = (member r's send)[(my index) * send_stride + i]
+// (send_stride = count: all-to-all, 0: allgather); bounded hipIpc footprint (a bounce window of at most `bounce` doubles,
+// eigx_tune key 9), one RCCL collective / grouped send + receive on a node
+void comm_exchange_big(Context& ctx, CommGroup grp, const double* send, size_t send_stride, double* recv, size_t count,
+                       hipStream_t s);
 int comm_set_bounce(int doubles);
 
 // ---- per-step exchange of the reduction (channel CH_STEP, double-buffered by step parity) ---------------------

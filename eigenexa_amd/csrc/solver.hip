@@ -231,7 +231,7 @@ static int bc_to_cyclic(Context& ctx, const double* a, int lda, int n, int nb, d
   if (nr > 0 && nc > 0)
     hipLaunchKernelGGL(bc_pack_kernel, dim3(8, nc), dim3(256), 0, st, a, lda, nr, nc, nb, G.Px, G.px, G.Py, G.py, G.row_major,
                        d_rrank, d_crank, nrp, piece, sendb);
-  comm_alltoall_big(ctx, COMM_WORLD, sendb, recvb, piece, st);
+  comm_exchange_big(ctx, COMM_WORLD, sendb, piece, recvb, piece, st);
   if (clr > 0 && clc > 0)
     hipLaunchKernelGGL(bc_unpack_kernel, dim3(8, clc), dim3(256), 0, st, (const double*)recvb, piece, nrp, clr, clc, G.Px,
                        G.Py, G.row_major, d_srcx, d_posr, d_srcy, d_posc, out, ldo);
@@ -390,7 +390,7 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
     if (zcnt > 0)
       hipLaunchKernelGGL(pack_z_pieces_kernel, dim3(8, zcnt, G.Px), dim3(256), 0, st, (const double*)z, ldz, n, zc0, zcnt, nb, G.Px,
                          G.Py, G.row_major, nrmax, piece, sendb);
-    comm_alltoall_big(ctx, COMM_WORLD, sendb, recvb, piece, st);
+    comm_exchange_big(ctx, COMM_WORLD, sendb, piece, recvb, piece, st);
     if (nloc_r > 0)
       hipLaunchKernelGGL(unpack_z_pieces_kernel, dim3(8, ncmax, P), dim3(256), 0, st, (const double*)recvb, piece, nrmax,
                          nvec, zcols_per_rank, nb, G.py, G.Py, nloc_r, z_user, ldz_user);

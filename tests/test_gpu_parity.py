@@ -401,10 +401,10 @@ def test_multi_rank_dc_chunk_by_chunk(world, n, route, dims, chunk):
 
 
 @pytest.mark.parametrize("world,n,route,nb,dims", [(4, 517, "sx", 0, "2x2"), (3, 400, "s", 0, ""), (4, 301, "sx", 32, "2x2"),
-                                                    (2, 333, "s", 7, "")])
+                                                    (2, 333, "s", 7, ""), (4, 130, "h", 0, "2x2"), (3, 97, "h", 0, "")])
 def test_multi_rank_redistributions_through_small_bounce_window(world, n, route, nb, dims):
     """the eigenvector redistributions (row blocks -> column blocks after the D&C, column blocks -> the caller's
-    (block-)cyclic z at the exit, block-cyclic -> cyclic at the entry) go through ONE bounded bounce window in pairwise
+    (block-)cyclic z at the exit, block-cyclic -> cyclic at the entry, eigen_h's matrix gather) go through ONE bounded bounce window in pairwise
     rounds, slice by slice (what keeps the hipIpc footprint bounded at N = 32768); eigx_tune key 9 shrinks the window to
     1024 doubles so that every piece of these small cases takes several slices"""
     _run_multi_rank(world, n, route, nb, dims, {"EIGX_TEST_TUNE": "9=1024"})
