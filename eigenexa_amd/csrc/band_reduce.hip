@@ -250,7 +250,6 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   // (N = 32768: 5.15 against 5.48 s).
   const int G = LG ? S.G : 1;
   const int r = (blockIdx.x * G) * KA_ROWS + rr;      // row of group 0
-  const bool rowok = r < S.rows;
   EIGX_STAMP_INIT
   if (MG && S.wait.n > 0) {
     // several GPUs, one per rank: lane q of the first wave waits for rank q's step message (bounded spin; a time-out
