@@ -317,6 +317,7 @@ int eigx_tune(int key, int value) {
   if (key == 7) return value > 0 ? set_symv_threshold(3, value) : -1;
   if (key == 8) return set_dc_chunk(value);
   if (key == 9) return comm_set_bounce(value);
+  if (key == 10) return set_symv_threshold(4, value);
   return -1;
 }
 

@@ -100,6 +100,7 @@ struct SymvGeom { int L, T, nt; };
 // reads 6.5-6.9 TB/s; adding the tile's partial-sum stores (1.6 % of the bytes) costs 10-17 % of that on their own,
 // and nothing when they stay inside L2.  Walking the triangle tile column by tile column instead
 // of row by row changes nothing (A/B on one buffer).
+int g_ka_rpb5 = 1;    // K_A (eigx_tune key 10): 1 = the 80-slot form of its partial-sum batch when a row has at most 80 partial sums
 int g_ka_wgs = 256;   // K_A (eigx_tune key 7): beyond 2 * this many row groups a workgroup takes several of them, ~this many workgroups
 int g_symv_t128 = 9000, g_symv_t256 = 40000;
 int g_symv_nt = 9000;
@@ -223,7 +224,7 @@ __device__ __forceinline__ const double* mg_partial(const RedArgs& R, int par, i
   return R.MSG + ((size_t)par * R.P + src) * R.msg_stride + off;
 }
 
-template <int NB, bool MG, bool LG>
+template <int NB, bool MG, bool LG, int RPBT, int SPBT, int KBT>
 __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   __shared__ double red[64];
   __shared__ double kd[4][256];        // reduced panel-dot vectors: [UuA, WuA, UuB, WuB][kk]  (m <= 256)
@@ -276,10 +277,16 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   // straight-line batches whose extent is cut by wave-uniform conditions (no per-thread branches, no integer
   // divisions, clamped indices; out-of-range entries are dropped by a select afterwards), and nothing is
   // consumed before the last load is issued: the chain costs about one memory round trip.
-  constexpr int KB = 8;                 // panel columns per slice in the first batch (8 * KA_SL = 128)
-  constexpr int RPB = 10;               // SYMV partials per slice in the first batch (10 * KA_SL = 160)
+  // The first batches are unconditional loads (clamped addresses), so their sizes are template parameters that the
+  // host matches to the step (launch_ka): every size is correct for every step -- what a batch does not cover goes
+  // through the remainder loops below -- a matched one just carries fewer dummy loads (N=8192 reduction 141.1 -> 137.5 ms
+  // with the partial-sum batch alone).
+  constexpr int KB = KBT;               // panel columns per slice in the first batch (KB * KA_SL columns: 2 / 4 / 8 -> 32 / 64 / 128)
+  // SYMV partials per slice in the first batch: 10 (10 * KA_SL = 160 slots) or 5 (80 slots: every step of N <= 10000,
+  // half the unconditional loads of that phase); several GPUs: one message entry per slice
+  constexpr int RPB = MG ? 1 : RPBT;
   constexpr int CHB = 4;                // K_P row chunks (pd_rows_for() never makes more)
-  constexpr int SPB = 8;                // folded SP rows per wave in the first batch (covers nt <= 64)
+  constexpr int SPB = MG ? 8 : SPBT;    // folded SP rows per wave in the first batch (covers nt <= 8 * SPB - 1)
   struct RowRegs { double tu[KB], tw[KB], ta[RPB], tb[RPB], uA, uB, ai, aim; };   // what a thread loads for its row of a group
   RowRegs cur, nxt;
   double kdl[4][CHB];
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       const bool first = lane < cnt;
       const int ty = first ? f : f2;
       const int tx = first ? f + lane : f2 + (lane - cnt);
-      const bool ok = hp && nt <= 63 && 2 * f < nt && (first || ((f2 > f) && tx < nt));
+      const bool ok = hp && nt <= 8 * SPB - 1 && 2 * f < nt && (first || ((f2 > f) && tx < nt));
       const double* sp = R.SP + ((size_t)(ok ? ty : 0) * R.maxseg + (ok ? tx : 0)) * 3;
       spr[j][0] = sp[0];
       spr[j][1] = sp[NB == 2 ? 1 : 0];
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
         v[0] += spl[j][0];
         if (NB == 2) { v[1] += spl[j][1]; v[2] += spl[j][2]; }
       }
-      if (nt > 63) {   // more tiles than the folded batch covers: plain sweep of the upper tile triangle
+      if (nt > 8 * SPB - 1) {   // more tiles than the folded batch covers: plain sweep of the upper tile triangle
         for (int ty = wave; ty < nt; ty += 4)
           for (int tx = ty + lane; tx < nt; tx += 64) {
             const double* sp = R.SP + ((size_t)ty * R.maxseg + tx) * 3;
@@ -1497,6 +1504,33 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
 
   const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   KAArgs S;
+  // ka_kernel's first batches of loads are unconditional (clamped), so their sizes are template parameters matched to
+  // the step: partial sums of a row (nt + 1 slots: 1 / 2 / 3 / 5 / 10 batches of KA_SL = 16), folded rows of tile
+  // scalars (nt <= 15 / 31 / 63: 2 / 4 / 8 per wave), panel columns (k <= 32 / 64 / more: 2 / 4 / 8 per slice)
+  auto launch_ka = [&](int nwg, const KAArgs& K) {
+    const bool fit = g_ka_rpb5 != 0;
+    const int nslot = fit ? K.nt_prev + 1 : 1 << 30, ntp = fit ? K.nt_prev : 1 << 30;
+    const int kk = fit ? (K.has_prev ? K.kprev : K.k) : 1 << 30;
+#define EIGX_KA3(MGV, RPBV, SPBV, KBV)                                                                                  \
+    do {                                                                                                                \
+      if (K.G > 1) hipLaunchKernelGGL((ka_kernel<NB, MGV, true, RPBV, SPBV, KBV>), dim3(nwg), dim3(256), 0, st, R, K);   \
+      else hipLaunchKernelGGL((ka_kernel<NB, MGV, false, RPBV, SPBV, KBV>), dim3(nwg), dim3(256), 0, st, R, K);          \
+    } while (0)
+#define EIGX_KA2(MGV, RPBV, SPBV)                                                                                       \
+    do {                                                                                                                \
+      if (kk <= 2 * KA_SL) EIGX_KA3(MGV, RPBV, SPBV, 2);                                                                \
+      else if (kk <= 4 * KA_SL) EIGX_KA3(MGV, RPBV, SPBV, 4);                                                           \
+      else EIGX_KA3(MGV, RPBV, SPBV, 8);                                                                                \
+    } while (0)
+    if (mg) EIGX_KA2(true, 1, 8);
+    else if (nslot <= 1 * KA_SL && ntp <= 15) EIGX_KA2(false, 1, 2);
+    else if (nslot <= 2 * KA_SL && ntp <= 31) EIGX_KA2(false, 2, 4);
+    else if (nslot <= 3 * KA_SL) EIGX_KA2(false, 3, 8);
+    else if (nslot <= 5 * KA_SL) EIGX_KA2(false, 5, 8);
+    else EIGX_KA2(false, 10, 8);
+#undef EIGX_KA2
+#undef EIGX_KA3
+  };
   S.has_prev = 0; S.iprev = 0; S.Lprev = 0; S.kprev = 0; S.nchunk_prev = 0; S.nt_prev = 0; S.lgT_prev = 7;
   S.par = 0; S.pan_c0 = 0; S.G = 1;
   S.wait.n = 0; S.wait.flag = nullptr; S.wait.err = nullptr; S.wait.ticks = nullptr; S.wait.limit_ticks = 0; S.wait.epoch = 0;
@@ -1533,13 +1567,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
         if (fuse_wait) S.wait = comm_step_wait_args(ctx, epoch);
         else comm_step_wait(ctx, epoch, st);
       }
-      if (mg) {
-        if (S.G > 1) hipLaunchKernelGGL((ka_kernel<NB, true, true>), dim3(nb_ka), dim3(256), 0, st, R, S);
-        else hipLaunchKernelGGL((ka_kernel<NB, true, false>), dim3(nb_ka), dim3(256), 0, st, R, S);
-      } else {
-        if (S.G > 1) hipLaunchKernelGGL((ka_kernel<NB, false, true>), dim3(nb_ka), dim3(256), 0, st, R, S);
-        else hipLaunchKernelGGL((ka_kernel<NB, false, false>), dim3(nb_ka), dim3(256), 0, st, R, S);
-      }
+      launch_ka(nb_ka, S);
       S.wait.n = 0;
     }
     if (!do_step) break;
@@ -1623,13 +1651,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
         if (fuse_wait) F.wait = comm_step_wait_args(ctx, epoch);
         else comm_step_wait(ctx, epoch, st);
       }
-      if (mg) {
-        if (F.G > 1) hipLaunchKernelGGL((ka_kernel<NB, true, true>), dim3(nb_kf), dim3(256), 0, st, R, F);
-        else hipLaunchKernelGGL((ka_kernel<NB, true, false>), dim3(nb_kf), dim3(256), 0, st, R, F);
-      } else {
-        if (F.G > 1) hipLaunchKernelGGL((ka_kernel<NB, false, true>), dim3(nb_kf), dim3(256), 0, st, R, F);
-        else hipLaunchKernelGGL((ka_kernel<NB, false, false>), dim3(nb_kf), dim3(256), 0, st, R, F);
-      }
+      launch_ka(nb_kf, F);
       const int nr = i + 1;
       if (ctx.prof_stride > 0) ctx.prof_begin(1, 2.0 * (double)nr * nr * m / R.P, st);
       if (!mg) {
@@ -1696,7 +1718,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
 }  // namespace
 
 int set_symv_threshold(int which, int v) {
-  int& t = (which == 3) ? g_ka_wgs : (which == 2) ? g_symv_nt : (which ? g_symv_t256 : g_symv_t128);
+  int& t = (which == 4) ? g_ka_rpb5 : (which == 3) ? g_ka_wgs : (which == 2) ? g_symv_nt : (which ? g_symv_t256 : g_symv_t128);
   const int old = t; t = v; return old;
 }
 

@@ -227,7 +227,7 @@ int eigx_profile_read(double* out6);
  * past L2; key 7 = workgroups of the column-formation kernel beyond which a workgroup loops over row groups;
  * key 8 = chunk width (roots, 64 .. 2048) of the multi-rank D&C's eigenvector-row buffer; key 9 = doubles per slice of
  * the bounce window of the multi-rank eigenvector redistributions (keys 7-9 exist so that the tests reach the
- * large-N code paths at small sizes).  Returns the previous value, or -1 for an unknown key.  Not part of the
+ * large-N code paths at small sizes); key 10 = 0: the column-formation kernel always uses its largest load batches (A/B).  Returns the previous value, or -1 for an unknown key.  Not part of the
  * reference's interface. */
 int eigx_tune(int key, int value);
 
