@@ -69,9 +69,9 @@ anorm_ = float(inv[1].sqrt())
 tr_err = abs(float(w.sum().item()) - float(inv[0])) / anorm_
 fro_err = abs(float(torch.linalg.norm(w).item()) - anorm_) / anorm_
 srt = bool((w[1:] >= w[:-1]).all().item())
-print(f"[rank {rank}] trace error / ||A|| {tr_err:.2e}, Frobenius error / ||A|| {fro_err:.2e}, ascending {srt} "
-      f"(sum w {float(w.sum().item())!r}, tr A {float(inv[0])!r}, ||w|| {float(torch.linalg.norm(w).item())!r}, ||A|| {anorm_!r}, "
-      f"w[0] {float(w[0])!r}, w[-1] {float(w[-1])!r})", flush=True)
+if rank == 0:
+    print(f"[rank 0] trace error / ||A|| {tr_err:.2e}, Frobenius error / ||A|| {fro_err:.2e}, ascending {srt} (w[0] {float(w[0]):.6f}, "
+          f"w[-1] {float(w[-1]):.6f})", flush=True)
 assert tr_err < 1e-12 and fro_err < 1e-12 and srt
 if mode != "A":
     dist.barrier()
