@@ -100,7 +100,7 @@ struct SymvGeom { int L, T, nt; };
 // reads 6.5-6.9 TB/s; adding the tile's partial-sum stores (1.6 % of the bytes) costs 10-17 % of that on their own,
 // and nothing when they stay inside L2.  Walking the triangle tile column by tile column instead
 // of row by row changes nothing (A/B on one buffer).
-int g_ka_rpb5 = 1;    // K_A (eigx_tune key 10): 1 = the 80-slot form of its partial-sum batch when a row has at most 80 partial sums
+int g_ka_fit = 1;     // K_A (eigx_tune key 10): 1 = load batches matched to the step (launch_ka), 0 = always the largest (A/B)
 int g_ka_wgs = 256;   // K_A (eigx_tune key 7): beyond 2 * this many row groups a workgroup takes several of them, ~this many workgroups
 int g_symv_t128 = 9000, g_symv_t256 = 40000;
 int g_symv_nt = 9000;
@@ -1508,7 +1508,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   // the step: partial sums of a row (nt + 1 slots: 1 / 2 / 3 / 5 / 10 batches of KA_SL = 16), folded rows of tile
   // scalars (nt <= 15 / 31 / 63: 2 / 4 / 8 per wave), panel columns (k <= 32 / 64 / more: 2 / 4 / 8 per slice)
   auto launch_ka = [&](int nwg, const KAArgs& K) {
-    const bool fit = g_ka_rpb5 != 0;
+    const bool fit = g_ka_fit != 0;
     const int nslot = fit ? K.nt_prev + 1 : 1 << 30, ntp = fit ? K.nt_prev : 1 << 30;
     const int kk = fit ? (K.has_prev ? K.kprev : K.k) : 1 << 30;
 #define EIGX_KA3(MGV, RPBV, SPBV, KBV)                                                                                  \
@@ -1718,7 +1718,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
 }  // namespace
 
 int set_symv_threshold(int which, int v) {
-  int& t = (which == 4) ? g_ka_rpb5 : (which == 3) ? g_ka_wgs : (which == 2) ? g_symv_nt : (which ? g_symv_t256 : g_symv_t128);
+  int& t = (which == 4) ? g_ka_fit : (which == 3) ? g_ka_wgs : (which == 2) ? g_symv_nt : (which ? g_symv_t256 : g_symv_t128);
   const int old = t; t = v; return old;
 }
 
