@@ -94,15 +94,16 @@ struct SymvGeom { int L, T, nt; };
 // non-temporal loads (its 512 MB matrix still profits from the 256 MB Infinity Cache).  Round 2, same box, same call:
 // N=32768 4871 ms (512 tile beyond L = 20000) / 4807 (beyond 26000) / 4732 (256 tile throughout) -- the 512 tile's 172
 // VGPRs leave two workgroups per CU and its 2080 tiles two "generations" -- so the 512 tile now starts at L = 40000
-// (beyond that the 256 tile would give a row more than the 160 partial sums K_A loads in its first batch); and the
-// 128 tile up to L = 9000 instead of 4500: N=8192 141.7 -> 140.9 ms (below ~8000 the 256 tile leaves fewer than two
-// workgroups per CU), N=32768 unchanged.  tools/symv_stream.hip (the kernel's load loop alone, same tiles and order)
+// (beyond that the 256 tile would give a row more than the 160 partial sums K_A loads in its first batch).  The
+// 128 / 256 switch stays at L = 4500: once K_A's load batches were matched to the step (fewer partial sums and tile
+// scalars with the larger tile), an A/B on one buffer gave N=8192 133.1 / 133.3 / 134.0 / 134.6 ms (penta) and
+// 227.0 / 229.0 / - / 234.1 ms (tri) for a switch at 4500 / 6000 / 7000 / 9000, and 134.5 / 135.9 for 3500 / 3000.  tools/symv_stream.hip (the kernel's load loop alone, same tiles and order)
 // reads 6.5-6.9 TB/s; adding the tile's partial-sum stores (1.6 % of the bytes) costs 10-17 % of that on their own,
 // and nothing when they stay inside L2.  Walking the triangle tile column by tile column instead
 // of row by row changes nothing (A/B on one buffer).
 int g_ka_fit = 1;     // K_A (eigx_tune key 10): 1 = load batches matched to the step (launch_ka), 0 = always the largest (A/B)
 int g_ka_wgs = 256;   // K_A (eigx_tune key 7): beyond 2 * this many row groups a workgroup takes several of them, ~this many workgroups
-int g_symv_t128 = 9000, g_symv_t256 = 40000;
+int g_symv_t128 = 4500, g_symv_t256 = 40000;
 int g_symv_nt = 9000;
 
 inline SymvGeom symv_geom(int L) {
