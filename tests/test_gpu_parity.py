@@ -464,6 +464,33 @@ def test_symv_tile_sizes_forced_small(gpu_lib, orc, band):
         assert np.abs(dg - do).max() < 1e-9 * scale and np.abs(np.abs(eg[0]) - np.abs(eo[0])).max() < 1e-9 * scale
 
 
+@pytest.mark.parametrize("band", [1, 2])
+@pytest.mark.parametrize("n,m", [(700, 48), (1500, 128)])
+def test_ka_load_batch_sizes_do_not_change_the_result(gpu_lib, band, n, m):
+    """ka_kernel's load batches are template parameters matched to the step (partial-sum slots, tile-scalar rows, panel
+    columns); eigx_tune key 10 = 0 forces the largest batches everywhere.  Every size sums the same numbers in the same
+    order, so the band matrix must come out bit-identical either way."""
+    import torch
+    from eigenexa_amd import layout
+
+    A = layout.random_symmetric(n, seed=17)
+    out = []
+    for fit in (1, 0):
+        old = gpu_lib.eigx_tune(10, fit)
+        try:
+            a, lda = _to_colmajor(A)
+            d = torch.zeros(n, dtype=torch.float64, device=_dev())
+            e = torch.zeros(2 * n, dtype=torch.float64, device=_dev())
+            assert gpu_lib.eigx_band_reduce_dev(n, a.data_ptr(), lda, d.data_ptr(), e.data_ptr(), n, m, band) == 0
+        finally:
+            gpu_lib.eigx_tune(10, old)
+        out.append((d.cpu().numpy().copy(), e.cpu().numpy().copy()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    wr = np.linalg.eigvalsh(A)
+    eg = out[0][1].reshape(2, n)
+    assert np.abs(np.linalg.eigvalsh(_band_matrix(out[0][0], eg[:band], band)) - wr).max() < 1e-13 * n * np.abs(wr).max()
+
+
 @pytest.mark.parametrize("world,n,route,dims", [(4, 210, "edge-sx", ""), (2, 170, "edge-s", "2x1")])
 def test_multi_rank_error_behaviour_and_scaling(world, n, route, dims):
     """NaN / Inf input, matrices scaled by 1e+-200 and a NaN-poisoned strict lower triangle on the process grid"""
