@@ -22,14 +22,13 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP64_MFMA_PEAK_TF = 78.6   # MI355X fp64 matrix peak (v_mfma_f64_16x16x4_f64 = vector rate)
@@ -38,7 +37,7 @@ REFERENCE_PUBLISHED = {"seconds": 30.1, "gflops": 114.0, "cores": 8, "n": 8192,
                        "where": "BASELINE.md: reference 2.13 built with flang + MKL, 8 host cores of the survey container"}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -46,17 +45,76 @@ def main():
     ap.add_argument("--size", dest="n", type=int, default=0, help="matrix size (default 8192 on one GPU, 32768 on several)")
     ap.add_argument("--route", default="sx", choices=["sx", "s"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="--gpus 1: skip the extra N=32768 solve")
-    ap.add_argument("--cpu-n", type=int, default=2048)
+    ap.add_argument("--no-extra", action="store_true", help="--gpus 1: skip the extra N=32768 / N=65536 solves")
+    ap.add_argument("--cpu-n", type=int, default=4096, help="size of the cpu_baseline solve (OpenMP oracle, all host cores)")
     ap.add_argument("--mf", type=int, default=128, help="m_forward (panel width) of the main line")
     ap.add_argument("--extra-mf", type=int, default=256, help="m_forward of the extra N=32768 solve (K = 512 slabs for the trailing update)")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of the distributed solve")
     ap.add_argument("--weak", action="store_true", help="N>1: weak scaling, N = size*sqrt(P) (size defaults to 8192)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: this process becomes the launcher.  It touches no GPU (torch is
+    not even imported yet), starts N copies of this script as child processes with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set (what `python -m torch.distributed.run --nproc-per-node N` would do), relays their
+    output (rank 0 prints the JSON line) and exits with the worst exit code."""
+    n = args.gpus
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "EIGX_BENCH_SPAWNED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    deadline = None
+    while procs:
+        for p_ in list(procs):
+            rc = p_.poll()
+            if rc is None:
+                continue
+            procs.remove(p_)
+            if rc != 0:
+                worst = worst or (rc if rc > 0 else 1)
+                if deadline is None:
+                    deadline = time.time() + 60.0    # a rank died: the others get a minute to notice and leave
+        if deadline is not None and time.time() > deadline:
+            for p_ in procs:
+                p_.kill()                             # exact PIDs we started
+            for p_ in procs:
+                p_.wait()
+            procs = []
+        time.sleep(0.05)
+    sys.exit(worst)
+
+
+ARGS = parse_args() if __name__ == "__main__" else None
+if ARGS is not None and ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    spawn_ranks(ARGS)          # never returns
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    args = ARGS if ARGS is not None else parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # a line that says n_gpus = world while the caller asked for --gpus N would void a scaling run
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE = {world}: launch with `python bench.py --gpus N` (spawns the ranks "
+              f"itself) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`", file=sys.stderr, flush=True)
+        sys.exit(2)
+    if os.environ.get("EIGX_BENCH_DRYRUN"):   # launcher plumbing test (tests/test_host.py): no GPU is touched
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": world, "master_port": os.environ.get("MASTER_PORT")}), flush=True)
+        sys.exit(0 if os.environ.get("EIGX_BENCH_DRYRUN") != f"fail{rank}" else 3)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -85,7 +143,9 @@ def main():
         k_, v_ = kv.split("=")
         lib.eigx_tune(int(k_), int(v_))
     replicas = args.replicas or world == 1
-    scaling = "weak"
+    # one GPU: the P = 1 point of the strong-scaling series (the multi-GPU lines solve configs[2]'s fixed N = 32768
+    # matrix; its one-GPU time is this line's extra.seconds); independent replicas are weak scaling by construction
+    scaling = "strong" if world == 1 else "weak"
     if world == 1 or args.replicas:
         n = args.n or 8192
     elif args.weak:
@@ -342,50 +402,71 @@ def main():
         }
         out.update(roofline_blocks(prof, n))
 
-    # ---- extra: one solve of BASELINE configs[2]'s matrix (N=32768) on this one GPU --------------------------
-    if world == 1 and not args.no_extra and n != 32768 and args.route == "sx":
-        try:
-            del a_bufs, z, w, A_loc_T
-            torch.cuda.empty_cache()
-            n2 = 32768
-            lda2 = n2 + 34
-            a2 = torch.empty(n2, lda2, dtype=torch.float64, device=dev)
-            a2[:, n2:] = 0.0
-            fro2 = 0.0
-            for c0 in range(0, n2, 4096):
-                blk = layout.random_symmetric_torch(n2, dev, rows=np.arange(n2), cols=np.arange(c0, c0 + 4096))
-                a2[c0:c0 + 4096, :n2] = blk.T
-                fro2 += float((blk * blk).sum().item())
-                del blk
-            w2 = torch.zeros(n2, dtype=torch.float64, device=dev)
-            z2 = torch.empty(n2, lda2, dtype=torch.float64, device=dev)
+    # ---- extra blocks (one GPU): driver-timed solves of the other BASELINE configs on this GPU -----------------
+    #   extra          configs[2]'s matrix, N=32768 eigen_sx all eigenpairs (north_star's 70 % trailing-update target)
+    #   extra_s        configs[3]'s, N=32768 eigen_s (tridiagonal route) all eigenpairs
+    #   extra_n65536   configs[4]'s, N=65536 eigenvalues only (mode 'N': reduction + bisection)
+    def gen_big(n2):
+        lda2 = n2 + 34
+        a2 = torch.empty(n2, lda2, dtype=torch.float64, device=dev)
+        a2[:, n2:] = 0.0
+        fro2 = 0.0
+        tr2 = 0.0
+        for c0 in range(0, n2, 4096):
+            blk = layout.random_symmetric_torch(n2, dev, rows=np.arange(n2), cols=np.arange(c0, c0 + 4096))
+            a2[c0:c0 + 4096, :n2] = blk.T
+            fro2 += float((blk * blk).sum().item())
+            tr2 += float(torch.diagonal(blk[c0:c0 + 4096, :]).sum().item())
+            del blk
+        return a2, lda2, fro2, tr2
+
+    def extra_block(n2, route, mode, mf2, warm):
+        fn2 = lib.eigx_sx_dev if route == "sx" else lib.eigx_s_dev
+        a2, lda2, fro2, tr2 = gen_big(n2)
+        nvec2 = n2 if mode == "A" else 0
+        w2 = torch.zeros(n2, dtype=torch.float64, device=dev)
+        z2 = torch.empty(n2, lda2, dtype=torch.float64, device=dev) if nvec2 else torch.zeros(8, dtype=torch.float64, device=dev)
+        if warm:
             a2w = a2.clone()                                   # pristine copy for the warm-up (the solver destroys a)
-            _lib.check(lib.eigx_sx_dev(n2, n2, a2w.data_ptr(), lda2, w2.data_ptr(), z2.data_ptr(), lda2, args.extra_mf, 128, b"A"),
-                       "eigen_sx")                             # warm-up: workspace allocation (~26 GB) happens here
+            _lib.check(fn2(n2, nvec2, a2w.data_ptr(), lda2, w2.data_ptr(), z2.data_ptr(), lda2, mf2, 128, mode.encode()),
+                       "eigen_" + route)                       # warm-up: workspace allocation (~26 GB) happens here
             del a2w
-            lib.eigx_profile(8)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            _lib.check(lib.eigx_sx_dev(n2, n2, a2.data_ptr(), lda2, w2.data_ptr(), z2.data_ptr(), lda2, args.extra_mf, 128, b"A"),
-                       "eigen_sx")
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t0
-            prof2 = read_prof()
-            lib.eigx_profile(0)
-            tm2 = np.zeros(16)
-            lib.eigx_get_timers(tm2.ctypes.data_as(C.POINTER(C.c_double)))
-            fro_err = abs(float(torch.linalg.norm(w2).item()) - fro2 ** 0.5) / fro2 ** 0.5
-            ex = {"workload": f"N=32768 random symmetric fp64, eigen_sx all eigenpairs, m_forward={args.extra_mf}, ONE timed solve on this GPU "
-                              "after one warm-up solve (BASELINE.json configs[2]'s matrix)",
-                  "seconds": round(dt2, 3), "gflops": round(abs(float(tm2[12])) / dt2 / 1e9, 1),
-                  "stage_ms": {"reduction": round(tm2[1] * 1e3, 1), "dc": round(tm2[2] * 1e3, 1),
-                               "backtransform": round(tm2[3] * 1e3, 1)},
-                  "frobenius_error_over_anorm": fro_err}
-            ex.update(roofline_blocks(prof2, n2))
-            out["extra"] = ex
-            del a2, z2, w2
-        except Exception as exc_x:   # the extra block never invalidates the main line
-            out["extra"] = {"error": str(exc_x)}
+        lib.eigx_profile(8)
+        torch.cuda.synchronize()
+        t0x = time.perf_counter()
+        _lib.check(fn2(n2, nvec2, a2.data_ptr(), lda2, w2.data_ptr(), z2.data_ptr(), lda2, mf2, 128, mode.encode()),
+                   "eigen_" + route)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0x
+        prof2 = read_prof()
+        lib.eigx_profile(0)
+        tm2 = np.zeros(16)
+        lib.eigx_get_timers(tm2.ctypes.data_as(C.POINTER(C.c_double)))
+        anorm2 = fro2 ** 0.5
+        what = "all eigenpairs" if mode == "A" else "eigenvalues only (mode 'N': reduction + multi-section bisection)"
+        ex = {"workload": f"N={n2} random symmetric fp64, eigen_{route} {what}, m_forward={mf2}, ONE timed solve on this GPU "
+                          + ("after one warm-up solve" if warm else "without a warm-up solve (workspace allocation included)"),
+              "seconds": round(dt2, 3), "gflops": round(abs(float(tm2[12])) / dt2 / 1e9, 1),
+              "stage_ms": {"reduction": round(tm2[1] * 1e3, 1), "dc_or_bisection": round(tm2[2] * 1e3, 1),
+                           "backtransform": round(tm2[3] * 1e3, 1)},
+              "frobenius_error_over_anorm": abs(float(torch.linalg.norm(w2).item()) - anorm2) / anorm2,
+              "trace_error_over_anorm": abs(float(w2.sum().item()) - tr2) / anorm2,
+              "sorted": bool((w2[1:] >= w2[:-1]).all().item())}
+        ex.update(roofline_blocks(prof2, n2))
+        del a2, z2, w2
+        torch.cuda.empty_cache()
+        return ex
+
+    if world == 1 and not args.no_extra and n != 32768 and args.route == "sx":
+        del a_bufs, z, w, A_loc_T
+        torch.cuda.empty_cache()
+        for key, (n2, route2, mode2, mf2, warm2) in {"extra": (32768, "sx", "A", args.extra_mf, True),
+                                                     "extra_s": (32768, "s", "A", args.extra_mf, True),
+                                                     "extra_n65536": (65536, "sx", "N", args.extra_mf, False)}.items():
+            try:
+                out[key] = extra_block(n2, route2, mode2, mf2, warm2)
+            except Exception as exc_x:   # an extra block never invalidates the main line
+                out[key] = {"error": str(exc_x)}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
@@ -393,16 +474,18 @@ def main():
 
             nc = args.cpu_n
             Ac = layout.random_symmetric(nc)
+            cores = orc.threads()          # OpenMP threads the oracle runs on = host cores this process may use
             t0c = time.perf_counter()
             _, _, stats, st = orc.eigen(Ac, args.route)
             tc = time.perf_counter() - t0c
             out["cpu_baseline"] = {
-                "value": round(abs(stats[0]) / tc / 1e9, 3), "unit": "GFLOP/s", "cores": 1,
+                "value": round(abs(stats[0]) / tc / 1e9, 3), "unit": "GFLOP/s", "cores": cores,
                 "kind": "port", "n": nc,
-                "sample": f"oracle/eigx_oracle.c eigen_{args.route} (single-thread unblocked C restatement, the only CPU code "
-                          f"that can run on the GPU box) at N={nc} -- NOT the GPU line's N={n}: the same generator, all "
-                          f"eigenpairs, {tc:.1f} s on one host core (reduction {st[0]:.1f} s, D&C {st[1]:.1f} s, "
-                          f"back-transform {st[2]:.1f} s); the reference's own CPU path is in reference_published",
+                "sample": f"oracle/eigx_oracle.c eigen_{args.route} (unblocked C restatement, its O(N^3) loops threaded with "
+                          f"OpenMP over {cores} host cores of this box; the only CPU code that can run on the GPU box) at "
+                          f"N={nc} -- NOT the GPU line's N={n}: the same generator, all eigenpairs, {tc:.1f} s "
+                          f"(reduction {st[0]:.1f} s, D&C {st[1]:.1f} s, back-transform {st[2]:.1f} s); the reference's own "
+                          f"MPI CPU path (another box) is in reference_published",
                 "reference_published": REFERENCE_PUBLISHED,
             }
         print(json.dumps(out), flush=True)

@@ -4,8 +4,11 @@
  * This file is the checker, never the product: only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may build, load or call it.  libeigenexa_amd.so does not link it.
  *
- * It restates, in plain scalar C (column-major, 0-based internally, one thread), the algorithm of the
- * reference's path (paths relative to RIKEN-RCCS/EigenExa 2.13):
+ * It restates, in plain scalar C (column-major, 0-based internally), the algorithm of the reference's path.  The
+ * three O(N^3) loop nests (two-sided reflector application, the D&C's eigenvector product, the back-transformation)
+ * and the bisection are threaded with OpenMP over INDEPENDENT rows / columns / eigenvalues: every number is still
+ * summed in the same order, so the results do not depend on OMP_NUM_THREADS (bench.py's cpu_baseline runs it on
+ * all host cores; the tests run it with whatever the environment gives).  Reference (paths relative to RIKEN-RCCS/EigenExa 2.13):
  *   stage 1  Householder reduction, bottom-up, to tridiagonal (band=1) or pentadiagonal (band=2):
  *            eigen_trd  src/eigen_trd.F:349-723, reflector convention src/eigen_trd_t2.F:486-489,:574-584
  *            eigen_prd  src/eigen_prd.F:341-578, pair reflectors src/eigen_prd_t4x.F:83-373,
@@ -41,6 +44,13 @@
 #define Z_(i, j) z[(size_t)(i) + (size_t)(j) * ldz]
 #define E_(i, b) e[(size_t)(i) + (size_t)((b)-1) * lde] /* e(i,b) = T(i-b,i), 0-based i */
 
+#ifdef _OPENMP
+#include <omp.h>
+int orc_threads(void) { return omp_get_max_threads(); }
+#else
+int orc_threads(void) { return 1; }
+#endif
+
 static double sign_of(double mag, double s) { return s >= 0.0 ? fabs(mag) : -fabs(mag); }
 
 /* ------------------------------------------------------------------------------------------------
@@ -53,17 +63,24 @@ static double sign_of(double mag, double s) { return s >= 0.0 ? fabs(mag) : -fab
 static void apply_two_sided(int len, double* w, int n, const double* u, double beta, double* p) {
   /* W(0:len,0:len) <- H W H with H = I - u u^T/beta (full symmetric storage) */
   if (beta == 0.0) return;
-  for (int r = 0; r < len; ++r) p[r] = 0.0;
-  for (int c = 0; c < len; ++c) {
-    const double uc = u[c];
-    if (uc == 0.0) continue;
-    const double* wc = &W_(0, c);
-    for (int r = 0; r < len; ++r) p[r] += wc[r] * uc;
+  /* threads own blocks of rows; every p[r] is still summed over c = 0, 1, ... in that order, so the result does
+   * not depend on the thread count */
+#pragma omp parallel for schedule(static)
+  for (int r0 = 0; r0 < len; r0 += 512) {
+    const int r1 = (r0 + 512 < len) ? r0 + 512 : len;
+    for (int r = r0; r < r1; ++r) p[r] = 0.0;
+    for (int c = 0; c < len; ++c) {
+      const double uc = u[c];
+      if (uc == 0.0) continue;
+      const double* wc = &W_(0, c);
+      for (int r = r0; r < r1; ++r) p[r] += wc[r] * uc;
+    }
   }
   double up = 0.0;
   for (int r = 0; r < len; ++r) up += u[r] * p[r];
   const double alpha = up / (2.0 * beta);
   for (int r = 0; r < len; ++r) p[r] = (p[r] - alpha * u[r]) / beta; /* p is now v */
+#pragma omp parallel for schedule(static)
   for (int c = 0; c < len; ++c) {
     double* wc = &W_(0, c);
     const double uc = u[c], vc = p[c];
@@ -377,8 +394,10 @@ static void rank_one_merge(int n, double* d, double* z, double rho, double* q, i
         }
       }
       /* re-normalise the kept part (deflated z were zeroed) as DLAED3 does implicitly via rho */
+#pragma omp parallel for schedule(dynamic, 16)
       for (int j = 0; j < K; ++j) secular_root(K, j, dl, wz, rho, &S[(size_t)j * K], &lam[j]);
       /* Gu-Eisenstat: zhat_i^2 = prod_j (lam_j - d_i) / prod_{j!=i} (d_j - d_i) */
+#pragma omp parallel for schedule(static)
       for (int i = 0; i < K; ++i) {
         double prod = -S[(size_t)i * K + i]; /* lam_i - d_i */
         for (int j = 0; j < K; ++j) {
@@ -388,6 +407,7 @@ static void rank_one_merge(int n, double* d, double* z, double rho, double* q, i
         zh[i] = sign_of(sqrt(fabs(prod)), wz[i]);
       }
       /* eigenvectors of the rank-one update, column j: zhat_i/(d_i - lam_j), normalised */
+#pragma omp parallel for schedule(static)
       for (int j = 0; j < K; ++j) {
         double* sj = &S[(size_t)j * K];
         double nrm = 0.0;
@@ -396,21 +416,37 @@ static void rank_one_merge(int n, double* d, double* z, double rho, double* q, i
         for (int i = 0; i < K; ++i) sj[i] *= nrm;
       }
       /* Q(:, nd) <- Q(:, nd) * S */
-      double* row = (double*)malloc((size_t)K * sizeof(double));
-      double* out = (double*)malloc((size_t)K * sizeof(double));
-      for (int r = 0; r < qrows; ++r) {
-        for (int k = 0; k < K; ++k) row[k] = Q_(r, nd[k]);
-        for (int j = 0; j < K; ++j) {
-          const double* sj = &S[(size_t)j * K];
-          double acc = 0.0;
-          for (int k = 0; k < K; ++k) acc += row[k] * sj[k];
-          out[j] = acc;
+      /* blocks of RBK rows share one pass over S; the rows of a block are the vector dimension (each (r, j) entry is
+       * still the sum over k = 0, 1, ... in that order) */
+      enum { RBK = 16 };
+#pragma omp parallel
+      {
+        double* row = (double*)malloc((size_t)K * RBK * sizeof(double));   /* [k][rr] */
+        double* out = (double*)malloc((size_t)K * RBK * sizeof(double));   /* [j][rr] */
+#pragma omp for schedule(static)
+        for (int r0 = 0; r0 < qrows; r0 += RBK) {
+          const int nr = (r0 + RBK < qrows) ? RBK : qrows - r0;
+          for (int k = 0; k < K; ++k)
+            for (int rr = 0; rr < RBK; ++rr) row[(size_t)k * RBK + rr] = (rr < nr) ? Q_(r0 + rr, nd[k]) : 0.0;
+          for (int j = 0; j < K; ++j) {
+            const double* sj = &S[(size_t)j * K];
+            double acc[RBK];
+            for (int rr = 0; rr < RBK; ++rr) acc[rr] = 0.0;
+            for (int k = 0; k < K; ++k) {
+              const double sv = sj[k];
+              const double* rw = &row[(size_t)k * RBK];
+              for (int rr = 0; rr < RBK; ++rr) acc[rr] += rw[rr] * sv;
+            }
+            for (int rr = 0; rr < RBK; ++rr) out[(size_t)j * RBK + rr] = acc[rr];
+          }
+          for (int k = 0; k < K; ++k)
+            for (int rr = 0; rr < nr; ++rr) Q_(r0 + rr, nd[k]) = out[(size_t)k * RBK + rr];
         }
-        for (int k = 0; k < K; ++k) Q_(r, nd[k]) = out[k];
+        free(row); free(out);
       }
       if (flops) *flops += 2.0 * qrows * (double)K * K;
       for (int k = 0; k < K; ++k) d[nd[k]] = lam[k];
-      free(row); free(out); free(dl); free(wz); free(lam); free(S); free(zh);
+      free(dl); free(wz); free(lam); free(S); free(zh);
     }
     free(nd);
   }
@@ -548,17 +584,24 @@ int orc_band_dc(int n, const double* d, const double* e_in, int lde, int band, d
 int orc_trbak(int n, int nvec, const double* a, int lda, double* z, int ldz, const double* e, int lde,
               int band) {
   if (n <= 0 || nvec < 0 || (band != 1 && band != 2)) return -1;
-  for (int i = band; i < n; ++i) {
-    const int L = i - band + 1; /* rows 0..L-1 */
-    const double beta = -A_(L - 1, i) * E_(i, band);
-    if (beta == 0.0) continue;
-    const double* u = &A_(0, i);
-    for (int j = 0; j < nvec; ++j) {
-      double* zj = &Z_(0, j);
-      double dot = 0.0;
-      for (int r = 0; r < L; ++r) dot += u[r] * zj[r];
-      dot /= beta;
-      for (int r = 0; r < L; ++r) zj[r] -= dot * u[r];
+  /* the columns of Z are independent: a thread takes a block of CB columns through ALL reflectors (the block stays in
+   * cache, `a` streams past once per block); per column the arithmetic and its order are those of the plain loop */
+  enum { CB = 8 };
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int j0 = 0; j0 < nvec; j0 += CB) {
+    const int j1 = (j0 + CB < nvec) ? j0 + CB : nvec;
+    for (int i = band; i < n; ++i) {
+      const int L = i - band + 1; /* rows 0..L-1 */
+      const double beta = -A_(L - 1, i) * E_(i, band);
+      if (beta == 0.0) continue;
+      const double* u = &A_(0, i);
+      for (int j = j0; j < j1; ++j) {
+        double* zj = &Z_(0, j);
+        double dot = 0.0;
+        for (int r = 0; r < L; ++r) dot += u[r] * zj[r];
+        dot /= beta;
+        for (int r = 0; r < L; ++r) zj[r] -= dot * u[r];
+      }
     }
   }
   return 0;
@@ -686,6 +729,7 @@ int orc_band_bisect(int n, const double* d, const double* e, int lde, int band, 
   const double x0 = (fabs(lo) + fabs(hi)) * DBL_EPSILON;
   const double lb_ = (lo - x0) - DBL_EPSILON * em - DBL_MIN, ub_ = (hi + x0) + DBL_EPSILON * em + DBL_MIN;
   const double pivmin = fmax(DBL_MIN * fmax(1.0, em * em), DBL_MIN);
+#pragma omp parallel for schedule(dynamic, 8)
   for (int k = 0; k < n; ++k) {
     double lb = lb_, ub = ub_, x = lb;
     for (int it = 0; it < 128; ++it) {   /* ITRMAX of src/bisect2.F:128 */

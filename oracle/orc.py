@@ -35,6 +35,11 @@ def load():
     return _lib
 
 
+def threads():
+    """OpenMP threads the oracle's parallel loops run on"""
+    return int(load().orc_threads())
+
+
 def _p(a):
     return a.ctypes.data_as(_dp)
 

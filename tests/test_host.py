@@ -394,3 +394,26 @@ def test_matrix_market_reader(tmp_path):
     assert np.array_equal(A, ref)
     with pytest.raises(ValueError):
         layout.read_matrix_market(str(p), 5)
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher starts N ranks itself (before anything touches a GPU) and relays
+    rank 0's line and the worst exit code; `--gpus N` under a different WORLD_SIZE is refused."""
+    import json
+    import subprocess
+
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["EIGX_BENCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, bench, "--gpus", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 4
+    env["EIGX_BENCH_DRYRUN"] = "fail2"           # rank 2 exits with code 3: the launcher reports it
+    r = subprocess.run([sys.executable, bench, "--gpus", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3
+    env["EIGX_BENCH_DRYRUN"] = "1"
+    env["WORLD_SIZE"] = "2"
+    env["RANK"] = "0"
+    r = subprocess.run([sys.executable, bench, "--gpus", "8"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
