@@ -287,6 +287,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof = read_prof()
+    kinds = np.zeros(15)
+    lib.eigx_profile_read_kinds(kinds.ctypes.data_as(C.POINTER(C.c_double)), 5)
     lib.eigx_profile(0)
     tm = np.zeros(16)
     lib.eigx_get_timers(tm.ctypes.data_as(C.POINTER(C.c_double)))
@@ -361,7 +363,15 @@ def main():
                "frobenius_error_over_anorm": abs(float(torch.linalg.norm(w).item()) - anorm) / anorm,
                "max_abs_znorm2_minus_1": float((zc - 1.0).abs().max().item()),
                "comm_seconds_per_solve_max_over_ranks": round(comm_max, 4),
-               "sanity": mg_note}
+               "sanity": mg_note,
+               # what carried the per-step exchange and the bulk collectives, and the init-time self-test of both transports
+               "transport": ee.eigen_comm_info(),
+               # rank 0's sampled reduction steps (every 8th), HIP events on the compute stream, averages in microseconds:
+               # local mat-vec | local reduce of the tile partial sums + push of the step message to every rank | wait for
+               # the peers' messages | replicated ka_kernel
+               "per_step_us": {name: (round(kinds[3 * k_ + 2] / kinds[3 * k_] * 1e6, 2) if kinds[3 * k_] > 0 else None)
+                               for k_, name in ((0, "symv"), (2, "exchange_reduce_and_push"), (3, "wait"), (4, "ka"))},
+               "per_step_samples": int(kinds[0])}
     total_flops_all = flops_one * args.steps * (world if replicas else 1)
 
     out = None
@@ -373,10 +383,11 @@ def main():
             par = f"{world} independent replicas of the N={n} solve (fallback: the distributed path was not usable)"
         else:
             par = (f"{world} GPUs, {Px}x{Py} grid, A 2-D cyclic and sharded (N^2*8/P bytes per GPU, used in place); per step ONE "
-                   f"peer-write exchange of the locally reduced mat-vec partial sums into every rank's window over xGMI "
-                   f"(hipIpc-mapped, no host, no RCCL on the critical path), panel gather on a side stream under the local "
-                   f"trailing update (look-ahead), D&C row-distributed, back-transformation column-parallel with "
-                   f"streamed reflector panels; {scaling} scaling")
+                   f"exchange of the locally reduced mat-vec partial sums into every rank's window (config.transport says how: "
+                   f"kernel stores over xGMI into hipIpc-mapped windows, or one allgather), panel gather on a side stream under "
+                   f"the local trailing update (look-ahead), D&C row-distributed, back-transformation column-parallel with "
+                   f"streamed reflector panels; {scaling} scaling; the one-GPU time of this matrix is extra.seconds of the "
+                   f"--gpus 1 line")
         out = {
             "metric": "eigen_sx full-solve throughput (reference flop model: 4/3 N^3 + D&C GEMM + 2 nvec N^2)"
             if args.route == "sx" else "eigen_s full-solve throughput (reference flop model)",
@@ -474,7 +485,9 @@ def main():
 
             nc = args.cpu_n
             Ac = layout.random_symmetric(nc)
-            cores = orc.threads()          # OpenMP threads the oracle runs on = host cores this process may use
+            # OpenMP threads = host cores this process may use: affinity mask and cgroup quota, and never more than a GPU
+            # box's CPU share of 16 cores per visible GPU (more threads than cores only add barrier time)
+            cores = orc.set_threads(int(os.environ.get("EIGX_CPU_CORES", 0)) or min(orc.host_cores(), 16 * max(1, torch.cuda.device_count())))
             t0c = time.perf_counter()
             _, _, stats, st = orc.eigen(Ac, args.route)
             tc = time.perf_counter() - t0c

@@ -7,6 +7,7 @@ entry-point names, argument meaning and defaults, over the C-ABI of ``libeigenex
 from .api import (  # noqa: F401
     eigen_init,
     eigen_free,
+    eigen_comm_info,
     eigen_get_matdims,
     eigen_get_procs,
     eigen_get_id,

@@ -20,6 +20,7 @@ SIGNATURES = {
     "eigx_get_device_count": (C.c_int, []),
     "eigx_get_comm": (C.c_int, [C.POINTER(C.c_int)] * 4),
     "eigx_comm_seconds": (C.c_double, []),
+    "eigx_comm_info": (C.c_int, [C.c_char_p, C.c_int]),
     "eigx_rccl_selftest": (C.c_int, []),
     "eigx_free": (C.c_int, []),
     "eigx_get_version": (C.c_int, [_c_int_p, C.c_char_p, C.c_char_p]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     "eigx_get_timers": (C.c_int, [_c_double_p]),
     "eigx_profile": (C.c_int, [C.c_int]),
     "eigx_profile_read": (C.c_int, [_c_double_p]),
+    "eigx_profile_read_kinds": (C.c_int, [_c_double_p, C.c_int]),
     "eigx_tune": (C.c_int, [C.c_int, C.c_int]),
     "eigx_device_synchronize": (C.c_int, []),
     "eigx_malloc_dev": (C.c_void_p, [C.c_int64]),

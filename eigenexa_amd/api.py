@@ -88,6 +88,17 @@ def eigen_init(comm=None, order="C", device=None, dims=None):
     return None
 
 
+def eigen_comm_info():
+    """transports chosen at eigen_init (per-step exchange, its wait, bulk collectives) and the init-time self-test's
+    counts, as a dict (eigx_comm_info); {"ranks": 1} on one GPU"""
+    import json
+
+    lib = _lib.load()
+    buf = C.create_string_buffer(1024)
+    _lib.check(lib.eigx_comm_info(buf, 1024), "eigx_comm_info")
+    return json.loads(buf.value.decode())
+
+
 def eigen_free():
     lib = _lib.load()
     lib.eigx_free()

@@ -156,6 +156,11 @@ int eigx_get_comm(int* x_color, int* x_key, int* y_color, int* y_key) {
 
 double eigx_comm_seconds(void) { return g_ctx.timers[4]; }
 
+int eigx_comm_info(char* buf, int len) {
+  if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  return comm_info(g_ctx, buf, len);
+}
+
 int eigx_get_errinfo(int64_t* info) {
   if (info) *info = g_ctx.errinfo;
   return EIGX_OK;
@@ -272,10 +277,29 @@ int eigx_profile_read(double* out6) {
   for (size_t q = 0; q < g_ctx.prof_kind.size(); ++q) {
     float ms = 0.f;
     EIGX_HIP_CHECK(hipEventElapsedTime(&ms, g_ctx.prof_ev[2 * q], g_ctx.prof_ev[2 * q + 1]));
+    if (g_ctx.prof_kind[q] > 1) continue;   // kinds 2.. are the multi-rank step breakdown (eigx_profile_read_kinds)
     const int k = g_ctx.prof_kind[q] ? 3 : 0;
     out6[k + 0] += 1.0;
     out6[k + 1] += g_ctx.prof_units[q];
     out6[k + 2] += 1e-3 * ms;
+  }
+  return EIGX_OK;
+}
+
+int eigx_profile_read_kinds(double* out, int nkinds) {
+  if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  if (!out || nkinds < 1) return EIGX_ERR_BAD_ARG;
+  EIGX_HIP_CHECK(hipSetDevice(g_ctx.device));
+  EIGX_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+  for (int q = 0; q < 3 * nkinds; ++q) out[q] = 0.0;
+  for (size_t q = 0; q < g_ctx.prof_kind.size(); ++q) {
+    const int k = g_ctx.prof_kind[q];
+    if (k < 0 || k >= nkinds) continue;
+    float ms = 0.f;
+    EIGX_HIP_CHECK(hipEventElapsedTime(&ms, g_ctx.prof_ev[2 * q], g_ctx.prof_ev[2 * q + 1]));
+    out[3 * k + 0] += 1.0;
+    out[3 * k + 1] += g_ctx.prof_units[q];
+    out[3 * k + 2] += 1e-3 * ms;
   }
   return EIGX_OK;
 }

@@ -259,11 +259,12 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
     if (tid < S.wait.n) {
       const unsigned long long* f = S.wait.flag + (S.wait.epoch & 1) * EIGX_MAXP + tid;
       const long long t0 = wall_clock64();
-      if (__hip_atomic_load(S.wait.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      if (__hip_atomic_load(S.wait.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
         while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < S.wait.epoch) {
           __builtin_amdgcn_s_sleep(1);
+          if (__hip_atomic_load(S.wait.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;   // a peer failed
           if (wall_clock64() - t0 > S.wait.limit_ticks) {
-            __hip_atomic_store(S.wait.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(S.wait.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
           }
         }
@@ -839,7 +840,8 @@ __global__ __launch_bounds__(256) void kl_kernel(RedArgs R, KLArgs K) {
     if (last) *K.peers.counter = 0;
   }
   __syncthreads();
-  if (last && (int)threadIdx.x < K.peers.n)
+  // (collective form of the exchange: one local destination, no flag -- comm_step_allgather follows in stream order)
+  if (last && (int)threadIdx.x < K.peers.n && K.peers.flag[threadIdx.x])
     __hip_atomic_store(K.peers.flag[threadIdx.x] + K.par * EIGX_MAXP, K.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -1536,6 +1538,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   S.par = 0; S.pan_c0 = 0; S.G = 1;
   S.wait.n = 0; S.wait.flag = nullptr; S.wait.err = nullptr; S.wait.ticks = nullptr; S.wait.limit_ticks = 0; S.wait.epoch = 0;
   const bool fuse_wait = mg && comm_step_wait_fused(ctx);
+  const bool step_coll = mg && comm_step_collective(ctx);   // per-step exchange as an allgather (RCCL / emulated)
   int k = 0;        // panel fill
   int i = n - 1;    // top column of the current block
   if (mg) {
@@ -1544,6 +1547,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   }
   double t_symv_bytes = 0.0;
   long n_symv = 0, n_k1 = 0;
+  bool prof_step = false;   // several ranks: the previous step's mat-vec was sampled -> sample its wait and K_A as well
   double k1_flops = 0.0;
   while (true) {
     const int L = i - NB + 1;  // rows above the block
@@ -1564,11 +1568,18 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     if (S.rows > 0 && (S.has_prev || ncols > 0)) {
       // the previous step's messages of every rank must be in: a wait kernel, or the wait folded into K_A's prologue
       S.wait.n = 0;
-      if (mg && S.has_prev) {
+      if (mg && S.has_prev && !step_coll) {
         if (fuse_wait) S.wait = comm_step_wait_args(ctx, epoch);
-        else comm_step_wait(ctx, epoch, st);
+        else {
+          if (prof_step) ctx.prof_begin(3, 0.0, st);
+          comm_step_wait(ctx, epoch, st);
+          if (prof_step) ctx.prof_end(st);
+        }
       }
+      if (prof_step) ctx.prof_begin(4, 0.0, st);
       launch_ka(nb_ka, S);
+      if (prof_step) ctx.prof_end(st);
+      prof_step = false;
       S.wait.n = 0;
     }
     if (!do_step) break;
@@ -1629,7 +1640,11 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       K.epoch = epoch;
       K.peers = peers;
       const int nbc = ceil_div(B.Lc > 0 ? B.Lc : 1, 64);
+      if (prof) ctx.prof_begin(2, 8.0 * R.msg_stride, st);
       hipLaunchKernelGGL((kl_kernel<NB>), dim3(K.nbr + nbc), dim3(256), 0, st, R, K);
+      if (step_coll) comm_step_allgather(ctx, peers.slot[0], K.par, st);
+      if (prof) ctx.prof_end(st);
+      prof_step = prof;
       S.par = K.par;
     }
     t_symv_bytes += 8.0 * ((double)L * (L + 1) / 2);
@@ -1643,12 +1658,13 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     if (k >= m && i - NB + 1 >= 1) {
       // panel full and more reflectors to come: finish W, trailing update, start a new panel
       KAArgs F = S;
+      prof_step = false;   // (the panel-closing K_A is not part of the sampled step breakdown)
       F.ncols = 0; F.i = i; F.L = 0; F.k = k; F.rows = S.iprev + 1;
       const int fgroups = (F.rows + KA_ROWS - 1) / KA_ROWS;
       F.G = (fgroups > 2 * g_ka_wgs) ? (fgroups + g_ka_wgs - 1) / g_ka_wgs : 1;
       const int nb_kf = (fgroups + F.G - 1) / F.G;
       F.wait.n = 0;
-      if (mg) {
+      if (mg && !step_coll) {
         if (fuse_wait) F.wait = comm_step_wait_args(ctx, epoch);
         else comm_step_wait(ctx, epoch, st);
       }

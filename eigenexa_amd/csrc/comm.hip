@@ -49,18 +49,28 @@ struct RcclApi {
   const char* (*GetErrorString)(int) = nullptr;
 } api;
 
+// 0 = not tried, 1 = every entry point resolved, -1 = unusable (a failed load is final: a library that lacks one entry
+// point is closed again and never half-used)
+int g_rccl_state = 0;
+uint64_t g_uid_hash_from_rccl = 0;   // hash of the last session id that ncclGetUniqueId produced in this process
+
 bool load_rccl() {
-  if (api.lib) return true;
-  api.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!api.lib) api.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!api.lib) api.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!api.lib) {
+  if (g_rccl_state != 0) return g_rccl_state > 0;
+  g_rccl_state = -1;
+  if (getenv("EIGX_NO_RCCL")) return false;
+  void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) {
     fprintf(stderr, "[eigx] cannot load librccl: %s\n", dlerror());
     return false;
   }
+  RcclApi a;
+  a.lib = lib;
+  bool ok = true;
 #define EIGX_SYM(field, name)                                                    \
-  *(void**)(&api.field) = dlsym(api.lib, name);                                  \
-  if (!api.field) { fprintf(stderr, "[eigx] librccl lacks %s\n", name); return false; }
+  *(void**)(&a.field) = dlsym(lib, name);                                        \
+  if (!a.field) { fprintf(stderr, "[eigx] librccl lacks %s\n", name); ok = false; }
   EIGX_SYM(GetUniqueId, "ncclGetUniqueId");
   EIGX_SYM(CommInitRank, "ncclCommInitRank");
   EIGX_SYM(CommSplit, "ncclCommSplit");
@@ -74,6 +84,9 @@ bool load_rccl() {
   EIGX_SYM(Recv, "ncclRecv");
   EIGX_SYM(GetErrorString, "ncclGetErrorString");
 #undef EIGX_SYM
+  if (!ok) { dlclose(lib); return false; }
+  api = a;
+  g_rccl_state = 1;
   return true;
 }
 
@@ -95,6 +108,8 @@ struct InitBlob {          // what the ranks tell each other at init
   char bus_id[32];                  // PCI bus id of the rank's GPU: equal ids = shared device
   int pid;
   int ipc_ok;
+  int rccl_loaded;                  // librccl resolved completely in this process
+  int uid_from_rccl;                // this process made the session id with ncclGetUniqueId (only its maker can know)
 };
 static_assert(sizeof(InitBlob) <= 128, "board slot too small");
 struct BufBlob { hipIpcMemHandle_t handle; uint64_t bytes; int ok; };
@@ -104,21 +119,32 @@ static_assert(sizeof(BufBlob) <= 128, "board slot too small");
 
 // flag block of a rank (u64 words): [channel][kind 0 = data / parity 0, 1 = ready / parity 1][source rank]
 constexpr int kFlagWords = CH_COUNT * 2 * EIGX_MAXP;
+// + one more line of words behind the flags: word kFlagWords = the rank's sticky failure word.  It lives in the
+// peer-mapped block so that a FAILING rank can set it on every peer (comm_fail): their bounded spins poll it and
+// return at once instead of running out their time limit.
+constexpr int kFlagWordsTotal = kFlagWords + 16;
 __host__ __device__ inline int flag_index(int ch, int kind, int src) { return (ch * 2 + kind) * EIGX_MAXP + src; }
 
 struct CommState {
   int P = 1, me = 0;
   Board* board = nullptr;
   uint64_t board_seq = 0;
-  bool ipc = false;            // peer windows usable
+  bool ipc = false;            // peer windows usable (mapped and self-tested)
   bool shared_device = false;  // two ranks on one GPU (tests): RCCL unusable
   bool failed = false;
+  bool board_dead = false;     // a board exchange timed out: the ranks' sequence numbers no longer agree, never use it again
   double timeout_s = 120.0;
   // RCCL
   void* world = nullptr;
   void* x = nullptr;
   void* y = nullptr;
-  bool rccl = false;
+  bool rccl_ok = false;        // communicators exist on every rank and passed the self-test
+  bool rccl = false;           // the BULK collectives go through RCCL (otherwise through the peer windows)
+  bool step_coll = false;      // the per-step exchange is a collective allgather (RCCL / emulated), not peer writes
+  bool err_in_flags = false;   // err_dev is a word of the peer-mapped flag block
+  // init-time transport self-test (recorded for eigx_comm_info)
+  int st_ipc_rounds = 0, st_ipc_errors = -1, st_step_rounds = 0, st_step_errors = -1, st_rccl_checks = 0, st_rccl_errors = -1;
+  double st_ipc_us = 0.0, st_step_us = 0.0, st_rccl_us = 0.0;
   // peer-mapped flag block + local bookkeeping words
   PeerBuf flags;
   unsigned long long epoch[CH_COUNT] = {0, 0, 0, 0};
@@ -137,8 +163,18 @@ namespace {
 
 void comm_fail(CommState* cs, const char* what) {
   if (!cs->failed) fprintf(stderr, "[eigx] rank %d: communication failure: %s\n", cs->me, what);
+  const bool first = !cs->failed;
   cs->failed = true;
-  if (cs->err_dev) { const int one = 1; (void)hipMemcpy(cs->err_dev, &one, sizeof(int), hipMemcpyHostToDevice); }
+  const int one = 1;
+  if (cs->err_dev) { if (hipMemcpy(cs->err_dev, &one, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) (void)hipGetLastError(); }
+  // ... and the peers: their device-side waits poll their own failure word, which sits in the peer-mapped flag block
+  if (first && cs->err_in_flags && cs->flags.mapped) {
+    for (int q = 0; q < cs->P; ++q) {
+      if (q == cs->me || !cs->flags.peer[q]) continue;
+      if (hipMemcpy((unsigned long long*)cs->flags.peer[q] + kFlagWords, &one, sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+        (void)hipGetLastError();
+    }
+  }
 }
 
 #define EIGX_NCCL_TRY(cs, expr)                                                                      \
@@ -154,9 +190,10 @@ void comm_fail(CommState* cs, const char* what) {
 // every rank contributes len <= 128 bytes and receives everybody's; false on time-out
 bool board_exchange(CommState* cs, const void* mine, size_t len, unsigned char (*all)[128]) {
   Board* b = cs->board;
+  if (!b || cs->board_dead) return false;
   const uint64_t seq = ++cs->board_seq;
   const double t0 = now_s();
-  auto timed_out = [&]() { return now_s() - t0 > cs->timeout_s; };
+  auto timed_out = [&]() { if (now_s() - t0 > cs->timeout_s) { cs->board_dead = true; return true; } return false; };
   for (int q = 0; q < cs->P; ++q)
     while (b->seq_read[q].load(std::memory_order_acquire) + 1 < seq) {
       if (timed_out()) return false;
@@ -186,8 +223,10 @@ uint64_t fnv1a(const void* p, size_t n) {
 double* alloc_window(size_t bytes) {
   void* p = nullptr;
   if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    // no fallback to coarse-grained memory: kernels poll flags and messages in these windows while the producer is
+    // still running, which plain hipMalloc memory does not support; the caller treats this as "no peer windows"
     (void)hipGetLastError();
-    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return nullptr;
   }
   return (double*)p;
 }
@@ -198,12 +237,14 @@ typedef unsigned long long u64;
 // Bounded spin on an epoch flag.  A spin that runs out sets the sticky error word; once it is set every later wait
 // of this rank returns at once (the solver reports the failure at the next stage boundary).
 __device__ __forceinline__ bool spin_until(const u64* flag, u64 epoch, int* err, long long limit_ticks) {
-  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
   const long long t0 = wall_clock64();
   while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
     __builtin_amdgcn_s_sleep(1);
+    // a peer that failed (or this rank's host) sets the failure word: leave at once
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
     if (wall_clock64() - t0 > limit_ticks) {
-      __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return false;
     }
   }
@@ -310,6 +351,64 @@ __global__ void copy_sys_kernel(const double* __restrict__ in, size_t count, dou
     out[i] = __hip_atomic_load(in + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- init-time transport self-test (comm_init) -------------------------------------------------------------------
+// payload of (source rank, round, index): exact in fp64, different for every triple that could be confused
+__device__ __host__ inline double st_value(int rank, int round, size_t i) {
+  return (double)((long long)(rank + 1) * 1000003ll + (long long)round * 1009ll + (long long)(i % 977));
+}
+__global__ void st_fill_kernel(double* buf, size_t count, int rank, int round) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+    buf[i] = st_value(rank, round, i);
+}
+struct StMembers { int r[EIGX_MAXP]; };
+// win[q * stride + i] must be member q's payload of this round
+__global__ void st_check_kernel(const double* win, size_t stride, size_t count, int n, StMembers M, int round, unsigned* errs) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count * n; i += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i / count);
+    const size_t j = i - (size_t)q * count;
+    const double v = __hip_atomic_load(win + (size_t)q * stride + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (v != st_value(M.r[q], round, j)) atomicAdd(errs, 1u);
+  }
+}
+// buf[i] must be the sum over the members of their payloads (exact: small integers)
+__global__ void st_check_sum_kernel(const double* buf, size_t count, int n, StMembers M, int round, unsigned* errs) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    double want = 0.0;
+    for (int q = 0; q < n; ++q) want += st_value(M.r[q], round, i);
+    if (buf[i] != want) atomicAdd(errs, 1u);
+  }
+}
+// the per-step exchange in miniature (band_reduce.hip kl_kernel's tail): system-scope stores into every rank's step
+// window, drained, last workgroup publishes the epoch flag on every rank -- no ready handshake, double-buffered by parity
+struct StStepArgs {
+  double* slot[EIGX_MAXP];        // my message area (parity 0) in rank q's window
+  u64* flag[EIGX_MAXP];           // my arrival flag (parity 0) in rank q's flag block
+  size_t parity_stride, count;
+  unsigned* counter;
+  int n, rank, round;
+  u64 epoch;
+};
+__global__ __launch_bounds__(256) void st_step_push_kernel(StStepArgs A) {
+  const int par = (int)(A.epoch & 1);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < A.count; i += (size_t)gridDim.x * blockDim.x) {
+    const double v = st_value(A.rank, A.round, i);
+    for (int d = 0; d < A.n; ++d)
+      __hip_atomic_store(A.slot[d] + (size_t)par * A.parity_stride + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __threadfence_system();
+  __syncthreads();
+  __shared__ int last;
+  if (threadIdx.x == 0) {
+    const unsigned tk = atomicAdd(A.counter, 1u);
+    last = (tk == gridDim.x - 1);
+    if (last) *A.counter = 0;
+  }
+  __syncthreads();
+  if (last && (int)threadIdx.x < A.n)
+    __hip_atomic_store(A.flag[threadIdx.x] + par * EIGX_MAXP, A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 long long g_comm_bounce = (long long)32 << 20;   // doubles per slice of comm_exchange_big's bounce window (eigx_tune key 9)
 
 long long limit_ticks(const CommState* cs) { return (long long)(cs->timeout_s * 1e8); }   // wall_clock64: 100 MHz
@@ -396,7 +495,7 @@ int comm_get_unique_id(void* out128) {
   memset(out128, 0, 128);
   // an ncclUniqueId when RCCL is present (it seeds the RCCL communicators as well); otherwise random bytes --
   // either way the 128 bytes name the session (and its shared-memory board)
-  if (load_rccl() && api.GetUniqueId(out128) == 0) return EIGX_OK;
+  if (load_rccl() && api.GetUniqueId(out128) == 0) { g_uid_hash_from_rccl = fnv1a(out128, 128); return EIGX_OK; }
   FILE* f = fopen("/dev/urandom", "rb");
   size_t got = f ? fread(out128, 1, 128, f) : 0;
   if (f) fclose(f);
@@ -444,48 +543,69 @@ int comm_init(Context& ctx, const void* uid) {
   EIGX_HIP_CHECK(hipMemset(cs->counters, 0, CH_COUNT * sizeof(unsigned)));
   EIGX_HIP_CHECK(hipMalloc(&cs->ticks_dev, sizeof(u64)));
   EIGX_HIP_CHECK(hipMemset(cs->ticks_dev, 0, sizeof(u64)));
-  EIGX_HIP_CHECK(hipMalloc(&cs->err_dev, sizeof(int)));
-  EIGX_HIP_CHECK(hipMemset(cs->err_dev, 0, sizeof(int)));
   // ---- flag block + identity exchange -----------------------------------------------------------------
   InitBlob mine;
   memset(&mine, 0, sizeof(mine));
   mine.pid = (int)getpid();
   if (hipDeviceGetPCIBusId(mine.bus_id, sizeof(mine.bus_id), ctx.device) != hipSuccess) { (void)hipGetLastError(); mine.bus_id[0] = 0; }
-  cs->flags.bytes = kFlagWords * sizeof(u64);
+  cs->flags.bytes = kFlagWordsTotal * sizeof(u64);
   cs->flags.local = alloc_window(cs->flags.bytes);
   mine.ipc_ok = 0;
   if (cs->flags.local) {
     EIGX_HIP_CHECK(hipMemset(cs->flags.local, 0, cs->flags.bytes));
     if (hipIpcGetMemHandle(&mine.flags_handle, cs->flags.local) == hipSuccess) mine.ipc_ok = 1;
     else (void)hipGetLastError();
+    // the sticky failure word is a word of the peer-mapped block: a failing rank sets it on every peer (comm_fail)
+    cs->err_dev = (int*)((u64*)cs->flags.local + kFlagWords);
+    cs->err_in_flags = true;
+  } else {
+    // no fine-grained memory: no peer windows (the flag block is polled while peers write it); plain words for RCCL-only use
+    EIGX_HIP_CHECK(hipMalloc((void**)&cs->flags.local, cs->flags.bytes));
+    EIGX_HIP_CHECK(hipMemset(cs->flags.local, 0, cs->flags.bytes));
+    cs->err_dev = (int*)((u64*)cs->flags.local + kFlagWords);
   }
+  cs->flags.peer[cs->me] = cs->flags.local;
   if (getenv("EIGX_NO_IPC")) mine.ipc_ok = 0;
+  // RCCL is used only if EVERY rank resolved the library and the session id really is an ncclUniqueId (only the process
+  // that made it can tell): both facts travel with the bootstrap blob, so the decision is the same everywhere BEFORE
+  // anybody enters the blocking ncclCommInitRank
+  mine.rccl_loaded = load_rccl() ? 1 : 0;
+  mine.uid_from_rccl = (g_uid_hash_from_rccl != 0 && fnv1a(uid, 128) == g_uid_hash_from_rccl) ? 1 : 0;
   unsigned char all[EIGX_MAXP][128];
+  ctx.comm = cs;
   auto give_up = [&](const char* why) {   // nothing of a rejected init stays behind
     fprintf(stderr, "[eigx] rank %d: %s\n", cs->me, why);
     if (cs->me == 0) shm_unlink(name);
-    Board* b = cs->board;
-    cs->board = nullptr;                  // no farewell exchange in comm_free: the peers may be gone
-    ctx.comm = cs;
+    cs->board_dead = true;                // no farewell exchange in comm_free: the peers may be gone
     comm_free(ctx);
-    if (b) munmap(b, sizeof(Board));
     return EIGX_ERR_INTERNAL;
   };
   if (!board_exchange(cs, &mine, sizeof(mine), all)) return give_up("bootstrap exchange timed out");
   if (cs->me == 0) shm_unlink(name);   // everybody has it mapped: the name can go (the memory lives until the last munmap)
-  bool all_ipc = true;
+  bool all_ipc = true, all_rccl_loaded = true, uid_is_nccl = false;
   for (int q = 0; q < cs->P; ++q) {
     InitBlob b; memcpy(&b, all[q], sizeof(b));
     if (!b.ipc_ok) all_ipc = false;
+    if (!b.rccl_loaded) all_rccl_loaded = false;
+    if (b.uid_from_rccl) uid_is_nccl = true;
     for (int r = 0; r < q; ++r) {
       InitBlob c; memcpy(&c, all[r], sizeof(c));
       if (b.bus_id[0] && strncmp(b.bus_id, c.bus_id, sizeof(b.bus_id)) == 0) cs->shared_device = true;
     }
   }
+  // one agreed yes / no over all ranks (a board round); false also when the board timed out
+  auto vote = [&](int my_ok, bool* verdict) {
+    unsigned char ok_all[EIGX_MAXP][128];
+    if (!board_exchange(cs, &my_ok, sizeof(my_ok), ok_all)) return false;
+    bool v = true;
+    for (int q = 0; q < cs->P; ++q) { int x; memcpy(&x, ok_all[q], sizeof(x)); if (!x) v = false; }
+    *verdict = v;
+    return true;
+  };
   int map_ok = all_ipc ? 1 : 0;
   if (all_ipc) {
     for (int q = 0; q < cs->P; ++q) {
-      if (q == cs->me) { cs->flags.peer[q] = cs->flags.local; continue; }
+      if (q == cs->me) continue;
       InitBlob b; memcpy(&b, all[q], sizeof(b));
       void* p = nullptr;
       if (hipIpcOpenMemHandle(&p, b.flags_handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
@@ -493,21 +613,17 @@ int comm_init(Context& ctx, const void* uid) {
         map_ok = 0;
         break;
       }
-      cs->flags.peer[q] = (double*)p;
+      cs->flags.peer[q] = (double*)p;     // closed by comm_free whatever the verdict below
     }
   }
-  {  // the decision must be the same everywhere
-    unsigned char ok_all[EIGX_MAXP][128];
-    if (!board_exchange(cs, &map_ok, sizeof(map_ok), ok_all)) return give_up("bootstrap exchange timed out");
-    for (int q = 0; q < cs->P; ++q) { int v; memcpy(&v, ok_all[q], sizeof(v)); if (!v) map_ok = 0; }
-  }
-  cs->ipc = map_ok != 0;
-  cs->flags.mapped = cs->ipc;
-  // ---- RCCL: needs one GPU per rank ---------------------------------------------------------------------
-  const char* want = getenv("EIGX_BULK");   // "ipc" forces the peer-window transport for the bulk collectives too
-  const bool try_rccl = !cs->shared_device && !(want && strcmp(want, "ipc") == 0 && cs->ipc);
+  bool ipc_mapped = false;
+  if (!vote(map_ok, &ipc_mapped)) return give_up("bootstrap exchange timed out");
+  cs->ipc = ipc_mapped;
+  cs->flags.mapped = ipc_mapped;
+  // ---- RCCL communicators: need one GPU per rank, the library on every rank, a real ncclUniqueId ------------------
+  const bool try_rccl = !cs->shared_device && all_rccl_loaded && uid_is_nccl;
   int rccl_ok = 0;
-  if (try_rccl && load_rccl()) {
+  if (try_rccl) {
     ncclUniqueIdBlob id;
     memcpy(id.internal, uid, 128);
     const int rc_init = api.CommInitRank(&cs->world, g.nranks, id, g.rank);
@@ -522,48 +638,192 @@ int comm_init(Context& ctx, const void* uid) {
       else fprintf(stderr, "[eigx] ncclCommSplit failed: %d %d\n", rx, ry);
     }
   }
-  {
-    unsigned char ok_all[EIGX_MAXP][128];
-    if (!board_exchange(cs, &rccl_ok, sizeof(rccl_ok), ok_all)) return give_up("bootstrap exchange timed out");
-    for (int q = 0; q < cs->P; ++q) { int v; memcpy(&v, ok_all[q], sizeof(v)); if (!v) rccl_ok = 0; }
+  bool rccl_up = false;
+  if (!vote(rccl_ok, &rccl_up)) return give_up("bootstrap exchange timed out");
+
+  // ---- transport self-test: both transports carry checksummed payloads before the solver relies on them --------------
+  // (what a multi-rank test on ONE card cannot show: cross-device IPC mappings, xGMI visibility of system-scope stores
+  // and flags, RCCL's X / Y sub-communicators).  EIGX_SELFTEST_ROUNDS=0 skips it; EIGX_SELFTEST_FAIL=ipc|rccl makes the
+  // named leg report failure (tests of the fallback ladder).
+  int rounds = 400;
+  if (const char* e = getenv("EIGX_SELFTEST_ROUNDS")) rounds = atoi(e);
+  const char* force_fail = getenv("EIGX_SELFTEST_FAIL");
+  hipStream_t ts = nullptr;
+  EIGX_HIP_CHECK(hipStreamCreateWithFlags(&ts, hipStreamNonBlocking));
+  unsigned* errs = nullptr;
+  EIGX_HIP_CHECK(hipMalloc(&errs, 2 * sizeof(unsigned)));
+  EIGX_HIP_CHECK(hipMemset(errs, 0, 2 * sizeof(unsigned)));
+  const size_t cnt = 1024;   // doubles per message
+  double* sendb = nullptr;
+  EIGX_HIP_CHECK(hipMalloc(&sendb, cnt * EIGX_MAXP * sizeof(double)));
+  StMembers Mw, Mx, My;
+  int nx_ = 0, ny_ = 0;
+  { int mi; comm_group(ctx, COMM_WORLD, Mw.r, &mi); nx_ = comm_group(ctx, COMM_X, Mx.r, &mi); ny_ = comm_group(ctx, COMM_Y, My.r, &mi); }
+  auto read_errs = [&](int which) {
+    unsigned h[2] = {1, 1};
+    if (hipStreamSynchronize(ts) != hipSuccess) { (void)hipGetLastError(); return 1u << 30; }
+    if (hipMemcpy(h, errs, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 1u << 30; }
+    return h[which];
+  };
+  bool ipc_good = false;
+  if (cs->ipc) {
+    int my_ok = 1;
+    // (1) bulk protocol: ready handshake + push kernel + flag + wait kernel, world all-gather, every round checked
+    cs->rccl = false;
+    PeerBuf* w = comm_buffer(ctx, "comm.selftest", (size_t)EIGX_MAXP * cnt * sizeof(double));
+    if (!w->mapped || cs->failed) my_ok = 0;
+    const double t0 = now_s();
+    for (int r = 1; my_ok && r <= rounds; ++r) {
+      hipLaunchKernelGGL(st_fill_kernel, dim3(4), dim3(256), 0, ts, sendb, cnt, cs->me, r);
+      comm_exchange(ctx, COMM_WORLD, sendb, 0, w, 0, cnt, ts, CH_BULK);
+      hipLaunchKernelGGL(st_check_kernel, dim3(8), dim3(256), 0, ts, (const double*)w->local, cnt, cnt, cs->P, Mw, r, errs);
+    }
+    cs->st_ipc_rounds = my_ok ? rounds : 0;
+    cs->st_ipc_errors = my_ok ? (int)read_errs(0) : 1;
+    cs->st_ipc_us = rounds > 0 ? (now_s() - t0) * 1e6 / rounds : 0.0;
+    // (2) step protocol: system-scope stores straight into every rank's step window, epoch flags, parity double
+    // buffering, no ready handshake -- the per-step exchange of the reduction in miniature
+    if (my_ok && cs->st_ipc_errors == 0 && !cs->failed) {
+      StepPeers sp;
+      double* win = comm_step_window(ctx, cnt, &sp);
+      if (cs->failed) my_ok = 0;
+      StStepArgs A;
+      A.n = cs->P; A.rank = cs->me; A.count = cnt; A.parity_stride = sp.parity_stride; A.counter = sp.counter;
+      for (int q = 0; q < EIGX_MAXP; ++q) { A.slot[q] = sp.slot[q]; A.flag[q] = sp.flag[q]; }
+      const u64 base = comm_step_epoch_base(ctx, (u64)rounds + 2);
+      const double t1 = now_s();
+      for (int r = 1; my_ok && r <= rounds; ++r) {
+        A.round = r; A.epoch = base + r;
+        hipLaunchKernelGGL(st_step_push_kernel, dim3(4), dim3(256), 0, ts, A);
+        comm_step_wait(ctx, A.epoch, ts);
+        hipLaunchKernelGGL(st_check_kernel, dim3(8), dim3(256), 0, ts, (const double*)(win + (A.epoch & 1) * sp.parity_stride), cnt, cnt,
+                           cs->P, Mw, r, errs + 1);
+      }
+      cs->st_step_rounds = my_ok ? rounds : 0;
+      cs->st_step_errors = my_ok ? (int)read_errs(1) : 1;
+      cs->st_step_us = rounds > 0 ? (now_s() - t1) * 1e6 / rounds : 0.0;
+    }
+    if (cs->st_ipc_errors != 0 || (cs->st_step_rounds > 0 && cs->st_step_errors != 0) || cs->failed) my_ok = 0;
+    if (my_ok && comm_failed(ctx)) my_ok = 0;
+    if (force_fail && strcmp(force_fail, "ipc") == 0) my_ok = 0;
+    if (!my_ok && cs->me == 0)
+      fprintf(stderr, "[eigx] transport self-test: peer windows FAILED (bulk errors %d, step errors %d%s)\n", cs->st_ipc_errors,
+              cs->st_step_errors, (force_fail && strcmp(force_fail, "ipc") == 0) ? ", forced by EIGX_SELFTEST_FAIL" : "");
+    // a failed self-test leaves the failure word set; the verdict is what counts from here on
+    cs->failed = false;
+    { const int zero = 0; EIGX_HIP_CHECK(hipMemcpy(cs->err_dev, &zero, sizeof(int), hipMemcpyHostToDevice)); }
+    if (!vote(my_ok, &ipc_good)) { (void)hipFree(errs); (void)hipFree(sendb); (void)hipStreamDestroy(ts); return give_up("bootstrap exchange timed out"); }
   }
-  cs->rccl = rccl_ok != 0;
-  if (!cs->ipc && !cs->rccl) {
+  bool rccl_good = false;
+  if (rccl_up) {
+    int my_ok = 1;
+    EIGX_HIP_CHECK(hipMemset(errs, 0, 2 * sizeof(unsigned)));
+    double* recvb = nullptr;
+    EIGX_HIP_CHECK(hipMalloc(&recvb, cnt * EIGX_MAXP * sizeof(double)));
+    const int checks = rounds > 0 ? (rounds < 20 ? rounds : 20) : 0;
+    const double t0 = now_s();
+    for (int r = 1; r <= checks; ++r) {
+      // all-reduce over X, Y and world against the exact sum; all-gather over world; grouped send / receive all-to-all
+      struct { void* c; int n; StMembers* M; } grp[3] = {{cs->x, nx_, &Mx}, {cs->y, ny_, &My}, {cs->world, cs->P, &Mw}};
+      for (int gi = 0; gi < 3; ++gi) {
+        hipLaunchKernelGGL(st_fill_kernel, dim3(4), dim3(256), 0, ts, sendb, cnt, cs->me, r);
+        if (api.AllReduce(sendb, sendb, cnt, kNcclFloat64, kNcclSum, grp[gi].c, ts) != 0) my_ok = 0;
+        hipLaunchKernelGGL(st_check_sum_kernel, dim3(4), dim3(256), 0, ts, (const double*)sendb, cnt, grp[gi].n, *grp[gi].M, r, errs);
+      }
+      hipLaunchKernelGGL(st_fill_kernel, dim3(4), dim3(256), 0, ts, sendb, cnt, cs->me, r);
+      if (api.AllGather(sendb, recvb, cnt, kNcclFloat64, cs->world, ts) != 0) my_ok = 0;
+      hipLaunchKernelGGL(st_check_kernel, dim3(8), dim3(256), 0, ts, (const double*)recvb, cnt, cnt, cs->P, Mw, r, errs);
+      EIGX_HIP_CHECK(hipMemsetAsync(recvb, 0, cnt * cs->P * sizeof(double), ts));
+      if (api.GroupStart() != 0) my_ok = 0;
+      for (int q = 0; q < cs->P; ++q) {
+        if (api.Send(sendb, cnt, kNcclFloat64, q, cs->world, ts) != 0) my_ok = 0;
+        if (api.Recv(recvb + (size_t)q * cnt, cnt, kNcclFloat64, q, cs->world, ts) != 0) my_ok = 0;
+      }
+      if (api.GroupEnd() != 0) my_ok = 0;
+      hipLaunchKernelGGL(st_check_kernel, dim3(8), dim3(256), 0, ts, (const double*)recvb, cnt, cnt, cs->P, Mw, r, errs);
+    }
+    cs->st_rccl_checks = checks * 5;
+    cs->st_rccl_errors = (int)read_errs(0) + (my_ok ? 0 : 1);
+    cs->st_rccl_us = checks > 0 ? (now_s() - t0) * 1e6 / (checks * 5) : 0.0;
+    (void)hipFree(recvb);
+    if (cs->st_rccl_errors != 0) my_ok = 0;
+    if (force_fail && strcmp(force_fail, "rccl") == 0) my_ok = 0;
+    if (!my_ok && cs->me == 0) fprintf(stderr, "[eigx] transport self-test: RCCL FAILED (%d errors)\n", cs->st_rccl_errors);
+    if (!vote(my_ok, &rccl_good)) { (void)hipFree(errs); (void)hipFree(sendb); (void)hipStreamDestroy(ts); return give_up("bootstrap exchange timed out"); }
+  }
+  (void)hipFree(errs);
+  (void)hipFree(sendb);
+  (void)hipStreamDestroy(ts);
+  cs->ipc = ipc_good;
+  cs->rccl_ok = rccl_good;
+
+  // ---- the ladder: peer windows -> RCCL -> (caller falls back to independent replicas) -----------------------------
+  // Default = the transport that every multi-rank test runs: peer windows for the per-step exchange AND the bulk
+  // collectives, wait kernels.  RCCL takes over what the peer windows cannot do (failed mapping / failed self-test) or
+  // what the environment asks for: EIGX_BULK=rccl (bulk collectives), EIGX_STEP=coll (per-step exchange as an allgather:
+  // ncclAllGather on a node, the same group semantics emulated over the peer windows when ranks share a card).
+  if (!cs->ipc && !cs->rccl_ok) {
     fprintf(stderr, "[eigx] rank %d: neither peer windows (hipIpc) nor RCCL are usable between the ranks\n", cs->me);
-    ctx.comm = cs;
     comm_free(ctx);
     return EIGX_ERR_INTERNAL;
   }
-  if (getenv("EIGX_TRACE_COMM") && cs->me == 0)
-    fprintf(stderr, "[eigx] transport: peer windows %s, RCCL %s, shared device %s\n", cs->ipc ? "yes" : "no",
-            cs->rccl ? "yes" : "no", cs->shared_device ? "yes" : "no");
-  ctx.comm = cs;
+  const char* want_bulk = getenv("EIGX_BULK");
+  const char* want_step = getenv("EIGX_STEP");
+  cs->rccl = cs->rccl_ok && (!cs->ipc || (want_bulk && strcmp(want_bulk, "rccl") == 0));
+  cs->step_coll = !cs->ipc || (want_step && strcmp(want_step, "coll") == 0);
+  if (getenv("EIGX_TRACE_COMM") && cs->me == 0) {
+    char info[512];
+    comm_info(ctx, info, sizeof(info));
+    fprintf(stderr, "[eigx] transport: %s\n", info);
+  }
+  return EIGX_OK;
+}
+
+int comm_info(const Context& ctx, char* buf, int len) {
+  const CommState* cs = ctx.comm;
+  if (!buf || len <= 0) return EIGX_ERR_BAD_ARG;
+  if (!cs) { snprintf(buf, (size_t)len, "{\"ranks\": 1}"); return EIGX_OK; }
+  const char* e = getenv("EIGX_FUSE_WAIT");
+  const bool fused = e && atoi(e) != 0 && !cs->step_coll;
+  snprintf(buf, (size_t)len,
+           "{\"ranks\": %d, \"shared_device\": %s, \"peer_windows\": %s, \"rccl\": %s, \"step_exchange\": \"%s\", "
+           "\"step_wait\": \"%s\", \"bulk\": \"%s\", \"selftest\": {\"ipc_rounds\": %d, \"ipc_errors\": %d, \"ipc_us_per_round\": %.1f, "
+           "\"step_rounds\": %d, \"step_errors\": %d, \"step_us_per_round\": %.1f, \"rccl_checks\": %d, \"rccl_errors\": %d, "
+           "\"rccl_us_per_call\": %.1f}}",
+           cs->P, cs->shared_device ? "true" : "false", cs->ipc ? "true" : "false", cs->rccl_ok ? "true" : "false",
+           cs->step_coll ? (cs->rccl ? "allgather (RCCL)" : "allgather (peer-window emulation)") : "peer writes (hipIpc windows, kernel stores over xGMI)",
+           cs->step_coll ? "stream order" : (fused ? "fused into ka_kernel" : "wait kernel"), cs->rccl ? "rccl" : "peer windows",
+           cs->st_ipc_rounds, cs->st_ipc_errors, cs->st_ipc_us, cs->st_step_rounds, cs->st_step_errors, cs->st_step_us,
+           cs->st_rccl_checks, cs->st_rccl_errors, cs->st_rccl_us);
   return EIGX_OK;
 }
 
 void comm_free(Context& ctx) {
   CommState* cs = ctx.comm;
   if (!cs) return;
-  // nobody unmaps while a peer may still be writing: meet at the board first (bounded)
-  if (cs->board) { int z = 0; unsigned char all[EIGX_MAXP][128]; (void)board_exchange(cs, &z, sizeof(z), all); }
+  // nobody unmaps while a peer may still be writing: meet at the board first (bounded) -- unless the communicator has
+  // already failed or a board round timed out: the peers may be gone, and waiting for them twice more would stall
+  // eigx_free for minutes
+  const bool polite = cs->board && !cs->board_dead && !cs->failed;
+  if (polite) { int z = 0; unsigned char all[EIGX_MAXP][128]; (void)board_exchange(cs, &z, sizeof(z), all); }
   std::vector<PeerBuf> allb(cs->retired);
   for (auto& kv : cs->bufs) allb.push_back(kv.second);
+  // every imported mapping is closed, whether or not the import round as a whole succeeded
   for (PeerBuf& b : allb) {
     for (int q = 0; q < cs->P; ++q)
-      if (q != cs->me && b.peer[q] && b.mapped) { if (hipIpcCloseMemHandle(b.peer[q]) != hipSuccess) (void)hipGetLastError(); }
+      if (q != cs->me && b.peer[q]) { if (hipIpcCloseMemHandle(b.peer[q]) != hipSuccess) (void)hipGetLastError(); }
   }
   for (int q = 0; q < cs->P; ++q)
-    if (q != cs->me && cs->flags.peer[q] && cs->flags.mapped) { if (hipIpcCloseMemHandle(cs->flags.peer[q]) != hipSuccess) (void)hipGetLastError(); }
-  if (cs->board) { int z = 0; unsigned char all[EIGX_MAXP][128]; (void)board_exchange(cs, &z, sizeof(z), all); }
+    if (q != cs->me && cs->flags.peer[q]) { if (hipIpcCloseMemHandle(cs->flags.peer[q]) != hipSuccess) (void)hipGetLastError(); }
+  if (polite && !cs->board_dead) { int z = 0; unsigned char all[EIGX_MAXP][128]; (void)board_exchange(cs, &z, sizeof(z), all); }
   for (PeerBuf& b : allb)
     if (b.local) { if (hipFree(b.local) != hipSuccess) (void)hipGetLastError(); }
-  if (cs->flags.local) { if (hipFree(cs->flags.local) != hipSuccess) (void)hipGetLastError(); }
+  if (cs->flags.local) { if (hipFree(cs->flags.local) != hipSuccess) (void)hipGetLastError(); }   // holds the failure word too
   if (cs->x) api.CommDestroy(cs->x);
   if (cs->y) api.CommDestroy(cs->y);
   if (cs->world) api.CommDestroy(cs->world);
   if (cs->counters) (void)hipFree(cs->counters);
   if (cs->ticks_dev) (void)hipFree(cs->ticks_dev);
-  if (cs->err_dev) (void)hipFree(cs->err_dev);
   for (hipEvent_t e : cs->tev) (void)hipEventDestroy(e);
   if (cs->board) munmap(cs->board, sizeof(Board));
   delete cs;
@@ -589,8 +849,9 @@ PeerBuf* comm_buffer(Context& ctx, const std::string& name, size_t bytes) {
   const size_t want = (bytes < ((size_t)64 << 20)) ? bytes + bytes / 2 + 256 : bytes + 256;
   // only what kernels store into needs a peer mapping: everything when the peer windows carry the bulk collectives too
   // (ranks sharing a card), otherwise just the per-step window -- RCCL takes plain device pointers
-  const bool map = cs->ipc && (!cs->rccl || name == "comm.step");
+  const bool map = cs->ipc && (!cs->rccl || (name == "comm.step" && !cs->step_coll));
   b.local = map ? alloc_window(want) : nullptr;
+  const bool window_ok = b.local != nullptr;      // false with map: no fine-grained memory -> reported as a failed mapping below
   if (!b.local) EIGX_HIP_CHECK(hipMalloc((void**)&b.local, want));
   stage_trace(cs->me, "  allocated");
   b.bytes = want;
@@ -598,7 +859,7 @@ PeerBuf* comm_buffer(Context& ctx, const std::string& name, size_t bytes) {
   if (map) {
     BufBlob mine; memset(&mine, 0, sizeof(mine));
     mine.bytes = want;
-    hipError_t e1 = hipIpcGetMemHandle(&mine.handle, b.local);
+    hipError_t e1 = window_ok ? hipIpcGetMemHandle(&mine.handle, b.local) : hipErrorOutOfMemory;
     mine.ok = (e1 == hipSuccess) ? 1 : 0;
     if (!mine.ok) { fprintf(stderr, "[eigx] rank %d: hipIpcGetMemHandle(%s, %zu bytes): %s\n", cs->me, name.c_str(), want, hipGetErrorString(e1)); (void)hipGetLastError(); }
     unsigned char all[EIGX_MAXP][128];
@@ -836,12 +1097,41 @@ double* comm_step_window(Context& ctx, size_t msg_doubles, StepPeers* peers) {
   peers->parity_stride = (size_t)cs->P * msg_doubles;
   peers->counter = cs->counters + CH_STEP;
   for (int q = 0; q < EIGX_MAXP; ++q) { peers->slot[q] = nullptr; peers->flag[q] = nullptr; }
+  if (cs->step_coll) {
+    // collective form: the producer writes its message into a local send buffer (comm_step_send) and
+    // comm_step_allgather moves it; nothing is stored into a peer by the producer kernel
+    double* sendb = ctx.pool.get_t<double>("comm.stepsend", msg_doubles + 8);
+    peers->n = 1;
+    peers->parity_stride = 0;
+    peers->slot[0] = sendb;
+    return w->local;
+  }
   for (int q = 0; q < cs->P; ++q) {
     peers->slot[q] = (w->mapped ? w->peer[q] : w->local) + (size_t)cs->me * msg_doubles;
     peers->flag[q] = flag_word(cs->flags.mapped ? cs->flags.peer[q] : cs->flags.local, CH_STEP, 0, cs->me);
   }
   if (!w->mapped) comm_fail(cs, "the per-step exchange needs peer windows (hipIpc) between the ranks");
   return w->local;
+}
+
+bool comm_step_collective(const Context& ctx) { return ctx.comm && ctx.comm->step_coll; }
+
+// collective form of the per-step exchange (the north_star's literal "allgather / allreduce on RCCL", src/comm.F:1192-1247
+// reduce_dbl): every rank's message of msg_doubles lands in every rank's step window at the given parity; the consumer
+// adds the contributions in rank order as with the peer-write form, so the replicated results stay bit-identical.
+// Enqueued on s; the consumer kernel follows in stream order (no wait kernel).
+void comm_step_allgather(Context& ctx, const double* sendmsg, int parity, hipStream_t s) {
+  CommState* cs = ctx.comm;
+  if (cs->failed) return;
+  PeerBuf* w = &cs->bufs["comm.step"];
+  const size_t off = (size_t)parity * cs->P * cs->step_msg;
+  if (cs->rccl) {
+    rccl_time_begin(cs, s);
+    EIGX_NCCL_TRY(cs, api.AllGather(sendmsg, w->local + off, cs->step_msg, kNcclFloat64, cs->world, s));
+    rccl_time_end(cs, s);
+    return;
+  }
+  comm_exchange(ctx, COMM_WORLD, sendmsg, 0, w, off, cs->step_msg, s, CH_STEP2);
 }
 
 unsigned long long comm_step_epoch_base(Context& ctx, unsigned long long nsteps) {
@@ -853,10 +1143,12 @@ unsigned long long comm_step_epoch_base(Context& ctx, unsigned long long nsteps)
 
 bool comm_step_wait_fused(const Context& ctx) {
   const CommState* cs = ctx.comm;
-  if (!cs) return false;
+  if (!cs || cs->step_coll) return false;
+  // Opt-in (EIGX_FUSE_WAIT=1).  The default is the wait kernel: it is the form every multi-rank test and rehearsal
+  // runs; the fused spin has only run in small tests on a shared card and gets switched on by default only after a
+  // run on physically separate GPUs has passed tests/mg_worker.py with it.
   const char* e = getenv("EIGX_FUSE_WAIT");
-  if (e) return atoi(e) != 0;
-  return !cs->shared_device;
+  return e && atoi(e) != 0;
 }
 StepWait comm_step_wait_args(Context& ctx, unsigned long long epoch) {
   CommState* cs = ctx.comm;

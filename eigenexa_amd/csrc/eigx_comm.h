@@ -29,7 +29,7 @@ struct PeerBuf {
 enum CommGroup { COMM_WORLD = 0, COMM_X = 1, COMM_Y = 2 };
 
 // flag channels: one per (stream, purpose) so that operations in flight on different streams never share an epoch
-enum CommChannel { CH_STEP = 0, CH_BULK = 1, CH_SIDE = 2, CH_COUNT = 4 };
+enum CommChannel { CH_STEP = 0, CH_BULK = 1, CH_SIDE = 2, CH_STEP2 = 3, CH_COUNT = 4 };
 
 struct CommState;
 
@@ -90,6 +90,15 @@ struct StepWait {
 };
 bool comm_step_wait_fused(const Context& ctx);
 StepWait comm_step_wait_args(Context& ctx, unsigned long long epoch);
+// Collective form of the per-step exchange (selected when the peer windows are not usable, or by EIGX_STEP=coll):
+// the producer kernel writes its message into peers.slot[0] (a local send buffer; peers.n == 1, no flags) and
+// comm_step_allgather delivers every rank's message into every rank's step window at the given parity --
+// ncclAllGather over the world communicator on a node, the same group semantics through the peer windows when ranks
+// share a card.  The consumer follows in stream order.
+bool comm_step_collective(const Context& ctx);
+void comm_step_allgather(Context& ctx, const double* sendmsg, int parity, hipStream_t s);
+// JSON description of the transports in use and of the init-time self-test (eigx_comm_info)
+int comm_info(const Context& ctx, char* buf, int len);
 // first epoch number of the next reduction (epochs are monotone over the life of the communicator)
 unsigned long long comm_step_epoch_base(Context& ctx, unsigned long long nsteps);
 

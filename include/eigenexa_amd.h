@@ -57,8 +57,17 @@ int eigx_init(int device);
  * communication windows and map them: kernels then write into the peers' HBM over xGMI directly.
  * Replaces MPI_Comm_dup/MPI_Comm_split of eigen_init_comm_setup/eigen_init_cartesian_check,
  * src/eigen_libs0.F:382-428, :579-715.  Several ranks may share one GPU (the tests do): RCCL is then not used and
- * every collective goes through the peer windows.  Environment: EIGX_COMM_TIMEOUT_S (default 120) bounds every wait
- * for a peer; EIGX_BULK=ipc keeps the bulk collectives off RCCL. */
+ * every collective goes through the peer windows.
+ * Transport ladder, decided at init by a self-test with checksummed payloads on both transports (a few hundred
+ * ready / push / flag / wait rounds and step-window rounds over the peer windows; all-reduces over the X, Y and world
+ * RCCL communicators, all-gather and grouped send / receive): peer windows for everything if they pass (the form
+ * every multi-rank test runs), RCCL for whatever they cannot carry (the per-step exchange then is one ncclAllGather
+ * of the step messages -- the reference's reduce_dbl over X and Y, src/comm.F:1192-1247, as one collective), an error
+ * return if neither works (bench.py then runs independent replicas).  eigx_comm_info reports what was chosen.
+ * Environment: EIGX_COMM_TIMEOUT_S (default 120) bounds every wait for a peer; EIGX_BULK=rccl moves the bulk
+ * collectives to RCCL; EIGX_STEP=coll selects the collective form of the per-step exchange; EIGX_FUSE_WAIT=1 folds the
+ * step wait into the consumer kernel; EIGX_NO_IPC / EIGX_NO_RCCL disable a transport; EIGX_SELFTEST_ROUNDS (default 400,
+ * 0 = skip), EIGX_SELFTEST_FAIL=ipc|rccl (make that leg report failure: tests of the ladder). */
 int eigx_init_multi(int device, int rank, int nranks, const void* session_id, char order);
 /* visible HIP devices (0 without a GPU): lets an MPI host map its node-local rank to a device
  * (eigen_libs_mod.F90: MPI_Comm_split_type + modulo) */
@@ -77,6 +86,11 @@ int eigx_get_comm(int* x_color, int* x_key, int* y_color, int* y_key);
 /* Seconds this rank spent in communication (pushes, waits for peers, RCCL calls) during the last solve:
  * the a(3,1) statistic of src/eigen_sx.F:285-296 and the "COMM_STAT" tables of src/eigen_devel.F:364-526. */
 double eigx_comm_seconds(void);
+
+/* JSON text describing the transports in use (per-step exchange, its wait, bulk collectives) and the counts / errors /
+ * microseconds per round of the init-time self-test; "{"ranks": 1}" on one GPU.  The reference prints the analogous
+ * communicator facts at init (src/eigen_libs0.F:774-1109 measures its collectives there). */
+int eigx_comm_info(char* buf, int len);
 
 /* 1-rank RCCL self-test (dlopen, communicator from a unique id, ncclCommSplit, allreduce / allgather / send-recv on
  * the library stream): validates the RCCL plumbing on a one-GPU box.  Returns 0 on success. */
@@ -218,6 +232,11 @@ int eigx_get_timers(double* out16);
  * trailing-update launches, their flops, their seconds} accumulated since the last eigx_profile call. */
 int eigx_profile(int stride);
 int eigx_profile_read(double* out6);
+/* the same events by kind: out[3 k + {0, 1, 2}] = {launches sampled, units, seconds} for kind k < nkinds;
+ * kinds: 0 fused mat-vec, 1 trailing update, and on several ranks the rest of a sampled reduction step:
+ * 2 local reduce + push of the step message (kl_kernel, or kl_kernel + the allgather in the collective form),
+ * 3 wait for the peers' messages (wait kernel), 4 ka_kernel (with the wait when it is fused into it). */
+int eigx_profile_read_kinds(double* out, int nkinds);
 
 /* Tuning hook for A/B measurements (tools/, tests/): key 0 = GEMM kernel (2 = LDS-DMA ring kernel where it
  * applies [default], 1 = register-staged kernel everywhere); key 1 = target number of concurrent Sturm

@@ -47,8 +47,10 @@
 #ifdef _OPENMP
 #include <omp.h>
 int orc_threads(void) { return omp_get_max_threads(); }
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 #else
 int orc_threads(void) { return 1; }
+void orc_set_threads(int n) { (void)n; }
 #endif
 
 static double sign_of(double mag, double s) { return s >= 0.0 ? fabs(mag) : -fabs(mag); }

@@ -40,6 +40,31 @@ def threads():
     return int(load().orc_threads())
 
 
+def host_cores():
+    """CPU cores this process may actually use: the scheduler affinity mask cut by the cgroup CPU quota (a GPU box shows
+    all of the host's logical CPUs but grants a share of them; more threads than that only add barrier time)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "quota period" or "max period"
+            q, p = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, p = int(f.read()), int(g.read())
+                if q > 0:
+                    n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def set_threads(n):
+    load().orc_set_threads(int(n))
+    return threads()
+
+
 def _p(a):
     return a.ctypes.data_as(_dp)
 

@@ -21,7 +21,30 @@ dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank
 import eigenexa_amd as ee
 from eigenexa_amd import api, layout
 
+if route == "initfail":
+    # bottom rung of the transport ladder: no usable transport (EIGX_SELFTEST_FAIL=ipc on a shared card, where RCCL cannot
+    # run) -> eigen_init fails on EVERY rank, promptly and without leaving anything behind; a later 1-rank init works
+    import time
+
+    t0 = time.time()
+    try:
+        ee.eigen_init(comm=True, device=0, dims=dims)
+        raise SystemExit("eigen_init should have failed")
+    except RuntimeError:
+        pass
+    assert time.time() - t0 < 30.0
+    ee.eigen_init()
+    assert ee.eigen_comm_info() == {"ranks": 1}
+    ee.eigen_free()
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"OK rank {rank}/{world} init failure agreed on", flush=True)
+    sys.exit(0)
 ee.eigen_init(comm=True, device=0, dims=dims)
+info = ee.eigen_comm_info()
+assert info["ranks"] == world and info["selftest"]["ipc_errors"] == 0 and info["selftest"]["step_errors"] == 0, info
+if os.environ.get("EIGX_EXPECT_STEP"):
+    assert info["step_exchange"].startswith(os.environ["EIGX_EXPECT_STEP"]), info
 for kv in filter(None, os.environ.get("EIGX_TEST_TUNE", "").split(",")):   # e.g. "7=4": K_A's row-group loop at small sizes
     api._lib.load().eigx_tune(int(kv.split("=")[0]), int(kv.split("=")[1]))
 procs, xp, yp = ee.eigen_get_procs()

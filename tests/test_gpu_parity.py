@@ -504,6 +504,65 @@ def test_multi_rank_wait_folded_into_consumer(world, n, route, dims):
     _run_multi_rank(world, n, route, 0, dims, {"EIGX_FUSE_WAIT": "1"})
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,route,dims", [(2, 300, "sx", ""), (4, 517, "s", ""), (4, 700, "sx", "1x4"), (3, 260, "sx", ""),
+                                                (4, 333, "sx", "")])
+def test_multi_rank_collective_step_exchange(world, n, route, dims):
+    """second rung of the transport ladder: the per-step exchange as ONE allgather of the step messages through the
+    comm_* interface (ncclAllGather over the world communicator on a node -- the reference's reduce_dbl over X and Y,
+    src/comm.F:1192-1247, as one collective; the same group semantics emulated over the peer windows when the ranks
+    share a card, as here), consumer in stream order, no flags, no wait kernel"""
+    _run_multi_rank(world, n, route, 0, dims, {"EIGX_STEP": "coll", "EIGX_EXPECT_STEP": "allgather"})
+
+
+@pytest.mark.gpu
+def test_multi_rank_default_rung_is_peer_writes():
+    """first rung: peer windows passed the init-time self-test (checksummed bulk rounds and step-window rounds) and carry
+    the per-step exchange as kernel stores, with the wait kernel (the tested default; the fused wait is opt-in)"""
+    _run_multi_rank(2, 200, "sx", 0, "", {"EIGX_EXPECT_STEP": "peer writes"})
+
+
+@pytest.mark.gpu
+def test_multi_rank_no_transport_fails_on_every_rank():
+    """bottom rung: the self-test of the only available transport fails (forced) -> eigx_init_multi returns an error on
+    every rank at once (agreed on through the bootstrap board), nothing stays behind, a 1-rank init still works;
+    bench.py turns exactly this into its replica fallback"""
+    _run_multi_rank(3, 64, "initfail", 0, "", {"EIGX_SELFTEST_FAIL": "ipc"})
+
+
+def _run_bench(args, env_extra):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0]), r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_launches_ranks_and_walks_the_ladder():
+    """`python bench.py --gpus 3` (no launcher; gloo rehearsal with the ranks sharing this card): an n_gpus = 3 strong-scaling
+    line that names its transport and carries the per-step breakdown; with the peer windows' self-test forced to fail
+    the same command reports independent replicas instead"""
+    common = ["--gpus", "3", "--steps", "1", "--warmup", "1", "--size", "1536", "--no-cpu-baseline"]
+    out, _ = _run_bench(common, {"EIGX_BENCH_BACKEND": "gloo"})
+    assert out["n_gpus"] == 3 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["transport"]["step_exchange"].startswith("peer writes")
+    assert out["config"]["transport"]["selftest"]["ipc_errors"] == 0
+    assert out["config"]["probe_residual_over_anorm"] < 1e-13
+    steps = out["config"]["per_step_us"]
+    assert steps["symv"] > 0 and steps["exchange_reduce_and_push"] > 0 and steps["ka"] > 0
+    out, err = _run_bench(common, {"EIGX_BENCH_BACKEND": "gloo", "EIGX_SELFTEST_FAIL": "ipc"})
+    assert out["n_gpus"] == 3 and out["scaling"] == "weak" and "replicas" in out["config"]["parallelism"]
+    assert "falls back to independent replicas" in err
+
+
 def test_gemm_gather_vs_torch(gpu_lib):
     """the D&C product Q(:, map_a) * S(:, map_b)^T with column gathers on both operands"""
     import torch
