@@ -31,6 +31,7 @@
 #include "eigx_comm.h"
 #include "../../include/eigenexa_amd.h"
 #include <chrono>
+#include <cstring>
 
 namespace eigx {
 
@@ -105,6 +106,9 @@ int g_ka_fit = 1;     // K_A (eigx_tune key 10): 1 = load batches matched to the
 int g_ka_wgs = 256;   // K_A (eigx_tune key 7): beyond 2 * this many row groups a workgroup takes several of them, ~this many workgroups
 int g_symv_t128 = 4500, g_symv_t256 = 40000;
 int g_symv_nt = 9000;
+// strip form of the mat-vec (symv_strip_kernel, one GPU): active sizes above g_symv_strip; g_strip_jobs = jobs per launch
+// (<= resident workgroups: 2 per CU); strips of 1024 rows from g_strip_h1024 on, 512 below (eigx_tune keys 11, 12, 13)
+int g_symv_strip = 14000, g_strip_jobs = 512, g_strip_h1024 = 24000;
 
 inline SymvGeom symv_geom(int L) {
   SymvGeom g;
@@ -210,6 +214,9 @@ struct KAArgs {
   StepWait wait;          // multi-GPU: wait for the step messages here instead of in a wait kernel (wait.n = 0: no)
   int G;                  // row groups (of KA_ROWS rows) per workgroup: the scalar work of a workgroup is done once, then
                           // its G row groups follow in a loop (the next group's loads in flight behind the current one)
+  // previous mat-vec in strip form (symv_strip_kernel): strip height 1 << lgH, its jobs, pieces per strip
+  int lgH, njobs_prev;
+  unsigned char npc[64];
 };
 
 // multi-GPU: partial number t (0 <= t < Py + Px) of global row r in the step messages of parity `par`:
@@ -225,7 +232,9 @@ __device__ __forceinline__ const double* mg_partial(const RedArgs& R, int par, i
   return R.MSG + ((size_t)par * R.P + src) * R.msg_stride + off;
 }
 
-template <int NB, bool MG, bool LG, int RPBT, int SPBT, int KBT>
+// STRIP: the previous step's mat-vec ran in strip form: partial sums of row r sit in the column-sum slots 0 .. r >> lgH and
+// in the row-sum slots KS_MAXSTRIPS .. KS_MAXSTRIPS + npc[r >> lgH] - 1 of the unified array; one bilinear entry per job
+template <int NB, bool MG, bool LG, int RPBT, int SPBT, int KBT, bool STRIP = false>
 __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   __shared__ double red[64];
   __shared__ double kd[4][256];        // reduced panel-dot vectors: [UuA, WuA, UuB, WuB][kk]  (m <= 256)
@@ -243,6 +252,11 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   const int kp = hp ? S.kprev : 0;
   const int kloop = hp ? S.kprev : S.k;
   const int kold = hp ? S.kprev : S.k;  // panel slots that are final in memory
+  // strip form: is slot t a partial sum of row r ?
+  auto slot_ok = [&](int t, int r_) {
+    const int st = r_ >> S.lgH;
+    return t <= st || (t >= 64 && t - 64 < (int)S.npc[st < 63 ? st : 63]);
+  };
   // The workgroup owns the row groups blockIdx.x * G + g, g = 0 .. G-1 (KA_ROWS rows each).  Everything that does not
   // depend on the row -- ~85 % of the kernel's instructions: the re-reduction of the tile / panel partial sums, the 2x2
   // algebra, the LDS tables -- is done ONCE per workgroup; with one row group per workgroup the chip ran that overhead
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       const unsigned voff = (unsigned)ks * (unsigned)(NB * ldp) + (unsigned)(okp ? rg : 0);
 #pragma unroll
       for (int j = 0; j < RPB; ++j) {
-        const int jb = (j * KA_SL < nt + 1) ? j * KA_SL : 0;        // uniform; unused batches re-read batch 0
+        const int jb = (STRIP || j * KA_SL < nt + 1) ? j * KA_SL : 0;        // uniform; unused batches re-read batch 0
         const double* by = R.YC + (size_t)jb * NB * ldp;
         Q.ta[j] = by[voff];
         Q.tb[j] = by[voff + (NB == 2 ? (unsigned)ldp : 0u)];
@@ -373,7 +387,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
     if (!(hp && ks == 0 && ok)) { Q.uA = 0.0; Q.uB = 0.0; }
     if (NB == 1) Q.uB = 0.0;
 #pragma unroll
-    for (int j = 0; j < RPB; ++j) { if (!hp || (!mg && !(j * KA_SL < nt + 1)) || (mg && j > 0)) { Q.ta[j] = 0.0; Q.tb[j] = 0.0; } }
+    for (int j = 0; j < RPB; ++j) { if (!hp || (!mg && !STRIP && !(j * KA_SL < nt + 1)) || (mg && j > 0)) { Q.ta[j] = 0.0; Q.tb[j] = 0.0; } }
   };
   load_rows(r, cur);
   {
@@ -400,7 +414,18 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   // bilinear partials of the SYMV tiles, SP[ty][tx] with the fixed row stride maxseg, tx >= ty only.
   // Folded rows: row f (nt - f tiles) and row nt-1-f (f + 1 tiles) together fill nt + 1 <= 64 lanes;
   // wave w takes the folded rows f = w, w + 4, ...
-  if (!mg) {   // (compile-time)
+  if (!mg && STRIP) {   // (compile-time)  one entry per job of the strip-form mat-vec
+#pragma unroll
+    for (int j = 0; j < SPB; ++j) {
+      const int e = tid + 256 * j;
+      const bool ok = hp && j < 2 && e < S.njobs_prev;
+      const double* sp = R.SP + (size_t)(ok ? e : 0) * 3;
+      spr[j][0] = sp[0];
+      spr[j][1] = sp[NB == 2 ? 1 : 0];
+      spr[j][2] = sp[NB == 2 ? 2 : 0];
+      spok |= ok ? (1u << j) : 0u;
+    }
+  } else if (!mg) {   // (compile-time)
 #pragma unroll
     for (int j = 0; j < SPB; ++j) {
       const int f = wave + 4 * j;
@@ -429,7 +454,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   for (int cc = 0; cc < 2; ++cc) {
     const int c = (S.i - cc > 0) ? S.i - cc : 0;
     if (!mg) {   // (compile-time)
-      const unsigned t = (tid < nt + 1) ? (unsigned)tid : 0u;
+      const unsigned t = (STRIP ? tid < 160 : tid < nt + 1) ? (unsigned)tid : 0u;
       const double* bc = R.YC + c;                                  // uniform
       pcl[cc][0] = bc[t * (unsigned)(NB * ldp)];
       pcl[cc][1] = bc[t * (unsigned)(NB * ldp) + (NB == 2 ? (unsigned)ldp : 0u)];
@@ -488,7 +513,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
         v[0] += spl[j][0];
         if (NB == 2) { v[1] += spl[j][1]; v[2] += spl[j][2]; }
       }
-      if (nt > 8 * SPB - 1) {   // more tiles than the folded batch covers: plain sweep of the upper tile triangle
+      if (!STRIP && nt > 8 * SPB - 1) {   // more tiles than the folded batch covers: plain sweep of the upper tile triangle
         for (int ty = wave; ty < nt; ty += 4)
           for (int tx = ty + lane; tx < nt; tx += 64) {
             const double* sp = R.SP + ((size_t)ty * R.maxseg + tx) * 3;
@@ -499,11 +524,11 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
         if (cc < S.ncols) {
-          const bool ok = tid < nt + 1;
+          const bool ok = STRIP ? (tid < 160 && slot_ok(tid, S.i - cc > 0 ? S.i - cc : 0)) : tid < nt + 1;
           v[7 + 2 * cc] += ok ? pcl[cc][0] : 0.0;
           if (NB == 2) v[8 + 2 * cc] += ok ? pcl[cc][1] : 0.0;
           const int c = S.i - cc, ty = c >> lgT;
-          for (int t = tid + 256; t < nt + 1; t += 256) {
+          for (int t = tid + 256; !STRIP && t < nt + 1; t += 256) {
             const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
             v[7 + 2 * cc] += base[c];
             if (NB == 2) v[8 + 2 * cc] += base[ldp + c];
@@ -603,11 +628,11 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
         } else {
 #pragma unroll
           for (int j = 0; j < RPB; ++j) {
-            const bool ok = okp && (ks + j * KA_SL < nt + 1);
+            const bool ok = okp && (STRIP ? slot_ok(ks + j * KA_SL, rg) : (ks + j * KA_SL < nt + 1));
             prA += ok ? cur.ta[j] : 0.0;
             if (NB == 2) prB += ok ? cur.tb[j] : 0.0;
           }
-          if (okp) {   // more than RPB * KA_SL = 160 partials per row: not reached by symv_geom below N ~ 80000
+          if (okp && !STRIP) {   // more than RPB * KA_SL = 160 partials per row: not reached by symv_geom below N ~ 80000
             for (int t = ks + RPB * KA_SL; t < nt + 1; t += KA_SL) {
               const double* base = R.YC + (size_t)t * NB * ldp;
               prA += base[rg];
@@ -845,6 +870,178 @@ __global__ __launch_bounds__(256) void kl_kernel(RedArgs R, KLArgs K) {
     __hip_atomic_store(K.peers.flag[threadIdx.x] + K.par * EIGX_MAXP, K.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Reflector scalars of a step, computed by EVERY workgroup of the mat-vec launch in the same order (bit-identical
+// replicas) from the Gram partials that K_A left in GP (gpt = this thread's two preloaded entries) and four elements of x.
+// NV = 1: s = -sign(||x||, x_piv), beta = ||x||^2 - s x_piv.
+// NV = 2: two sequential Householder steps on the column pair (x0 = column i, x1 = column i-1) without a
+// kernel in between: reflector A from g00 = x0.x0; gamma = uA.x1 / betaA from g01; the reflected second
+// column x1' = x1 - gamma uA is formed on the fly wherever it is needed; its norm above the pivot row
+// follows from the isometry of H_A: ||x1'(0:L-1)||^2 = g11 - x1'(L-1)^2.  If that difference cancels
+// (more than 3/4 of the column's weight in the pivot row) the sum is taken explicitly instead -- same
+// order in every workgroup, so the replicas stay bit-identical either way.
+struct HouseScalars { double sA, sB, betaA, betaB, gammaB, eL1; };
+template <int NV>
+__device__ __forceinline__ HouseScalars house_scalars(const RedArgs& R, int ngp, int L, const double (&gpt)[2][3], double x0L,
+                                                      double x1L, double x0P, double x1P, double* red) {
+  const int tid = threadIdx.x;
+  const int ldp = R.ldp;
+  const int pivB = L - 2;
+  double sA, sB = 0.0, betaA, betaB = 0.0, gammaB = 0.0, eL1 = 0.0;
+  {
+    double gv[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = tid + 256 * j < ngp;
+      gv[0] += ok ? gpt[j][0] : 0.0;
+      if (NV == 2) { gv[1] += ok ? gpt[j][1] : 0.0; gv[2] += ok ? gpt[j][2] : 0.0; }
+    }
+    for (int q = tid + 512; q < ngp; q += 256) {   // more than 512 K_A workgroups (N > 8192)
+      gv[0] += R.GP[3 * q];
+      if (NV == 2) { gv[1] += R.GP[3 * q + 1]; gv[2] += R.GP[3 * q + 2]; }
+    }
+    if (EIGX_ABL(128)) { gv[0] = 1.0; gv[1] = 0.1; gv[2] = 1.0; }   // diagnostic build: no scalar reduction
+    else block_sum_multi<3>(gv, red);
+    if (EIGX_ABL(2048)) {   // diagnostic build: the scalar reduction a second time (what one such phase costs)
+      double g2[3] = {gv[0] + tid, gv[1], gv[2]};
+      __syncthreads();
+      block_sum_multi<3>(g2, red);
+      if (g2[0] == 1.2345678) gv[0] = g2[1];
+      __syncthreads();
+    }
+    if (gv[0] > 0.0) { sA = -sign_of(sqrt(gv[0]), x0L); betaA = gv[0] - sA * x0L; }
+    else { sA = x0L; betaA = 0.0; }
+    if (NV == 2) {
+      if (betaA != 0.0) gammaB = (gv[1] - sA * x1L) / betaA;
+      eL1 = x1L - gammaB * (x0L - sA);              // x1'(L-1) = T(i-2, i-1)
+      double hB = gv[2] - eL1 * eL1;                // ||x1'(0:L-1)||^2
+      if (!(hB >= 0.25 * gv[2])) {
+        double h[1] = {0.0};
+        for (int j = tid; j < L - 1; j += 256) {
+          const double t = R.X[ldp + j] - gammaB * R.X[j];
+          h[0] += t * t;
+        }
+        block_sum_multi<1>(h, red);
+        hB = h[0];
+      }
+      const double xP = x1P - gammaB * x0P;         // x1'(L-2)
+      if (hB > 0.0 && pivB >= 0) { sB = -sign_of(sqrt(hB), xP); betaB = hB - sB * xP; }
+      else { sB = (pivB >= 0) ? xP : 0.0; betaB = 0.0; }
+    }
+  }
+  HouseScalars hs;
+  hs.sA = sA; hs.sB = sB; hs.betaA = betaA; hs.betaB = betaB; hs.gammaB = gammaB; hs.eL1 = eL1;
+  return hs;
+}
+
+// u_A(j) = x0(j) - [j == L-1] sA ;  u_B(j) = x1'(j) - [j == L-2] sB, u_B(L-1) = 0 ;
+// zero when the reflector is trivial or j >= L.  raw0 / raw1 = x0(j), x1(j).
+template <int NV>
+__device__ __forceinline__ double u_fix(const HouseScalars& h, int L, int a, int j, double raw0, double raw1) {
+  if (j >= L) return 0.0;
+  if (a == 0) return (h.betaA != 0.0) ? raw0 - (j == L - 1 ? h.sA : 0.0) : 0.0;
+  if (j >= L - 1 || h.betaB == 0.0) return 0.0;
+  return raw1 - h.gammaB * raw0 - (j == L - 2 ? h.sB : 0.0);
+}
+
+// K_P role of a mat-vec launch: panel dot products U^T u, W^T u over one row chunk (cg < ncg: panel columns
+// [cg*PD_COLS, +PD_COLS)), or (cg == ncg) the reflector store into the panel (both U copies), into `a`, and the
+// partial uA.uB of the chunk.
+template <int NV, bool MG>
+__device__ __forceinline__ void kp_role(const RedArgs& R, const HouseScalars& hs, int i, int L, int k, int ncg, int toprows,
+                                        int pdr, int chunk, int cg, double* red) {
+  // No LDS staging: u_A, u_B are recomputed from the x vectors (L2-hot) next to every U/W load, so the
+  // chunk length is free and there are never more than 4 row chunks to re-reduce in K_A.
+  const int m = R.m;
+  const int ldp = R.ldp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rbase = chunk * pdr;
+  double* Up = R.UW;
+  double* Wp = R.UW + (size_t)ldp * m;
+  double* U2 = R.UW + (size_t)2 * ldp * m;
+  if (cg == ncg) {
+    // reflector store: panel slots (both U copies), column(s) of `a`, partial uA.uB
+    double ab[1] = {0.0};
+    const int rend = (rbase + pdr < toprows) ? rbase + pdr : toprows;
+    for (int r = rbase + tid; r < rend; r += 256) {
+      const double x0 = R.X[r];
+      const double x1 = (NV == 2) ? R.X[ldp + r] : 0.0;
+      const double uA = u_fix<NV>(hs, L, 0, r, x0, x1);
+      const double uB = (NV == 2) ? u_fix<NV>(hs, L, NV - 1, r, x0, x1) : 0.0;
+      Up[(size_t)k * ldp + r] = uA;
+      U2[(size_t)k * ldp + r] = uA;
+      if (NV == 2) { Up[(size_t)(k + 1) * ldp + r] = uB; U2[(size_t)(k + 1) * ldp + r] = uB; }
+      if (r < L) {
+        if (!MG) {
+          R.A[(size_t)i * R.lda + r] = uA;
+          if (NV == 2) R.A[(size_t)(i - 1) * R.lda + r] = uB;  // row L-1 gets 0 (src/eigen_prd_t4x.F:333-343)
+        } else if (r % R.Px == R.px) {
+          // the owners of columns i, i-1 keep their rows of the reflectors (2-D cyclic, as in the reference)
+          if (i % R.Py == R.py) R.A[(size_t)(i / R.Py) * R.lda + r / R.Px] = uA;
+          if (NV == 2 && (i - 1) % R.Py == R.py) R.A[(size_t)((i - 1) / R.Py) * R.lda + r / R.Px] = uB;
+        }
+      }
+      ab[0] += uA * uB;
+    }
+    if (NV == 2) {
+      block_sum_multi<1>(ab, red);
+      if (tid == 0) R.KD[R.kdab_off + chunk] = ab[0];
+    }
+    return;
+  }
+  // panel dots: wave w owns panel columns kk0 .. kk0+3; lanes stride the chunk's rows, two row groups
+  // (20 loads) per batch
+  const int kk0 = cg * PD_COLS + wave * 4;
+  if (kk0 >= k) return;
+  const int rend = (rbase + pdr < L) ? rbase + pdr : L;
+  double su[4][2], sw[4][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { su[c][0] = su[c][1] = sw[c][0] = sw[c][1] = 0.0; }
+  for (int r0 = rbase + lane; r0 < rend; r0 += 128) {
+    double x0[2], x1[2], tu[2][4], tw[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = (r0 + 64 * j < rend) ? r0 + 64 * j : rbase;
+      x0[j] = R.X[r];
+      x1[j] = (NV == 2) ? R.X[ldp + r] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int kk = (kk0 + c < k) ? kk0 + c : kk0;
+        tu[j][c] = Up[(size_t)kk * ldp + r];
+        tw[j][c] = Wp[(size_t)kk * ldp + r];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = r0 + 64 * j;
+      if (r < rend) {
+        const double a = u_fix<NV>(hs, L, 0, r, x0[j], x1[j]);
+        const double b = (NV == 2) ? u_fix<NV>(hs, L, NV - 1, r, x0[j], x1[j]) : 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          su[c][0] += tu[j][c] * a; sw[c][0] += tw[j][c] * a;
+          if (NV == 2) { su[c][1] += tu[j][c] * b; sw[c][1] += tw[j][c] * b; }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    su[c][0] = wave_sum(su[c][0]); sw[c][0] = wave_sum(sw[c][0]);
+    if (NV == 2) { su[c][1] = wave_sum(su[c][1]); sw[c][1] = wave_sum(sw[c][1]); }
+  }
+  if (lane == 0) {
+    double* kdp = R.KD + (size_t)chunk * 2 * NV * m;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int kk = kk0 + c;
+      if (kk < k) {
+        kdp[0 * m + kk] = su[c][0]; kdp[1 * m + kk] = sw[c][0];
+        if (NV == 2) { kdp[2 * m + kk] = su[c][1]; kdp[3 * m + kk] = sw[c][1]; }
+      }
+    }
+  }
+}
+
 template <int K> struct IC { static constexpr int value = K; };
 
 template <int NV, int RB, bool NTL, bool MG>
@@ -984,45 +1181,8 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   // order in every workgroup, so the replicas stay bit-identical either way.
   double sA, sB = 0.0, betaA, betaB = 0.0, gammaB = 0.0, eL1 = 0.0;
   {
-    double gv[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const bool ok = tid + 256 * j < B.ngp;
-      gv[0] += ok ? gpt[j][0] : 0.0;
-      if (NV == 2) { gv[1] += ok ? gpt[j][1] : 0.0; gv[2] += ok ? gpt[j][2] : 0.0; }
-    }
-    for (int q = tid + 512; q < B.ngp; q += 256) {   // more than 512 K_A workgroups (N > 8192)
-      gv[0] += R.GP[3 * q];
-      if (NV == 2) { gv[1] += R.GP[3 * q + 1]; gv[2] += R.GP[3 * q + 2]; }
-    }
-    if (EIGX_ABL(128)) { gv[0] = 1.0; gv[1] = 0.1; gv[2] = 1.0; }   // diagnostic build: no scalar reduction
-    else block_sum_multi<3>(gv, red);
-    if (EIGX_ABL(2048)) {   // diagnostic build: the scalar reduction a second time (what one such phase costs)
-      double g2[3] = {gv[0] + tid, gv[1], gv[2]};
-      __syncthreads();
-      block_sum_multi<3>(g2, red);
-      if (g2[0] == 1.2345678) gv[0] = g2[1];
-      __syncthreads();
-    }
-    if (gv[0] > 0.0) { sA = -sign_of(sqrt(gv[0]), x0L); betaA = gv[0] - sA * x0L; }
-    else { sA = x0L; betaA = 0.0; }
-    if (NV == 2) {
-      if (betaA != 0.0) gammaB = (gv[1] - sA * x1L) / betaA;
-      eL1 = x1L - gammaB * (x0L - sA);              // x1'(L-1) = T(i-2, i-1)
-      double hB = gv[2] - eL1 * eL1;                // ||x1'(0:L-1)||^2
-      if (!(hB >= 0.25 * gv[2])) {
-        double h[1] = {0.0};
-        for (int j = tid; j < L - 1; j += 256) {
-          const double t = R.X[ldp + j] - gammaB * R.X[j];
-          h[0] += t * t;
-        }
-        block_sum_multi<1>(h, red);
-        hB = h[0];
-      }
-      const double xP = x1P - gammaB * x0P;         // x1'(L-2)
-      if (hB > 0.0 && pivB >= 0) { sB = -sign_of(sqrt(hB), xP); betaB = hB - sB * xP; }
-      else { sB = (pivB >= 0) ? xP : 0.0; betaB = 0.0; }
-    }
+    HouseScalars hs = house_scalars<NV>(R, B.ngp, L, gpt, x0L, x1L, x0P, x1P, red);
+    sA = hs.sA; sB = hs.sB; betaA = hs.betaA; betaB = hs.betaB; gammaB = hs.gammaB; eL1 = hs.eL1;
   }
   // the store-role panel workgroup of chunk 0 publishes the scalars (it exists on every rank)
   if (panel_role && tx == B.ncg && ty == B.nt && tid == 0) {
@@ -1046,97 +1206,9 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   };
   if (panel_role) {
     // ================================================================ K_P
-    // No LDS staging: u_A, u_B are recomputed from the x vectors (L2-hot) next to every U/W load, so the
-    // chunk length is free and there are never more than 4 row chunks to re-reduce in K_A.
-    const int m = R.m, k = B.k;
-    const int chunk = ty - B.nt, cg = tx;
-    const int pdr = B.pdr;
-    const int rbase = chunk * pdr;
-    double* Up = R.UW;
-    double* Wp = R.UW + (size_t)ldp * m;
-    double* U2 = R.UW + (size_t)2 * ldp * m;
-    if (cg == B.ncg) {
-      // reflector store: panel slots (both U copies), column(s) of `a`, partial uA.uB
-      double ab[1] = {0.0};
-      const int rend = (rbase + pdr < B.toprows) ? rbase + pdr : B.toprows;
-      for (int r = rbase + tid; r < rend; r += 256) {
-        const double x0 = R.X[r];
-        const double x1 = (NV == 2) ? R.X[ldp + r] : 0.0;
-        const double uA = ufix2(0, r, x0, x1);
-        const double uB = (NV == 2) ? ufix2(NV - 1, r, x0, x1) : 0.0;
-        Up[(size_t)k * ldp + r] = uA;
-        U2[(size_t)k * ldp + r] = uA;
-        if (NV == 2) { Up[(size_t)(k + 1) * ldp + r] = uB; U2[(size_t)(k + 1) * ldp + r] = uB; }
-        if (r < L) {
-          if (!MG) {
-            R.A[(size_t)i * R.lda + r] = uA;
-            if (NV == 2) R.A[(size_t)(i - 1) * R.lda + r] = uB;  // row L-1 gets 0 (src/eigen_prd_t4x.F:333-343)
-          } else if (r % R.Px == R.px) {
-            // the owners of columns i, i-1 keep their rows of the reflectors (2-D cyclic, as in the reference)
-            if (i % R.Py == R.py) R.A[(size_t)(i / R.Py) * R.lda + r / R.Px] = uA;
-            if (NV == 2 && (i - 1) % R.Py == R.py) R.A[(size_t)((i - 1) / R.Py) * R.lda + r / R.Px] = uB;
-          }
-        }
-        ab[0] += uA * uB;
-      }
-      if (NV == 2) {
-        block_sum_multi<1>(ab, red);
-        if (tid == 0) R.KD[R.kdab_off + chunk] = ab[0];
-      }
-      return;
-    }
-    // panel dots: wave w owns panel columns kk0 .. kk0+3; lanes stride the chunk's rows, two row groups
-    // (20 loads) per batch
-    const int kk0 = cg * PD_COLS + wave * 4;
-    if (kk0 >= k) return;
-    const int rend = (rbase + pdr < L) ? rbase + pdr : L;
-    double su[4][2], sw[4][2];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { su[c][0] = su[c][1] = sw[c][0] = sw[c][1] = 0.0; }
-    for (int r0 = rbase + lane; r0 < rend; r0 += 128) {
-      double x0[2], x1[2], tu[2][4], tw[2][4];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int r = (r0 + 64 * j < rend) ? r0 + 64 * j : rbase;
-        x0[j] = R.X[r];
-        x1[j] = (NV == 2) ? R.X[ldp + r] : 0.0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int kk = (kk0 + c < k) ? kk0 + c : kk0;
-          tu[j][c] = Up[(size_t)kk * ldp + r];
-          tw[j][c] = Wp[(size_t)kk * ldp + r];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int r = r0 + 64 * j;
-        if (r < rend) {
-          const double a = ufix2(0, r, x0[j], x1[j]);
-          const double b = (NV == 2) ? ufix2(NV - 1, r, x0[j], x1[j]) : 0.0;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            su[c][0] += tu[j][c] * a; sw[c][0] += tw[j][c] * a;
-            if (NV == 2) { su[c][1] += tu[j][c] * b; sw[c][1] += tw[j][c] * b; }
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      su[c][0] = wave_sum(su[c][0]); sw[c][0] = wave_sum(sw[c][0]);
-      if (NV == 2) { su[c][1] = wave_sum(su[c][1]); sw[c][1] = wave_sum(sw[c][1]); }
-    }
-    if (lane == 0) {
-      double* kdp = R.KD + (size_t)chunk * 2 * NV * m;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int kk = kk0 + c;
-        if (kk < k) {
-          kdp[0 * m + kk] = su[c][0]; kdp[1 * m + kk] = sw[c][0];
-          if (NV == 2) { kdp[2 * m + kk] = su[c][1]; kdp[3 * m + kk] = sw[c][1]; }
-        }
-      }
-    }
+    HouseScalars hs;
+    hs.sA = sA; hs.sB = sB; hs.betaA = betaA; hs.betaB = betaB; hs.gammaB = gammaB; hs.eL1 = eL1;
+    kp_role<NV, MG>(R, hs, i, L, B.k, B.ncg, B.toprows, B.pdr, ty - B.nt, tx, red);
     return;
   }
 
@@ -1359,6 +1431,288 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   if (R.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) atomicAdd(&R.dbg[15], 1ull);
 }
 
+
+// =================================================================================================
+// K_S : strip form of the fused symmetric mat-vec for large active sizes (one GPU).
+//
+// The tile form above writes, per launch, a row sum and a column sum for every (row, tile) pair: L (L/T + 1) NV
+// doubles -- 67 MB at L = 32768 -- and those dirty lines leave the 4-MB L2s DURING the stream, where a written byte
+// costs about ten times a read one (6.5-6.9 TB/s for the loads alone, 5.6-6.0 with the stores);
+// K_A then reads them all back.  Here a launch is a PERSISTENT grid of <= G workgroups (all resident at once), one job
+// each: job = (strip of H = 512 / 1024 rows, column range [c0, c1) in multiples of 8), all jobs of (nearly) equal area of
+// the upper triangle.  The 4 waves read the SAME 8 columns at different 128-row blocks (wave w owns blocks w and
+// 2 HB - 1 - w of the strip: the pairing balances the diagonal job), so
+//   * row sums are wave-private registers over the whole job, stored once at its end: ONE row-sum slot per job of the
+//     strip (slot = piece number within the strip);
+//   * column sums are complete over the strip's H rows: ONE column-sum slot per strip (combined over the 4 waves
+//     through LDS every 256 columns);
+//   * the reflector scalars, the u values of the rows and the launch / drain of a workgroup are paid once per job
+//     instead of once per tile.
+// Partial sums per launch: L (L/H + pieces per strip) NV doubles, about a quarter of the tile form's.
+// The job list is a function of (L, npc[]): npc[s] = pieces of strip s (host, per step, kernel argument); piece
+// boundaries by the equal-area rule below, evaluated identically by every workgroup.
+// Grid: K_P workgroups first (as in the tile form), then the jobs in strip order.
+// =================================================================================================
+constexpr int KS_MAXSTRIPS = 64;     // column-sum slots 0 .. 63, row-sum slots from KS_MAXSTRIPS on
+constexpr int KS_MAXPIECES = 96;     // per strip (K_A's first batch covers 160 slots)
+struct KSArgs {
+  int i, L, k, ncg, toprows, pdr, npd, ngp;   // as KBArgs
+  int nstrips, njobs;
+  unsigned char npc[KS_MAXSTRIPS];            // pieces per strip
+};
+
+// columns of strip s (rows [R0, R0 + h), columns [R0, L)) left of piece boundary number p of n: equal areas
+__host__ __device__ inline int ks_boundary(int R0, int h, int L, int p, int n) {
+  if (p <= 0) return R0;
+  if (p >= n) return L;
+  const double tri = 0.5 * (double)h * (h + 1);
+  const double total = tri + (double)(L - R0 - h) * h;
+  const double t = total * (double)p / (double)n;
+  const double x = (t <= tri) ? 0.5 * (sqrt(8.0 * t + 1.0) - 1.0) : (double)h + (t - tri) / (double)h;
+  int c = R0 + ((int)(x / 8.0 + 0.5)) * 8;
+  if (c > L) c = L;
+  return c;
+}
+
+template <int NV, int HB, bool NTL>
+__global__ __launch_bounds__(256) void symv_strip_kernel(RedArgs R, KSArgs B) {
+  constexpr int H = 4 * HB * 128;
+  __shared__ double colpart[4][NV][256];    // per-wave column sums of the current 256-column block
+  __shared__ double ucs[NV][256];           // u at the columns of the current block
+  __shared__ double red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ldp = R.ldp;
+  const int L = B.L, i = B.i;
+  const int nkp = B.npd * (B.ncg + 1);
+  const bool panel_role = (int)blockIdx.x < nkp;
+  // ---- which job ------------------------------------------------------------------------------------------------
+  int js = 0, jp = 0, jn = 1;
+  if (!panel_role) {
+    int j = (int)blockIdx.x - nkp;
+    for (int q = 0; q < B.nstrips; ++q) {
+      const int n = B.npc[q];
+      if (j < n) { js = q; jp = j; jn = n; break; }
+      j -= n;
+    }
+  }
+  const int R0 = js * H;
+  const int hrows = (R0 + H <= L) ? H : L - R0;
+  const int c0 = ks_boundary(R0, hrows, L, jp, jn), c1 = ks_boundary(R0, hrows, L, jp + 1, jn);
+  // ---- loads that feed the reflector scalars first, then this job's x values and its first unit of A -----------------
+  double gpt[2][3];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = (tid + 256 * j < B.ngp) ? tid + 256 * j : 0;
+    gpt[j][0] = R.GP[3 * q];
+    if (NV == 2) { gpt[j][1] = R.GP[3 * q + 1]; gpt[j][2] = R.GP[3 * q + 2]; }
+  }
+  const int pivB = L - 2;
+  const double x0L = R.X[L - 1];
+  const double x1L = (NV == 2) ? R.X[ldp + L - 1] : 0.0;
+  const double x1P = (NV == 2 && pivB >= 0) ? R.X[ldp + pivB] : 0.0;
+  const double x0P = (NV == 2 && pivB >= 0) ? R.X[pivB] : 0.0;
+  asm volatile("" ::: "memory");
+  // my row blocks: wave w -> blocks w and 2 HB - 1 - w (HB = 1: block w only)
+  int rowb[HB];
+  rowb[0] = R0 + wave * 128;
+  if (HB == 2) rowb[HB - 1] = R0 + (7 - wave) * 128;
+  double rraw[NV][HB][2];
+  double craw[NV];
+  double2 av0[8], av1[8];
+  auto load8 = [&](double2 (&av)[8], int c, int b) {
+    const int r0 = rowb[b] + lane * 2;
+    // whole unit strictly below the diagonal (first row beyond its last column) or beyond the active rows: nothing to read
+    const bool any = rowb[b] <= c + 7 && r0 < L;
+    const double* Ap = R.A + (any ? r0 : 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (any && c + j < L) av[j] = ld2<NTL>(Ap + (size_t)(c + j) * R.lda);
+      else av[j] = make_double2(0.0, 0.0);
+    }
+  };
+  if (!panel_role) {
+#pragma unroll
+    for (int b = 0; b < HB; ++b)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = rowb[b] + lane * 2 + h;
+        const bool ok = r < L;
+        rraw[0][b][h] = ok ? R.X[r] : 0.0;
+        if (NV == 2) rraw[NV - 1][b][h] = ok ? R.X[ldp + r] : 0.0;
+      }
+    {
+      const int c = c0 + tid;
+      const bool ok = c < c1;
+      craw[0] = ok ? R.X[c] : 0.0;
+      if (NV == 2) craw[NV - 1] = ok ? R.X[ldp + c] : 0.0;
+    }
+    if (c0 < c1) load8(av0, c0, 0);
+  }
+  const HouseScalars hs = house_scalars<NV>(R, B.ngp, L, gpt, x0L, x1L, x0P, x1P, red);
+  if (panel_role) {
+    const int q = blockIdx.x;
+    const int chunk = q / (B.ncg + 1), cg = q - chunk * (B.ncg + 1);
+    // the store-role panel workgroup of chunk 0 publishes the scalars
+    if (cg == B.ncg && chunk == 0 && tid == 0) {
+      R.sc[SC_SA] = hs.sA; R.sc[SC_BETA_A] = hs.betaA;
+      if (NV == 1) {
+        R.e[i] = hs.sA;
+      } else {
+        R.sc[SC_SB] = hs.sB; R.sc[SC_BETA_B] = hs.betaB;
+        R.e[R.lde + i] = hs.sA;
+        R.e[i - 1] = hs.eL1;
+        if (i - 1 >= 2) R.e[R.lde + i - 1] = hs.sB;
+      }
+    }
+    kp_role<NV, false>(R, hs, i, L, B.k, B.ncg, B.toprows, B.pdr, chunk, cg, red);
+    return;
+  }
+  // ---- u at my rows (registers, for the whole job) --------------------------------------------------------------------
+  double ux[NV][HB][2], yr[NV][HB][2];
+#pragma unroll
+  for (int b = 0; b < HB; ++b)
+#pragma unroll
+    for (int a = 0; a < NV; ++a)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        ux[a][b][h] = u_fix<NV>(hs, L, a, rowb[b] + lane * 2 + h, rraw[0][b][h], rraw[NV - 1][b][h]);
+        yr[a][b][h] = 0.0;
+      }
+  double sp[3] = {0.0, 0.0, 0.0};
+  double yc[NV][8];
+  // one unit = 8 columns x one of my 128-row blocks
+  auto compute8 = [&](const double2 (&av)[8], int c, int cb, auto bc) {
+    constexpr int b = decltype(bc)::value;
+    const int r0 = rowb[b] + lane * 2, r1 = r0 + 1;
+    if (b == 0) {
+#pragma unroll
+      for (int a = 0; a < NV; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) yc[a][j] = 0.0;
+    }
+    if (rowb[b] + 127 < c) {         // strictly above the diagonal: every element counts for both products
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int a = 0; a < NV; ++a) {
+          const double uc = ucs[a][c - cb + j];
+          yr[a][b][0] += av[j].x * uc;
+          yr[a][b][1] += av[j].y * uc;
+          yc[a][j] += av[j].x * ux[a][b][0] + av[j].y * ux[a][b][1];
+        }
+      }
+    } else if (rowb[b] <= c + 7) {   // the diagonal crosses the unit: select (never multiply: the lower triangle may hold NaN)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int cc = c + j;
+        const double ax_s = (r0 < cc) ? av[j].x : 0.0, ay_s = (r1 < cc) ? av[j].y : 0.0;     // strict upper
+        const double ax_d = (r0 <= cc) ? av[j].x : 0.0, ay_d = (r1 <= cc) ? av[j].y : 0.0;   // with diagonal
+#pragma unroll
+        for (int a = 0; a < NV; ++a) {
+          const double uc = ucs[a][cc - cb];
+          yr[a][b][0] += ax_s * uc;
+          yr[a][b][1] += ay_s * uc;
+          yc[a][j] += ax_d * ux[a][b][0] + ay_d * ux[a][b][1];
+        }
+      }
+    }
+    if (b == HB - 1) {
+      // halving butterfly: 8 column sums over 64 lanes (as in the tile form); lane with (lane & 7) == 0 ends up with the
+      // sum of column j = 4 bit5 + 2 bit4 + bit3 over this wave's rows
+#pragma unroll
+      for (int a = 0; a < NV; ++a) {
+        double v4[4], v2[2], v1;
+        const bool hi8 = lane & 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v4[j] = swapadd32(yc[a][j], yc[a][j + 4]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) v2[j] = swapadd16(v4[j], v4[j + 2]);
+        {
+          const double keep = hi8 ? v2[1] : v2[0];
+          const double send = hi8 ? v2[0] : v2[1];
+          v1 = keep + dpp_mov<0x128>(send);
+        }
+        v1 = dpp_add<0xB1>(v1);
+        v1 = dpp_add<0x4E>(v1);
+        v1 = dpp_add<0x141>(v1);
+        if ((lane & 7) == 0) {
+          const int j = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+          colpart[wave][a][c - cb + j] = v1;
+        }
+      }
+    }
+  };
+  // ---- the job: 256-column blocks, 8-column groups, two units in flight --------------------------------------------------
+  for (int cb = c0; cb < c1; cb += 256) {
+    const int ce = (cb + 256 < c1) ? cb + 256 : c1;
+    // u at the block's columns (craw = x at column cb + tid, loaded one block ahead)
+#pragma unroll
+    for (int a = 0; a < NV; ++a) ucs[a][tid] = (cb + tid < ce) ? u_fix<NV>(hs, L, a, cb + tid, craw[0], craw[NV - 1]) : 0.0;
+    {
+      const int c = cb + 256 + tid;
+      const bool ok = c < c1;
+      craw[0] = ok ? R.X[c] : 0.0;
+      if (NV == 2) craw[NV - 1] = ok ? R.X[ldp + c] : 0.0;
+    }
+    __syncthreads();
+    const int ng = (ce - cb + 7) / 8;
+#pragma unroll 1
+    for (int g = 0; g < ng; ++g) {
+      const int c = cb + g * 8;
+      if (HB == 2) {
+        load8(av1, c, HB - 1);
+        compute8(av0, c, cb, IC<0>());
+        if (c + 8 < c1) load8(av0, c + 8, 0);
+        compute8(av1, c, cb, IC<HB - 1>());
+      } else {
+        // one row block per wave: groups in pairs (a block holds an even number of groups unless it is the job's last)
+        if (c + 8 < c1) load8(av1, c + 8, 0);
+        compute8(av0, c, cb, IC<0>());
+        ++g;
+        if (g < ng) {
+          if (c + 16 < c1) load8(av0, c + 16, 0);
+          compute8(av1, c + 8, cb, IC<0>());
+        }
+      }
+    }
+    __syncthreads();
+    // combine the 4 waves' column sums (fixed order), store the strip's column-sum slot, bilinear column part
+    if (cb + tid < ce) {
+      const int c = cb + tid;
+      double cs[NV];
+#pragma unroll
+      for (int a = 0; a < NV; ++a) {
+        cs[a] = (colpart[0][a][tid] + colpart[1][a][tid]) + (colpart[2][a][tid] + colpart[3][a][tid]);
+        R.YC[((size_t)js * NV + a) * ldp + c] = cs[a];
+      }
+      sp[0] += ucs[0][tid] * cs[0];
+      if (NV == 2) { sp[1] += ucs[0][tid] * cs[NV - 1]; sp[2] += ucs[NV - 1][tid] * cs[NV - 1]; }
+    }
+    __syncthreads();
+  }
+  // ---- row sums of the job: one slot per piece of the strip -------------------------------------------------------------
+#pragma unroll
+  for (int b = 0; b < HB; ++b) {
+    const int r0 = rowb[b] + lane * 2;
+#pragma unroll
+    for (int a = 0; a < NV; ++a) {
+      double* dst = R.YC + ((size_t)(KS_MAXSTRIPS + jp) * NV + a) * ldp + r0;
+      if (r0 + 1 < L) { dst[0] = yr[a][b][0]; dst[1] = yr[a][b][1]; }
+      else if (r0 < L) dst[0] = yr[a][b][0];
+    }
+    sp[0] += ux[0][b][0] * yr[0][b][0] + ux[0][b][1] * yr[0][b][1];
+    if (NV == 2) {
+      sp[1] += ux[0][b][0] * yr[NV - 1][b][0] + ux[0][b][1] * yr[NV - 1][b][1];
+      sp[2] += ux[NV - 1][b][0] * yr[NV - 1][b][0] + ux[NV - 1][b][1] * yr[NV - 1][b][1];
+    }
+  }
+  block_sum_multi<3>(sp, red);
+  if (tid == 0) {
+    const size_t w = (size_t)((int)blockIdx.x - nkp);
+    R.SP[w * 3 + 0] = sp[0]; R.SP[w * 3 + 1] = sp[1]; R.SP[w * 3 + 2] = sp[2];
+  }
+}
+
 // zero-fill helper
 __global__ void fill_kernel(double* p, size_t n, double v) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
@@ -1450,7 +1804,8 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   }
   R.kdab_off = R.maxchunk * 2 * NB * m;
   R.KD = ctx.pool.get_t<double>("red.KD", (size_t)R.kdab_off + R.maxchunk + 8 + 512);   // + slack: K_A loads kk < 256 unclamped
-  R.SP = ctx.pool.get_t<double>("red.SP", (size_t)(maxseg * maxseg) * 3 + 8);
+  const size_t sp_count = (size_t)(maxseg * maxseg > 1024 ? maxseg * maxseg : 1024) * 3 + 8;   // tiles, or <= 1024 strip jobs
+  R.SP = ctx.pool.get_t<double>("red.SP", sp_count);
   const int maxgp = (n + KA_ROWS - 1) / KA_ROWS + 2;
   R.gp2_off = 0;
   R.GP = ctx.pool.get_t<double>("red.GP", (size_t)maxgp * 3 + 8);
@@ -1503,13 +1858,14 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, st, R.UW, (size_t)ldp * m * 3, 0.0);
   hipLaunchKernelGGL(fill_kernel, dim3(8), dim3(256), 0, st, e, (size_t)lde * NB, 0.0);
   hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, R.sc, (size_t)SC_COUNT, 0.0);
-  hipLaunchKernelGGL(fill_kernel, dim3(16), dim3(256), 0, st, R.SP, (size_t)(maxseg * maxseg) * 3 + 8, 0.0);
+  hipLaunchKernelGGL(fill_kernel, dim3(16), dim3(256), 0, st, R.SP, sp_count, 0.0);
 
   const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   KAArgs S;
   // ka_kernel's first batches of loads are unconditional (clamped), so their sizes are template parameters matched to
   // the step: partial sums of a row (nt + 1 slots: 1 / 2 / 3 / 5 / 10 batches of KA_SL = 16), folded rows of tile
   // scalars (nt <= 15 / 31 / 63: 2 / 4 / 8 per wave), panel columns (k <= 32 / 64 / more: 2 / 4 / 8 per slice)
+  bool strip_prev = false;   // the pending step's mat-vec ran in strip form (K_A then reads its slot layout)
   auto launch_ka = [&](int nwg, const KAArgs& K) {
     const bool fit = g_ka_fit != 0;
     const int nslot = fit ? K.nt_prev + 1 : 1 << 30, ntp = fit ? K.nt_prev : 1 << 30;
@@ -1519,13 +1875,22 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       if (K.G > 1) hipLaunchKernelGGL((ka_kernel<NB, MGV, true, RPBV, SPBV, KBV>), dim3(nwg), dim3(256), 0, st, R, K);   \
       else hipLaunchKernelGGL((ka_kernel<NB, MGV, false, RPBV, SPBV, KBV>), dim3(nwg), dim3(256), 0, st, R, K);          \
     } while (0)
+#define EIGX_KAS(KBV)                                                                                                   \
+    do {                                                                                                                \
+      if (K.G > 1) hipLaunchKernelGGL((ka_kernel<NB, false, true, 10, 8, KBV, true>), dim3(nwg), dim3(256), 0, st, R, K); \
+      else hipLaunchKernelGGL((ka_kernel<NB, false, false, 10, 8, KBV, true>), dim3(nwg), dim3(256), 0, st, R, K);       \
+    } while (0)
 #define EIGX_KA2(MGV, RPBV, SPBV)                                                                                       \
     do {                                                                                                                \
       if (kk <= 2 * KA_SL) EIGX_KA3(MGV, RPBV, SPBV, 2);                                                                \
       else if (kk <= 4 * KA_SL) EIGX_KA3(MGV, RPBV, SPBV, 4);                                                           \
       else EIGX_KA3(MGV, RPBV, SPBV, 8);                                                                                \
     } while (0)
-    if (mg) EIGX_KA2(true, 1, 8);
+    if (!mg && K.has_prev && strip_prev) {   // the previous mat-vec ran in strip form
+      if (kk <= 2 * KA_SL) EIGX_KAS(2);
+      else if (kk <= 4 * KA_SL) EIGX_KAS(4);
+      else EIGX_KAS(8);
+    } else if (mg) EIGX_KA2(true, 1, 8);
     else if (nslot <= 1 * KA_SL && ntp <= 15) EIGX_KA2(false, 1, 2);
     else if (nslot <= 2 * KA_SL && ntp <= 31) EIGX_KA2(false, 2, 4);
     else if (nslot <= 3 * KA_SL) EIGX_KA2(false, 3, 8);
@@ -1533,9 +1898,12 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     else EIGX_KA2(false, 10, 8);
 #undef EIGX_KA2
 #undef EIGX_KA3
+#undef EIGX_KAS
   };
   S.has_prev = 0; S.iprev = 0; S.Lprev = 0; S.kprev = 0; S.nchunk_prev = 0; S.nt_prev = 0; S.lgT_prev = 7;
   S.par = 0; S.pan_c0 = 0; S.G = 1;
+  S.lgH = 10; S.njobs_prev = 0;
+  memset(S.npc, 0, sizeof(S.npc));
   S.wait.n = 0; S.wait.flag = nullptr; S.wait.err = nullptr; S.wait.ticks = nullptr; S.wait.limit_ticks = 0; S.wait.epoch = 0;
   const bool fuse_wait = mg && comm_step_wait_fused(ctx);
   const bool step_coll = mg && comm_step_collective(ctx);   // per-step exchange as an allgather (RCCL / emulated)
@@ -1619,6 +1987,50 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     const bool prof = ctx.prof_stride > 0 && (n_symv % ctx.prof_stride) == 0;
     if (prof) ctx.prof_begin(0, 8.0 * ((double)L * (L + 1) / 2) / R.P, st);  // this rank's share of the triangle
     const bool nt_loads = (mg ? sqrt((double)B.Lr * B.Lc) : (double)L) > g_symv_nt;
+    const bool strip = !mg && L > g_symv_strip;
+    if (strip) {
+      // strip form: equal-area jobs, <= g_strip_jobs of them (a persistent grid: every job resident from the start)
+      KSArgs K;
+      K.i = i; K.L = L; K.k = k; K.ncg = B.ncg; K.toprows = B.toprows; K.pdr = B.pdr; K.npd = npd; K.ngp = nb_ka;
+      const int lgH = (L >= g_strip_h1024) ? 10 : 9, H = 1 << lgH;
+      int ns = ceil_div(L, H);
+      if (ns > KS_MAXSTRIPS) ns = KS_MAXSTRIPS;   // (callers keep L <= 64 H; asserted by the threshold choice below)
+      const double total = 0.5 * (double)L * (L + 1);
+      int G = g_strip_jobs;
+      if (G > 1024) G = 1024;
+      if (G < ns) G = ns;
+      int npc[KS_MAXSTRIPS], sum = 0;
+      double area[KS_MAXSTRIPS];
+      for (int q = 0; q < ns; ++q) {
+        const int R0 = q * H, h = (R0 + H <= L) ? H : L - R0;
+        area[q] = 0.5 * (double)h * (h + 1) + (double)(L - R0 - h) * h;
+        int np = (int)(area[q] * G / total + 0.5);
+        if (np < 1) np = 1;
+        if (np > KS_MAXPIECES) np = KS_MAXPIECES;
+        npc[q] = np;
+        sum += np;
+      }
+      while (sum > G) {   // rounding went over: take pieces from the strips whose pieces are smallest
+        int best = -1;
+        for (int q = 0; q < ns; ++q)
+          if (npc[q] > 1 && (best < 0 || area[q] / npc[q] < area[best] / npc[best])) best = q;
+        if (best < 0) break;
+        --npc[best];
+        --sum;
+      }
+      K.nstrips = ns; K.njobs = sum;
+      memset(K.npc, 0, sizeof(K.npc));
+      for (int q = 0; q < ns; ++q) K.npc[q] = (unsigned char)npc[q];
+      const int gs = sum + npd * (B.ncg + 1);
+#define EIGX_STRIP(HBv, NTv) hipLaunchKernelGGL((symv_strip_kernel<NB, HBv, NTv>), dim3(gs), dim3(256), 0, st, R, K)
+      if (lgH == 10 && nt_loads) EIGX_STRIP(2, true);
+      else if (lgH == 10) EIGX_STRIP(2, false);
+      else if (nt_loads) EIGX_STRIP(1, true);
+      else EIGX_STRIP(1, false);
+#undef EIGX_STRIP
+      S.lgH = lgH; S.njobs_prev = sum;
+      memcpy(S.npc, K.npc, sizeof(S.npc));
+    } else {
 #define EIGX_SYMV(RBv, NTv)                                                                                         \
   do {                                                                                                              \
     if (mg) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true>), dim3(gx), dim3(256), 0, st, R, B);                \
@@ -1630,6 +2042,8 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     else if (!nt_loads) EIGX_SYMV(4, false);
     else EIGX_SYMV(4, true);
 #undef EIGX_SYMV
+    }
+    strip_prev = strip;
     if (prof) ctx.prof_end(st);
     if (mg) {
       ++epoch;
@@ -1735,6 +2149,10 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
 }  // namespace
 
 int set_symv_threshold(int which, int v) {
+  if (which >= 5) {
+    int& u = (which == 5) ? g_symv_strip : (which == 6) ? g_strip_jobs : g_strip_h1024;
+    const int old = u; u = v; return old;
+  }
   int& t = (which == 4) ? g_ka_fit : (which == 3) ? g_ka_wgs : (which == 2) ? g_symv_nt : (which ? g_symv_t256 : g_symv_t128);
   const int old = t; t = v; return old;
 }

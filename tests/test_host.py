@@ -417,3 +417,59 @@ def test_bench_spawns_its_own_ranks():
     env["RANK"] = "0"
     r = subprocess.run([sys.executable, bench, "--gpus", "8"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+def test_reference_benchmark_sources_find_their_symbols_in_the_module():
+    """Build-container-only boundary check (skipped where /root/reference is absent): every entity of eigen_libs_mod /
+    eigen_blacs_mod that the reference's OWN benchmark sources (benchmark/main2.f, mat_set.f, w_test.f, ev_test.f) call,
+    and every keyword argument they pass, exists in eigenexa_amd/fortran/eigen_libs_mod.F90 with that dummy-argument
+    name.  The sources are read as TEXT: a `flang -fsyntax-only` pass over them is not possible here, because they also
+    `use mpi` and the image's mpi.mod is in gfortran's format (unreadable by flang) -- writing a replacement module would
+    be a stand-in for something the image lacks, which this project's rules exclude."""
+    ref = "/root/reference/benchmark"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present")
+    mod = open(os.path.join(ROOT, "eigenexa_amd", "fortran", "eigen_libs_mod.F90")).read().lower()
+    public = set()
+    for m in re.finditer(r"^\s*public\s*::\s*(.+)$", mod, re.M):
+        public |= {t.strip() for t in m.group(1).split("!")[0].split(",") if t.strip()}
+    # dummy-argument names per procedure (generic interfaces: union over their module procedures)
+    dummies = {}
+    for m in re.finditer(r"^\s*(?:[a-z0-9_()]+\s+)*(?:subroutine|function)\s+([a-z0-9_]+)\s*\(([^)]*)\)", mod, re.M):
+        dummies[m.group(1)] = {a.strip() for a in m.group(2).split(",") if a.strip()}
+    for m in re.finditer(r"^\s*interface\s+([a-z0-9_]+)\s*$(.*?)^\s*end interface", mod, re.M | re.S):
+        names = re.findall(r"module procedure\s+(.+)", m.group(2))
+        args = set()
+        for line in names:
+            for nm in line.split(","):
+                args |= dummies.get(nm.strip(), set())
+        dummies[m.group(1)] = args
+    used, kw = set(), {}
+    for fn in ("main2.f", "mat_set.f", "w_test.f", "ev_test.f"):
+        text = open(os.path.join(ref, fn), errors="replace").read()
+        lines = []
+        for ln in text.splitlines():
+            if not ln or ln[0] in "cC*!":          # fixed-form comment lines
+                continue
+            ln = ln.split("!")[0]
+            if len(ln) > 5 and ln[5] not in " 0" and lines:   # continuation line (column 6)
+                lines[-1] += ln[6:]
+            else:
+                lines.append(ln)
+        for ln in lines:
+            low = ln.lower()
+            for m in re.finditer(r"\b(eigen_[a-z0-9_]+|get_constant_[a-z0-9_]+)\s*\(([^)]*)\)", low):
+                name = m.group(1)
+                used.add(name)
+                for k in re.findall(r"\b([a-z_][a-z0-9_]*)\s*=", m.group(2)):
+                    kw.setdefault(name, set()).add(k)
+            for m in re.finditer(r"call\s+(eigen_[a-z0-9_]+)\b", low):
+                used.add(m.group(1))
+    used -= {"eigen_libs_mod", "eigen_blacs_mod"}
+    assert {"eigen_init", "eigen_sx", "eigen_s", "eigen_free", "eigen_get_matdims", "eigen_get_comm",
+            "eigen_get_blacs_context", "eigen_memory_internal", "eigen_loop_start", "eigen_owner_node"} <= used   # the scan sees the calls
+    missing = sorted(n for n in used if n not in public)
+    assert not missing, f"the reference's benchmark sources use {missing}, which eigen_libs_mod.F90 does not export"
+    for name, keys in kw.items():
+        bad = sorted(k for k in keys if k not in dummies.get(name, set()))
+        assert not bad, f"{name}: keyword argument(s) {bad} of the reference's callers are not dummy names here ({sorted(dummies.get(name, []))})"

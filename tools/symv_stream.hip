@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -154,6 +155,66 @@ __global__ __launch_bounds__(256) void rd_super(const double* __restrict__ A, in
   if (s == 1.23456789) { out[0] = s; dyn_lds[0] = s; }
 }
 
+
+// strip pieces (round 3): a PERSISTENT grid of G workgroups, one job each: job = (strip of H = 1024 rows, column range
+// [c0, c1) in units of 8 columns) of the upper triangle, all jobs of (nearly) equal area.  The 4 waves read the SAME 8
+// columns at different 128-row blocks (wave w: blocks w and 7 - w of the strip), so row sums are wave-private registers
+// over the whole job (stored once at its end: one row-sum slot per job of the strip) and column sums complete over the
+// strip's 1024 rows (one column-sum slot per strip: combined over the 4 waves through LDS every 256 columns).
+struct StripJob { int s, c0, c1, slot; };
+template <bool STORES>
+__global__ __launch_bounds__(256) void rd_strip(const double* __restrict__ A, int ld, int L, const StripJob* jobs, double* out,
+                                                double* Y, int ldp, int CS) {
+  __shared__ double colpart[4][2][256];
+  constexpr int H = 1024;
+  const StripJob J = jobs[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk[2] = {wave, 7 - wave};
+  double s = 0.0;
+  const int r0[2] = {J.s * H + blk[0] * 128 + lane * 2, J.s * H + blk[1] * 128 + lane * 2};
+  auto load = [&](d2 (&v)[8], int c, int b) {
+    // whole unit below the diagonal -> nothing to read (the product kernel skips it as well)
+    const bool any = (J.s * H + blk[b] * 128) <= c + 7 && r0[b] < L;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (any) v[k] = __builtin_nontemporal_load((const d2*)(A + (size_t)(c + k) * ld + r0[b]));
+      else v[k] = d2{0.0, 0.0};
+    }
+  };
+  d2 a0[8], a1[8];
+  load(a0, J.c0, 0);
+  int cb = J.c0;   // start of the current 256-column block
+#pragma unroll 1
+  for (int c = J.c0; c < J.c1; c += 8) {
+    load(a1, c, 1);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += a0[k].x + a0[k].y;
+    if (c + 8 < J.c1) load(a0, c + 8, 0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += a1[k].x + a1[k].y;
+    if (STORES) {
+      if ((lane & 7) == 0) { colpart[wave][0][(c - cb) + (lane >> 3)] = s; colpart[wave][1][(c - cb) + (lane >> 3)] = s; }
+      if (c + 8 - cb == 256 || c + 8 >= J.c1) {
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (cb + t < J.c1)
+          for (int a = 0; a < 2; ++a)
+            Y[((size_t)J.s * 2 + a) * ldp + cb + t] = (colpart[0][a][t] + colpart[1][a][t]) + (colpart[2][a][t] + colpart[3][a][t]);
+        __syncthreads();
+        cb = c + 8;
+      }
+    }
+  }
+  if (STORES) {
+    for (int b = 0; b < 2; ++b)
+      for (int a = 0; a < 2; ++a) {
+        double* q = Y + ((size_t)(CS + J.slot) * 2 + a) * ldp + r0[b];
+        q[0] = s; q[1] = s;
+      }
+  }
+  if (s == 1.23456789) out[0] = s;
+}
+
 __global__ void fill_rand(double* p, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     unsigned long long h = i * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
@@ -208,6 +269,56 @@ int main(int argc, char** argv) {
       snprintf(nm, 96, "super-tiles %dx%d of 256, nt, lds 40 KB, stores %d", SUPv, SUPv, (int)STv);                    \
       time(nm, [&] { hipLaunchKernelGGL((rd_super<SUPv, STv>), dim3(st), dim3(256), 40 * 1024, 0, p, ld, nts, out, Y, ldp); }, \
            8.0 * tl * T * T);                                                                                         \
+    }
+
+    for (int G : {256, 512, 768, 1024}) {
+      // equal-area partition of the upper triangle of order n into G jobs of strips of 1024 rows
+      const int H = 1024, ns = (n + H - 1) / H;
+      std::vector<StripJob> jobs;
+      const double total = 0.5 * (double)n * (n + 1);
+      auto strip_area = [&](int s_, int c) {   // elements of strip s_ in columns [s_ H, c)
+        double a = 0;
+        const int rb = s_ * H, re = (rb + H < n) ? rb + H : n;
+        const int x = c - rb;
+        const int hh = re - rb;
+        if (x <= 0) return 0.0;
+        if (x <= hh) return 0.5 * (double)x * (x + 1);
+        a = 0.5 * (double)hh * (hh + 1) + (double)(x - hh) * hh;
+        return a;
+      };
+      double maxa = 0, suma = 0;
+      for (int s_ = 0; s_ < ns; ++s_) {
+        const double as = strip_area(s_, n);
+        int np = (int)(as / (total / G) + 0.5);
+        if (np < 1) np = 1;
+        int cprev = s_ * H;
+        for (int p_ = 0; p_ < np; ++p_) {
+          int c1 = n;
+          if (p_ + 1 < np) {
+            const double want = as * (p_ + 1) / np;
+            int lo = cprev, hi = n;
+            while (hi - lo > 8) { const int mid = ((lo + hi) / 2) / 8 * 8; if (strip_area(s_, mid) < want) lo = mid; else hi = mid; }
+            c1 = hi / 8 * 8;
+          }
+          if (c1 > cprev) {
+            jobs.push_back({s_, cprev, c1, p_});
+            const double ja = strip_area(s_, c1) - strip_area(s_, cprev);
+            if (ja > maxa) maxa = ja;
+            suma += ja;
+          }
+          cprev = c1;
+        }
+      }
+      StripJob* dj; CK(hipMalloc(&dj, jobs.size() * sizeof(StripJob)));
+      CK(hipMemcpy(dj, jobs.data(), jobs.size() * sizeof(StripJob), hipMemcpyHostToDevice));
+      const int CS = ns;
+      double* Y2; CK(hipMalloc(&Y2, (size_t)(CS + 160) * 2 * ldp * 8));
+      char nm[128];
+      snprintf(nm, 128, "strip pieces H=1024, %d jobs (target %d), max/mean area %.3f, no stores", (int)jobs.size(), G, maxa / (suma / jobs.size()));
+      time(nm, [&] { hipLaunchKernelGGL((rd_strip<false>), dim3((unsigned)jobs.size()), dim3(256), 0, 0, p, ld, n, dj, out, Y2, ldp, CS); }, 8.0 * suma);
+      snprintf(nm, 128, "strip pieces H=1024, %d jobs (target %d), with partial-sum stores", (int)jobs.size(), G);
+      time(nm, [&] { hipLaunchKernelGGL((rd_strip<true>), dim3((unsigned)jobs.size()), dim3(256), 0, 0, p, ld, n, dj, out, Y2, ldp, CS); }, 8.0 * suma);
+      CK(hipFree(dj)); CK(hipFree(Y2));
     }
     if (argc > 5) { RUNSUP(1, false) RUNSUP(1, true) RUNSUP(2, false) RUNSUP(2, true) RUNSUP(4, false) RUNSUP(4, true) }
     {
