@@ -351,6 +351,7 @@ int eigx_tune(int key, int value) {
 int eigx_dgemm_dev(char opa, char opb, int m, int n, int k, double alpha, const double* a, int lda,
                    const double* b, int ldb, double beta, double* c, int ldc, int tri_upper) {
   if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  EIGX_HIP_CHECK(hipStreamSynchronize(nullptr));   // the caller's default-stream work on the operands
   dgemm_dev(g_ctx.stream, opa, opb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, tri_upper ? 1 : 0,
             &g_ctx.grid);
   EIGX_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
@@ -361,6 +362,7 @@ int eigx_dgemm_gather_dev(char opa, char opb, int m, int n, int k, double alpha,
                           const double* b, int ldb, double beta, double* c, int ldc, const int* kmap_a,
                           const int* kmap_b) {
   if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
+  EIGX_HIP_CHECK(hipStreamSynchronize(nullptr));
   dgemm_dev(g_ctx.stream, opa, opb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, 0, nullptr, kmap_a, nullptr, 1, 0,
             0, 0, 1, 0, 0, 0, 1, 0, kmap_b);
   EIGX_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));

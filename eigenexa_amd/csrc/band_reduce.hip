@@ -81,6 +81,7 @@ struct RedArgs {
   const double* MSG;              // my step window: message of source q, parity h at MSG + (h*P + q)*msg_stride
   int msg_stride;                 // doubles per message: NB*(nxs + nys) + 8
   const double* PAN; int ldpan;   // columns of the current panel gathered from their owners (global row order)
+  const double* zero16;           // 16 bytes of zeros: where the mat-vec's loads of rows beyond the active block go (see load8)
   int abl;                        // EIGX_STAMPS diagnostic build only: ablation mask (timing experiments)
   unsigned long long* dbg;        // EIGX_STAMPS diagnostic build only: accumulated s_memtime stamps
 };
@@ -1156,14 +1157,16 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
       }
     }
     {
+      // (unconditional loads: see load8 below)
       const int r0 = row0 + lane * 2;
       const bool rok = r0 < Lr;
-      const double* Ap = R.A + (rok ? r0 : 0);
+      const double* Ap = rok ? R.A + r0 : R.zero16;
+      const size_t cstride = rok ? (size_t)R.lda : 0;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = col0 + wcol0 + j;
-        if (rok && c < Lc) av0[j] = ld2<NTL>(Ap + (size_t)c * R.lda);
-        else av0[j] = make_double2(0.0, 0.0);
+        const int cc = (c < Lc) ? c : Lc - 1;
+        av0[j] = ld2<NTL>(Ap + (size_t)cc * cstride);
       }
     }
   }
@@ -1243,15 +1246,21 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   double yc[NV][8];
   double sp[3] = {0.0, 0.0, 0.0};
 
+  // Every load of a unit is issued UNCONDITIONALLY: a branch around a load makes the compiler lose count of what is in
+  // flight and wait for everything (s_waitcnt vmcnt(0)) at each use, i.e. the unit requested ahead would have to arrive
+  // before the current one is consumed.  Lanes whose rows lie beyond the active block read a page of zeros; columns beyond
+  // it re-read the last active column: those are genuine upper-triangle elements (finite), and they only ever meet a zero
+  // u (column >= Lc), a select by index (tiles on the diagonal), or sums that are not stored.
   auto load8 = [&](double2 (&av)[8], int g, int rb) {
     const int r0 = row0 + rb * 128 + lane * 2;
     const bool rok = r0 < Lr;
-    const double* Ap = R.A + (rok ? r0 : 0);
+    const double* Ap = rok ? R.A + r0 : R.zero16;      // (base and column stride per lane: no select at the loads)
+    const size_t cstride = rok ? (size_t)R.lda : 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = col0 + wcol0 + g * 8 + j;
-      if (rok && c < Lc) av[j] = ld2<NTL>(Ap + (size_t)c * R.lda);
-      else av[j] = make_double2(0.0, 0.0);
+      const int cc = (c < Lc) ? c : Lc - 1;
+      av[j] = ld2<NTL>(Ap + (size_t)cc * cstride);
     }
   };
   // one unit = (column group g, row block rb): accumulate; after the last row block reduce the 8 column sums
@@ -1286,8 +1295,9 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = gcol(col0 + tc0 + j);
-        const double ax_s = (g0 < c) ? av[j].x : 0.0, ay_s = (g1 < c) ? av[j].y : 0.0;     // strict upper
-        const double ax_d = (g0 <= c) ? av[j].x : 0.0, ay_d = (g1 <= c) ? av[j].y : 0.0;   // with diagonal
+        const bool cin = col0 + tc0 + j < Lc;   // (columns beyond the block were loaded from the last active column: drop them by index too)
+        const double ax_s = (cin && g0 < c) ? av[j].x : 0.0, ay_s = (cin && g1 < c) ? av[j].y : 0.0;     // strict upper
+        const double ax_d = (cin && g0 <= c) ? av[j].x : 0.0, ay_d = (cin && g1 <= c) ? av[j].y : 0.0;   // with diagonal
 #pragma unroll
         for (int a = 0; a < NV; ++a) {
           const double uc = ucs[a * T + tc0 + j];
@@ -1334,14 +1344,19 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
     }
   };
 
-  // software pipeline, two units in flight, all register indices static
+  // software pipeline, two units in flight, all register indices static.  The empty asm statements pin the order
+  // "request the next unit, THEN consume the current one": without them the scheduler sinks the (now branch-free)
+  // loads down to their first use to shorten live ranges, and nothing is in flight while a unit is consumed.
+#define EIGX_PIN asm volatile("" ::: "memory")
   {
     // av0 holds unit (g = 0, rb = 0), loaded at kernel entry
     if (RB == 1) {
       for (int g = 0; g < NG; g += 2) {
         load8(av1, g + 1, 0);
+        EIGX_PIN;
         compute8(av0, g, IC<0>());
-        if (g + 2 < NG) load8(av0, g + 2, 0);
+        load8(av0, (g + 2 < NG) ? g + 2 : g + 1, 0);   // (last pair: an unused re-read instead of a branch around loads)
+        EIGX_PIN;
         compute8(av1, g + 1, IC<0>());
       }
     } else if (RB == 2) {
@@ -1349,8 +1364,10 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
 #pragma unroll 1
       for (int g = 0; g < ng; ++g) {
         load8(av1, g, 1);
+        EIGX_PIN;
         compute8(av0, g, IC<0>());
-        if (g + 1 < ng) load8(av0, g + 1, 0);
+        load8(av0, (g + 1 < ng) ? g + 1 : g, 0);       // (last group: an unused re-read instead of a branch around loads)
+        EIGX_PIN;
         compute8(av1, g, IC<(RB > 1 ? 1 : 0)>());
       }
     } else {
@@ -1358,12 +1375,16 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
 #pragma unroll 1
       for (int g = 0; g < ng; ++g) {
         load8(av1, g, 1);
+        EIGX_PIN;
         compute8(av0, g, IC<0>());
         load8(av0, g, 2);
+        EIGX_PIN;
         compute8(av1, g, IC<(RB > 1 ? 1 : 0)>());
         load8(av1, g, 3);
+        EIGX_PIN;
         compute8(av0, g, IC<(RB > 2 ? 2 : 0)>());
-        if (g + 1 < ng) load8(av0, g + 1, 0);
+        load8(av0, (g + 1 < ng) ? g + 1 : g, 0);
+        EIGX_PIN;
         compute8(av1, g, IC<(RB > 3 ? 3 : 0)>());
       }
     }
@@ -1522,12 +1543,14 @@ __global__ __launch_bounds__(256) void symv_strip_kernel(RedArgs R, KSArgs B) {
   auto load8 = [&](double2 (&av)[8], int c, int b) {
     const int r0 = rowb[b] + lane * 2;
     // whole unit strictly below the diagonal (first row beyond its last column) or beyond the active rows: nothing to read
+    // (unconditional loads, as in the tile form: such units read the page of zeros instead of HBM)
     const bool any = rowb[b] <= c + 7 && r0 < L;
-    const double* Ap = R.A + (any ? r0 : 0);
+    const double* Ap = any ? R.A + r0 : R.zero16;
+    const size_t cstride = any ? (size_t)R.lda : 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      if (any && c + j < L) av[j] = ld2<NTL>(Ap + (size_t)(c + j) * R.lda);
-      else av[j] = make_double2(0.0, 0.0);
+      const int cc = (c + j < L) ? c + j : L - 1;
+      av[j] = ld2<NTL>(Ap + (size_t)cc * cstride);
     }
   };
   if (!panel_role) {
@@ -1605,8 +1628,9 @@ __global__ __launch_bounds__(256) void symv_strip_kernel(RedArgs R, KSArgs B) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int cc = c + j;
-        const double ax_s = (r0 < cc) ? av[j].x : 0.0, ay_s = (r1 < cc) ? av[j].y : 0.0;     // strict upper
-        const double ax_d = (r0 <= cc) ? av[j].x : 0.0, ay_d = (r1 <= cc) ? av[j].y : 0.0;   // with diagonal
+        const bool cin = cc < L;
+        const double ax_s = (cin && r0 < cc) ? av[j].x : 0.0, ay_s = (cin && r1 < cc) ? av[j].y : 0.0;     // strict upper
+        const double ax_d = (cin && r0 <= cc) ? av[j].x : 0.0, ay_d = (cin && r1 <= cc) ? av[j].y : 0.0;   // with diagonal
 #pragma unroll
         for (int a = 0; a < NV; ++a) {
           const double uc = ucs[a][cc - cb];
@@ -1661,18 +1685,20 @@ __global__ __launch_bounds__(256) void symv_strip_kernel(RedArgs R, KSArgs B) {
       const int c = cb + g * 8;
       if (HB == 2) {
         load8(av1, c, HB - 1);
+        EIGX_PIN;
         compute8(av0, c, cb, IC<0>());
-        if (c + 8 < c1) load8(av0, c + 8, 0);
+        load8(av0, (c + 8 < c1) ? c + 8 : c, 0);       // (job's last group: an unused re-read instead of a branch around loads)
+        EIGX_PIN;
         compute8(av1, c, cb, IC<HB - 1>());
       } else {
         // one row block per wave: groups in pairs (a block holds an even number of groups unless it is the job's last)
-        if (c + 8 < c1) load8(av1, c + 8, 0);
+        load8(av1, (c + 8 < c1) ? c + 8 : c, 0);
+        EIGX_PIN;
         compute8(av0, c, cb, IC<0>());
         ++g;
-        if (g < ng) {
-          if (c + 16 < c1) load8(av0, c + 16, 0);
-          compute8(av1, c + 8, cb, IC<0>());
-        }
+        load8(av0, (c + 16 < c1) ? c + 16 : c, 0);
+        EIGX_PIN;
+        if (g < ng) compute8(av1, c + 8, cb, IC<0>());
       }
     }
     __syncthreads();
@@ -1809,7 +1835,8 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   const int maxgp = (n + KA_ROWS - 1) / KA_ROWS + 2;
   R.gp2_off = 0;
   R.GP = ctx.pool.get_t<double>("red.GP", (size_t)maxgp * 3 + 8);
-  R.sc = ctx.pool.get_t<double>("red.sc", SC_COUNT);
+  R.sc = ctx.pool.get_t<double>("red.sc", SC_COUNT + 8);
+  R.zero16 = R.sc + SC_COUNT;             // zero-filled below with the scalars, never written afterwards
   R.dbg = nullptr;
   R.abl = getenv("EIGX_ABL") ? atoi(getenv("EIGX_ABL")) : 0;
 #ifdef EIGX_STAMPS
@@ -1857,7 +1884,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   };
   hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, st, R.UW, (size_t)ldp * m * 3, 0.0);
   hipLaunchKernelGGL(fill_kernel, dim3(8), dim3(256), 0, st, e, (size_t)lde * NB, 0.0);
-  hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, R.sc, (size_t)SC_COUNT, 0.0);
+  hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, R.sc, (size_t)SC_COUNT + 8, 0.0);
   hipLaunchKernelGGL(fill_kernel, dim3(16), dim3(256), 0, st, R.SP, sp_count, 0.0);
 
   const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();

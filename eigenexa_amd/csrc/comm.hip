@@ -98,6 +98,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 // ---- bootstrap board: a few hundred bytes of POSIX shared memory, one slot per rank ------------------------
 struct Board {
   std::atomic<uint32_t> attached;
+  std::atomic<uint32_t> abort_flag;   // set by a rank whose communicator failed: every board round ends at once, everywhere
   std::atomic<uint64_t> seq_written[EIGX_MAXP];
   std::atomic<uint64_t> seq_read[EIGX_MAXP];
   unsigned char slot[EIGX_MAXP][128];
@@ -142,6 +143,7 @@ struct CommState {
   bool rccl = false;           // the BULK collectives go through RCCL (otherwise through the peer windows)
   bool step_coll = false;      // the per-step exchange is a collective allgather (RCCL / emulated), not peer writes
   bool err_in_flags = false;   // err_dev is a word of the peer-mapped flag block
+  bool in_selftest = false;    // init-time self-test: failures stay local (the verdict is voted on), device waits are short
   // init-time transport self-test (recorded for eigx_comm_info)
   int st_ipc_rounds = 0, st_ipc_errors = -1, st_step_rounds = 0, st_step_errors = -1, st_rccl_checks = 0, st_rccl_errors = -1;
   double st_ipc_us = 0.0, st_step_us = 0.0, st_rccl_us = 0.0;
@@ -165,10 +167,11 @@ void comm_fail(CommState* cs, const char* what) {
   if (!cs->failed) fprintf(stderr, "[eigx] rank %d: communication failure: %s\n", cs->me, what);
   const bool first = !cs->failed;
   cs->failed = true;
+  if (cs->board && !cs->in_selftest) cs->board->abort_flag.store(1u, std::memory_order_release);   // host side: peers waiting in a board round leave
   const int one = 1;
   if (cs->err_dev) { if (hipMemcpy(cs->err_dev, &one, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) (void)hipGetLastError(); }
   // ... and the peers: their device-side waits poll their own failure word, which sits in the peer-mapped flag block
-  if (first && cs->err_in_flags && cs->flags.mapped) {
+  if (first && cs->err_in_flags && cs->flags.mapped && !cs->in_selftest) {
     for (int q = 0; q < cs->P; ++q) {
       if (q == cs->me || !cs->flags.peer[q]) continue;
       if (hipMemcpy((unsigned long long*)cs->flags.peer[q] + kFlagWords, &one, sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
@@ -193,7 +196,12 @@ bool board_exchange(CommState* cs, const void* mine, size_t len, unsigned char (
   if (!b || cs->board_dead) return false;
   const uint64_t seq = ++cs->board_seq;
   const double t0 = now_s();
-  auto timed_out = [&]() { if (now_s() - t0 > cs->timeout_s) { cs->board_dead = true; return true; } return false; };
+  // a round ends without result when it runs out of time or when any rank has reported a failure
+  auto timed_out = [&]() {
+    if (now_s() - t0 > cs->timeout_s || b->abort_flag.load(std::memory_order_acquire) != 0) { cs->board_dead = true; return true; }
+    return false;
+  };
+  if (timed_out()) return false;
   for (int q = 0; q < cs->P; ++q)
     while (b->seq_read[q].load(std::memory_order_acquire) + 1 < seq) {
       if (timed_out()) return false;
@@ -411,7 +419,10 @@ __global__ __launch_bounds__(256) void st_step_push_kernel(StStepArgs A) {
 
 long long g_comm_bounce = (long long)32 << 20;   // doubles per slice of comm_exchange_big's bounce window (eigx_tune key 9)
 
-long long limit_ticks(const CommState* cs) { return (long long)(cs->timeout_s * 1e8); }   // wall_clock64: 100 MHz
+long long limit_ticks(const CommState* cs) {   // wall_clock64: 100 MHz
+  const double t = (cs->in_selftest && cs->timeout_s > 10.0) ? 10.0 : cs->timeout_s;
+  return (long long)(t * 1e8);
+}
 
 void* pick(const CommState* cs, CommGroup grp) { return grp == COMM_X ? cs->x : grp == COMM_Y ? cs->y : cs->world; }
 
@@ -426,6 +437,10 @@ void rccl_time_end(CommState* cs, hipStream_t s) {
 }
 
 }  // namespace
+
+void comm_report_failure(Context& ctx, const char* what) {
+  if (ctx.comm) comm_fail(ctx.comm, what);
+}
 
 int comm_group(const Context& ctx, CommGroup grp, int* members, int* my_index) {
   const Grid& g = ctx.grid;
@@ -666,6 +681,7 @@ int comm_init(Context& ctx, const void* uid) {
     return h[which];
   };
   bool ipc_good = false;
+  cs->in_selftest = true;
   if (cs->ipc) {
     int my_ok = 1;
     // (1) bulk protocol: ready handshake + push kernel + flag + wait kernel, world all-gather, every round checked
@@ -754,6 +770,7 @@ int comm_init(Context& ctx, const void* uid) {
   (void)hipFree(errs);
   (void)hipFree(sendb);
   (void)hipStreamDestroy(ts);
+  cs->in_selftest = false;
   cs->ipc = ipc_good;
   cs->rccl_ok = rccl_good;
 

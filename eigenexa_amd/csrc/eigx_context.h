@@ -10,6 +10,11 @@ namespace eigx {
 
 // Workspace cache: named device buffers that persist between solves (hipMalloc of multi-GB buffers
 // costs milliseconds; the reference allocates per call on the host where that is free).
+// Thrown by the workspace pool when the device is out of memory; caught at the C-ABI boundary (eigx_guard), which
+// tells the other ranks (their bounded waits return at once instead of running out their time limit) and returns
+// EIGX_ERR_NO_MEMORY.  The reference aborts the whole job here (eigen_abort -> MPI_Abort, src/eigen_devel.F:148-164).
+struct DeviceAllocError { size_t bytes; std::string name; };
+
 struct Pool {
   struct Buf { void* p = nullptr; size_t bytes = 0; };
   std::map<std::string, Buf> bufs;
@@ -18,8 +23,15 @@ struct Pool {
     if (b.bytes < bytes) {
       if (b.p) EIGX_HIP_CHECK(hipFree(b.p));
       b.p = nullptr;
+      b.bytes = 0;
       size_t want = bytes + bytes / 16 + 256;
-      EIGX_HIP_CHECK(hipMalloc(&b.p, want));
+      // EIGX_TEST_FAIL_ALLOC=<buffer name>: this allocation fails (tests of the failure path)
+      static const char* fail_name = getenv("EIGX_TEST_FAIL_ALLOC");
+      if ((fail_name && name == fail_name) || hipMalloc(&b.p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        b.p = nullptr;
+        throw DeviceAllocError{want, name};
+      }
       b.bytes = want;
     }
     return b.p;
@@ -94,6 +106,21 @@ struct Context {
 };
 
 extern Context g_ctx;
+
+void comm_report_failure(Context& ctx, const char* what);   // comm.hip: sets this rank's and every peer's sticky failure word (P > 1)
+
+// C-ABI boundary guard of the solver entry points: a failed workspace allocation becomes an error code
+template <class F>
+int eigx_guard(Context& ctx, F&& f) {
+  try {
+    return f();
+  } catch (const DeviceAllocError& e) {
+    fprintf(stderr, "[eigx] out of device memory: workspace '%s' needs %zu bytes\n", e.name.c_str(), e.bytes);
+    comm_report_failure(ctx, "out of device memory on this rank");
+    if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+    return -8;   // EIGX_ERR_NO_MEMORY
+  }
+}
 
 // comm.hip
 int comm_get_unique_id(void* out128);

@@ -634,6 +634,7 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
   if (m > HM) m = HM;
   if (m > n) m = n;
   EIGX_HIP_CHECK(hipSetDevice(ctx.device));
+  EIGX_HIP_CHECK(hipStreamSynchronize(nullptr));   // the caller's default-stream work on the arguments (see solve_dev)
   hipStream_t st = ctx.stream;
   ctx.errinfo = 0;
   for (int q = 0; q < 16; ++q) ctx.timers[q] = 0.0;
@@ -943,10 +944,10 @@ using namespace eigx;
 extern "C" {
 
 int eigx_h(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb, char mode) {
-  return herm_solve_host(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode);
+  return eigx_guard(g_ctx, [&] { return herm_solve_host(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode); });
 }
 int eigx_h_dev(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb, char mode) {
-  return herm_solve_dev(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode);
+  return eigx_guard(g_ctx, [&] { return herm_solve_dev(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode); });
 }
 
 }

@@ -262,6 +262,11 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   if (mf <= 0) mf = 128;
   if (mb <= 0) mb = 128;
   EIGX_HIP_CHECK(hipSetDevice(ctx.device));
+  // The library works on its own non-blocking streams: whatever the caller queued on the default stream to fill a
+  // (a copy, a generator kernel) has to be complete before the first kernel here reads it.  (Found by a test that
+  // filled `a` with an asynchronous copy and called the C-ABI directly: the second solve of a process -- workspace
+  // already allocated, nothing else in the way -- overtook the copy.)
+  EIGX_HIP_CHECK(hipStreamSynchronize(nullptr));
   hipStream_t st = ctx.stream;
   ctx.errinfo = 0;
   ctx.dc_zero_n = 0;
@@ -484,6 +489,7 @@ int gev_dev(Context& ctx, int n, double* a, int lda, double* b, int ldb, double*
   if (ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;
   if (n <= 0 || !a || !b || !w || !z || lda < n || ldb < n || ldz < n || ((lda | ldb | ldz) & 1)) return EIGX_ERR_BAD_ARG;
   EIGX_HIP_CHECK(hipSetDevice(ctx.device));
+  EIGX_HIP_CHECK(hipStreamSynchronize(nullptr));
   hipStream_t st = ctx.stream;
   const double t0 = now_s();
   hipLaunchKernelGGL(symmetrize_kernel, dim3(8, n), dim3(256), 0, st, a, lda, n);
@@ -579,27 +585,27 @@ using namespace eigx;
 extern "C" {
 
 int eigx_sx(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb, char mode) {
-  return solve_host(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 2, 1);
+  return eigx_guard(g_ctx, [&] { return solve_host(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 2, 1); });
 }
 int eigx_s(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb, char mode) {
-  return solve_host(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 1, 1);
+  return eigx_guard(g_ctx, [&] { return solve_host(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 1, 1); });
 }
 int eigx_sx_dev(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb, char mode) {
-  return solve_dev(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 2, 1);
+  return eigx_guard(g_ctx, [&] { return solve_dev(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 2, 1); });
 }
 int eigx_s_dev(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb, char mode) {
-  return solve_dev(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 1, 1);
+  return eigx_guard(g_ctx, [&] { return solve_dev(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 1, 1); });
 }
 // block-cyclic (ScaLAPACK descriptor MB = NB = nb) local blocks in and out; route 2 = eigen_sx, 1 = eigen_s
 int eigx_solve_bc(int route, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int nb, int mf, int mb,
                   char mode) {
   if (route != 1 && route != 2) return EIGX_ERR_BAD_ARG;
-  return solve_host(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, route, nb);
+  return eigx_guard(g_ctx, [&] { return solve_host(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, route, nb); });
 }
 int eigx_solve_bc_dev(int route, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int nb, int mf,
                       int mb, char mode) {
   if (route != 1 && route != 2) return EIGX_ERR_BAD_ARG;
-  return solve_dev(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, route, nb);
+  return eigx_guard(g_ctx, [&] { return solve_dev(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, route, nb); });
 }
 int eigx_numroc(int n, int nb, int iproc, int nprocs) {
   if (n < 0 || nb < 1 || nprocs < 1 || iproc < 0 || iproc >= nprocs) return -1;
@@ -610,6 +616,7 @@ int eigx_band_reduce_dev(int n, double* a, int lda, double* d, double* e, int ld
   if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
   if (n <= 0 || lda < n || (lda & 1) || lde < n || (band != 1 && band != 2)) return EIGX_ERR_BAD_ARG;
   if (g_ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;
+  EIGX_HIP_CHECK(hipStreamSynchronize(nullptr));   // the caller's default-stream work on the arguments (see solve_dev)
   band_reduce_dev(g_ctx, n, a, lda, d, e, lde, mf > 0 ? mf : 128, band);
   EIGX_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
   return EIGX_OK;
@@ -621,20 +628,22 @@ int eigx_band_dc_dev(int n, int nvec, const double* d, const double* e, int lde,
   if (n <= 0 || nvec < 0 || nvec > n || lde < n || (band != 1 && band != 2) || (nvec > 0 && ldz < n))
     return EIGX_ERR_BAD_ARG;
   if (g_ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;
+  EIGX_HIP_CHECK(hipStreamSynchronize(nullptr));
   band_dc_dev(g_ctx, n, nvec, d, e, lde, band, w, z, ldz);
   return EIGX_OK;
 }
 
 int eigx_gev(int n, double* a, int lda, double* b, int ldb, double* w, double* z, int ldz) {
-  return gev_host(g_ctx, n, a, lda, b, ldb, w, z, ldz);
+  return eigx_guard(g_ctx, [&] { return gev_host(g_ctx, n, a, lda, b, ldb, w, z, ldz); });
 }
 int eigx_gev_dev(int n, double* a, int lda, double* b, int ldb, double* w, double* z, int ldz) {
-  return gev_dev(g_ctx, n, a, lda, b, ldb, w, z, ldz);
+  return eigx_guard(g_ctx, [&] { return gev_dev(g_ctx, n, a, lda, b, ldb, w, z, ldz); });
 }
 
 int eigx_band_bisect_dev(int n, const double* d, const double* e, int lde, int band, double* w) {
   if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
   if (n <= 0 || lde < n || (band != 1 && band != 2) || !d || !e || !w) return EIGX_ERR_BAD_ARG;
+  EIGX_HIP_CHECK(hipStreamSynchronize(nullptr));
   band_bisect_dev(g_ctx, n, d, e, lde, band, w);
   return EIGX_OK;
 }
@@ -644,6 +653,7 @@ int eigx_trbak_dev(int n, int nvec, const double* a, int lda, double* z, int ldz
   if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
   if (n <= 0 || nvec < 0 || lda < n || ldz < n || lde < n || (band != 1 && band != 2)) return EIGX_ERR_BAD_ARG;
   if (g_ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;
+  EIGX_HIP_CHECK(hipStreamSynchronize(nullptr));
   trbak_dev(g_ctx, n, nvec, const_cast<double*>(a), lda, z, ldz, e, lde, mb > 0 ? mb : 128, band);
   EIGX_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
   return EIGX_OK;

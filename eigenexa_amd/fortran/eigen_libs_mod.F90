@@ -177,7 +177,7 @@ contains
     integer, intent(in), optional :: comm
     character(*), intent(in), optional :: order
     character(kind=c_char) :: ord, uid(128)
-    integer :: rc, rank, nranks, ierr, dev, lcomm, topo, ndims, dims(2), coords(2), ndev, lrank, ncomm
+    integer :: rc, rank, nranks, ierr, dev, lcomm, topo, ndims, dims(2), coords(2), ndev, lrank, ncomm, nlocal
     integer :: p, xp, yp, id, xi, yi
     logical :: periods(2)
     ord = 'C'
@@ -199,7 +199,16 @@ contains
       ! number the GPUs), modulo the visible devices (ranks may share a card); ROCR_VISIBLE_DEVICES remaps further
       call MPI_Comm_split_type(lcomm, MPI_COMM_TYPE_SHARED, rank, MPI_INFO_NULL, ncomm, ierr)
       call MPI_Comm_rank(ncomm, lrank, ierr)
+      call MPI_Comm_size(ncomm, nlocal, ierr)
       call MPI_Comm_free(ncomm, ierr)
+      ! The library serves the ranks of ONE node (at most 8, one xGMI domain: its ranks meet on a shared-memory board and
+      ! map each other's windows).  A communicator that spans nodes -- which the reference supports -- is refused at
+      ! once with the reference's fatal-error policy (MPI_Abort, src/eigen_libs0.F:392-404), not after a bootstrap time-out.
+      if (nlocal /= nranks .or. nranks > 8) then
+        if (rank == 0) print *, "eigen_init: this build serves up to 8 ranks of one node; the communicator has ", nranks, &
+                                " ranks, ", nlocal, " of them on this node"
+        call MPI_Abort(lcomm, 1, ierr)
+      end if
       ndev = eigx_get_device_count()
       dev = 0
       if (ndev > 0) dev = mod(lrank, ndev)

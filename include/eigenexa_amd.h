@@ -41,6 +41,7 @@ extern "C" {
 #define EIGX_ERR_NONFINITE (-5)
 #define EIGX_ERR_INTERNAL (-6)
 #define EIGX_ERR_NOT_SPD (-7)
+#define EIGX_ERR_NO_MEMORY (-8)   /* a workspace allocation failed; on several ranks the others return EIGX_ERR_INTERNAL at once */
 
 /* ---- life cycle -------------------------------------------------------------------------- */
 
@@ -145,6 +146,9 @@ int eigx_s(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, i
 /* Same solvers on device-resident arrays (a_dev, w_dev, z_dev are HBM pointers of this rank's GPU).  lda >= the local
  * row count (any parity: an odd lda or a base that is not 16-byte aligned is served from an internal padded copy); like
  * the reference `a` is destroyed, and its padding rows (local rows beyond the matrix, up to lda) are scratch as well. */
+/* Device entry points synchronise the (legacy) default stream on entry, so whatever the caller queued there to fill
+ * the arguments is complete; a caller that fills them on another stream synchronises that stream itself.  They return
+ * after the result is complete. */
 int eigx_sx_dev(int n, int nvec, double* a_dev, int lda, double* w_dev, double* z_dev, int ldz,
                 int m_forward, int m_backward, char mode);
 int eigx_s_dev(int n, int nvec, double* a_dev, int lda, double* w_dev, double* z_dev, int ldz,

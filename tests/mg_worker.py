@@ -40,6 +40,8 @@ if route == "initfail":
     dist.destroy_process_group()
     print(f"OK rank {rank}/{world} init failure agreed on", flush=True)
     sys.exit(0)
+if route == "allocfail" and rank == 1:
+    os.environ["EIGX_TEST_FAIL_ALLOC"] = "red.UW"      # this rank's first panel allocation fails
 ee.eigen_init(comm=True, device=0, dims=dims)
 info = ee.eigen_comm_info()
 assert info["ranks"] == world and info["selftest"]["ipc_errors"] == 0 and info["selftest"]["step_errors"] == 0, info
@@ -47,6 +49,33 @@ if os.environ.get("EIGX_EXPECT_STEP"):
     assert info["step_exchange"].startswith(os.environ["EIGX_EXPECT_STEP"]), info
 for kv in filter(None, os.environ.get("EIGX_TEST_TUNE", "").split(",")):   # e.g. "7=4": K_A's row-group loop at small sizes
     api._lib.load().eigx_tune(int(kv.split("=")[0]), int(kv.split("=")[1]))
+if route == "allocfail":
+    # one rank runs out of device memory inside the solver: it returns EIGX_ERR_NO_MEMORY, sets the failure word of every
+    # peer, and the peers -- waiting for its step messages -- return EIGX_ERR_INTERNAL at once instead of after the
+    # 60 s bound of their waits (the reference aborts the job here: eigen_abort, src/eigen_devel.F:148-164)
+    import time
+
+    procs, xp, yp = ee.eigen_get_procs()
+    _, xi, yi = ee.eigen_get_id()
+    rows = np.arange(xi - 1, n, xp)
+    cols = np.arange(yi - 1, n, yp)
+    nx, ny = ee.eigen_get_matdims(n)
+    a = np.zeros((nx, ny), order="F")
+    a[: len(rows), : len(cols)] = layout.random_symmetric(n)[np.ix_(rows, cols)]
+    z = np.zeros((nx, ny), order="F")
+    w = np.zeros(n)
+    t0 = time.time()
+    ee.eigen_sx(n, n, a, nx, w, z, nx, m_forward=32)
+    dt = time.time() - t0
+    assert api.last_status() == (-8 if rank == 1 else -6), api.last_status()
+    assert dt < 25.0, dt
+    t0 = time.time()
+    ee.eigen_free()
+    assert time.time() - t0 < 25.0
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"OK rank {rank}/{world} allocation failure reported in {dt:.1f} s", flush=True)
+    sys.exit(0)
 procs, xp, yp = ee.eigen_get_procs()
 idn, xi, yi = ee.eigen_get_id()
 assert (xp, yp) == (dims or layout.grid_shape(world)) and idn == rank + 1

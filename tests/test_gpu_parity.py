@@ -512,6 +512,7 @@ def test_strip_form_full_solve(gpu_lib, route):
         z = torch.zeros(n, n + 34, dtype=torch.float64, device=_dev())
         w = torch.zeros(n, dtype=torch.float64, device=_dev())
         fn = gpu_lib.eigx_sx_dev if route == "sx" else gpu_lib.eigx_s_dev
+        # (no torch.cuda.synchronize() here on purpose: the device entry points wait for the default stream themselves)
         assert fn(n, n, a.data_ptr(), n + 34, w.data_ptr(), z.data_ptr(), n + 34, 128, 128, b"A") == 0
     finally:
         for key, v in zip((11, 12, 13), old):
@@ -588,6 +589,13 @@ def test_multi_rank_no_transport_fails_on_every_rank():
     every rank at once (agreed on through the bootstrap board), nothing stays behind, a 1-rank init still works;
     bench.py turns exactly this into its replica fallback"""
     _run_multi_rank(3, 64, "initfail", 0, "", {"EIGX_SELFTEST_FAIL": "ipc"})
+
+
+def test_multi_rank_allocation_failure_reaches_the_peers():
+    """one rank's workspace allocation fails inside the solver: that rank returns EIGX_ERR_NO_MEMORY, the others
+    EIGX_ERR_INTERNAL within seconds (their waits poll the failure word that the failing rank sets on every peer), and
+    eigen_free does not wait for lost peers"""
+    _run_multi_rank(3, 400, "allocfail", 0, "")
 
 
 def _run_bench(args, env_extra):
