@@ -342,9 +342,7 @@ int eigx_tune(int key, int value) {
   if (key == 8) return set_dc_chunk(value);
   if (key == 9) return comm_set_bounce(value);
   if (key == 10) return set_symv_threshold(4, value);
-  if (key == 11) return set_symv_threshold(5, value);   // strip form of the mat-vec above this active size
-  if (key == 12) return value > 0 ? set_symv_threshold(6, value) : -1;   // ... its jobs per launch
-  if (key == 13) return set_symv_threshold(7, value);   // ... strips of 1024 rows from this size on (512 below)
+  if (key == 11) return set_symv_threshold(5, value);   // branch-free pipelined form of the mat-vec up to this active size
   return -1;
 }
 

@@ -107,9 +107,7 @@ int g_ka_fit = 1;     // K_A (eigx_tune key 10): 1 = load batches matched to the
 int g_ka_wgs = 256;   // K_A (eigx_tune key 7): beyond 2 * this many row groups a workgroup takes several of them, ~this many workgroups
 int g_symv_t128 = 4500, g_symv_t256 = 40000;
 int g_symv_nt = 9000;
-// strip form of the mat-vec (symv_strip_kernel, one GPU): active sizes above g_symv_strip; g_strip_jobs = jobs per launch
-// (<= resident workgroups: 2 per CU); strips of 1024 rows from g_strip_h1024 on, 512 below (eigx_tune keys 11, 12, 13)
-int g_symv_strip = 14000, g_strip_jobs = 512, g_strip_h1024 = 24000;
+int g_symv_unc = 9000;   // the fused mat-vec's branch-free pipelined form up to this active size (eigx_tune key 11)
 
 inline SymvGeom symv_geom(int L) {
   SymvGeom g;
@@ -215,9 +213,6 @@ struct KAArgs {
   StepWait wait;          // multi-GPU: wait for the step messages here instead of in a wait kernel (wait.n = 0: no)
   int G;                  // row groups (of KA_ROWS rows) per workgroup: the scalar work of a workgroup is done once, then
                           // its G row groups follow in a loop (the next group's loads in flight behind the current one)
-  // previous mat-vec in strip form (symv_strip_kernel): strip height 1 << lgH, its jobs, pieces per strip
-  int lgH, njobs_prev;
-  unsigned char npc[64];
 };
 
 // multi-GPU: partial number t (0 <= t < Py + Px) of global row r in the step messages of parity `par`:
@@ -233,9 +228,7 @@ __device__ __forceinline__ const double* mg_partial(const RedArgs& R, int par, i
   return R.MSG + ((size_t)par * R.P + src) * R.msg_stride + off;
 }
 
-// STRIP: the previous step's mat-vec ran in strip form: partial sums of row r sit in the column-sum slots 0 .. r >> lgH and
-// in the row-sum slots KS_MAXSTRIPS .. KS_MAXSTRIPS + npc[r >> lgH] - 1 of the unified array; one bilinear entry per job
-template <int NB, bool MG, bool LG, int RPBT, int SPBT, int KBT, bool STRIP = false>
+template <int NB, bool MG, bool LG, int RPBT, int SPBT, int KBT>
 __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   __shared__ double red[64];
   __shared__ double kd[4][256];        // reduced panel-dot vectors: [UuA, WuA, UuB, WuB][kk]  (m <= 256)
@@ -253,11 +246,6 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   const int kp = hp ? S.kprev : 0;
   const int kloop = hp ? S.kprev : S.k;
   const int kold = hp ? S.kprev : S.k;  // panel slots that are final in memory
-  // strip form: is slot t a partial sum of row r ?
-  auto slot_ok = [&](int t, int r_) {
-    const int st = r_ >> S.lgH;
-    return t <= st || (t >= 64 && t - 64 < (int)S.npc[st < 63 ? st : 63]);
-  };
   // The workgroup owns the row groups blockIdx.x * G + g, g = 0 .. G-1 (KA_ROWS rows each).  Everything that does not
   // depend on the row -- ~85 % of the kernel's instructions: the re-reduction of the tile / panel partial sums, the 2x2
   // algebra, the LDS tables -- is done ONCE per workgroup; with one row group per workgroup the chip ran that overhead
@@ -363,7 +351,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       const unsigned voff = (unsigned)ks * (unsigned)(NB * ldp) + (unsigned)(okp ? rg : 0);
 #pragma unroll
       for (int j = 0; j < RPB; ++j) {
-        const int jb = (STRIP || j * KA_SL < nt + 1) ? j * KA_SL : 0;        // uniform; unused batches re-read batch 0
+        const int jb = (j * KA_SL < nt + 1) ? j * KA_SL : 0;        // uniform; unused batches re-read batch 0
         const double* by = R.YC + (size_t)jb * NB * ldp;
         Q.ta[j] = by[voff];
         Q.tb[j] = by[voff + (NB == 2 ? (unsigned)ldp : 0u)];
@@ -388,7 +376,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
     if (!(hp && ks == 0 && ok)) { Q.uA = 0.0; Q.uB = 0.0; }
     if (NB == 1) Q.uB = 0.0;
 #pragma unroll
-    for (int j = 0; j < RPB; ++j) { if (!hp || (!mg && !STRIP && !(j * KA_SL < nt + 1)) || (mg && j > 0)) { Q.ta[j] = 0.0; Q.tb[j] = 0.0; } }
+    for (int j = 0; j < RPB; ++j) { if (!hp || (!mg && !(j * KA_SL < nt + 1)) || (mg && j > 0)) { Q.ta[j] = 0.0; Q.tb[j] = 0.0; } }
   };
   load_rows(r, cur);
   {
@@ -415,18 +403,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   // bilinear partials of the SYMV tiles, SP[ty][tx] with the fixed row stride maxseg, tx >= ty only.
   // Folded rows: row f (nt - f tiles) and row nt-1-f (f + 1 tiles) together fill nt + 1 <= 64 lanes;
   // wave w takes the folded rows f = w, w + 4, ...
-  if (!mg && STRIP) {   // (compile-time)  one entry per job of the strip-form mat-vec
-#pragma unroll
-    for (int j = 0; j < SPB; ++j) {
-      const int e = tid + 256 * j;
-      const bool ok = hp && j < 2 && e < S.njobs_prev;
-      const double* sp = R.SP + (size_t)(ok ? e : 0) * 3;
-      spr[j][0] = sp[0];
-      spr[j][1] = sp[NB == 2 ? 1 : 0];
-      spr[j][2] = sp[NB == 2 ? 2 : 0];
-      spok |= ok ? (1u << j) : 0u;
-    }
-  } else if (!mg) {   // (compile-time)
+  if (!mg) {   // (compile-time)
 #pragma unroll
     for (int j = 0; j < SPB; ++j) {
       const int f = wave + 4 * j;
@@ -455,7 +432,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   for (int cc = 0; cc < 2; ++cc) {
     const int c = (S.i - cc > 0) ? S.i - cc : 0;
     if (!mg) {   // (compile-time)
-      const unsigned t = (STRIP ? tid < 160 : tid < nt + 1) ? (unsigned)tid : 0u;
+      const unsigned t = (tid < nt + 1) ? (unsigned)tid : 0u;
       const double* bc = R.YC + c;                                  // uniform
       pcl[cc][0] = bc[t * (unsigned)(NB * ldp)];
       pcl[cc][1] = bc[t * (unsigned)(NB * ldp) + (NB == 2 ? (unsigned)ldp : 0u)];
@@ -514,7 +491,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
         v[0] += spl[j][0];
         if (NB == 2) { v[1] += spl[j][1]; v[2] += spl[j][2]; }
       }
-      if (!STRIP && nt > 8 * SPB - 1) {   // more tiles than the folded batch covers: plain sweep of the upper tile triangle
+      if (nt > 8 * SPB - 1) {   // more tiles than the folded batch covers: plain sweep of the upper tile triangle
         for (int ty = wave; ty < nt; ty += 4)
           for (int tx = ty + lane; tx < nt; tx += 64) {
             const double* sp = R.SP + ((size_t)ty * R.maxseg + tx) * 3;
@@ -525,11 +502,11 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
         if (cc < S.ncols) {
-          const bool ok = STRIP ? (tid < 160 && slot_ok(tid, S.i - cc > 0 ? S.i - cc : 0)) : tid < nt + 1;
+          const bool ok = tid < nt + 1;
           v[7 + 2 * cc] += ok ? pcl[cc][0] : 0.0;
           if (NB == 2) v[8 + 2 * cc] += ok ? pcl[cc][1] : 0.0;
           const int c = S.i - cc, ty = c >> lgT;
-          for (int t = tid + 256; !STRIP && t < nt + 1; t += 256) {
+          for (int t = tid + 256; t < nt + 1; t += 256) {
             const double* base = (t <= ty) ? R.YC + (size_t)t * NB * ldp : R.YR + (size_t)(t - 1) * NB * ldp;
             v[7 + 2 * cc] += base[c];
             if (NB == 2) v[8 + 2 * cc] += base[ldp + c];
@@ -629,11 +606,11 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
         } else {
 #pragma unroll
           for (int j = 0; j < RPB; ++j) {
-            const bool ok = okp && (STRIP ? slot_ok(ks + j * KA_SL, rg) : (ks + j * KA_SL < nt + 1));
+            const bool ok = okp && (ks + j * KA_SL < nt + 1);
             prA += ok ? cur.ta[j] : 0.0;
             if (NB == 2) prB += ok ? cur.tb[j] : 0.0;
           }
-          if (okp && !STRIP) {   // more than RPB * KA_SL = 160 partials per row: not reached by symv_geom below N ~ 80000
+          if (okp) {   // more than RPB * KA_SL = 160 partials per row: not reached by symv_geom below N ~ 80000
             for (int t = ks + RPB * KA_SL; t < nt + 1; t += KA_SL) {
               const double* base = R.YC + (size_t)t * NB * ldp;
               prA += base[rg];
@@ -1045,7 +1022,12 @@ __device__ __forceinline__ void kp_role(const RedArgs& R, const HouseScalars& hs
 
 template <int K> struct IC { static constexpr int value = K; };
 
-template <int NV, int RB, bool NTL, bool MG>
+// UNC: branch-free loads + pinned order (true two-unit pipeline, counted waits); false: the loads of a unit sit behind
+// wave-uniform branches and every use waits for everything in flight.  The first form wins where the launch is latency-bound
+// (N = 8192: reduction 133.3 -> 131.0 ms), the second where it is bandwidth-bound (N = 32768, same box, alternating
+// processes: 4751 ms against 5326 ms with the pipeline -- more requests in flight per CU than the memory system likes);
+// the launch picks by active size (g_symv_unc, eigx_tune key 14).
+template <int NV, int RB, bool NTL, bool MG, bool UNC>
 __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   constexpr int T = 128 * RB;
   // NTL: non-temporal A loads, chosen by the launch for triangles far beyond L2 + Infinity Cache (g_symv_nt)
@@ -1160,13 +1142,18 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
       // (unconditional loads: see load8 below)
       const int r0 = row0 + lane * 2;
       const bool rok = r0 < Lr;
-      const double* Ap = rok ? R.A + r0 : R.zero16;
-      const size_t cstride = rok ? (size_t)R.lda : 0;
+      const double* Ap = (rok || !UNC) ? R.A + (rok ? r0 : 0) : R.zero16;
+      const size_t cstride = (rok || !UNC) ? (size_t)R.lda : 0;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = col0 + wcol0 + j;
-        const int cc = (c < Lc) ? c : Lc - 1;
-        av0[j] = ld2<NTL>(Ap + (size_t)cc * cstride);
+        if (UNC) {
+          const int cc = (c < Lc) ? c : Lc - 1;
+          av0[j] = ld2<NTL>(Ap + (size_t)cc * cstride);
+        } else {
+          if (rok && c < Lc) av0[j] = ld2<NTL>(Ap + (size_t)c * R.lda);
+          else av0[j] = make_double2(0.0, 0.0);
+        }
       }
     }
   }
@@ -1254,14 +1241,24 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   auto load8 = [&](double2 (&av)[8], int g, int rb) {
     const int r0 = row0 + rb * 128 + lane * 2;
     const bool rok = r0 < Lr;
-    const double* Ap = rok ? R.A + r0 : R.zero16;      // (base and column stride per lane: no select at the loads)
-    const size_t cstride = rok ? (size_t)R.lda : 0;
+    const double* Ap = (rok || !UNC) ? R.A + (rok ? r0 : 0) : R.zero16;      // (base and column stride per lane: no select at the loads)
+    const size_t cstride = (rok || !UNC) ? (size_t)R.lda : 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = col0 + wcol0 + g * 8 + j;
-      const int cc = (c < Lc) ? c : Lc - 1;
-      av[j] = ld2<NTL>(Ap + (size_t)cc * cstride);
+      if (UNC) {
+        const int cc = (c < Lc) ? c : Lc - 1;
+        av[j] = ld2<NTL>(Ap + (size_t)cc * cstride);
+      } else {
+        if (rok && c < Lc) av[j] = ld2<NTL>(Ap + (size_t)c * R.lda);
+        else av[j] = make_double2(0.0, 0.0);
+      }
     }
+  };
+  // the unit after the last one: UNC re-reads the last unit (unused) instead of branching around the loads
+  auto load8_next = [&](double2 (&av)[8], int gnext, int glast, bool more) {
+    if (UNC) load8(av, more ? gnext : glast, 0);
+    else if (more) load8(av, gnext, 0);
   };
   // one unit = (column group g, row block rb): accumulate; after the last row block reduce the 8 column sums
   auto compute8 = [&](const double2 (&av)[8], int g, auto rbc) {
@@ -1347,7 +1344,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   // software pipeline, two units in flight, all register indices static.  The empty asm statements pin the order
   // "request the next unit, THEN consume the current one": without them the scheduler sinks the (now branch-free)
   // loads down to their first use to shorten live ranges, and nothing is in flight while a unit is consumed.
-#define EIGX_PIN asm volatile("" ::: "memory")
+#define EIGX_PIN do { if (UNC) asm volatile("" ::: "memory"); } while (0)
   {
     // av0 holds unit (g = 0, rb = 0), loaded at kernel entry
     if (RB == 1) {
@@ -1355,7 +1352,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
         load8(av1, g + 1, 0);
         EIGX_PIN;
         compute8(av0, g, IC<0>());
-        load8(av0, (g + 2 < NG) ? g + 2 : g + 1, 0);   // (last pair: an unused re-read instead of a branch around loads)
+        load8_next(av0, g + 2, g + 1, g + 2 < NG);
         EIGX_PIN;
         compute8(av1, g + 1, IC<0>());
       }
@@ -1366,7 +1363,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
         load8(av1, g, 1);
         EIGX_PIN;
         compute8(av0, g, IC<0>());
-        load8(av0, (g + 1 < ng) ? g + 1 : g, 0);       // (last group: an unused re-read instead of a branch around loads)
+        load8_next(av0, g + 1, g, g + 1 < ng);
         EIGX_PIN;
         compute8(av1, g, IC<(RB > 1 ? 1 : 0)>());
       }
@@ -1383,7 +1380,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
         load8(av1, g, 3);
         EIGX_PIN;
         compute8(av0, g, IC<(RB > 2 ? 2 : 0)>());
-        load8(av0, (g + 1 < ng) ? g + 1 : g, 0);
+        load8_next(av0, g + 1, g, g + 1 < ng);
         EIGX_PIN;
         compute8(av1, g, IC<(RB > 3 ? 3 : 0)>());
       }
@@ -1452,292 +1449,6 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   if (R.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) atomicAdd(&R.dbg[15], 1ull);
 }
 
-
-// =================================================================================================
-// K_S : strip form of the fused symmetric mat-vec for large active sizes (one GPU).
-//
-// The tile form above writes, per launch, a row sum and a column sum for every (row, tile) pair: L (L/T + 1) NV
-// doubles -- 67 MB at L = 32768 -- and those dirty lines leave the 4-MB L2s DURING the stream, where a written byte
-// costs about ten times a read one (6.5-6.9 TB/s for the loads alone, 5.6-6.0 with the stores);
-// K_A then reads them all back.  Here a launch is a PERSISTENT grid of <= G workgroups (all resident at once), one job
-// each: job = (strip of H = 512 / 1024 rows, column range [c0, c1) in multiples of 8), all jobs of (nearly) equal area of
-// the upper triangle.  The 4 waves read the SAME 8 columns at different 128-row blocks (wave w owns blocks w and
-// 2 HB - 1 - w of the strip: the pairing balances the diagonal job), so
-//   * row sums are wave-private registers over the whole job, stored once at its end: ONE row-sum slot per job of the
-//     strip (slot = piece number within the strip);
-//   * column sums are complete over the strip's H rows: ONE column-sum slot per strip (combined over the 4 waves
-//     through LDS every 256 columns);
-//   * the reflector scalars, the u values of the rows and the launch / drain of a workgroup are paid once per job
-//     instead of once per tile.
-// Partial sums per launch: L (L/H + pieces per strip) NV doubles, about a quarter of the tile form's.
-// The job list is a function of (L, npc[]): npc[s] = pieces of strip s (host, per step, kernel argument); piece
-// boundaries by the equal-area rule below, evaluated identically by every workgroup.
-// Grid: K_P workgroups first (as in the tile form), then the jobs in strip order.
-// =================================================================================================
-constexpr int KS_MAXSTRIPS = 64;     // column-sum slots 0 .. 63, row-sum slots from KS_MAXSTRIPS on
-constexpr int KS_MAXPIECES = 96;     // per strip (K_A's first batch covers 160 slots)
-struct KSArgs {
-  int i, L, k, ncg, toprows, pdr, npd, ngp;   // as KBArgs
-  int nstrips, njobs;
-  unsigned char npc[KS_MAXSTRIPS];            // pieces per strip
-};
-
-// columns of strip s (rows [R0, R0 + h), columns [R0, L)) left of piece boundary number p of n: equal areas
-__host__ __device__ inline int ks_boundary(int R0, int h, int L, int p, int n) {
-  if (p <= 0) return R0;
-  if (p >= n) return L;
-  const double tri = 0.5 * (double)h * (h + 1);
-  const double total = tri + (double)(L - R0 - h) * h;
-  const double t = total * (double)p / (double)n;
-  const double x = (t <= tri) ? 0.5 * (sqrt(8.0 * t + 1.0) - 1.0) : (double)h + (t - tri) / (double)h;
-  int c = R0 + ((int)(x / 8.0 + 0.5)) * 8;
-  if (c > L) c = L;
-  return c;
-}
-
-template <int NV, int HB, bool NTL>
-__global__ __launch_bounds__(256) void symv_strip_kernel(RedArgs R, KSArgs B) {
-  constexpr int H = 4 * HB * 128;
-  __shared__ double colpart[4][NV][256];    // per-wave column sums of the current 256-column block
-  __shared__ double ucs[NV][256];           // u at the columns of the current block
-  __shared__ double red[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ldp = R.ldp;
-  const int L = B.L, i = B.i;
-  const int nkp = B.npd * (B.ncg + 1);
-  const bool panel_role = (int)blockIdx.x < nkp;
-  // ---- which job ------------------------------------------------------------------------------------------------
-  int js = 0, jp = 0, jn = 1;
-  if (!panel_role) {
-    int j = (int)blockIdx.x - nkp;
-    for (int q = 0; q < B.nstrips; ++q) {
-      const int n = B.npc[q];
-      if (j < n) { js = q; jp = j; jn = n; break; }
-      j -= n;
-    }
-  }
-  const int R0 = js * H;
-  const int hrows = (R0 + H <= L) ? H : L - R0;
-  const int c0 = ks_boundary(R0, hrows, L, jp, jn), c1 = ks_boundary(R0, hrows, L, jp + 1, jn);
-  // ---- loads that feed the reflector scalars first, then this job's x values and its first unit of A -----------------
-  double gpt[2][3];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int q = (tid + 256 * j < B.ngp) ? tid + 256 * j : 0;
-    gpt[j][0] = R.GP[3 * q];
-    if (NV == 2) { gpt[j][1] = R.GP[3 * q + 1]; gpt[j][2] = R.GP[3 * q + 2]; }
-  }
-  const int pivB = L - 2;
-  const double x0L = R.X[L - 1];
-  const double x1L = (NV == 2) ? R.X[ldp + L - 1] : 0.0;
-  const double x1P = (NV == 2 && pivB >= 0) ? R.X[ldp + pivB] : 0.0;
-  const double x0P = (NV == 2 && pivB >= 0) ? R.X[pivB] : 0.0;
-  asm volatile("" ::: "memory");
-  // my row blocks: wave w -> blocks w and 2 HB - 1 - w (HB = 1: block w only)
-  int rowb[HB];
-  rowb[0] = R0 + wave * 128;
-  if (HB == 2) rowb[HB - 1] = R0 + (7 - wave) * 128;
-  double rraw[NV][HB][2];
-  double craw[NV];
-  double2 av0[8], av1[8];
-  auto load8 = [&](double2 (&av)[8], int c, int b) {
-    const int r0 = rowb[b] + lane * 2;
-    // whole unit strictly below the diagonal (first row beyond its last column) or beyond the active rows: nothing to read
-    // (unconditional loads, as in the tile form: such units read the page of zeros instead of HBM)
-    const bool any = rowb[b] <= c + 7 && r0 < L;
-    const double* Ap = any ? R.A + r0 : R.zero16;
-    const size_t cstride = any ? (size_t)R.lda : 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int cc = (c + j < L) ? c + j : L - 1;
-      av[j] = ld2<NTL>(Ap + (size_t)cc * cstride);
-    }
-  };
-  if (!panel_role) {
-#pragma unroll
-    for (int b = 0; b < HB; ++b)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int r = rowb[b] + lane * 2 + h;
-        const bool ok = r < L;
-        rraw[0][b][h] = ok ? R.X[r] : 0.0;
-        if (NV == 2) rraw[NV - 1][b][h] = ok ? R.X[ldp + r] : 0.0;
-      }
-    {
-      const int c = c0 + tid;
-      const bool ok = c < c1;
-      craw[0] = ok ? R.X[c] : 0.0;
-      if (NV == 2) craw[NV - 1] = ok ? R.X[ldp + c] : 0.0;
-    }
-    if (c0 < c1) load8(av0, c0, 0);
-  }
-  const HouseScalars hs = house_scalars<NV>(R, B.ngp, L, gpt, x0L, x1L, x0P, x1P, red);
-  if (panel_role) {
-    const int q = blockIdx.x;
-    const int chunk = q / (B.ncg + 1), cg = q - chunk * (B.ncg + 1);
-    // the store-role panel workgroup of chunk 0 publishes the scalars
-    if (cg == B.ncg && chunk == 0 && tid == 0) {
-      R.sc[SC_SA] = hs.sA; R.sc[SC_BETA_A] = hs.betaA;
-      if (NV == 1) {
-        R.e[i] = hs.sA;
-      } else {
-        R.sc[SC_SB] = hs.sB; R.sc[SC_BETA_B] = hs.betaB;
-        R.e[R.lde + i] = hs.sA;
-        R.e[i - 1] = hs.eL1;
-        if (i - 1 >= 2) R.e[R.lde + i - 1] = hs.sB;
-      }
-    }
-    kp_role<NV, false>(R, hs, i, L, B.k, B.ncg, B.toprows, B.pdr, chunk, cg, red);
-    return;
-  }
-  // ---- u at my rows (registers, for the whole job) --------------------------------------------------------------------
-  double ux[NV][HB][2], yr[NV][HB][2];
-#pragma unroll
-  for (int b = 0; b < HB; ++b)
-#pragma unroll
-    for (int a = 0; a < NV; ++a)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        ux[a][b][h] = u_fix<NV>(hs, L, a, rowb[b] + lane * 2 + h, rraw[0][b][h], rraw[NV - 1][b][h]);
-        yr[a][b][h] = 0.0;
-      }
-  double sp[3] = {0.0, 0.0, 0.0};
-  double yc[NV][8];
-  // one unit = 8 columns x one of my 128-row blocks
-  auto compute8 = [&](const double2 (&av)[8], int c, int cb, auto bc) {
-    constexpr int b = decltype(bc)::value;
-    const int r0 = rowb[b] + lane * 2, r1 = r0 + 1;
-    if (b == 0) {
-#pragma unroll
-      for (int a = 0; a < NV; ++a)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) yc[a][j] = 0.0;
-    }
-    if (rowb[b] + 127 < c) {         // strictly above the diagonal: every element counts for both products
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-#pragma unroll
-        for (int a = 0; a < NV; ++a) {
-          const double uc = ucs[a][c - cb + j];
-          yr[a][b][0] += av[j].x * uc;
-          yr[a][b][1] += av[j].y * uc;
-          yc[a][j] += av[j].x * ux[a][b][0] + av[j].y * ux[a][b][1];
-        }
-      }
-    } else if (rowb[b] <= c + 7) {   // the diagonal crosses the unit: select (never multiply: the lower triangle may hold NaN)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int cc = c + j;
-        const bool cin = cc < L;
-        const double ax_s = (cin && r0 < cc) ? av[j].x : 0.0, ay_s = (cin && r1 < cc) ? av[j].y : 0.0;     // strict upper
-        const double ax_d = (cin && r0 <= cc) ? av[j].x : 0.0, ay_d = (cin && r1 <= cc) ? av[j].y : 0.0;   // with diagonal
-#pragma unroll
-        for (int a = 0; a < NV; ++a) {
-          const double uc = ucs[a][cc - cb];
-          yr[a][b][0] += ax_s * uc;
-          yr[a][b][1] += ay_s * uc;
-          yc[a][j] += ax_d * ux[a][b][0] + ay_d * ux[a][b][1];
-        }
-      }
-    }
-    if (b == HB - 1) {
-      // halving butterfly: 8 column sums over 64 lanes (as in the tile form); lane with (lane & 7) == 0 ends up with the
-      // sum of column j = 4 bit5 + 2 bit4 + bit3 over this wave's rows
-#pragma unroll
-      for (int a = 0; a < NV; ++a) {
-        double v4[4], v2[2], v1;
-        const bool hi8 = lane & 8;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v4[j] = swapadd32(yc[a][j], yc[a][j + 4]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) v2[j] = swapadd16(v4[j], v4[j + 2]);
-        {
-          const double keep = hi8 ? v2[1] : v2[0];
-          const double send = hi8 ? v2[0] : v2[1];
-          v1 = keep + dpp_mov<0x128>(send);
-        }
-        v1 = dpp_add<0xB1>(v1);
-        v1 = dpp_add<0x4E>(v1);
-        v1 = dpp_add<0x141>(v1);
-        if ((lane & 7) == 0) {
-          const int j = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
-          colpart[wave][a][c - cb + j] = v1;
-        }
-      }
-    }
-  };
-  // ---- the job: 256-column blocks, 8-column groups, two units in flight --------------------------------------------------
-  for (int cb = c0; cb < c1; cb += 256) {
-    const int ce = (cb + 256 < c1) ? cb + 256 : c1;
-    // u at the block's columns (craw = x at column cb + tid, loaded one block ahead)
-#pragma unroll
-    for (int a = 0; a < NV; ++a) ucs[a][tid] = (cb + tid < ce) ? u_fix<NV>(hs, L, a, cb + tid, craw[0], craw[NV - 1]) : 0.0;
-    {
-      const int c = cb + 256 + tid;
-      const bool ok = c < c1;
-      craw[0] = ok ? R.X[c] : 0.0;
-      if (NV == 2) craw[NV - 1] = ok ? R.X[ldp + c] : 0.0;
-    }
-    __syncthreads();
-    const int ng = (ce - cb + 7) / 8;
-#pragma unroll 1
-    for (int g = 0; g < ng; ++g) {
-      const int c = cb + g * 8;
-      if (HB == 2) {
-        load8(av1, c, HB - 1);
-        EIGX_PIN;
-        compute8(av0, c, cb, IC<0>());
-        load8(av0, (c + 8 < c1) ? c + 8 : c, 0);       // (job's last group: an unused re-read instead of a branch around loads)
-        EIGX_PIN;
-        compute8(av1, c, cb, IC<HB - 1>());
-      } else {
-        // one row block per wave: groups in pairs (a block holds an even number of groups unless it is the job's last)
-        load8(av1, (c + 8 < c1) ? c + 8 : c, 0);
-        EIGX_PIN;
-        compute8(av0, c, cb, IC<0>());
-        ++g;
-        load8(av0, (c + 16 < c1) ? c + 16 : c, 0);
-        EIGX_PIN;
-        if (g < ng) compute8(av1, c + 8, cb, IC<0>());
-      }
-    }
-    __syncthreads();
-    // combine the 4 waves' column sums (fixed order), store the strip's column-sum slot, bilinear column part
-    if (cb + tid < ce) {
-      const int c = cb + tid;
-      double cs[NV];
-#pragma unroll
-      for (int a = 0; a < NV; ++a) {
-        cs[a] = (colpart[0][a][tid] + colpart[1][a][tid]) + (colpart[2][a][tid] + colpart[3][a][tid]);
-        R.YC[((size_t)js * NV + a) * ldp + c] = cs[a];
-      }
-      sp[0] += ucs[0][tid] * cs[0];
-      if (NV == 2) { sp[1] += ucs[0][tid] * cs[NV - 1]; sp[2] += ucs[NV - 1][tid] * cs[NV - 1]; }
-    }
-    __syncthreads();
-  }
-  // ---- row sums of the job: one slot per piece of the strip -------------------------------------------------------------
-#pragma unroll
-  for (int b = 0; b < HB; ++b) {
-    const int r0 = rowb[b] + lane * 2;
-#pragma unroll
-    for (int a = 0; a < NV; ++a) {
-      double* dst = R.YC + ((size_t)(KS_MAXSTRIPS + jp) * NV + a) * ldp + r0;
-      if (r0 + 1 < L) { dst[0] = yr[a][b][0]; dst[1] = yr[a][b][1]; }
-      else if (r0 < L) dst[0] = yr[a][b][0];
-    }
-    sp[0] += ux[0][b][0] * yr[0][b][0] + ux[0][b][1] * yr[0][b][1];
-    if (NV == 2) {
-      sp[1] += ux[0][b][0] * yr[NV - 1][b][0] + ux[0][b][1] * yr[NV - 1][b][1];
-      sp[2] += ux[NV - 1][b][0] * yr[NV - 1][b][0] + ux[NV - 1][b][1] * yr[NV - 1][b][1];
-    }
-  }
-  block_sum_multi<3>(sp, red);
-  if (tid == 0) {
-    const size_t w = (size_t)((int)blockIdx.x - nkp);
-    R.SP[w * 3 + 0] = sp[0]; R.SP[w * 3 + 1] = sp[1]; R.SP[w * 3 + 2] = sp[2];
-  }
-}
 
 // zero-fill helper
 __global__ void fill_kernel(double* p, size_t n, double v) {
@@ -1830,7 +1541,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   }
   R.kdab_off = R.maxchunk * 2 * NB * m;
   R.KD = ctx.pool.get_t<double>("red.KD", (size_t)R.kdab_off + R.maxchunk + 8 + 512);   // + slack: K_A loads kk < 256 unclamped
-  const size_t sp_count = (size_t)(maxseg * maxseg > 1024 ? maxseg * maxseg : 1024) * 3 + 8;   // tiles, or <= 1024 strip jobs
+  const size_t sp_count = (size_t)(maxseg * maxseg) * 3 + 8;
   R.SP = ctx.pool.get_t<double>("red.SP", sp_count);
   const int maxgp = (n + KA_ROWS - 1) / KA_ROWS + 2;
   R.gp2_off = 0;
@@ -1892,7 +1603,6 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   // ka_kernel's first batches of loads are unconditional (clamped), so their sizes are template parameters matched to
   // the step: partial sums of a row (nt + 1 slots: 1 / 2 / 3 / 5 / 10 batches of KA_SL = 16), folded rows of tile
   // scalars (nt <= 15 / 31 / 63: 2 / 4 / 8 per wave), panel columns (k <= 32 / 64 / more: 2 / 4 / 8 per slice)
-  bool strip_prev = false;   // the pending step's mat-vec ran in strip form (K_A then reads its slot layout)
   auto launch_ka = [&](int nwg, const KAArgs& K) {
     const bool fit = g_ka_fit != 0;
     const int nslot = fit ? K.nt_prev + 1 : 1 << 30, ntp = fit ? K.nt_prev : 1 << 30;
@@ -1902,22 +1612,13 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       if (K.G > 1) hipLaunchKernelGGL((ka_kernel<NB, MGV, true, RPBV, SPBV, KBV>), dim3(nwg), dim3(256), 0, st, R, K);   \
       else hipLaunchKernelGGL((ka_kernel<NB, MGV, false, RPBV, SPBV, KBV>), dim3(nwg), dim3(256), 0, st, R, K);          \
     } while (0)
-#define EIGX_KAS(KBV)                                                                                                   \
-    do {                                                                                                                \
-      if (K.G > 1) hipLaunchKernelGGL((ka_kernel<NB, false, true, 10, 8, KBV, true>), dim3(nwg), dim3(256), 0, st, R, K); \
-      else hipLaunchKernelGGL((ka_kernel<NB, false, false, 10, 8, KBV, true>), dim3(nwg), dim3(256), 0, st, R, K);       \
-    } while (0)
 #define EIGX_KA2(MGV, RPBV, SPBV)                                                                                       \
     do {                                                                                                                \
       if (kk <= 2 * KA_SL) EIGX_KA3(MGV, RPBV, SPBV, 2);                                                                \
       else if (kk <= 4 * KA_SL) EIGX_KA3(MGV, RPBV, SPBV, 4);                                                           \
       else EIGX_KA3(MGV, RPBV, SPBV, 8);                                                                                \
     } while (0)
-    if (!mg && K.has_prev && strip_prev) {   // the previous mat-vec ran in strip form
-      if (kk <= 2 * KA_SL) EIGX_KAS(2);
-      else if (kk <= 4 * KA_SL) EIGX_KAS(4);
-      else EIGX_KAS(8);
-    } else if (mg) EIGX_KA2(true, 1, 8);
+    if (mg) EIGX_KA2(true, 1, 8);
     else if (nslot <= 1 * KA_SL && ntp <= 15) EIGX_KA2(false, 1, 2);
     else if (nslot <= 2 * KA_SL && ntp <= 31) EIGX_KA2(false, 2, 4);
     else if (nslot <= 3 * KA_SL) EIGX_KA2(false, 3, 8);
@@ -1925,12 +1626,9 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     else EIGX_KA2(false, 10, 8);
 #undef EIGX_KA2
 #undef EIGX_KA3
-#undef EIGX_KAS
   };
   S.has_prev = 0; S.iprev = 0; S.Lprev = 0; S.kprev = 0; S.nchunk_prev = 0; S.nt_prev = 0; S.lgT_prev = 7;
   S.par = 0; S.pan_c0 = 0; S.G = 1;
-  S.lgH = 10; S.njobs_prev = 0;
-  memset(S.npc, 0, sizeof(S.npc));
   S.wait.n = 0; S.wait.flag = nullptr; S.wait.err = nullptr; S.wait.ticks = nullptr; S.wait.limit_ticks = 0; S.wait.epoch = 0;
   const bool fuse_wait = mg && comm_step_wait_fused(ctx);
   const bool step_coll = mg && comm_step_collective(ctx);   // per-step exchange as an allgather (RCCL / emulated)
@@ -2014,54 +1712,13 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     const bool prof = ctx.prof_stride > 0 && (n_symv % ctx.prof_stride) == 0;
     if (prof) ctx.prof_begin(0, 8.0 * ((double)L * (L + 1) / 2) / R.P, st);  // this rank's share of the triangle
     const bool nt_loads = (mg ? sqrt((double)B.Lr * B.Lc) : (double)L) > g_symv_nt;
-    const bool strip = !mg && L > g_symv_strip;
-    if (strip) {
-      // strip form: equal-area jobs, <= g_strip_jobs of them (a persistent grid: every job resident from the start)
-      KSArgs K;
-      K.i = i; K.L = L; K.k = k; K.ncg = B.ncg; K.toprows = B.toprows; K.pdr = B.pdr; K.npd = npd; K.ngp = nb_ka;
-      const int lgH = (L >= g_strip_h1024) ? 10 : 9, H = 1 << lgH;
-      int ns = ceil_div(L, H);
-      if (ns > KS_MAXSTRIPS) ns = KS_MAXSTRIPS;   // (callers keep L <= 64 H; asserted by the threshold choice below)
-      const double total = 0.5 * (double)L * (L + 1);
-      int G = g_strip_jobs;
-      if (G > 1024) G = 1024;
-      if (G < ns) G = ns;
-      int npc[KS_MAXSTRIPS], sum = 0;
-      double area[KS_MAXSTRIPS];
-      for (int q = 0; q < ns; ++q) {
-        const int R0 = q * H, h = (R0 + H <= L) ? H : L - R0;
-        area[q] = 0.5 * (double)h * (h + 1) + (double)(L - R0 - h) * h;
-        int np = (int)(area[q] * G / total + 0.5);
-        if (np < 1) np = 1;
-        if (np > KS_MAXPIECES) np = KS_MAXPIECES;
-        npc[q] = np;
-        sum += np;
-      }
-      while (sum > G) {   // rounding went over: take pieces from the strips whose pieces are smallest
-        int best = -1;
-        for (int q = 0; q < ns; ++q)
-          if (npc[q] > 1 && (best < 0 || area[q] / npc[q] < area[best] / npc[best])) best = q;
-        if (best < 0) break;
-        --npc[best];
-        --sum;
-      }
-      K.nstrips = ns; K.njobs = sum;
-      memset(K.npc, 0, sizeof(K.npc));
-      for (int q = 0; q < ns; ++q) K.npc[q] = (unsigned char)npc[q];
-      const int gs = sum + npd * (B.ncg + 1);
-#define EIGX_STRIP(HBv, NTv) hipLaunchKernelGGL((symv_strip_kernel<NB, HBv, NTv>), dim3(gs), dim3(256), 0, st, R, K)
-      if (lgH == 10 && nt_loads) EIGX_STRIP(2, true);
-      else if (lgH == 10) EIGX_STRIP(2, false);
-      else if (nt_loads) EIGX_STRIP(1, true);
-      else EIGX_STRIP(1, false);
-#undef EIGX_STRIP
-      S.lgH = lgH; S.njobs_prev = sum;
-      memcpy(S.npc, K.npc, sizeof(S.npc));
-    } else {
+    const bool unc = (mg ? sqrt((double)B.Lr * B.Lc) : (double)L) <= g_symv_unc;   // latency-bound sizes: the true two-unit pipeline
 #define EIGX_SYMV(RBv, NTv)                                                                                         \
   do {                                                                                                              \
-    if (mg) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true>), dim3(gx), dim3(256), 0, st, R, B);                \
-    else hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false>), dim3(gx), dim3(256), 0, st, R, B);                  \
+    if (mg && unc) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true, true>), dim3(gx), dim3(256), 0, st, R, B);   \
+    else if (mg) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true, false>), dim3(gx), dim3(256), 0, st, R, B);    \
+    else if (unc) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false, true>), dim3(gx), dim3(256), 0, st, R, B);   \
+    else hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false, false>), dim3(gx), dim3(256), 0, st, R, B);           \
   } while (0)
     if (T == 128) EIGX_SYMV(1, false);
     else if (T == 256 && !nt_loads) EIGX_SYMV(2, false);
@@ -2069,8 +1726,6 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     else if (!nt_loads) EIGX_SYMV(4, false);
     else EIGX_SYMV(4, true);
 #undef EIGX_SYMV
-    }
-    strip_prev = strip;
     if (prof) ctx.prof_end(st);
     if (mg) {
       ++epoch;
@@ -2176,10 +1831,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
 }  // namespace
 
 int set_symv_threshold(int which, int v) {
-  if (which >= 5) {
-    int& u = (which == 5) ? g_symv_strip : (which == 6) ? g_strip_jobs : g_strip_h1024;
-    const int old = u; u = v; return old;
-  }
+  if (which == 5) { const int old = g_symv_unc; g_symv_unc = v; return old; }
   int& t = (which == 4) ? g_ka_fit : (which == 3) ? g_ka_wgs : (which == 2) ? g_symv_nt : (which ? g_symv_t256 : g_symv_t128);
   const int old = t; t = v; return old;
 }

@@ -465,64 +465,67 @@ def test_symv_tile_sizes_forced_small(gpu_lib, orc, band):
 
 
 @pytest.mark.parametrize("band", [1, 2])
-@pytest.mark.parametrize("n,m,h1024,jobs", [(1700, 64, 1 << 30, 24), (2300, 128, 0, 40), (1333, 48, 0, 7), (2050, 64, 1 << 30, 300)])
-def test_symv_strip_form_forced_small(gpu_lib, orc, band, n, m, h1024, jobs):
-    """the strip form of the fused mat-vec (symv_strip_kernel: persistent equal-area jobs over strips of 512 / 1024 rows,
-    one row-sum slot per job and one column-sum slot per strip; what runs above L = 14000) forced at sizes the oracle
-    handles: eigx_tune key 11 moves its threshold down to L = 500, key 12 sets the jobs per launch, key 13 picks the strip
-    height (0: 1024 rows everywhere, 1 << 30: 512 rows), so a reduction passes through the strip form, the switch to the
-    tile form and the partially filled last strip; the ka_kernel variant that reads the strip form's slots is the same run"""
+@pytest.mark.parametrize("n,m", [(900, 64), (1, 8), (2, 8), (5, 4), (131, 32)])
+def test_symv_load_forms_are_bit_identical(gpu_lib, band, n, m):
+    """the fused mat-vec has two forms of its load loop: branch-free (columns beyond the block re-read the last active
+    column, rows beyond it a page of zeros; order pinned so that a unit is in flight while another is consumed -- used
+    where a launch is latency-bound) and the loads behind wave-uniform branches (used where it is bandwidth-bound);
+    eigx_tune key 11 moves the switch.  Both sum the same numbers in the same order: the band matrix must be bit-identical,
+    with the strict lower triangle poisoned by NaN, all tile sizes forced at n = 900"""
     import torch
     from eigenexa_amd import layout
 
-    A = layout.random_symmetric(n, seed=29)
-    old = [gpu_lib.eigx_tune(11, 500), gpu_lib.eigx_tune(12, jobs), gpu_lib.eigx_tune(13, h1024)]
+    A = layout.random_symmetric(n, seed=31)
+    out = []
+    tiles = [gpu_lib.eigx_tune(3, 200), gpu_lib.eigx_tune(4, 450), gpu_lib.eigx_tune(5, 300)]
     try:
-        a, lda = _to_colmajor(A)
-        il = torch.tril_indices(n, n, -1, device=_dev())
-        a[il[1], il[0]] = float("nan")   # the strict lower triangle must never be read (src/eigen_trd_t8.F:84-94)
-        d = torch.zeros(n, dtype=torch.float64, device=_dev())
-        e = torch.zeros(2 * n, dtype=torch.float64, device=_dev())
-        assert gpu_lib.eigx_band_reduce_dev(n, a.data_ptr(), lda, d.data_ptr(), e.data_ptr(), n, m, band) == 0
+        for unc in (1 << 30, 0):
+            old = gpu_lib.eigx_tune(11, unc)
+            try:
+                a, lda = _to_colmajor(A)
+                il = torch.tril_indices(n, n, -1, device=_dev())
+                a[il[1], il[0]] = float("nan")   # the strict lower triangle must never be read (src/eigen_trd_t8.F:84-94)
+                d = torch.zeros(n, dtype=torch.float64, device=_dev())
+                e = torch.zeros(2 * n, dtype=torch.float64, device=_dev())
+                assert gpu_lib.eigx_band_reduce_dev(n, a.data_ptr(), lda, d.data_ptr(), e.data_ptr(), n, m, band) == 0
+                out.append((d.cpu().numpy().copy(), e.cpu().numpy().copy(), a.cpu().numpy().copy()))
+            finally:
+                gpu_lib.eigx_tune(11, old)
     finally:
-        for key, v in zip((11, 12, 13), old):
+        for key, v in zip((3, 4, 5), tiles):
             gpu_lib.eigx_tune(key, v)
-    dg, eg = d.cpu().numpy(), e.cpu().numpy().reshape(2, n)
-    assert np.isfinite(dg).all() and np.isfinite(eg).all()
+    assert np.isfinite(out[0][0]).all() and np.isfinite(out[0][1]).all()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    up = np.triu(np.ones((n, n), dtype=bool)).T          # a[j, i] = A(i, j): upper triangle + reflectors
+    assert np.array_equal(out[0][2][:, :n][up], out[1][2][:, :n][up])
     wr = np.linalg.eigvalsh(A)
-    assert np.abs(np.linalg.eigvalsh(_band_matrix(dg, eg[:band], band)) - wr).max() < 1e-13 * n * np.abs(wr).max()
-    if band == 1:
-        do, eo, _ = orc.band_reduce(A, 1)
-        scale = np.abs(A).max() * n
-        assert np.abs(dg - do).max() < 1e-9 * scale and np.abs(np.abs(eg[0]) - np.abs(eo[0])).max() < 1e-9 * scale
+    dg, eg = out[0][0], out[0][1].reshape(2, n)
+    assert np.abs(np.linalg.eigvalsh(_band_matrix(dg, eg[:band], band)) - wr).max() < 1e-13 * max(n, 8) * max(np.abs(wr).max(), 1e-300)
 
 
 @pytest.mark.parametrize("route", ["sx", "s"])
-def test_strip_form_full_solve(gpu_lib, route):
-    """a complete solve with the strip form active over most of the reduction: the reference's gates"""
+def test_device_entry_points_wait_for_the_default_stream(gpu_lib, route):
+    """the matrix is filled by an asynchronous copy on torch's (default) stream and the C-ABI is called at once, twice in a
+    row -- the second call finds the workspace allocated and nothing else in its way: the library's own streams must not
+    overtake the copy (found by exactly this sequence: garbage eigenpairs from the second solve of a process)"""
     import torch
     from eigenexa_amd import layout
 
     n = 3000
-    old = [gpu_lib.eigx_tune(11, 700), gpu_lib.eigx_tune(12, 96), gpu_lib.eigx_tune(13, 2000)]
-    try:
+    for rep in range(2):
         A = layout.random_symmetric_torch(n, _dev())
         a = torch.zeros(n, n + 34, dtype=torch.float64, device=_dev())
         a[:, :n] = A.T
         z = torch.zeros(n, n + 34, dtype=torch.float64, device=_dev())
         w = torch.zeros(n, dtype=torch.float64, device=_dev())
         fn = gpu_lib.eigx_sx_dev if route == "sx" else gpu_lib.eigx_s_dev
-        # (no torch.cuda.synchronize() here on purpose: the device entry points wait for the default stream themselves)
+        # (no torch.cuda.synchronize() here on purpose)
         assert fn(n, n, a.data_ptr(), n + 34, w.data_ptr(), z.data_ptr(), n + 34, 128, 128, b"A") == 0
-    finally:
-        for key, v in zip((11, 12, 13), old):
-            gpu_lib.eigx_tune(key, v)
-    Z = z[:, :n].T
-    anorm = torch.linalg.norm(A).item()
-    assert torch.linalg.norm(A @ Z - Z * w[None, :]).item() / (n * EPS * anorm) < GATE_RES
-    assert torch.linalg.norm(Z.T @ Z - torch.eye(n, dtype=torch.float64, device=_dev())).item() / (n * EPS) < GATE_ORTH
-    wr = np.linalg.eigvalsh(A.cpu().numpy())
-    assert np.abs(w.cpu().numpy() - wr).max() < 1e-12 * np.abs(wr).max()
+        Z = z[:, :n].T
+        anorm = torch.linalg.norm(A).item()
+        assert torch.linalg.norm(A @ Z - Z * w[None, :]).item() / (n * EPS * anorm) < GATE_RES
+        assert torch.linalg.norm(Z.T @ Z - torch.eye(n, dtype=torch.float64, device=_dev())).item() / (n * EPS) < GATE_ORTH
+        del A, a, z, w, Z
 
 
 @pytest.mark.parametrize("band", [1, 2])
