@@ -107,6 +107,9 @@ int g_ka_fit = 1;     // K_A (eigx_tune key 10): 1 = load batches matched to the
 int g_ka_wgs = 256;   // K_A (eigx_tune key 7): beyond 2 * this many row groups a workgroup takes several of them, ~this many workgroups
 int g_symv_t128 = 4500, g_symv_t256 = 40000;
 int g_symv_nt = 9000;
+// several GPUs: 1 = the step exchange runs inside the mat-vec launch (its last-arriving tiles reduce and push), 0 = as
+// kl_kernel behind it (EIGX_FOLD_KL, eigx_tune key 12)
+int g_fold_kl = 1;
 int g_symv_unc = 9000;   // the fused mat-vec's branch-free pipelined form up to this active size (eigx_tune key 11)
 
 inline SymvGeom symv_geom(int L) {
@@ -758,20 +761,29 @@ struct KLArgs {
   int L, Lr, Lc, T, ntc, nbr, par;
   unsigned long long epoch;
   StepPeers peers;
+  // folded form (the reduce + push runs inside the mat-vec launch, see symv_kernel): counters [tile rows | tile columns |
+  // tiles | pushes], all zero between launches; tiles of the launch; tile rows that hold at least one tile
+  unsigned* cnt;
+  int cnt_cols, ntiles, ntr, total, fold;   // total = pushes of a launch: tile rows + tile columns that hold tiles, + 1
 };
-template <int NB>
-__global__ __launch_bounds__(256) void kl_kernel(RedArgs R, KLArgs K) {
-  // 64 rows (columns) per workgroup; wave q takes every fourth partial sum of them (up to ~64 partials sit behind a
-  // cold L2: one thread per row walking them one after the other is a chain of memory round trips), the four waves
-  // are combined through LDS in a fixed order
-  __shared__ double comb[4][64][2];
-  __shared__ double red[16];
-  __shared__ int last;
+
+// loads / stores of partial sums that another workgroup of the SAME launch reads / wrote (folded form): agent scope,
+// past the per-XCD L2s (MI355X_MICROARCH.md, hand-off forms: sc1 stores, every storing wave drains, one agent-scope
+// atomic add per workgroup, the workgroup whose add came last reads with sc1 loads)
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// one chunk of 64 local rows (rows = true) or 64 local columns starting at l0: sum this rank's tile partial sums of
+// each and write the result into every rank's step window.  Wave q takes every fourth partial sum (up to ~64 of them sit
+// behind a cold L2: one thread per row walking them one after the other is a chain of memory round trips), the four
+// waves are combined through LDS in a fixed order.  AG: the partial sums were written by other workgroups of this launch.
+template <int NB, bool AG>
+__device__ __forceinline__ void kl_chunk(const RedArgs& R, const KLArgs& K, bool rows, int l0, double (*comb)[64][2]) {
   const int ldp = R.ldp;
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int T = K.T;
-  const bool rows = (int)blockIdx.x < K.nbr;
-  const int l = (rows ? blockIdx.x : blockIdx.x - K.nbr) * 64 + lane;   // local row / local column
+  const int l = l0 + lane;
+  auto ld = [&](const double* p) { return AG ? ld_agent(p) : *p; };
   double pA = 0.0, pB = 0.0;
   if (rows && l < K.Lr) {
     // row sums: tiles (ty, tx) with tx >= txmin, the tile column that holds the first local column at or right of
@@ -780,9 +792,20 @@ __global__ __launch_bounds__(256) void kl_kernel(RedArgs R, KLArgs K) {
     const long g0 = (long)ty * T * R.Px + R.px;
     const long cneed = g0 > R.py ? (g0 - R.py + R.Py - 1) / R.Py : 0;
     if (cneed <= K.Lc - 1) {
-      for (int tx = (int)(cneed / T) + q; tx < K.ntc; tx += 4) {
-        pA += R.YR[((size_t)tx * NB + 0) * ldp + l];
-        if (NB == 2) pB += R.YR[((size_t)tx * NB + 1) * ldp + l];
+      int tx = (int)(cneed / T) + q;
+      for (; tx + 12 < K.ntc; tx += 16) {
+        double a[4], b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] = ld(&R.YR[((size_t)(tx + 4 * e) * NB + 0) * ldp + l]);
+          b[e] = (NB == 2) ? ld(&R.YR[((size_t)(tx + 4 * e) * NB + 1) * ldp + l]) : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pA += a[e]; pB += b[e]; }
+      }
+      for (; tx < K.ntc; tx += 4) {
+        pA += ld(&R.YR[((size_t)tx * NB + 0) * ldp + l]);
+        if (NB == 2) pB += ld(&R.YR[((size_t)tx * NB + 1) * ldp + l]);
       }
     }
   } else if (!rows && l < K.Lc) {
@@ -793,15 +816,15 @@ __global__ __launch_bounds__(256) void kl_kernel(RedArgs R, KLArgs K) {
       double a[4], b[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        a[e] = R.YC[((size_t)(t + 4 * e) * NB + 0) * ldp + l];
-        b[e] = (NB == 2) ? R.YC[((size_t)(t + 4 * e) * NB + 1) * ldp + l] : 0.0;
+        a[e] = ld(&R.YC[((size_t)(t + 4 * e) * NB + 0) * ldp + l]);
+        b[e] = (NB == 2) ? ld(&R.YC[((size_t)(t + 4 * e) * NB + 1) * ldp + l]) : 0.0;
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) { pA += a[e]; pB += b[e]; }
     }
     for (; t < nty; t += 4) {
-      pA += R.YC[((size_t)t * NB + 0) * ldp + l];
-      if (NB == 2) pB += R.YC[((size_t)t * NB + 1) * ldp + l];
+      pA += ld(&R.YC[((size_t)t * NB + 0) * ldp + l]);
+      if (NB == 2) pB += ld(&R.YC[((size_t)t * NB + 1) * ldp + l]);
     }
   }
   comb[q][lane][0] = pA; comb[q][lane][1] = pB;
@@ -817,35 +840,78 @@ __global__ __launch_bounds__(256) void kl_kernel(RedArgs R, KLArgs K) {
       if (NB == 2) st_sys(K.peers.slot[d] + off + stv, sB);
     }
   }
-  if (blockIdx.x == 0) {
-    double v[3] = {0.0, 0.0, 0.0};
-    // every tile of this rank: tile column tx holds mg_nty(tx) tiles
-    for (int tx = q; tx < K.ntc; tx += 4) {
-      const int nty = mg_nty(tx, T, K.Lc, R.Px, R.px, R.Py, R.py);
-      for (int ty = lane; ty < nty; ty += 64) {
-        const double* sp = R.SP + ((size_t)ty * R.maxseg + tx) * 3;
-        v[0] += sp[0]; v[1] += sp[1]; v[2] += sp[2];
-      }
-    }
-    block_sum_multi<3>(v, red);
-    if (threadIdx.x < 3) {
-      const size_t off = pbase + (size_t)NB * (R.nxs + R.nys) + threadIdx.x;
-      for (int d = 0; d < K.peers.n; ++d) st_sys(K.peers.slot[d] + off, v[threadIdx.x]);
+  __syncthreads();   // comb is reused by the caller's next chunk
+}
+
+// the three bilinear scalars of this rank: sum over its tiles, written into every rank's step window
+template <int NB, bool AG>
+__device__ __forceinline__ void kl_scalars(const RedArgs& R, const KLArgs& K, double* red) {
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  double v[3] = {0.0, 0.0, 0.0};
+  // every tile of this rank: tile column tx holds mg_nty(tx) tiles
+  for (int tx = q; tx < K.ntc; tx += 4) {
+    const int nty = mg_nty(tx, K.T, K.Lc, R.Px, R.px, R.Py, R.py);
+    for (int ty = lane; ty < nty; ty += 64) {
+      const double* sp = R.SP + ((size_t)ty * R.maxseg + tx) * 3;
+      if (AG) { v[0] += ld_agent(sp); v[1] += ld_agent(sp + 1); v[2] += ld_agent(sp + 2); }
+      else { v[0] += sp[0]; v[1] += sp[1]; v[2] += sp[2]; }
     }
   }
-  // every storing wave drains its stores; the last workgroup to arrive publishes the flag on every rank
+  block_sum_multi<3>(v, red);
+  if (threadIdx.x < 3) {
+    const size_t off = (size_t)K.par * K.peers.parity_stride + (size_t)NB * (R.nxs + R.nys) + threadIdx.x;
+    for (int d = 0; d < K.peers.n; ++d) st_sys(K.peers.slot[d] + off, v[threadIdx.x]);
+  }
+}
+
+// zeros for the rows / columns of this rank that no tile covers (row blocks beyond the last tile row, tile columns
+// without tiles: they exist for tiny local blocks), so that the peers never read a stale entry of an older step
+template <int NB>
+__device__ __forceinline__ void kl_zero_uncovered(const RedArgs& R, const KLArgs& K) {
+  const size_t pbase = (size_t)K.par * K.peers.parity_stride;
+  for (int l = K.ntr * K.T + threadIdx.x; l < K.Lr; l += 256)
+    for (int d = 0; d < K.peers.n; ++d) {
+      st_sys(K.peers.slot[d] + pbase + l, 0.0);
+      if (NB == 2) st_sys(K.peers.slot[d] + pbase + R.nxs + l, 0.0);
+    }
+  for (int tx = 0; tx < K.ntc; ++tx) {
+    if (mg_nty(tx, K.T, K.Lc, R.Px, R.px, R.Py, R.py) > 0) continue;
+    for (int l = tx * K.T + threadIdx.x; l < (tx + 1) * K.T && l < K.Lc; l += 256)
+      for (int d = 0; d < K.peers.n; ++d) {
+        st_sys(K.peers.slot[d] + pbase + (size_t)NB * R.nxs + l, 0.0);
+        if (NB == 2) st_sys(K.peers.slot[d] + pbase + (size_t)NB * R.nxs + R.nys + l, 0.0);
+      }
+  }
+}
+
+// after a workgroup's pushes: drain, count, and let the workgroup that completes the count publish the step's flag on
+// every rank (`mine` pushes of `total` expected; the counter returns to zero for the next launch)
+__device__ __forceinline__ void kl_publish(const KLArgs& K, unsigned* counter, unsigned mine, unsigned total, int* lastw) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned tk = atomicAdd(K.peers.counter, 1u);
-    last = (tk == gridDim.x - 1);
-    if (last) *K.peers.counter = 0;
+    const unsigned tk = atomicAdd(counter, mine);
+    *lastw = (tk + mine == total);
+    if (*lastw) *counter = 0;
   }
   __syncthreads();
   // (collective form of the exchange: one local destination, no flag -- comm_step_allgather follows in stream order)
-  if (last && (int)threadIdx.x < K.peers.n && K.peers.flag[threadIdx.x])
+  if (*lastw && (int)threadIdx.x < K.peers.n && K.peers.flag[threadIdx.x])
     __hip_atomic_store(K.peers.flag[threadIdx.x] + K.par * EIGX_MAXP, K.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void kl_kernel(RedArgs R, KLArgs K) {
+  // 64 rows (columns) per workgroup
+  __shared__ double comb[4][64][2];
+  __shared__ double red[16];
+  __shared__ int last;
+  const bool rows = (int)blockIdx.x < K.nbr;
+  kl_chunk<NB, false>(R, K, rows, (rows ? blockIdx.x : blockIdx.x - K.nbr) * 64, comb);
+  if (blockIdx.x == 0) kl_scalars<NB, false>(R, K, red);
+  // every storing wave drains its stores; the last workgroup to arrive publishes the flag on every rank
+  kl_publish(K, K.peers.counter, 1u, gridDim.x, &last);
 }
 
 // Reflector scalars of a step, computed by EVERY workgroup of the mat-vec launch in the same order (bit-identical
@@ -1028,12 +1094,12 @@ template <int K> struct IC { static constexpr int value = K; };
 // processes: 4751 ms against 5326 ms with the pipeline -- more requests in flight per CU than the memory system likes);
 // the launch picks by active size (g_symv_unc, eigx_tune key 14).
 template <int NV, int RB, bool NTL, bool MG, bool UNC>
-__global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
+__global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B, KLArgs K) {
   constexpr int T = 128 * RB;
   // NTL: non-temporal A loads, chosen by the launch for triangles far beyond L2 + Infinity Cache (g_symv_nt)
   constexpr int DYN = 4 * NV * T;
   __shared__ __attribute__((aligned(16))) double dyn[DYN + NV * T];  // [4 waves][NV][T] row sums ; then uc[NV][T]
-  __shared__ double red[16];
+  __shared__ double red[32];   // [0, 12): block reductions; folded exchange: flags in [0, 2), its scalar reduction in [8, 20)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ldp = R.ldp;
   const int L = B.L, i = B.i;
@@ -1332,7 +1398,10 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
         const int c = col0 + tc0 + j;
         if (c < Lc) {
 #pragma unroll
-          for (int a = 0; a < NV; ++a) R.YC[((size_t)ty * NV + a) * ldp + c] = fin[a];
+          for (int a = 0; a < NV; ++a) {
+            double* q_ = &R.YC[((size_t)ty * NV + a) * ldp + c];
+            if (MG && K.fold) st_agent(q_, fin[a]); else *q_ = fin[a];   // (folded exchange: read by another workgroup of this launch)
+          }
           const double ua = ucs[tc0 + j];
           sp[0] += ua * fin[0];
           if (NV == 2) { sp[1] += ua * fin[NV - 1]; sp[2] += ucs[(NV - 1) * T + tc0 + j] * fin[NV - 1]; }
@@ -1429,7 +1498,8 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
       for (int a = 0; a < NV; ++a) {
         const double s = (yrs[((size_t)0 * NV + a) * T + t] + yrs[((size_t)1 * NV + a) * T + t]) +
                          (yrs[((size_t)2 * NV + a) * T + t] + yrs[((size_t)3 * NV + a) * T + t]);
-        R.YR[((size_t)tx * NV + a) * ldp + r] = s;
+        double* q_ = &R.YR[((size_t)tx * NV + a) * ldp + r];
+        if (MG && K.fold) st_agent(q_, s); else *q_ = s;
       }
     }
   }
@@ -1443,7 +1513,55 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   if (!EIGX_ABL(512)) block_sum_multi<3>(sp, red);
   if (tid == 0) {
     const size_t w = (size_t)ty * R.maxseg + tx;
-    R.SP[w * 3 + 0] = sp[0]; R.SP[w * 3 + 1] = sp[1]; R.SP[w * 3 + 2] = sp[2];
+    if (MG && K.fold) { st_agent(&R.SP[w * 3 + 0], sp[0]); st_agent(&R.SP[w * 3 + 1], sp[1]); st_agent(&R.SP[w * 3 + 2], sp[2]); }
+    else { R.SP[w * 3 + 0] = sp[0]; R.SP[w * 3 + 1] = sp[1]; R.SP[w * 3 + 2] = sp[2]; }
+  }
+  if (MG && K.fold) {
+    // ---- folded step exchange (several GPUs): the LAST tile to finish of a tile row reduces that row block's row sums
+    // over the rank's tiles and writes them into every rank's step window; the same per tile column; the last tile of the
+    // launch adds the bilinear scalars (and zeros for whatever no tile covers); the last of these pushes publishes the
+    // step's flag on every rank.  What was a kernel of its own behind the mat-vec (kl_kernel: launch + ~4 us) now
+    // overlaps the stream of the other tiles; only the last tile's share is on the critical path.
+    // Hand-off between workgroups of one launch (MI355X_MICROARCH.md): agent-scope stores above, every storing wave
+    // drains, barrier, ONE agent-scope atomic add per counter; the workgroup whose add came last reads with agent-scope loads.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* lastf = reinterpret_cast<int*>(red);         // [0] row block, [1] column block, [2] whole launch, [3] publisher
+    if (tid == 0) {
+      const long g0 = (long)ty * T * R.Px + R.px;
+      const long cneed = g0 > R.py ? (g0 - R.py + R.Py - 1) / R.Py : 0;
+      const unsigned nrow = (cneed <= K.Lc - 1) ? (unsigned)(K.ntc - (int)(cneed / T)) : 0u;   // tiles of tile row ty
+      const unsigned ncol = (unsigned)mg_nty(tx, T, K.Lc, R.Px, R.px, R.Py, R.py);             // tiles of tile column tx
+      unsigned* cr = K.cnt + ty;
+      unsigned* cc = K.cnt + K.cnt_cols + tx;
+      unsigned* ct = K.cnt + 2 * K.cnt_cols;
+      lastf[0] = (atomicAdd(cr, 1u) + 1u == nrow);
+      lastf[1] = (atomicAdd(cc, 1u) + 1u == ncol);
+      lastf[2] = (atomicAdd(ct, 1u) + 1u == (unsigned)K.ntiles);
+      if (lastf[0]) *cr = 0;
+      if (lastf[1]) *cc = 0;
+      if (lastf[2]) *ct = 0;
+    }
+    __syncthreads();
+    const bool lrow = lastf[0] != 0, lcol = lastf[1] != 0, lall = lastf[2] != 0;
+    __syncthreads();
+    if (!(lrow || lcol || lall)) return;
+    double (*comb)[64][2] = reinterpret_cast<double (*)[64][2]>(dyn);   // the tile's LDS is free now
+    unsigned mine = 0;
+    if (lrow) {
+      for (int l0 = row0; l0 < row0 + T && l0 < K.Lr; l0 += 64) kl_chunk<NV, true>(R, K, true, l0, comb);
+      ++mine;
+    }
+    if (lcol) {
+      for (int l0 = col0; l0 < col0 + T && l0 < K.Lc; l0 += 64) kl_chunk<NV, true>(R, K, false, l0, comb);
+      ++mine;
+    }
+    if (lall) {
+      kl_scalars<NV, true>(R, K, red + 8);
+      kl_zero_uncovered<NV>(R, K);
+      ++mine;
+    }
+    kl_publish(K, K.cnt + 2 * K.cnt_cols + 1, mine, (unsigned)K.total, lastf + 3);
   }
   EIGX_STAMP(11);
   if (R.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) atomicAdd(&R.dbg[15], 1ull);
@@ -1556,6 +1674,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
 #endif
   // ---- multi-GPU state: step window, gathered panel, compact panels ------------------------------------------
   StepPeers peers;
+  unsigned* step_cnt = nullptr;          // folded step exchange: arrival counters [tile rows | tile columns | tiles | pushes]
   unsigned long long epoch = 0;          // epoch of the step message that the NEXT K_A consumes
   PeerBuf* panr = nullptr;               // receive window of the panel gather: [rank][mloc_max][nxs]
   double *pan = nullptr, *pan_send = nullptr, *UWr = nullptr, *UWc = nullptr;
@@ -1575,6 +1694,8 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     UWc = ctx.pool.get_t<double>("red.UWc", (size_t)ldc * 2 * m);
     R.PAN = pan;
     EIGX_HIP_CHECK(hipMemsetAsync(pan_send, 0, pan_count * sizeof(double), st));
+    step_cnt = ctx.pool.get_t<unsigned>("red.cnt", (size_t)2 * maxseg + 8);
+    EIGX_HIP_CHECK(hipMemsetAsync(step_cnt, 0, ((size_t)2 * maxseg + 8) * sizeof(unsigned), st));
   }
   // gather the panel columns [clo, chi], rows < chi + 1, from their owners into `pan` (enqueued on stream s)
   auto gather_panel = [&](int clo, int chi, hipStream_t s, CommChannel ch) {
@@ -1631,7 +1752,8 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   S.par = 0; S.pan_c0 = 0; S.G = 1;
   S.wait.n = 0; S.wait.flag = nullptr; S.wait.err = nullptr; S.wait.ticks = nullptr; S.wait.limit_ticks = 0; S.wait.epoch = 0;
   const bool fuse_wait = mg && comm_step_wait_fused(ctx);
-  const bool step_coll = mg && comm_step_collective(ctx);   // per-step exchange as an allgather (RCCL / emulated)
+  const bool step_coll = mg && comm_step_collective(ctx);
+  if (const char* ef = getenv("EIGX_FOLD_KL")) g_fold_kl = atoi(ef);   // per-step exchange as an allgather (RCCL / emulated)
   int k = 0;        // panel fill
   int i = n - 1;    // top column of the current block
   if (mg) {
@@ -1713,12 +1835,33 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     if (prof) ctx.prof_begin(0, 8.0 * ((double)L * (L + 1) / 2) / R.P, st);  // this rank's share of the triangle
     const bool nt_loads = (mg ? sqrt((double)B.Lr * B.Lc) : (double)L) > g_symv_nt;
     const bool unc = (mg ? sqrt((double)B.Lr * B.Lc) : (double)L) <= g_symv_unc;   // latency-bound sizes: the true two-unit pipeline
+    // several GPUs: the step exchange -- reduce this rank's tile partial sums, write them into every rank's window,
+    // publish the flag -- folded into the mat-vec launch (its last-arriving tiles do it) or as kl_kernel behind it
+    KLArgs KL;
+    memset(&KL, 0, sizeof(KL));
+    if (mg) {
+      ++epoch;
+      KL.L = L; KL.Lr = B.Lr; KL.Lc = B.Lc; KL.T = T; KL.ntc = B.ntc;
+      KL.nbr = ceil_div(B.Lr > 0 ? B.Lr : 1, 64);
+      KL.par = (int)(epoch & 1);
+      KL.epoch = epoch;
+      KL.peers = peers;
+      KL.cnt = step_cnt; KL.cnt_cols = maxseg; KL.ntiles = ntiles;
+      int ntr = 0, ncovc = 0;
+      for (int tx = 0; tx < B.ntc; ++tx) {
+        const int c = mg_nty(tx, T, B.Lc, G.Px, G.px, G.Py, G.py);
+        if (c > ntr) ntr = c;
+        if (c > 0) ++ncovc;
+      }
+      KL.ntr = ntr; KL.total = ntr + ncovc + 1;
+      KL.fold = (g_fold_kl && ntiles > 0) ? 1 : 0;   // a rank without tiles at this step has nobody to do it: kl_kernel
+    }
 #define EIGX_SYMV(RBv, NTv)                                                                                         \
   do {                                                                                                              \
-    if (mg && unc) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true, true>), dim3(gx), dim3(256), 0, st, R, B);   \
-    else if (mg) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true, false>), dim3(gx), dim3(256), 0, st, R, B);    \
-    else if (unc) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false, true>), dim3(gx), dim3(256), 0, st, R, B);   \
-    else hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false, false>), dim3(gx), dim3(256), 0, st, R, B);           \
+    if (mg && unc) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true, true>), dim3(gx), dim3(256), 0, st, R, B, KL);   \
+    else if (mg) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true, false>), dim3(gx), dim3(256), 0, st, R, B, KL);    \
+    else if (unc) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false, true>), dim3(gx), dim3(256), 0, st, R, B, KL);   \
+    else hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false, false>), dim3(gx), dim3(256), 0, st, R, B, KL);           \
   } while (0)
     if (T == 128) EIGX_SYMV(1, false);
     else if (T == 256 && !nt_loads) EIGX_SYMV(2, false);
@@ -1728,20 +1871,13 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
 #undef EIGX_SYMV
     if (prof) ctx.prof_end(st);
     if (mg) {
-      ++epoch;
-      KLArgs K;
-      K.L = L; K.Lr = B.Lr; K.Lc = B.Lc; K.T = T; K.ntc = B.ntc;
-      K.nbr = ceil_div(B.Lr > 0 ? B.Lr : 1, 64);
-      K.par = (int)(epoch & 1);
-      K.epoch = epoch;
-      K.peers = peers;
       const int nbc = ceil_div(B.Lc > 0 ? B.Lc : 1, 64);
       if (prof) ctx.prof_begin(2, 8.0 * R.msg_stride, st);
-      hipLaunchKernelGGL((kl_kernel<NB>), dim3(K.nbr + nbc), dim3(256), 0, st, R, K);
-      if (step_coll) comm_step_allgather(ctx, peers.slot[0], K.par, st);
+      if (!KL.fold) hipLaunchKernelGGL((kl_kernel<NB>), dim3(KL.nbr + nbc), dim3(256), 0, st, R, KL);
+      if (step_coll) comm_step_allgather(ctx, peers.slot[0], KL.par, st);
       if (prof) ctx.prof_end(st);
       prof_step = prof;
-      S.par = K.par;
+      S.par = KL.par;
     }
     t_symv_bytes += 8.0 * ((double)L * (L + 1) / 2);
     ++n_symv;
@@ -1832,6 +1968,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
 
 int set_symv_threshold(int which, int v) {
   if (which == 5) { const int old = g_symv_unc; g_symv_unc = v; return old; }
+  if (which == 6) { const int old = g_fold_kl; g_fold_kl = v; return old; }
   int& t = (which == 4) ? g_ka_fit : (which == 3) ? g_ka_wgs : (which == 2) ? g_symv_nt : (which ? g_symv_t256 : g_symv_t128);
   const int old = t; t = v; return old;
 }

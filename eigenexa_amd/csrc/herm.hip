@@ -599,6 +599,10 @@ __global__ void h_join_kernel(const double* __restrict__ Zr, const double* __res
   }
 }
 
+__global__ void h_identity_kernel(double* __restrict__ z, int ldz, int nvec) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < nvec) z[(size_t)j * ldz + j] = 1.0;
+}
 __global__ void h_scale_vec_kernel(double* __restrict__ w, int n, double s) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) w[i] *= s;
@@ -627,7 +631,7 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
   if (nvec == 0) mode = 'N';                      // src/eigen_h.F:104-106
   if (nvec < 0) nvec = -nvec;
   if (nvec > n) nvec = n;
-  if (mode != 'N' && mode != 'A' && mode != 'X') mode = 'A';
+  if (mode != 'N' && mode != 'A' && mode != 'X' && mode != 'S') mode = 'A';   // 'S': identity + bisection + back-transformation (src/eigen_h.F:207-210)
   const bool want_vec = mode != 'N';
   if (want_vec && (!z || ldz < n)) return EIGX_ERR_BAD_ARG;
   int m = mf <= 0 ? 48 : mf;
@@ -744,7 +748,13 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
   } else {
     Zr = ctx.pool.get_t<double>("h.Zr", (size_t)ldzp * n);
     Zi = ctx.pool.get_t<double>("h.Zi", (size_t)ldzp * n);
-    {
+    if (mode == 'S') {
+      // Z = I (the first nvec columns), eigenvalues by bisection: the back-transformation then delivers the unitary
+      // matrix of the reduction itself, Z^H A Z = T (src/eigen_h.F:207-210, eigen_identity src/eigen_identity.F)
+      hipLaunchKernelGGL(h_fill_kernel, dim3(1024), dim3(256), 0, st, Zr, (size_t)ldzp * nvec, 0.0);
+      hipLaunchKernelGGL(h_identity_kernel, dim3(ceil_div(nvec, 256)), dim3(256), 0, st, Zr, ldzp, nvec);
+      band_bisect_dev(ctx, n, H.d, H.e, lde, 1, w);
+    } else {
       // multi-rank callers reach this point with the gathered (replicated) problem: the real tridiagonal D&C runs
       // replicated too (its distributed form delivers column blocks, which only the real solvers consume)
       const Grid saved = ctx.grid;

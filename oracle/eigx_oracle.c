@@ -933,7 +933,12 @@ int orc_eigen_h(int n, int nvec, double* a_ri, int lda, double* wout, double* z_
     rc = orc_band_bisect(n, d, e, n, 1, wout);
   } else {
     double* y = (double*)calloc((size_t)n * n, sizeof(double));
-    rc = orc_band_dc(n, d, e, n, 1, wout, y, n, NULL);
+    if (mode == 'S') {   /* identity eigenvector matrix + bisection, then the back-transformation (src/eigen_h.F:207-210) */
+      for (int k = 0; k < n; ++k) y[(size_t)k + (size_t)k * n] = 1.0;
+      rc = orc_band_bisect(n, d, e, n, 1, wout);
+    } else {
+      rc = orc_band_dc(n, d, e, n, 1, wout, y, n, NULL);
+    }
     if (mode == 'X' && rc == 0) rc = orc_band_bisect(n, d, e, n, 1, wout);
     if (rc == 0) {
       for (int k = 0; k < nvec; ++k) {

@@ -343,7 +343,9 @@ def _run_multi_rank(world, n, route, nb, dims, env_extra=None):
     port = s.getsockname()[1]
     s.close()
     script = os.path.join(os.path.dirname(__file__), "mg_worker.py")
-    env = dict(os.environ, **(env_extra or {}))
+    env = dict(os.environ)
+    env.setdefault("EIGX_SELFTEST_ROUNDS", "40")   # the init-time transport self-test, shortened (the ladder tests look at its verdicts)
+    env.update(env_extra or {})
     procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port), str(n), route, str(nb), dims or "-"],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
     outs = []
@@ -568,9 +570,7 @@ def test_multi_rank_wait_folded_into_consumer(world, n, route, dims):
     _run_multi_rank(world, n, route, 0, dims, {"EIGX_FUSE_WAIT": "1"})
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("world,n,route,dims", [(2, 300, "sx", ""), (4, 517, "s", ""), (4, 700, "sx", "1x4"), (3, 260, "sx", ""),
-                                                (4, 333, "sx", "")])
+@pytest.mark.parametrize("world,n,route,dims", [(2, 300, "sx", ""), (4, 517, "s", ""), (4, 700, "sx", "1x4"), (3, 260, "sx", "")])
 def test_multi_rank_collective_step_exchange(world, n, route, dims):
     """second rung of the transport ladder: the per-step exchange as ONE allgather of the step messages through the
     comm_* interface (ncclAllGather over the world communicator on a node -- the reference's reduce_dbl over X and Y,
@@ -579,14 +579,21 @@ def test_multi_rank_collective_step_exchange(world, n, route, dims):
     _run_multi_rank(world, n, route, 0, dims, {"EIGX_STEP": "coll", "EIGX_EXPECT_STEP": "allgather"})
 
 
-@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,route,dims", [(2, 300, "sx", ""), (4, 517, "s", ""), (4, 700, "sx", "1x4"), (4, 5, "s", ""),
+                                                (5, 7, "sx", "1x5")])
+def test_multi_rank_step_exchange_as_its_own_kernel(world, n, route, dims):
+    """the step exchange (reduce this rank's tile partial sums, write them into every rank's window, publish the flag) as
+    kl_kernel behind the mat-vec (EIGX_FOLD_KL=0) instead of inside the mat-vec launch, where its last-arriving tiles do it
+    (the default, which every other multi-rank test runs; ranks without tiles at a step use kl_kernel there as well)"""
+    _run_multi_rank(world, n, route, 0, dims, {"EIGX_FOLD_KL": "0"})
+
+
 def test_multi_rank_default_rung_is_peer_writes():
     """first rung: peer windows passed the init-time self-test (checksummed bulk rounds and step-window rounds) and carry
     the per-step exchange as kernel stores, with the wait kernel (the tested default; the fused wait is opt-in)"""
     _run_multi_rank(2, 200, "sx", 0, "", {"EIGX_EXPECT_STEP": "peer writes"})
 
 
-@pytest.mark.gpu
 def test_multi_rank_no_transport_fails_on_every_rank():
     """bottom rung: the self-test of the only available transport fails (forced) -> eigx_init_multi returns an error on
     every rank at once (agreed on through the bootstrap board), nothing stays behind, a 1-rank init still works;
@@ -616,7 +623,6 @@ def _run_bench(args, env_extra):
     return json.loads(lines[0]), r.stderr
 
 
-@pytest.mark.gpu
 def test_bench_launches_ranks_and_walks_the_ladder():
     """`python bench.py --gpus 3` (no launcher; gloo rehearsal with the ranks sharing this card): an n_gpus = 3 strong-scaling
     line that names its transport and carries the per-step breakdown; with the peer windows' self-test forced to fail
@@ -1146,6 +1152,22 @@ def test_eigen_h_known_spectrum_and_modes(gpu_lib, orc):
         if mode != "N":
             res, orth = _herm_check(A, w, z)
             assert res < GATE_RES and orth < GATE_ORTH, (mode, res, orth)
+    # mode 'S' (src/eigen_h.F:207-210): Z = the unitary matrix of the reduction (identity pushed through the
+    # back-transformation), w by bisection; Z^H A Z is real tridiagonal; element-wise against the oracle in the same mode
+    # up to the phase freedom that the reduction does not have (same reflector convention: none)
+    B = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    Hm = (B + B.conj().T) / 2
+    a = np.asfortranarray(np.triu(Hm))
+    z = np.zeros((n, n), dtype=np.complex128, order="F")
+    w = np.zeros(n)
+    ee.eigen_h(n, n, a, n, w, z, n, mode="S")
+    assert ee.api.last_status() == 0
+    assert np.abs(w - np.linalg.eigvalsh(Hm)).max() < 1e-12 * np.abs(Hm).sum(axis=1).max()
+    assert np.linalg.norm(z.conj().T @ z - np.eye(n)) / (n * EPS) < GATE_ORTH
+    Tm = z.conj().T @ Hm @ z
+    assert np.abs(np.triu(Tm, 2)).max() < 1e-12 * n * np.abs(Hm).max() and np.abs(Tm.imag).max() < 1e-12 * n * np.abs(Hm).max()
+    wo, Zo = orc.eigen_h(Hm, mode="S")
+    assert np.abs(w - wo).max() < 1e-12 * np.abs(Hm).sum(axis=1).max() and np.abs(z - Zo).max() < 1e-10
     # partial set, device API (column-major image: at[j, i] = A(i, j))
     nvec = 40
     at = torch.from_numpy(np.ascontiguousarray(np.triu(A).T)).cuda()

@@ -288,6 +288,14 @@ def test_oracle_eigen_h(orc, n):
             eps = np.finfo(float).eps
             assert np.linalg.norm(A @ Z - Z * w[None, :]) <= 768 * n * eps * max(np.linalg.norm(A), 1e-300)
             assert np.linalg.norm(Z.conj().T @ Z - np.eye(n)) <= 8 * n * eps
+    # mode 'S' (src/eigen_h.F:207-210): identity + bisection + back-transformation -> Z is the unitary matrix of the
+    # reduction itself: Z^H A Z is real symmetric tridiagonal with the spectrum of A
+    w, Z = orc.eigen_h(A, mode="S")
+    eps = np.finfo(float).eps
+    assert np.abs(w - np.linalg.eigvalsh(A)).max() < 1e-12 * max(1.0, np.abs(A).sum(axis=1).max())
+    assert np.linalg.norm(Z.conj().T @ Z - np.eye(n)) <= 8 * n * eps
+    Tm = Z.conj().T @ A @ Z
+    assert np.abs(np.triu(Tm, 2)).max() < 1e-12 * max(1.0, np.abs(A).max()) * n and np.abs(Tm.imag).max() < 1e-12 * max(1.0, np.abs(A).max()) * n
     ph = np.exp(1j * rng.uniform(0, 2 * np.pi, n))
     F = (ph[:, None] * layout.frank(n)) * ph.conj()[None, :]
     w, _ = orc.eigen_h(F)
