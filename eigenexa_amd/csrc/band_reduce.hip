@@ -108,8 +108,10 @@ int g_ka_wgs = 256;   // K_A (eigx_tune key 7): beyond 2 * this many row groups 
 int g_symv_t128 = 4500, g_symv_t256 = 40000;
 int g_symv_nt = 9000;
 // several GPUs: 1 = the step exchange runs inside the mat-vec launch (its last-arriving tiles reduce and push), 0 = as
-// kl_kernel behind it (EIGX_FOLD_KL, eigx_tune key 12)
-int g_fold_kl = 1;
+// kl_kernel behind it (EIGX_FOLD_KL, eigx_tune key 12).  Default 0: in the rehearsal of one rank of a 2 x 4 grid at
+// N = 32768 (tools/mg_step_rehearsal.py) the folded form made the mat-vec 23 us longer to save a 20-us kernel -- the last
+// tile's workgroup does a whole row block's and column block's reduction alone, on the critical path
+int g_fold_kl = 0;
 int g_symv_unc = 9000;   // the fused mat-vec's branch-free pipelined form up to this active size (eigx_tune key 11)
 
 inline SymvGeom symv_geom(int L) {
@@ -763,8 +765,13 @@ struct KLArgs {
   StepPeers peers;
   // folded form (the reduce + push runs inside the mat-vec launch, see symv_kernel): counters [tile rows | tile columns |
   // tiles | pushes], all zero between launches; tiles of the launch; tile rows that hold at least one tile
+  // second level of the panel dots (several GPUs, kl_kernel form): the mat-vec launch's K_P workgroups take short row
+  // chunks (the local tile stream is 1/P of one GPU's, a 4-chunk K_P would outlast it) and write kd2; kl_kernel's extra
+  // workgroup sums the npd2 chunks into the one-chunk array that K_A reads
+  const double* kd2; int npd2, kdab2_off, kfill;
   unsigned* cnt;
-  int cnt_cols, ntiles, ntr, total, fold;   // total = pushes of a launch: tile rows + tile columns that hold tiles, + 1
+  int cnt_cols, ntiles, ntr, total, fold;
+  int fence;   // 1: every pushing workgroup runs a system-scope fence behind its stores (EIGX_STEP_FENCE=1); 0: see kl_publish   // total = pushes of a launch: tile rows + tile columns that hold tiles, + 1
 };
 
 // loads / stores of partial sums that another workgroup of the SAME launch reads / wrote (folded form): agent scope,
@@ -785,46 +792,40 @@ __device__ __forceinline__ void kl_chunk(const RedArgs& R, const KLArgs& K, bool
   const int l = l0 + lane;
   auto ld = [&](const double* p) { return AG ? ld_agent(p) : *p; };
   double pA = 0.0, pB = 0.0;
-  if (rows && l < K.Lr) {
-    // row sums: tiles (ty, tx) with tx >= txmin, the tile column that holds the first local column at or right of
-    // the tile row's first global row
-    const int ty = l / T;
-    const long g0 = (long)ty * T * R.Px + R.px;
-    const long cneed = g0 > R.py ? (g0 - R.py + R.Py - 1) / R.Py : 0;
-    if (cneed <= K.Lc - 1) {
-      int tx = (int)(cneed / T) + q;
-      for (; tx + 12 < K.ntc; tx += 16) {
-        double a[4], b[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          a[e] = ld(&R.YR[((size_t)(tx + 4 * e) * NB + 0) * ldp + l]);
-          b[e] = (NB == 2) ? ld(&R.YR[((size_t)(tx + 4 * e) * NB + 1) * ldp + l]) : 0.0;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { pA += a[e]; pB += b[e]; }
-      }
-      for (; tx < K.ntc; tx += 4) {
-        pA += ld(&R.YR[((size_t)tx * NB + 0) * ldp + l]);
-        if (NB == 2) pB += ld(&R.YR[((size_t)tx * NB + 1) * ldp + l]);
-      }
+  // this lane's partial sums: tile index t0, t0 + 4, ... < tend of the row's / column's partial-sum array P (stride
+  // NB * ldp per tile).  They sit behind a cold L2 (written by tiles on other XCDs): ALL loads of a batch of 16 per vector
+  // are issued before the first add -- clamped indices, masked afterwards -- so a row costs one memory round trip, not
+  // one per tile (the earlier loop with a serial remainder took ~20 us per launch at 32-64 tiles per row).
+  const bool act = rows ? (l < K.Lr) : (l < K.Lc);
+  const double* P = rows ? R.YR : R.YC;
+  int t0 = q, tend = 0;
+  if (act) {
+    if (rows) {
+      // tiles (ty, tx) with tx >= txmin, the tile column that holds the first local column at or right of the tile row's
+      // first global row
+      const int ty = l / T;
+      const long g0 = (long)ty * T * R.Px + R.px;
+      const long cneed = g0 > R.py ? (g0 - R.py + R.Py - 1) / R.Py : 0;
+      if (cneed <= K.Lc - 1) { t0 = (int)(cneed / T) + q; tend = K.ntc; }
+    } else {
+      tend = mg_nty(l / T, T, K.Lc, R.Px, R.px, R.Py, R.py);
     }
-  } else if (!rows && l < K.Lc) {
-    const int tx = l / T;
-    const int nty = mg_nty(tx, T, K.Lc, R.Px, R.px, R.Py, R.py);
-    int t = q;
-    for (; t + 12 < nty; t += 16) {
-      double a[4], b[4];
+  }
+  const int lc = act ? l : 0;
+  for (int tb = t0; tb < tend; tb += 64) {
+    double a[16], b[16];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        a[e] = ld(&R.YC[((size_t)(t + 4 * e) * NB + 0) * ldp + l]);
-        b[e] = (NB == 2) ? ld(&R.YC[((size_t)(t + 4 * e) * NB + 1) * ldp + l]) : 0.0;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { pA += a[e]; pB += b[e]; }
+    for (int e = 0; e < 16; ++e) {
+      const int t = (tb + 4 * e < tend) ? tb + 4 * e : tb;
+      a[e] = ld(&P[((size_t)t * NB + 0) * ldp + lc]);
+      b[e] = (NB == 2) ? ld(&P[((size_t)t * NB + 1) * ldp + lc]) : 0.0;
     }
-    for (; t < nty; t += 4) {
-      pA += ld(&R.YC[((size_t)t * NB + 0) * ldp + l]);
-      if (NB == 2) pB += ld(&R.YC[((size_t)t * NB + 1) * ldp + l]);
+    asm volatile("" ::: "memory");   // every load of the batch issued
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const bool ok = tb + 4 * e < tend;
+      pA += ok ? a[e] : 0.0;
+      pB += ok ? b[e] : 0.0;
     }
   }
   comb[q][lane][0] = pA; comb[q][lane][1] = pB;
@@ -886,9 +887,16 @@ __device__ __forceinline__ void kl_zero_uncovered(const RedArgs& R, const KLArgs
 
 // after a workgroup's pushes: drain, count, and let the workgroup that completes the count publish the step's flag on
 // every rank (`mine` pushes of `total` expected; the counter returns to zero for the next launch)
+// The payload stores are system-scope write-through stores (st_sys): each storing wave waits until they are acknowledged
+// (vmcnt(0)), the workgroup barrier collects the waves, ONE agent-scope add counts the workgroup, and only the publishing
+// workgroup's flag store carries a system-scope release.  A system-scope fence in EVERY pushing workgroup (the earlier
+// form, kept behind EIGX_STEP_FENCE=1) writes back whatever is dirty in the XCD's L2 -- the mat-vec's partial sums of
+// the whole launch -- several hundred times per step: 20-38 us per launch in the rehearsal of one rank at N = 32768.  The
+// init-time self-test (comm.hip, st_step_push_kernel) runs this very protocol with checksummed payloads before the solver
+// relies on it.
 __device__ __forceinline__ void kl_publish(const KLArgs& K, unsigned* counter, unsigned mine, unsigned total, int* lastw) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __threadfence_system();
+  if (K.fence) __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned tk = atomicAdd(counter, mine);
@@ -907,9 +915,33 @@ __global__ __launch_bounds__(256) void kl_kernel(RedArgs R, KLArgs K) {
   __shared__ double comb[4][64][2];
   __shared__ double red[16];
   __shared__ int last;
-  const bool rows = (int)blockIdx.x < K.nbr;
-  kl_chunk<NB, false>(R, K, rows, (rows ? blockIdx.x : blockIdx.x - K.nbr) * 64, comb);
-  if (blockIdx.x == 0) kl_scalars<NB, false>(R, K, red);
+  if (K.npd2 > 0 && (int)blockIdx.x >= (int)gridDim.x - 2 * NB) {
+    // panel dots, second level: one workgroup per kind q; entry (q, panel column kk) = sum over the row chunks in chunk
+    // order (deterministic), ALL chunk loads of a thread in one batch (<= 4 P + 4 = 36 chunks: one memory round trip)
+    const int m = R.m, tid = threadIdx.x;
+    const int q = (int)blockIdx.x - ((int)gridDim.x - 2 * NB);
+    constexpr int MAXC = 4 * EIGX_MAXP + 4;
+    if (tid < K.kfill) {
+      double v[MAXC];
+#pragma unroll
+      for (int e = 0; e < MAXC; ++e) v[e] = K.kd2[((size_t)((e < K.npd2) ? e : 0) * 2 * NB + q) * m + tid];
+      asm volatile("" ::: "memory");
+      double acc = 0.0;
+#pragma unroll
+      for (int e = 0; e < MAXC; ++e) acc += (e < K.npd2) ? v[e] : 0.0;
+      R.KD[(size_t)q * m + tid] = acc;
+    }
+    if (NB == 2 && q == 1 && (tid >> 6) == 3) {   // uA.uB: one lane per chunk (<= 36), one wave reduction
+      const int lane = tid & 63;
+      double ab = (lane < K.npd2) ? K.kd2[K.kdab2_off + lane] : 0.0;
+      ab = wave_sum(ab);
+      if (lane == 0) R.KD[R.kdab_off] = ab;
+    }
+  } else {
+    const bool rows = (int)blockIdx.x < K.nbr;
+    kl_chunk<NB, false>(R, K, rows, (rows ? blockIdx.x : blockIdx.x - K.nbr) * 64, comb);
+    if (blockIdx.x == 0) kl_scalars<NB, false>(R, K, red);
+  }
   // every storing wave drains its stores; the last workgroup to arrive publishes the flag on every rank
   kl_publish(K, K.peers.counter, 1u, gridDim.x, &last);
 }
@@ -1659,6 +1691,10 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   }
   R.kdab_off = R.maxchunk * 2 * NB * m;
   R.KD = ctx.pool.get_t<double>("red.KD", (size_t)R.kdab_off + R.maxchunk + 8 + 512);   // + slack: K_A loads kk < 256 unclamped
+  // several GPUs: first-level panel dots of up to 4 P + 4 short row chunks (see KLArgs)
+  const int maxchunk2 = 4 * G.nranks + 4;
+  const int kdab2_off = maxchunk2 * 2 * NB * m;
+  double* KD2 = mg ? ctx.pool.get_t<double>("red.KD2", (size_t)kdab2_off + maxchunk2 + 8) : nullptr;
   const size_t sp_count = (size_t)(maxseg * maxseg) * 3 + 8;
   R.SP = ctx.pool.get_t<double>("red.SP", sp_count);
   const int maxgp = (n + KA_ROWS - 1) / KA_ROWS + 2;
@@ -1753,7 +1789,8 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   S.wait.n = 0; S.wait.flag = nullptr; S.wait.err = nullptr; S.wait.ticks = nullptr; S.wait.limit_ticks = 0; S.wait.epoch = 0;
   const bool fuse_wait = mg && comm_step_wait_fused(ctx);
   const bool step_coll = mg && comm_step_collective(ctx);
-  if (const char* ef = getenv("EIGX_FOLD_KL")) g_fold_kl = atoi(ef);   // per-step exchange as an allgather (RCCL / emulated)
+  if (const char* ef = getenv("EIGX_FOLD_KL")) g_fold_kl = atoi(ef);
+  const int step_fence = (getenv("EIGX_STEP_FENCE") && atoi(getenv("EIGX_STEP_FENCE")) != 0) ? 1 : 0;   // per-step exchange as an allgather (RCCL / emulated)
   int k = 0;        // panel fill
   int i = n - 1;    // top column of the current block
   if (mg) {
@@ -1803,6 +1840,12 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     B.ncg = (k + PD_COLS - 1) / PD_COLS;
     B.toprows = i + 1;
     B.pdr = pd_rows_for(B.toprows);
+    // several GPUs, kl_kernel form of the exchange: 4 P chunks (>= 512 rows each), reduced a second time by kl_kernel
+    const bool kd_two_level = mg && !g_fold_kl;
+    if (kd_two_level) {
+      int r_ = ((B.toprows + 4 * G.nranks - 1) / (4 * G.nranks) + 63) / 64 * 64;
+      B.pdr = r_ < 512 ? 512 : r_;
+    }
     const int npd = (B.toprows + B.pdr - 1) / B.pdr;
     B.npd = npd;
     B.ngp = nb_ka;
@@ -1855,11 +1898,15 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       }
       KL.ntr = ntr; KL.total = ntr + ncovc + 1;
       KL.fold = (g_fold_kl && ntiles > 0) ? 1 : 0;   // a rank without tiles at this step has nobody to do it: kl_kernel
+      if (kd_two_level) { KL.kd2 = KD2; KL.npd2 = npd; KL.kdab2_off = kdab2_off; KL.kfill = k; }
+      KL.fence = step_fence;
     }
+    RedArgs RS = R;                    // what the mat-vec launch sees: two-level panel dots write the first level
+    if (kd_two_level) { RS.KD = KD2; RS.kdab_off = kdab2_off; }
 #define EIGX_SYMV(RBv, NTv)                                                                                         \
   do {                                                                                                              \
-    if (mg && unc) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true, true>), dim3(gx), dim3(256), 0, st, R, B, KL);   \
-    else if (mg) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true, false>), dim3(gx), dim3(256), 0, st, R, B, KL);    \
+    if (mg && unc) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true, true>), dim3(gx), dim3(256), 0, st, RS, B, KL);   \
+    else if (mg) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true, false>), dim3(gx), dim3(256), 0, st, RS, B, KL);    \
     else if (unc) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false, true>), dim3(gx), dim3(256), 0, st, R, B, KL);   \
     else hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false, false>), dim3(gx), dim3(256), 0, st, R, B, KL);           \
   } while (0)
@@ -1873,7 +1920,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     if (mg) {
       const int nbc = ceil_div(B.Lc > 0 ? B.Lc : 1, 64);
       if (prof) ctx.prof_begin(2, 8.0 * R.msg_stride, st);
-      if (!KL.fold) hipLaunchKernelGGL((kl_kernel<NB>), dim3(KL.nbr + nbc), dim3(256), 0, st, R, KL);
+      if (!KL.fold) hipLaunchKernelGGL((kl_kernel<NB>), dim3(KL.nbr + nbc + (KL.npd2 > 0 ? 2 * NB : 0)), dim3(256), 0, st, R, KL);
       if (step_coll) comm_step_allgather(ctx, peers.slot[0], KL.par, st);
       if (prof) ctx.prof_end(st);
       prof_step = prof;
@@ -1883,7 +1930,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     ++n_symv;
     // bookkeeping for the next K_A
     S.has_prev = 1; S.iprev = i; S.Lprev = L; S.kprev = k;
-    S.nchunk_prev = npd;
+    S.nchunk_prev = kd_two_level ? 1 : npd;
     S.nt_prev = B.nt; S.lgT_prev = (T == 128) ? 7 : (T == 256 ? 8 : 9);
     k += NB;
     i -= NB;

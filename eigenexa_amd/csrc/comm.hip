@@ -143,6 +143,7 @@ struct CommState {
   bool rccl = false;           // the BULK collectives go through RCCL (otherwise through the peer windows)
   bool step_coll = false;      // the per-step exchange is a collective allgather (RCCL / emulated), not peer writes
   bool err_in_flags = false;   // err_dev is a word of the peer-mapped flag block
+  bool loop = false;           // EIGX_LOOPBACK (lab): this process plays ONE rank of a P-rank grid alone; every peer window is its own
   bool in_selftest = false;    // init-time self-test: failures stay local (the verdict is voted on), device waits are short
   // init-time transport self-test (recorded for eigx_comm_info)
   int st_ipc_rounds = 0, st_ipc_errors = -1, st_step_rounds = 0, st_step_errors = -1, st_rccl_checks = 0, st_rccl_errors = -1;
@@ -393,7 +394,7 @@ struct StStepArgs {
   u64* flag[EIGX_MAXP];           // my arrival flag (parity 0) in rank q's flag block
   size_t parity_stride, count;
   unsigned* counter;
-  int n, rank, round;
+  int n, rank, round, fence;
   u64 epoch;
 };
 __global__ __launch_bounds__(256) void st_step_push_kernel(StStepArgs A) {
@@ -403,8 +404,10 @@ __global__ __launch_bounds__(256) void st_step_push_kernel(StStepArgs A) {
     for (int d = 0; d < A.n; ++d)
       __hip_atomic_store(A.slot[d] + (size_t)par * A.parity_stride + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  // exactly band_reduce.hip's kl_publish: acknowledged write-through stores, barrier, one count per workgroup, the
+  // publisher's flag store alone carries the system-scope release (EIGX_STEP_FENCE=1: a fence in every workgroup)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __threadfence_system();
+  if (A.fence) __threadfence_system();
   __syncthreads();
   __shared__ int last;
   if (threadIdx.x == 0) {
@@ -531,6 +534,28 @@ int comm_init(Context& ctx, const void* uid) {
   CommState* cs = new CommState();
   cs->P = g.nranks; cs->me = g.rank;
   if (const char* t = getenv("EIGX_COMM_TIMEOUT_S")) { const double v = atof(t); if (v > 0.0) cs->timeout_s = v; }
+  if (getenv("EIGX_LOOPBACK")) {
+    // Lab mode (tools/mg_step_rehearsal.py): this process plays rank g.rank of the P-rank grid ALONE.  Every peer
+    // window and flag block is its own memory and it signals on behalf of every source, so the complete multi-rank
+    // kernel sequence of a rank -- local mat-vec with the folded exchange, waits, the replicated K_A, panel gathers --
+    // runs at the true local sizes on an otherwise idle GPU and can be timed; the numbers it computes are meaningless.
+    cs->loop = true;
+    cs->ipc = true;
+    EIGX_HIP_CHECK(hipMalloc(&cs->counters, CH_COUNT * sizeof(unsigned)));
+    EIGX_HIP_CHECK(hipMemset(cs->counters, 0, CH_COUNT * sizeof(unsigned)));
+    EIGX_HIP_CHECK(hipMalloc(&cs->ticks_dev, sizeof(u64)));
+    EIGX_HIP_CHECK(hipMemset(cs->ticks_dev, 0, sizeof(u64)));
+    cs->flags.bytes = kFlagWordsTotal * sizeof(u64);
+    cs->flags.local = alloc_window(cs->flags.bytes);
+    if (!cs->flags.local) EIGX_HIP_CHECK(hipMalloc((void**)&cs->flags.local, cs->flags.bytes));
+    EIGX_HIP_CHECK(hipMemset(cs->flags.local, 0, cs->flags.bytes));
+    cs->err_dev = (int*)((u64*)cs->flags.local + kFlagWords);
+    for (int q = 0; q < cs->P; ++q) cs->flags.peer[q] = cs->flags.local;
+    cs->flags.mapped = true;
+    ctx.comm = cs;
+    fprintf(stderr, "[eigx] LOOPBACK: rank %d of %d alone on this GPU (timing rehearsal, results meaningless)\n", cs->me, cs->P);
+    return EIGX_OK;
+  }
   // ---- board ------------------------------------------------------------------------------------------
   char name[64];
   snprintf(name, sizeof(name), "/eigx-%016llx", (unsigned long long)fnv1a(uid, 128));
@@ -705,6 +730,7 @@ int comm_init(Context& ctx, const void* uid) {
       if (cs->failed) my_ok = 0;
       StStepArgs A;
       A.n = cs->P; A.rank = cs->me; A.count = cnt; A.parity_stride = sp.parity_stride; A.counter = sp.counter;
+      A.fence = (getenv("EIGX_STEP_FENCE") && atoi(getenv("EIGX_STEP_FENCE")) != 0) ? 1 : 0;
       for (int q = 0; q < EIGX_MAXP; ++q) { A.slot[q] = sp.slot[q]; A.flag[q] = sp.flag[q]; }
       const u64 base = comm_step_epoch_base(ctx, (u64)rounds + 2);
       const double t1 = now_s();
@@ -828,10 +854,10 @@ void comm_free(Context& ctx) {
   // every imported mapping is closed, whether or not the import round as a whole succeeded
   for (PeerBuf& b : allb) {
     for (int q = 0; q < cs->P; ++q)
-      if (q != cs->me && b.peer[q]) { if (hipIpcCloseMemHandle(b.peer[q]) != hipSuccess) (void)hipGetLastError(); }
+      if (q != cs->me && b.peer[q] && !cs->loop) { if (hipIpcCloseMemHandle(b.peer[q]) != hipSuccess) (void)hipGetLastError(); }
   }
   for (int q = 0; q < cs->P; ++q)
-    if (q != cs->me && cs->flags.peer[q]) { if (hipIpcCloseMemHandle(cs->flags.peer[q]) != hipSuccess) (void)hipGetLastError(); }
+    if (q != cs->me && cs->flags.peer[q] && !cs->loop) { if (hipIpcCloseMemHandle(cs->flags.peer[q]) != hipSuccess) (void)hipGetLastError(); }
   if (polite && !cs->board_dead) { int z = 0; unsigned char all[EIGX_MAXP][128]; (void)board_exchange(cs, &z, sizeof(z), all); }
   for (PeerBuf& b : allb)
     if (b.local) { if (hipFree(b.local) != hipSuccess) (void)hipGetLastError(); }
@@ -866,6 +892,15 @@ PeerBuf* comm_buffer(Context& ctx, const std::string& name, size_t bytes) {
   const size_t want = (bytes < ((size_t)64 << 20)) ? bytes + bytes / 2 + 256 : bytes + 256;
   // only what kernels store into needs a peer mapping: everything when the peer windows carry the bulk collectives too
   // (ranks sharing a card), otherwise just the per-step window -- RCCL takes plain device pointers
+  if (cs->loop) {   // lab mode: every "peer" is this buffer
+    const size_t want_l = bytes + bytes / 2 + 256;
+    EIGX_HIP_CHECK(hipMalloc((void**)&b.local, want_l));
+    EIGX_HIP_CHECK(hipMemset(b.local, 0, want_l));
+    b.bytes = want_l;
+    for (int q = 0; q < cs->P; ++q) b.peer[q] = b.local;
+    b.mapped = true;
+    return &b;
+  }
   const bool map = cs->ipc && (!cs->rccl || (name == "comm.step" && !cs->step_coll));
   b.local = map ? alloc_window(want) : nullptr;
   const bool window_ok = b.local != nullptr;      // false with map: no fine-grained memory -> reported as a failed mapping below
@@ -927,6 +962,8 @@ PeerBuf* comm_buffer(Context& ctx, const std::string& name, size_t bytes) {
 }
 
 static u64* flag_word(double* block, int ch, int kind, int src) { return (u64*)block + flag_index(ch, kind, src); }
+// index under which this rank signals rank q (loopback: it stands in for q itself, so that its own waits are satisfied)
+static int sig_idx(const CommState* cs, int q) { return cs->loop ? q : cs->me; }
 
 void comm_exchange(Context& ctx, CommGroup grp, const double* send, size_t send_stride, PeerBuf* recv, size_t recv_off,
                    size_t count, hipStream_t s, CommChannel ch) {
@@ -967,10 +1004,10 @@ void comm_exchange(Context& ctx, CommGroup grp, const double* send, size_t send_
   A.src = send; A.src_stride = send_stride; A.count = count; A.counter = cs->counters + ch;
   for (int r = 0; r < n; ++r) {
     const int q = members[r];
-    R.remote[r] = flag_word(cs->flags.peer[q], ch, 1, cs->me);
+    R.remote[r] = flag_word(cs->flags.peer[q], ch, 1, sig_idx(cs, q));
     R.local[r] = flag_word(cs->flags.local, ch, 1, q);
-    A.dst[r] = recv->peer[q] + recv_off + (size_t)mine * count;
-    A.flag[r] = flag_word(cs->flags.peer[q], ch, 0, cs->me);
+    A.dst[r] = recv->peer[q] + recv_off + (size_t)(cs->loop ? r : mine) * count;
+    A.flag[r] = flag_word(cs->flags.peer[q], ch, 0, sig_idx(cs, q));
     W.flag[r] = flag_word(cs->flags.local, ch, 0, q);
   }
   hipLaunchKernelGGL(ready_kernel, dim3(1), dim3(64), 0, s, R);
@@ -1086,11 +1123,11 @@ void comm_exchange_big(Context& ctx, CommGroup grp, const double* send, size_t s
       R.err = W.err = cs->err_dev;
       R.ticks = W.ticks = A.ticks = cs->ticks_dev;
       R.limit_ticks = W.limit_ticks = limit_ticks(cs);
-      R.remote[0] = flag_word(cs->flags.peer[sq], ch, 1, cs->me);   // "my window is free" goes to the rank that fills it
+      R.remote[0] = flag_word(cs->flags.peer[sq], ch, 1, sig_idx(cs, dq));   // "my window is free" goes to the rank that fills it
       R.local[0] = flag_word(cs->flags.local, ch, 1, dq);           // ... and I wait for the same word of my destination
       A.src = send + (size_t)di * send_stride + off; A.src_stride = 0; A.count = c; A.counter = cs->counters + ch;
       A.dst[0] = w->peer[dq];
-      A.flag[0] = flag_word(cs->flags.peer[dq], ch, 0, cs->me);
+      A.flag[0] = flag_word(cs->flags.peer[dq], ch, 0, sig_idx(cs, sq));
       W.flag[0] = flag_word(cs->flags.local, ch, 0, sq);
       hipLaunchKernelGGL(ready_kernel, dim3(1), dim3(64), 0, s, R);
       size_t blocks = (c + 4095) / 4096;
@@ -1124,8 +1161,8 @@ double* comm_step_window(Context& ctx, size_t msg_doubles, StepPeers* peers) {
     return w->local;
   }
   for (int q = 0; q < cs->P; ++q) {
-    peers->slot[q] = (w->mapped ? w->peer[q] : w->local) + (size_t)cs->me * msg_doubles;
-    peers->flag[q] = flag_word(cs->flags.mapped ? cs->flags.peer[q] : cs->flags.local, CH_STEP, 0, cs->me);
+    peers->slot[q] = (w->mapped ? w->peer[q] : w->local) + (size_t)sig_idx(cs, q) * msg_doubles;
+    peers->flag[q] = flag_word(cs->flags.mapped ? cs->flags.peer[q] : cs->flags.local, CH_STEP, 0, sig_idx(cs, q));
   }
   if (!w->mapped) comm_fail(cs, "the per-step exchange needs peer windows (hipIpc) between the ranks");
   return w->local;

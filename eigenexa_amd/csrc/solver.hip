@@ -614,12 +614,15 @@ int eigx_numroc(int n, int nb, int iproc, int nprocs) {
 
 int eigx_band_reduce_dev(int n, double* a, int lda, double* d, double* e, int lde, int mf, int band) {
   if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
-  if (n <= 0 || lda < n || (lda & 1) || lde < n || (band != 1 && band != 2)) return EIGX_ERR_BAD_ARG;
-  if (g_ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;
-  EIGX_HIP_CHECK(hipStreamSynchronize(nullptr));   // the caller's default-stream work on the arguments (see solve_dev)
-  band_reduce_dev(g_ctx, n, a, lda, d, e, lde, mf > 0 ? mf : 128, band);
-  EIGX_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
-  return EIGX_OK;
+  // several ranks: collective; a = this rank's 2-D cyclic block a(lda, *), d / e replicated
+  const int nloc = local_count(n, g_ctx.grid.Px, g_ctx.grid.px);
+  if (n <= 0 || lda < (nloc > 1 ? nloc : 1) || (lda & 1) || lde < n || (band != 1 && band != 2)) return EIGX_ERR_BAD_ARG;
+  return eigx_guard(g_ctx, [&] {
+    EIGX_HIP_CHECK(hipStreamSynchronize(nullptr));   // the caller's default-stream work on the arguments (see solve_dev)
+    band_reduce_dev(g_ctx, n, a, lda, d, e, lde, mf > 0 ? mf : 128, band);
+    EIGX_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+    return (g_ctx.grid.nranks > 1 && comm_failed(g_ctx)) ? EIGX_ERR_INTERNAL : EIGX_OK;
+  });
 }
 
 int eigx_band_dc_dev(int n, int nvec, const double* d, const double* e, int lde, int band, double* w, double* z,

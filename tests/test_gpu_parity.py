@@ -581,11 +581,12 @@ def test_multi_rank_collective_step_exchange(world, n, route, dims):
 
 @pytest.mark.parametrize("world,n,route,dims", [(2, 300, "sx", ""), (4, 517, "s", ""), (4, 700, "sx", "1x4"), (4, 5, "s", ""),
                                                 (5, 7, "sx", "1x5")])
-def test_multi_rank_step_exchange_as_its_own_kernel(world, n, route, dims):
-    """the step exchange (reduce this rank's tile partial sums, write them into every rank's window, publish the flag) as
-    kl_kernel behind the mat-vec (EIGX_FOLD_KL=0) instead of inside the mat-vec launch, where its last-arriving tiles do it
-    (the default, which every other multi-rank test runs; ranks without tiles at a step use kl_kernel there as well)"""
-    _run_multi_rank(world, n, route, 0, dims, {"EIGX_FOLD_KL": "0"})
+def test_multi_rank_step_exchange_folded_into_the_mat_vec(world, n, route, dims):
+    """the step exchange (reduce this rank's tile partial sums, write them into every rank's window, publish the flag)
+    inside the mat-vec launch (EIGX_FOLD_KL=1: the last tile to finish of a tile row / tile column does that block, agent-scope
+    hand-off between workgroups of one launch) instead of kl_kernel behind it (the default, which every other multi-rank
+    test runs; ranks without tiles at a step use kl_kernel in the folded form as well)"""
+    _run_multi_rank(world, n, route, 0, dims, {"EIGX_FOLD_KL": "1"})
 
 
 def test_multi_rank_default_rung_is_peer_writes():
