@@ -1038,13 +1038,14 @@ def test_large_n_eigenvalues_only_invariants(gpu_lib):
     _spectrum_invariants(w.cpu().numpy(), tr, fro2, n)
 
 
-@pytest.mark.parametrize("route", ["sx", "s"])
-def test_baseline_config_n32768_all_eigenpairs(gpu_lib, route):
+@pytest.mark.parametrize("route,mf", [("sx", 128), ("sx", 256), ("s", 128)])
+def test_baseline_config_n32768_all_eigenpairs(gpu_lib, route, mf):
     """BASELINE.json configs[2] (N=32768 random symmetric, eigen_sx) and configs[3] (N=32768 eigen_s: eigen_trd +
     trbakwy4), all eigenpairs, at the full size on this one GPU (the 8-GPU partition of the same solve is covered by
     test_multi_rank_solver_on_one_gpu at sizes the ranks of one card can hold): the complete gates of
     benchmark/ev_test.f:181-204 through GPU matmuls -- ||AZ-ZW||_F/(N eps ||A||_F) < 768, ||Z^T Z - I||_F/(N eps) < 8,
-    north_star's ||AZ-ZW||/||A|| <= 1e-12 N -- plus trace / Frobenius invariants and sortedness."""
+    north_star's ||AZ-ZW||/||A|| <= 1e-12 N -- plus trace / Frobenius invariants and sortedness.  m_forward = 256 is the
+    panel width of bench.py's `extra` block (the one quoted for the trailing update's share of the MFMA peak)."""
     import torch
 
     n = 32768
@@ -1056,7 +1057,7 @@ def test_baseline_config_n32768_all_eigenpairs(gpu_lib, route):
     z = torch.empty(n, lda, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
     fn = gpu_lib.eigx_sx_dev if route == "sx" else gpu_lib.eigx_s_dev
-    assert fn(n, n, a.data_ptr(), lda, w.data_ptr(), z.data_ptr(), lda, 128, 128, b"A") == 0
+    assert fn(n, n, a.data_ptr(), lda, w.data_ptr(), z.data_ptr(), lda, mf, 128, b"A") == 0
     del a
     _spectrum_invariants(w.cpu().numpy(), tr, fro2, n)
     Z = z[:, :n].T                               # (n, n) eigenvectors in columns
