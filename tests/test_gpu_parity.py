@@ -366,8 +366,10 @@ def _run_multi_rank(world, n, route, nb, dims, env_extra=None):
     (4, 517, "sx", 32, ""), (4, 301, "s", 7, ""), (2, 260, "sx", 64, ""), (3, 200, "sx", 5, "3x1"), (4, 131, "s", 3, "1x4"),
     (2, 97, "sx", 0, ""), (4, 129, "sx", 0, ""), (3, 65, "s", 0, ""), (4, 3, "sx", 0, ""), (4, 1, "s", 0, ""),
     (2, 2, "sx", 0, ""), (4, 5, "s", 0, ""), (5, 7, "sx", 0, "1x5"),
-    (4, 200, "h", 0, ""), (3, 131, "h", 0, ""), (2, 1900, "sx", 0, ""), (4, 2500, "sx", 0, ""),
-    (4, 4608, "sx", 0, "")])   # n > 4096: two merges above the D&C's 2048-column chunk width at one height
+    (4, 200, "h", 0, ""), (3, 131, "h", 0, ""), (2, 1900, "sx", 0, ""), (4, 2500, "sx", 0, "")])
+    # (n > 4096 -- two merges above the D&C's 2048-column chunk width at one height -- took 84 s of the suite with four ranks
+    # on one card; that code path runs at n <= 700 in test_multi_rank_dc_chunk_by_chunk (eigx_tune key 8), and at
+    # n = 8192 .. 32768 in the rehearsals of tools/mg_big_check.sh)
 def test_multi_rank_solver_on_one_gpu(world, n, route, nb, dims):
     """the N>1 path -- 2-D cyclic ownership of A (nothing replicated), one peer-write exchange per reduction step,
     panel gathers, local trailing update, streamed back-transformation -- with `world` ranks sharing the GPU over
