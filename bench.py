@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="--gpus 1: skip the extra N=32768 / N=65536 solves")
     ap.add_argument("--cpu-n", type=int, default=4096, help="size of the cpu_baseline solve (OpenMP oracle, all host cores)")
-    ap.add_argument("--mf", type=int, default=128, help="m_forward (panel width) of the main line")
+    ap.add_argument("--mf", type=int, default=64, help="m_forward (panel width) of the main line (reference default 48; N=8192 reduction on one box: 132.8 / 132.0 / 132.6 / 133.7 ms for 48 / 64 / 96 / 128)")
     ap.add_argument("--extra-mf", type=int, default=256, help="m_forward of the extra N=32768 solve (K = 512 slabs for the trailing update)")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of the distributed solve")
     ap.add_argument("--weak", action="store_true", help="N>1: weak scaling, N = size*sqrt(P) (size defaults to 8192)")
