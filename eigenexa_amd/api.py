@@ -94,8 +94,8 @@ def eigen_comm_info():
     import json
 
     lib = _lib.load()
-    buf = C.create_string_buffer(1024)
-    _lib.check(lib.eigx_comm_info(buf, 1024), "eigx_comm_info")
+    buf = C.create_string_buffer(2048)
+    _lib.check(lib.eigx_comm_info(buf, 2048), "eigx_comm_info")
     return json.loads(buf.value.decode())
 
 

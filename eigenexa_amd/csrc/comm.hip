@@ -143,6 +143,9 @@ struct CommState {
   bool rccl = false;           // the BULK collectives go through RCCL (otherwise through the peer windows)
   bool step_coll = false;      // the per-step exchange is a collective allgather (RCCL / emulated), not peer writes
   bool err_in_flags = false;   // err_dev is a word of the peer-mapped flag block
+  // per-collective counts since init (the reference's COMM_STAT tables, src/eigen_devel.F:364-526): calls and bytes this rank
+  // SENT, by kind: 0 per-step exchange, 1 allgather / all-to-all of small pieces, 2 allreduce, 3 large all-to-all / allgather
+  double st_calls[4] = {0, 0, 0, 0}, st_bytes[4] = {0, 0, 0, 0};
   bool loop = false;           // EIGX_LOOPBACK (lab): this process plays ONE rank of a P-rank grid alone; every peer window is its own
   bool in_selftest = false;    // init-time self-test: failures stay local (the verdict is voted on), device waits are short
   // init-time transport self-test (recorded for eigx_comm_info)
@@ -815,7 +818,7 @@ int comm_init(Context& ctx, const void* uid) {
   cs->rccl = cs->rccl_ok && (!cs->ipc || (want_bulk && strcmp(want_bulk, "rccl") == 0));
   cs->step_coll = !cs->ipc || (want_step && strcmp(want_step, "coll") == 0);
   if (getenv("EIGX_TRACE_COMM") && cs->me == 0) {
-    char info[512];
+    char info[1536];
     comm_info(ctx, info, sizeof(info));
     fprintf(stderr, "[eigx] transport: %s\n", info);
   }
@@ -832,12 +835,14 @@ int comm_info(const Context& ctx, char* buf, int len) {
            "{\"ranks\": %d, \"shared_device\": %s, \"peer_windows\": %s, \"rccl\": %s, \"step_exchange\": \"%s\", "
            "\"step_wait\": \"%s\", \"bulk\": \"%s\", \"selftest\": {\"ipc_rounds\": %d, \"ipc_errors\": %d, \"ipc_us_per_round\": %.1f, "
            "\"step_rounds\": %d, \"step_errors\": %d, \"step_us_per_round\": %.1f, \"rccl_checks\": %d, \"rccl_errors\": %d, "
-           "\"rccl_us_per_call\": %.1f}}",
+           "\"rccl_us_per_call\": %.1f}, \"since_init\": {\"step_exchanges\": %.0f, \"step_bytes_sent\": %.0f, \"small_exchanges\": %.0f, "
+           "\"small_bytes_sent\": %.0f, \"allreduces\": %.0f, \"allreduce_bytes_sent\": %.0f, \"large_exchanges\": %.0f, \"large_bytes_sent\": %.0f}}",
            cs->P, cs->shared_device ? "true" : "false", cs->ipc ? "true" : "false", cs->rccl_ok ? "true" : "false",
            cs->step_coll ? (cs->rccl ? "allgather (RCCL)" : "allgather (peer-window emulation)") : "peer writes (hipIpc windows, kernel stores over xGMI)",
            cs->step_coll ? "stream order" : (fused ? "fused into ka_kernel" : "wait kernel"), cs->rccl ? "rccl" : "peer windows",
            cs->st_ipc_rounds, cs->st_ipc_errors, cs->st_ipc_us, cs->st_step_rounds, cs->st_step_errors, cs->st_step_us,
-           cs->st_rccl_checks, cs->st_rccl_errors, cs->st_rccl_us);
+           cs->st_rccl_checks, cs->st_rccl_errors, cs->st_rccl_us, cs->st_calls[0], cs->st_bytes[0], cs->st_calls[1], cs->st_bytes[1],
+           cs->st_calls[2], cs->st_bytes[2], cs->st_calls[3], cs->st_bytes[3]);
   return EIGX_OK;
 }
 
@@ -976,6 +981,7 @@ void comm_exchange(Context& ctx, CommGroup grp, const double* send, size_t send_
     return;
   }
   if (cs->failed) return;
+  if (ch != CH_STEP2) { cs->st_calls[1] += 1.0; cs->st_bytes[1] += 8.0 * (double)count * (n - 1); }
   if (cs->rccl) {
     rccl_time_begin(cs, s);
     if (send_stride == 0) {
@@ -1024,6 +1030,7 @@ static void allreduce_impl(Context& ctx, CommGroup grp, double* buf, size_t coun
   CommState* cs = ctx.comm;
   const int n = comm_size(ctx, grp);
   if (n == 1 || count == 0 || cs->failed) return;
+  cs->st_calls[2] += 1.0; cs->st_bytes[2] += 8.0 * (double)count * (n - 1);
   if (cs->rccl) {
     rccl_time_begin(cs, s);
     EIGX_NCCL_TRY(cs, api.AllReduce(buf, buf, count, kNcclFloat64, op, pick(cs, grp), s));
@@ -1087,6 +1094,7 @@ void comm_exchange_big(Context& ctx, CommGroup grp, const double* send, size_t s
     return;
   }
   if (cs->failed) return;
+  cs->st_calls[3] += 1.0; cs->st_bytes[3] += 8.0 * (double)count * (n - 1);
   if (cs->rccl) {
     rccl_time_begin(cs, s);
     if (send_stride == 0) {
@@ -1192,6 +1200,8 @@ unsigned long long comm_step_epoch_base(Context& ctx, unsigned long long nsteps)
   CommState* cs = ctx.comm;
   const u64 base = cs->epoch[CH_STEP];
   cs->epoch[CH_STEP] += nsteps;
+  // (an upper bound of the steps of the reduction that follows; every step sends one message to each of the P - 1 peers)
+  cs->st_calls[0] += (double)nsteps; cs->st_bytes[0] += 8.0 * (double)cs->step_msg * (double)nsteps * (cs->P - 1);
   return base;
 }
 

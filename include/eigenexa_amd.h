@@ -89,7 +89,8 @@ int eigx_get_comm(int* x_color, int* x_key, int* y_color, int* y_key);
 double eigx_comm_seconds(void);
 
 /* JSON text describing the transports in use (per-step exchange, its wait, bulk collectives) and the counts / errors /
- * microseconds per round of the init-time self-test; "{"ranks": 1}" on one GPU.  The reference prints the analogous
+ * microseconds per round of the init-time self-test, plus calls and bytes sent per kind of collective since init (the
+ * reference's COMM_STAT tables, src/eigen_devel.F:364-526); "{"ranks": 1}" on one GPU.  The reference prints the analogous
  * communicator facts at init (src/eigen_libs0.F:774-1109 measures its collectives there). */
 int eigx_comm_info(char* buf, int len);
 

@@ -609,6 +609,21 @@ int orc_trbak(int n, int nvec, const double* a, int lda, double* z, int ldz, con
   return 0;
 }
 
+/* The reference's own scaling rule, restated exactly (src/eigen_scaling.F:76-81, :127-135): SIGMA for a matrix whose largest
+ * |a_ij| over the upper triangle is anrm.  SAFMIN = DLAMCH('S'), EPS = DLAMCH('P') = 2^-52, RMIN = sqrt(SAFMIN / EPS)
+ * ~ 1.0e-146, RMAX = min(sqrt(EPS / SAFMIN), SAFMIN^(-1/4)) ~ 8.2e76.  The product and this oracle deviate from it on
+ * purpose (orc_eigen below); tests use this function to state exactly where the two rules differ. */
+double orc_scaling_sigma_reference(double anrm) {
+  const double safmin = DBL_MIN, eps = DBL_EPSILON;
+  const double smlnum = safmin / eps, bignum = 1.0 / smlnum;
+  const double rmin = sqrt(smlnum);
+  const double rmax = fmin(sqrt(bignum), 1.0 / sqrt(sqrt(safmin)));
+  double sigma = 1.0;
+  if (anrm != 0.0 && anrm < rmin) sigma = rmin / anrm;
+  else if (anrm > rmax) sigma = rmax / anrm;
+  return sigma;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * drivers (src/eigen_sx.F:30-308, src/eigen_s.F:30-307).  mode 'A' (all) or 'N' (values only).
  * On return a(0,0)=flops, a(1,0)=seconds, a(2,0)=-1 as in src/eigen_sx.F:285-296.

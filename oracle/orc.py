@@ -30,9 +30,16 @@ def load():
         lib.orc_band_bisect.argtypes = [C.c_int, _dp, _dp, C.c_int, C.c_int, _dp]
         lib.orc_gev.argtypes = [C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, _dp, C.c_int]
         lib.orc_eigen_h.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, _dp, C.c_void_p, C.c_int, C.c_char]
+        lib.orc_scaling_sigma_reference.argtypes = [C.c_double]
+        lib.orc_scaling_sigma_reference.restype = C.c_double
         lib.orc_trbak.argtypes = [C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int]
         _lib = lib
     return _lib
+
+
+def scaling_sigma_reference(anrm):
+    """SIGMA of the reference's eigen_scaling for max |a_ij| = anrm (src/eigen_scaling.F:76-81, :127-135)"""
+    return float(load().orc_scaling_sigma_reference(float(anrm)))
 
 
 def threads():

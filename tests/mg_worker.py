@@ -289,6 +289,8 @@ if rank == 0 and n <= 1200:
 if px == 0 and py == 0 and len(rows) >= 3:
     # a(1:3,1) statistics: flops, seconds, communication seconds (src/eigen_sx.F:285-296)
     assert abs(a[0, 0]) > 0 and a[1, 0] > 0 and 0 <= a[2, 0] <= a[1, 0] * 1.5, (a[0, 0], a[1, 0], a[2, 0])
+st = ee.eigen_comm_info()["since_init"]     # per-collective counts (the reference's COMM_STAT tables, src/eigen_devel.F:364-526)
+assert (st["step_exchanges"] > 0 and st["step_bytes_sent"] > 0) or n <= 2 or route == "h", st
 ee.eigen_free()
 dist.barrier()
 dist.destroy_process_group()

@@ -290,14 +290,17 @@ def test_error_behaviour(gpu_lib):
 
 
 def test_scaling_extremes(gpu_lib):
-    """eigen_scaling (src/eigen_scaling.F:127-147): tiny / huge matrices are rescaled, w unscaled"""
+    """eigen_scaling (src/eigen_scaling.F:127-147): tiny / huge matrices are rescaled, w unscaled; 1e80 and 1e-120 lie in
+    the two windows where this build's rule and the reference's differ (tests/test_oracle.py::
+    test_scaling_rule_against_the_reference_rule): the reference alone would rescale the first, this build alone rescales
+    the second -- the caller sees the same eigenpairs either way"""
     import eigenexa_amd as ee
     from eigenexa_amd import layout
 
     n = 120
     A0 = layout.random_symmetric(n, seed=4)
     wr = np.linalg.eigvalsh(A0)
-    for f in (1e-200, 1e200):
+    for f in (1e-200, 1e200, 1e80, 1e-120):
         a = np.asfortranarray(A0 * f)
         z = np.zeros((n, n), order="F")
         w = np.zeros(n)

@@ -301,3 +301,27 @@ def test_oracle_eigen_h(orc, n):
     w, _ = orc.eigen_h(F)
     lam = np.sort(layout.frank_eigenvalues(n))
     assert (np.abs(w - lam) / lam).max() < 1e-10
+
+
+def test_scaling_rule_against_the_reference_rule(orc):
+    """eigen_scaling (src/eigen_scaling.F:76-81, :127-135) restated exactly: RMIN = sqrt(SAFMIN / EPS) ~ 1.0e-146,
+    RMAX = min(sqrt(EPS / SAFMIN), SAFMIN^(-1/4)) ~ 8.2e76; SIGMA = RMIN / ANRM below RMIN, RMAX / ANRM above RMAX, else 1.
+    This build rescales (by an exact power of two, to O(1)) outside [1e-90, 1e90] instead: the rules
+    agree -- no scaling at all -- on [RMIN, 8.2e76] intersect [1e-90, 1e90]; the reference alone scales on (8.2e76, 1e90], this
+    build alone on [1.0e-146, 1e-90).  In both windows the results must agree with LAPACK on the unscaled problem, which
+    is what a caller can observe of either rule (w is unscaled at the end)."""
+    from eigenexa_amd import layout
+
+    rmin, rmax = 1.0010415475915505e-146, 8.1870e76
+    assert orc.scaling_sigma_reference(1.0) == 1.0 and orc.scaling_sigma_reference(0.0) == 1.0
+    assert orc.scaling_sigma_reference(2 * rmin) == 1.0 and orc.scaling_sigma_reference(rmax * 0.99) == 1.0
+    assert abs(orc.scaling_sigma_reference(1e-200) * 1e-200 / rmin - 1.0) < 1e-12        # scaled up to RMIN
+    assert abs(orc.scaling_sigma_reference(1e100) * 1e100 / rmax - 1.0) < 1e-4           # scaled down to RMAX
+    assert orc.scaling_sigma_reference(1e80) < 1.0 and orc.scaling_sigma_reference(1e-120) == 1.0   # the two windows
+    n = 60
+    A0 = layout.random_symmetric(n, seed=8)
+    wr = np.linalg.eigvalsh(A0)
+    for f in (1e80, 1e-120, 1e-200, 1e200, 3e76, 1e-146):
+        for route in ("sx", "s"):
+            w = orc.eigen(A0 * f, route)[0]
+            assert np.abs(w / f - wr).max() < 1e-12 * np.abs(wr).max(), (f, route)
