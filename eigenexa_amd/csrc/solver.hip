@@ -480,13 +480,90 @@ __global__ void scale_cols_rsqrt_kernel(const double* __restrict__ z, int ldz, c
     b[(size_t)j * ldb + i] = z[(size_t)j * ldz + i] * s;
 }
 
+
+// ---- multi-rank KMATH_EIGEN_GEV: cyclic blocks <-> the full matrix -------------------------------------------------
+__global__ void rg_pack_kernel(const double* __restrict__ a, int lda, int nr, int nc, double* __restrict__ out, int bx) {
+  const int lj = blockIdx.y;
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < bx; li += gridDim.x * blockDim.x)
+    out[(size_t)lj * bx + li] = (li < nr && lj < nc) ? a[(size_t)lj * lda + li] : 0.0;
+}
+__global__ void rg_cyclic_to_full_kernel(const double* __restrict__ recv, int bx, int by, int Px, int Py, int order_r, int n,
+                                         double* __restrict__ F, int ldf) {
+  const int q = blockIdx.z;
+  const int qx = order_r ? q / Py : q % Px, qy = order_r ? q % Py : q / Px;
+  const int lj = blockIdx.y;
+  const int gj = lj * Py + qy;
+  if (gj >= n) return;
+  const double* src = recv + (size_t)q * bx * by + (size_t)lj * bx;
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < bx; li += gridDim.x * blockDim.x) {
+    const int gi = li * Px + qx;
+    if (gi < n) F[(size_t)gj * ldf + gi] = __hip_atomic_load(src + li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+__global__ void rg_full_to_cyclic_kernel(const double* __restrict__ F, int ldf, int nloc_r, int n, int Px, int px, int Py, int py,
+                                         double* __restrict__ dst, int ldd) {
+  const int lj = blockIdx.y;
+  const int gj = lj * Py + py;
+  if (gj >= n) return;
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < nloc_r; li += gridDim.x * blockDim.x)
+    dst[(size_t)lj * ldd + li] = F[(size_t)gj * ldf + (size_t)li * Px + px];
+}
+
 // Same sequence as KMATH_EIGEN_GEV_1 (src/KMATH_EIGEN_GEV_1.F:57-139): eigen_s(B, 'X') -> B^(-1/2) := Z_B W_B^(-1/2);
 // A' = B^(-1/2)^T A B^(-1/2) by two GEMMs; eigen_s(A', 'X') -> w, Y; Z = B^(-1/2) Y (B-orthonormal).  On entry only
 // the upper triangles of a and b are significant; a, b are destroyed (a holds Y, b holds B^(-1/2) on exit, as in
 // the reference).  One GPU; all three products run on the fp64 MFMA GEMM.
+int gev_dev(Context& ctx, int n, double* a, int lda, double* b, int ldb, double* w, double* z, int ldz);
+
+// Several ranks (the reference's KMATH_EIGEN_GEV is distributed: two eigen_s calls + three PDGEMMs on the cyclic blocks,
+// src/KMATH_EIGEN_GEV_1.F:57-139): first version as for eigen_h -- the cyclic blocks of A and B are gathered (two
+// allgathers of n^2 / P doubles per rank), every rank solves the replicated problem with the one-GPU sequence, and z, a
+// (= Y) and b (= B^(-1/2)) go back to the callers' cyclic blocks.  Correct on every grid; the O(n^3) work is not divided.
+static int gev_dev_mg(Context& ctx, int n, double* a, int lda, double* b, int ldb, double* w, double* z, int ldz) {
+  const Grid G = ctx.grid;
+  const int nloc_r = local_count(n, G.Px, G.px), nloc_c = local_count(n, G.Py, G.py);
+  if (n <= 0 || !a || !b || !w || !z || lda < (nloc_r > 1 ? nloc_r : 1) || ldb < (nloc_r > 1 ? nloc_r : 1) ||
+      ldz < (nloc_r > 1 ? nloc_r : 1)) return EIGX_ERR_BAD_ARG;
+  EIGX_HIP_CHECK(hipSetDevice(ctx.device));
+  EIGX_HIP_CHECK(hipStreamSynchronize(nullptr));
+  hipStream_t st = ctx.stream;
+  const int bx = ceil_div(n, G.Px), by = ceil_div(n, G.Py);
+  const int ldf = pad_ld(n + 2);
+  double* sendb = ctx.pool.get_t<double>("gev.send", (size_t)bx * by);
+  double* recvb = ctx.pool.get_t<double>("gev.recv", (size_t)bx * by * G.nranks);
+  double* Af = ctx.pool.get_t<double>("gev.A", (size_t)ldf * n);
+  double* Bf = ctx.pool.get_t<double>("gev.B", (size_t)ldf * n);
+  double* Zf = ctx.pool.get_t<double>("gev.Z", (size_t)ldf * n);
+  double* const src[2] = {a, b};
+  const int lds[2] = {lda, ldb};
+  double* const full[2] = {Af, Bf};
+  for (int t = 0; t < 2; ++t) {
+    hipLaunchKernelGGL(rg_pack_kernel, dim3(8, by), dim3(256), 0, st, (const double*)src[t], lds[t], nloc_r, nloc_c, sendb, bx);
+    comm_allgather(ctx, COMM_WORLD, sendb, recvb, (size_t)bx * by, st);
+    hipLaunchKernelGGL(rg_cyclic_to_full_kernel, dim3(8, by, G.nranks), dim3(256), 0, st, (const double*)recvb, bx, by, G.Px, G.Py,
+                       G.row_major, n, full[t], ldf);
+  }
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  if (comm_failed(ctx)) return EIGX_ERR_INTERNAL;
+  ctx.grid = Grid();                       // the replicated problem runs the one-GPU sequence on every rank
+  const int rc = gev_dev(ctx, n, Af, ldf, Bf, ldf, w, Zf, ldf);
+  ctx.grid = G;
+  if (rc != EIGX_OK) return rc;
+  if (nloc_r > 0 && nloc_c > 0) {
+    double* const dst[3] = {z, a, b};
+    const int ldd[3] = {ldz, lda, ldb};
+    const double* const from[3] = {Zf, Af, Bf};
+    for (int t = 0; t < 3; ++t)
+      hipLaunchKernelGGL(rg_full_to_cyclic_kernel, dim3(8, nloc_c), dim3(256), 0, st, from[t], ldf, nloc_r, n, G.Px, G.px, G.Py,
+                         G.py, dst[t], ldd[t]);
+  }
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  return EIGX_OK;
+}
+
 int gev_dev(Context& ctx, int n, double* a, int lda, double* b, int ldb, double* w, double* z, int ldz) {
   if (!ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
-  if (ctx.grid.nranks != 1) return EIGX_ERR_INTERNAL;
+  if (ctx.grid.nranks != 1) return gev_dev_mg(ctx, n, a, lda, b, ldb, w, z, ldz);
   if (n <= 0 || !a || !b || !w || !z || lda < n || ldb < n || ldz < n || ((lda | ldb | ldz) & 1)) return EIGX_ERR_BAD_ARG;
   EIGX_HIP_CHECK(hipSetDevice(ctx.device));
   EIGX_HIP_CHECK(hipStreamSynchronize(nullptr));
@@ -521,21 +598,28 @@ int gev_dev(Context& ctx, int n, double* a, int lda, double* b, int ldb, double*
 
 int gev_host(Context& ctx, int n, double* a, int lda, double* b, int ldb, double* w, double* z, int ldz) {
   if (!ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
-  if (n <= 0 || !a || !b || !w || !z || lda < n || ldb < n || ldz < n) return EIGX_ERR_BAD_ARG;
+  // host arrays: the rank's 2-D cyclic blocks a(lda, *), b(ldb, *), z(ldz, *) (one rank: the whole matrices)
+  const int nr = local_count(n, ctx.grid.Px, ctx.grid.px), nc = local_count(n, ctx.grid.Py, ctx.grid.py);
+  if (n <= 0 || !a || !b || !w || !z || lda < nr || ldb < nr || ldz < nr) return EIGX_ERR_BAD_ARG;
   EIGX_HIP_CHECK(hipSetDevice(ctx.device));
-  const int ldd = pad_ld(n + 2);
-  double* ad = ctx.pool.get_t<double>("host.a", (size_t)ldd * n);
-  double* zd = ctx.pool.get_t<double>("host.z", (size_t)ldd * n);
-  double* bd = ctx.pool.get_t<double>("host.b", (size_t)ldd * n);
+  const int ldd = pad_ld(nr + 2);
+  const int ncd = nc > 0 ? nc : 1;
+  double* ad = ctx.pool.get_t<double>("host.a", (size_t)ldd * ncd);
+  double* zd = ctx.pool.get_t<double>("host.z", (size_t)ldd * ncd);
+  double* bd = ctx.pool.get_t<double>("host.b", (size_t)ldd * ncd);
   double* wd = ctx.pool.get_t<double>("host.w", (size_t)n);
-  EIGX_HIP_CHECK(hipMemcpy2D(ad, (size_t)ldd * 8, a, (size_t)lda * 8, (size_t)n * 8, (size_t)n, hipMemcpyHostToDevice));
-  EIGX_HIP_CHECK(hipMemcpy2D(bd, (size_t)ldd * 8, b, (size_t)ldb * 8, (size_t)n * 8, (size_t)n, hipMemcpyHostToDevice));
+  if (nr > 0 && nc > 0) {
+    EIGX_HIP_CHECK(hipMemcpy2D(ad, (size_t)ldd * 8, a, (size_t)lda * 8, (size_t)nr * 8, (size_t)nc, hipMemcpyHostToDevice));
+    EIGX_HIP_CHECK(hipMemcpy2D(bd, (size_t)ldd * 8, b, (size_t)ldb * 8, (size_t)nr * 8, (size_t)nc, hipMemcpyHostToDevice));
+  }
   const int rc = gev_dev(ctx, n, ad, ldd, bd, ldd, wd, zd, ldd);
   if (rc != EIGX_OK) return rc;
   EIGX_HIP_CHECK(hipMemcpy(w, wd, (size_t)n * 8, hipMemcpyDeviceToHost));
-  EIGX_HIP_CHECK(hipMemcpy2D(z, (size_t)ldz * 8, zd, (size_t)ldd * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToHost));
-  EIGX_HIP_CHECK(hipMemcpy2D(a, (size_t)lda * 8, ad, (size_t)ldd * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToHost));
-  EIGX_HIP_CHECK(hipMemcpy2D(b, (size_t)ldb * 8, bd, (size_t)ldd * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToHost));
+  if (nr > 0 && nc > 0) {
+    EIGX_HIP_CHECK(hipMemcpy2D(z, (size_t)ldz * 8, zd, (size_t)ldd * 8, (size_t)nr * 8, (size_t)nc, hipMemcpyDeviceToHost));
+    EIGX_HIP_CHECK(hipMemcpy2D(a, (size_t)lda * 8, ad, (size_t)ldd * 8, (size_t)nr * 8, (size_t)nc, hipMemcpyDeviceToHost));
+    EIGX_HIP_CHECK(hipMemcpy2D(b, (size_t)ldb * 8, bd, (size_t)ldd * 8, (size_t)nr * 8, (size_t)nc, hipMemcpyDeviceToHost));
+  }
   return EIGX_OK;
 }
 

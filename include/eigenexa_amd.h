@@ -197,7 +197,9 @@ int eigx_band_dc_dev(int n, int nvec, const double* d_dev, const double* e_dev, 
  * symmetric-definite problem A x = lambda B x through two eigen_s solves and three GEMMs.  Upper triangles of a, b
  * significant; w ascending; z B-orthonormal (z^T B z = I); a, b destroyed.  EIGX_ERR_NOT_SPD if B is not positive
  * definite (the reference prints "Matrix B is not positive definite!" and returns).  Host / device-resident arrays;
- * leading dimensions of the device form must be even.  One GPU. */
+ * leading dimensions of the device form must be even.  Several ranks: a, b, z are the ranks' 2-D cyclic blocks as for
+ * eigx_sx; first version: the blocks are gathered and every rank solves the replicated problem (the reference's is
+ * distributed, src/KMATH_EIGEN_GEV_1.F:57-139). */
 int eigx_gev(int n, double* a, int lda, double* b, int ldb, double* w, double* z, int ldz);
 int eigx_gev_dev(int n, double* a_dev, int lda, double* b_dev, int ldb, double* w_dev, double* z_dev, int ldz);
 

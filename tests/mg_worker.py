@@ -76,6 +76,42 @@ if route == "allocfail":
     dist.destroy_process_group()
     print(f"OK rank {rank}/{world} allocation failure reported in {dt:.1f} s", flush=True)
     sys.exit(0)
+if route == "gev":
+    # KMATH_EIGEN_GEV on the process grid (src/KMATH_EIGEN_GEV.F:1-64 is distributed in the reference): cyclic blocks of A, B
+    # in, eigenvalues replicated, B-orthonormal eigenvectors in cyclic blocks out; checks of benchmark/KMATH_EIGEN_GEV_check.f
+    procs, xp, yp = ee.eigen_get_procs()
+    _, xi, yi = ee.eigen_get_id()
+    A = layout.random_symmetric(n, seed=3)
+    B = layout.helmert_spectrum_matrix(n, 10)[0]
+    rows = np.arange(xi - 1, n, xp)
+    cols = np.arange(yi - 1, n, yp)
+    nx, ny = ee.eigen_get_matdims(n)
+    a = np.zeros((nx, ny), order="F"); a[: len(rows), : len(cols)] = A[np.ix_(rows, cols)]
+    b = np.zeros((nx, ny), order="F"); b[: len(rows), : len(cols)] = B[np.ix_(rows, cols)]
+    z = np.zeros((nx, ny), order="F")
+    w = np.zeros(n)
+    ee.KMATH_EIGEN_GEV(n, a, nx, b, nx, w, z, nx)
+    assert api.last_status() == 0, api.last_status()
+    zl = np.zeros(((n + xp - 1) // xp, (n + yp - 1) // yp))
+    zl[: len(rows), : len(cols)] = z[: len(rows), : len(cols)]
+    blocks = [torch.zeros(zl.shape, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(blocks, torch.from_numpy(np.ascontiguousarray(zl)))
+    Z = layout.gather_cyclic([b_.numpy() for b_ in blocks], n, n, dims=dims)
+    import scipy.linalg
+
+    wr = scipy.linalg.eigh(A, B, eigvals_only=True)
+    scale = max(1.0, np.abs(wr).max())
+    assert np.abs(w - wr).max() < 1e-11 * scale, np.abs(w - wr).max()
+    assert np.linalg.norm(A @ Z - B @ Z * w) < 1e-12 * scale * n
+    assert np.linalg.norm(Z.T @ B @ Z - np.eye(n)) < 1e-12 * n
+    wt = torch.from_numpy(w.copy())
+    dist.broadcast(wt, src=0)
+    assert np.array_equal(wt.numpy(), w)
+    ee.eigen_free()
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"OK rank {rank}/{world} n={n} gev", flush=True)
+    sys.exit(0)
 procs, xp, yp = ee.eigen_get_procs()
 idn, xi, yi = ee.eigen_get_id()
 assert (xp, yp) == (dims or layout.grid_shape(world)) and idn == rank + 1

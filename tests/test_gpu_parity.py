@@ -607,6 +607,14 @@ def test_multi_rank_no_transport_fails_on_every_rank():
     _run_multi_rank(3, 64, "initfail", 0, "", {"EIGX_SELFTEST_FAIL": "ipc"})
 
 
+@pytest.mark.parametrize("world,n,dims", [(2, 150, ""), (4, 301, ""), (3, 97, "3x1")])
+def test_multi_rank_kmath_eigen_gev(world, n, dims):
+    """KMATH_EIGEN_GEV on the process grid (the reference's is distributed, src/KMATH_EIGEN_GEV_1.F:57-139): cyclic blocks
+    in and out, first version by gathering the blocks and solving the replicated problem on every rank; against scipy's
+    generalised eigenvalues and the checks of benchmark/KMATH_EIGEN_GEV_check.f"""
+    _run_multi_rank(world, n, "gev", 0, dims)
+
+
 def test_multi_rank_allocation_failure_reaches_the_peers():
     """one rank's workspace allocation fails inside the solver: that rank returns EIGX_ERR_NO_MEMORY, the others
     EIGX_ERR_INTERNAL within seconds (their waits poll the failure word that the failing rank sets on every peer), and
