@@ -14,9 +14,9 @@
 //   x = A_eff(0:L, i);  g = -sign(||x||, Re x_{L-1});  u = x, u_{L-1} -= g;  beta = -u_{L-1} g       (src/eigen_hrd_t4.F:40-95)
 //   q = A_eff u;  s = u^H q;  alpha = s / (2 beta);  v = (q - alpha u) / conj(beta)                 (src/eigen_hrd_t6_3.F:256-272)
 //   A_eff = A - U W^H - W U^H  (panel of m columns, applied every m steps)                          (src/eigen_hrd_t1.F:2-110)
-// Three launches per column (form x [+ previous v] | reflector scalars + panel dots + tiled mat-vec | combine + store): this version is
-// latency-bound per step like the first real-symmetric version was; the fused / tiled structure of band_reduce.hip is the
-// template for the next one.  All cross-workgroup reductions are two-phase and deterministic (no atomics).
+// Two launches per column (finish the previous column + form x | reflector scalars + panel dots + tiled mat-vec): still
+// latency-bound per step; the fused / tiled structure of band_reduce.hip is the template.  All cross-workgroup reductions
+// are two-phase and deterministic (no atomics).
 #include "eigx_context.h"
 #include "eigx_common.h"
 #include "eigx_comm.h"
@@ -40,12 +40,12 @@ constexpr int HMB = 128;     // reflectors per back-transformation block (the pa
 struct HArgs {
   double *Ar, *Ai; int ld; int n;
   double *Ur, *Ui, *Wr, *Wi; int ldp;
-  double *xr, *xi, *pr, *pi;
+  double *xr, *xi;
   double *beta, *d, *e;
   double *pn;      // norm partials [workgroup]
   double *pd;      // panel-dot partials [chunk][HM][4]
   double *yrr, *yri, *ycr, *yci;  // mat-vec partials: row sums [tile column][ldp], column sums [tile row][ldp]
-  double *ps;      // s partials [workgroup][2]
+  double *ps;      // partials of u^H q [mat-vec tile][2]
 };
 
 __device__ __forceinline__ double hwave_sum(double v) {
@@ -128,66 +128,6 @@ __global__ void h_scale_kernel(double* __restrict__ a, int lda, int n, double s)
 
 __global__ void h_fill_kernel(double* p, size_t n, double v) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
-}
-
-// K1: x = A_eff(0:i, i) (rows 0..i-1), d_i = Re A_eff(i,i); partial ||x||^2 per workgroup.
-// If `pend` is set, the previous step's v (panel column k-1) is still pending: every workgroup reduces the s partials,
-// forms v = (p - alpha u) / conj(beta) for its rows on the fly (and stores it into W), so the separate v kernel -- one
-// launch per step -- only runs before a trailing update.
-__global__ __launch_bounds__(HT) void h_form_x_kernel(HArgs H, int i, int k, int pend, int nparts_prev) {
-  __shared__ double cwr[HM], cwi[HM], cur[HM], cui[HM];
-  __shared__ double red[8];
-  const int tid = threadIdx.x;
-  double alr = 0.0, ali = 0.0, br = 1.0, bi = 0.0, b2 = 1.0;
-  if (pend) {
-    double s[2] = {0.0, 0.0};
-    for (int q = tid; q < nparts_prev; q += HT) { s[0] += H.ps[2 * q]; s[1] += H.ps[2 * q + 1]; }
-    hblock_sum<2>(s, red);
-    br = H.beta[2 * (i + 1)]; bi = H.beta[2 * (i + 1) + 1];
-    b2 = br * br + bi * bi;
-    alr = (s[0] * br + s[1] * bi) / (2.0 * b2); ali = (s[1] * br - s[0] * bi) / (2.0 * b2);
-  }
-  auto pending_v = [&](int r, double& vr, double& vi) {   // v_r of panel column k-1
-    const double ur = H.Ur[(size_t)r + (size_t)(k - 1) * H.ldp], ui = H.Ui[(size_t)r + (size_t)(k - 1) * H.ldp];
-    const double tr = H.pr[r] - (alr * ur - ali * ui), ti = H.pi[r] - (alr * ui + ali * ur);
-    vr = (tr * br - ti * bi) / b2; vi = (tr * bi + ti * br) / b2;
-  };
-  const int kc = pend ? k - 1 : k;      // panel columns that are complete in memory
-  if (tid < kc) {   // conj of row i of the panel
-    cwr[tid] = H.Wr[(size_t)i + (size_t)tid * H.ldp]; cwi[tid] = -H.Wi[(size_t)i + (size_t)tid * H.ldp];
-    cur[tid] = H.Ur[(size_t)i + (size_t)tid * H.ldp]; cui[tid] = -H.Ui[(size_t)i + (size_t)tid * H.ldp];
-  } else if (pend && tid == k - 1) {
-    double vr, vi;
-    pending_v(i, vr, vi);
-    cwr[tid] = vr; cwi[tid] = -vi;
-    cur[tid] = H.Ur[(size_t)i + (size_t)tid * H.ldp]; cui[tid] = -H.Ui[(size_t)i + (size_t)tid * H.ldp];
-  }
-  __syncthreads();
-  const int r = blockIdx.x * HT + tid;
-  double nrm[1] = {0.0};
-  if (r <= i) {
-    double xr = H.Ar[(size_t)r + (size_t)i * H.ld], xi = H.Ai[(size_t)r + (size_t)i * H.ld];
-#pragma unroll 4
-    for (int j = 0; j < kc; ++j) {
-      const double ur = H.Ur[(size_t)r + (size_t)j * H.ldp], ui = H.Ui[(size_t)r + (size_t)j * H.ldp];
-      const double wr = H.Wr[(size_t)r + (size_t)j * H.ldp], wi = H.Wi[(size_t)r + (size_t)j * H.ldp];
-      xr -= (ur * cwr[j] - ui * cwi[j]) + (wr * cur[j] - wi * cui[j]);
-      xi -= (ur * cwi[j] + ui * cwr[j]) + (wr * cui[j] + wi * cur[j]);
-    }
-    if (pend) {
-      const int j = k - 1;
-      double wr, wi;
-      pending_v(r, wr, wi);
-      H.Wr[(size_t)r + (size_t)j * H.ldp] = wr; H.Wi[(size_t)r + (size_t)j * H.ldp] = wi;
-      const double ur = H.Ur[(size_t)r + (size_t)j * H.ldp], ui = H.Ui[(size_t)r + (size_t)j * H.ldp];
-      xr -= (ur * cwr[j] - ui * cwi[j]) + (wr * cur[j] - wi * cui[j]);
-      xi -= (ur * cwi[j] + ui * cwr[j]) + (wr * cui[j] + wi * cur[j]);
-    }
-    if (r < i) { H.xr[r] = xr; H.xi[r] = xi; nrm[0] = xr * xr + xi * xi; }
-    else H.d[i] = xr;
-  }
-  hblock_sum<1>(nrm, red);
-  if (tid == 0) H.pn[blockIdx.x] = nrm[0];
 }
 
 // Reflector scalars of column i (L = i rows) from the norm partials of K1: every workgroup of the mat-vec and of the
@@ -359,6 +299,7 @@ __global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int 
   __syncthreads();
   const double mur0 = urr[l0], mui0 = uri[l0], mur1 = urr[l1], mui1 = uri[l1];   // u at my rows
   double sr0 = 0.0, si0 = 0.0, sr1 = 0.0, si1 = 0.0;   // row sums over the wave's 32 columns
+  double sq[2] = {0.0, 0.0};                            // this tile's part of u^H q (K1 of the next column adds the tiles)
   auto compute4 = [&](const hd2_t (&vr_)[4], const hd2_t (&vi_)[4], int g) {
     double cr[4], ci[4];
 #pragma unroll
@@ -384,8 +325,12 @@ __global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int 
     const double tcr = hcolsum4(cr, lane), tci = hcolsum4(ci, lane);
     if ((lane & 15) == 0) {
       const int j = ((lane >> 5) & 1) * 2 + ((lane >> 4) & 1);
-      const int c = col0 + wc0 + g * 4 + j;
-      if (c < L) { H.ycr[(size_t)ty * H.ldp + c] = tcr; H.yci[(size_t)ty * H.ldp + c] = tci; }
+      const int cc = wc0 + g * 4 + j, c = col0 + cc;
+      if (c < L) {
+        H.ycr[(size_t)ty * H.ldp + c] = tcr; H.yci[(size_t)ty * H.ldp + c] = tci;
+        sq[0] += tcr * ucr[cc] + tci * uci[cc];    // q conj(u)
+        sq[1] += tci * ucr[cc] - tcr * uci[cc];
+      }
     }
   };
   // software pipeline: av0 holds unit g (loaded one iteration ahead), av1 unit g + 1
@@ -406,89 +351,135 @@ __global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int 
     for (int w = 0; w < HTH / 64; ++w) { a0 += part[w][tid][0]; a1 += part[w][tid][1]; }
     H.yrr[(size_t)tx * H.ldp + row0 + tid] = a0;
     H.yri[(size_t)tx * H.ldp + row0 + tid] = a1;
+    sq[0] += a0 * urr[tid] + a1 * uri[tid];
+    sq[1] += a1 * urr[tid] - a0 * uri[tid];
   }
+  hblock_sum_w<2, HTH / 64>(sq, &part[0][0][0]);
+  if (tid == 0) { H.ps[2 * bid] = sq[0]; H.ps[2 * bid + 1] = sq[1]; }
 }
 
-// K4: p = q - U (W^H u) - W (U^H u); partial s = sum p conj(u)
-__global__ __launch_bounds__(HT) void h_combine_kernel(HArgs H, int L, int k, int nt, int npdc, int nparts) {
-  // 64 rows per workgroup; wave q takes every fourth partial sum and every fourth panel column of those rows (the chain
-  // of dependent loads per row, not the bytes, is what this kernel costs), the four waves are combined through LDS
+// K1 (one launch per column, plus one at every panel end): finishes the PREVIOUS column (Lp rows, panel slot kp) and
+// forms the next one (column i), so a column costs two launches (this one and the mat-vec):
+//   p = q - U (W^H u) - W (U^H u)            q = sum of the nt + 1 mat-vec partials of a row, d = panel dots of K3
+//   s = u^H p = sum of the tile partials of u^H q (K3) - 2 Re sum_j conj(U_j^H u) (W_j^H u)
+//   alpha = s / (2 beta),  v = (p - alpha u) / conj(beta)  -> W(:, kp);  u -> U(:, kp) and column Lp of A
+//   x = A_eff(0:i, i) = A(:, i) - sum_{j <= kp} [U_j conj(W(i,j)) + W_j conj(U(i,j))],  d_i = Re A_eff(i,i),  partial ||x||^2
+// s and row i of (p, u, v) are needed by every workgroup before its own rows: each workgroup reduces them itself, in the
+// same order (bit-identical everywhere).  64 rows per workgroup; wave q takes every fourth partial sum and every fourth
+// panel column of those rows (the chain of dependent loads per row, not the bytes, is what this kernel costs), the four
+// waves are combined through LDS.  x overwrites the previous x in place: a row is read and written by the one thread
+// that owns it, and the previous pivot row (= row i) is not part of the new x.
+__global__ __launch_bounds__(HT) void h_step_kernel(HArgs H, int i, int do_x, int Lp, int kp, int ntp, int npdcp,
+                                                    int npartsp, double* __restrict__ pn_out) {
   __shared__ double dwr[HM], dwi[HM], dur[HM], dui[HM];
-  __shared__ double comb[4][64][2];
-  __shared__ double sred[4];
+  __shared__ double cwr[HM], cwi[HM], cur[HM], cui[HM];
+  __shared__ double comb[4][64][4];
+  __shared__ double sred[16];
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
-  const HRef f = h_scalars(H, L, nparts, sred);
-  if (tid < k) {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    for (int c = 0; c < npdc; ++c) {
-      const double* o = H.pd + ((size_t)c * HM + tid) * 4;
-      a0 += o[0]; a1 += o[1]; a2 += o[2]; a3 += o[3];
+  const bool prev = Lp > 0;
+  const int r = blockIdx.x * 64 + lane;
+  // column i of A for my row: in flight during the whole prologue
+  double axr = 0.0, axi = 0.0;
+  if (do_x && q == 0 && r <= i) { axr = H.Ar[(size_t)r + (size_t)i * H.ld]; axi = H.Ai[(size_t)r + (size_t)i * H.ld]; }
+  HRef f;
+  f.nrm2 = 0.0; f.g = 0.0; f.unr = 0.0; f.uni = 0.0; f.br = 1.0; f.bi = 0.0;
+  double alr = 0.0, ali = 0.0, br = 1.0, bi = 0.0, b2 = 1.0;
+  if (prev) {
+    f = h_scalars(H, Lp, npartsp, sred);
+    br = f.br; bi = f.bi; b2 = br * br + bi * bi;
+    double v4[4] = {0.0, 0.0, 0.0, 0.0};       // s (2) and row i of p (2)
+    if (tid < kp) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      for (int c = 0; c < npdcp; ++c) {
+        const double* o = H.pd + ((size_t)c * HM + tid) * 4;
+        a0 += o[0]; a1 += o[1]; a2 += o[2]; a3 += o[3];
+      }
+      dwr[tid] = a0; dwi[tid] = a1; dur[tid] = a2; dui[tid] = a3;
+      v4[0] = -2.0 * (a2 * a0 + a3 * a1);      // -2 Re conj(du) dw
+      if (do_x) {
+        const double ur = H.Ur[(size_t)i + (size_t)tid * H.ldp], ui = H.Ui[(size_t)i + (size_t)tid * H.ldp];
+        const double wr = H.Wr[(size_t)i + (size_t)tid * H.ldp], wi = H.Wi[(size_t)i + (size_t)tid * H.ldp];
+        v4[2] = -((ur * a0 - ui * a1) + (wr * a2 - wi * a3));
+        v4[3] = -((ur * a1 + ui * a0) + (wr * a3 + wi * a2));
+        cwr[tid] = wr; cwi[tid] = -wi; cur[tid] = ur; cui[tid] = -ui;
+      }
     }
-    dwr[tid] = a0; dwi[tid] = a1; dur[tid] = a2; dui[tid] = a3;
+    const int ntiles = ntp * (ntp + 1) / 2;
+    for (int t = tid; t < ntiles; t += HT) { v4[0] += H.ps[2 * t]; v4[1] += H.ps[2 * t + 1]; }
+    if (do_x) {
+      const int R = i / HTL;
+      for (int u = tid; u < ntp + 1; u += HT) {
+        v4[2] += (u <= R) ? H.ycr[(size_t)u * H.ldp + i] : H.yrr[(size_t)(u - 1) * H.ldp + i];
+        v4[3] += (u <= R) ? H.yci[(size_t)u * H.ldp + i] : H.yri[(size_t)(u - 1) * H.ldp + i];
+      }
+    }
+    hblock_sum<4>(v4, sred);
+    // alpha = s / (2 beta) = s conj(beta) / (2 |beta|^2)
+    alr = (v4[0] * br + v4[1] * bi) / (2.0 * b2); ali = (v4[1] * br - v4[0] * bi) / (2.0 * b2);
+    if (do_x && tid == kp) {   // row i of the column that is being finished: v(i), u(i)
+      double ur, ui;
+      h_u_of(H, f, Lp, i, ur, ui);
+      const double tr = v4[2] - (alr * ur - ali * ui), ti = v4[3] - (alr * ui + ali * ur);
+      cwr[kp] = (tr * br - ti * bi) / b2; cwi[kp] = -((tr * bi + ti * br) / b2);
+      cur[kp] = ur; cui[kp] = -ui;
+    }
   }
   __syncthreads();
-  const int r = blockIdx.x * 64 + lane;
-  double pr = 0.0, pi = 0.0;
-  if (r < L) {
+  double pr = 0.0, pi = 0.0, cr = 0.0, ci = 0.0;
+  if (prev && r < Lp) {
     const int R = r / HTL;   // my tile row.  Partial u of the row: u <= R -> column sums of tile (u, R); u > R -> row sums of tile (R, u-1)
     auto ldp_r = [&](int u) { return (u <= R) ? H.ycr[(size_t)u * H.ldp + r] : H.yrr[(size_t)(u - 1) * H.ldp + r]; };
     auto ldp_i = [&](int u) { return (u <= R) ? H.yci[(size_t)u * H.ldp + r] : H.yri[(size_t)(u - 1) * H.ldp + r]; };
     int u = q;
-    for (; u + 12 < nt + 1; u += 16) {
+    for (; u + 12 < ntp + 1; u += 16) {
       double a[4], b[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { a[e] = ldp_r(u + 4 * e); b[e] = ldp_i(u + 4 * e); }
 #pragma unroll
       for (int e = 0; e < 4; ++e) { pr += a[e]; pi += b[e]; }
     }
-    for (; u < nt + 1; u += 4) { pr += ldp_r(u); pi += ldp_i(u); }
+    for (; u < ntp + 1; u += 4) { pr += ldp_r(u); pi += ldp_i(u); }
 #pragma unroll 2
-    for (int j = q; j < k; j += 4) {
+    for (int j = q; j < kp; j += 4) {
       const double ur = H.Ur[(size_t)r + (size_t)j * H.ldp], ui = H.Ui[(size_t)r + (size_t)j * H.ldp];
       const double wr = H.Wr[(size_t)r + (size_t)j * H.ldp], wi = H.Wi[(size_t)r + (size_t)j * H.ldp];
       pr -= (ur * dwr[j] - ui * dwi[j]) + (wr * dur[j] - wi * dui[j]);
       pi -= (ur * dwi[j] + ui * dwr[j]) + (wr * dui[j] + wi * dur[j]);
+      if (do_x) {
+        cr += (ur * cwr[j] - ui * cwi[j]) + (wr * cur[j] - wi * cui[j]);
+        ci += (ur * cwi[j] + ui * cwr[j]) + (wr * cui[j] + wi * cur[j]);
+      }
     }
   }
-  comb[q][lane][0] = pr; comb[q][lane][1] = pi;
+  comb[q][lane][0] = pr; comb[q][lane][1] = pi; comb[q][lane][2] = cr; comb[q][lane][3] = ci;
   __syncthreads();
   if (q == 0) {
-    double s0 = 0.0, s1 = 0.0;
-    if (r < L) {
-      pr = (comb[0][lane][0] + comb[1][lane][0]) + (comb[2][lane][0] + comb[3][lane][0]);
-      pi = (comb[0][lane][1] + comb[1][lane][1]) + (comb[2][lane][1] + comb[3][lane][1]);
-      H.pr[r] = pr; H.pi[r] = pi;
+    double nrm = 0.0;
+    pr = (comb[0][lane][0] + comb[1][lane][0]) + (comb[2][lane][0] + comb[3][lane][0]);
+    pi = (comb[0][lane][1] + comb[1][lane][1]) + (comb[2][lane][1] + comb[3][lane][1]);
+    cr = (comb[0][lane][2] + comb[1][lane][2]) + (comb[2][lane][2] + comb[3][lane][2]);
+    ci = (comb[0][lane][3] + comb[1][lane][3]) + (comb[2][lane][3] + comb[3][lane][3]);
+    if (prev && r < Lp) {
       double ur, ui;
-      h_u_of(H, f, L, r, ur, ui);
-      // the reflector goes into the panel and stays in column i = L of A (rows 0..L-1), as the reference leaves it
-      H.Ur[(size_t)r + (size_t)k * H.ldp] = ur; H.Ui[(size_t)r + (size_t)k * H.ldp] = ui;
-      H.Ar[(size_t)r + (size_t)L * H.ld] = ur; H.Ai[(size_t)r + (size_t)L * H.ld] = ui;
-      s0 = pr * ur + pi * ui;    // p conj(u)
-      s1 = pi * ur - pr * ui;
+      h_u_of(H, f, Lp, r, ur, ui);
+      const double tr = pr - (alr * ur - ali * ui), ti = pi - (alr * ui + ali * ur);
+      const double wr = (tr * br - ti * bi) / b2, wi = (tr * bi + ti * br) / b2;   // t / conj(beta) = t beta / |beta|^2
+      H.Wr[(size_t)r + (size_t)kp * H.ldp] = wr; H.Wi[(size_t)r + (size_t)kp * H.ldp] = wi;
+      // the reflector goes into the panel and stays in column Lp of A (rows 0..Lp-1), as the reference leaves it
+      H.Ur[(size_t)r + (size_t)kp * H.ldp] = ur; H.Ui[(size_t)r + (size_t)kp * H.ldp] = ui;
+      H.Ar[(size_t)r + (size_t)Lp * H.ld] = ur; H.Ai[(size_t)r + (size_t)Lp * H.ld] = ui;
+      if (do_x) {
+        cr += (ur * cwr[kp] - ui * cwi[kp]) + (wr * cur[kp] - wi * cui[kp]);
+        ci += (ur * cwi[kp] + ui * cwr[kp]) + (wr * cui[kp] + wi * cur[kp]);
+      }
     }
-    s0 = hwave_sum(s0); s1 = hwave_sum(s1);
-    if (lane == 0) { H.ps[2 * blockIdx.x] = s0; H.ps[2 * blockIdx.x + 1] = s1; }
-  }
-}
-
-// K5: v = (p - alpha u) / conj(beta), alpha = s / (2 beta)
-__global__ __launch_bounds__(HT) void h_make_v_kernel(HArgs H, int i, int k, int nparts) {
-  __shared__ double red[8];
-  const int tid = threadIdx.x, L = i;
-  double s[2] = {0.0, 0.0};
-  for (int q = tid; q < nparts; q += HT) { s[0] += H.ps[2 * q]; s[1] += H.ps[2 * q + 1]; }
-  hblock_sum<2>(s, red);
-  const double br = H.beta[2 * i], bi = H.beta[2 * i + 1];
-  const double b2 = br * br + bi * bi;
-  // alpha = s / (2 beta) = s conj(beta) / (2 |beta|^2)
-  const double alr = (s[0] * br + s[1] * bi) / (2.0 * b2), ali = (s[1] * br - s[0] * bi) / (2.0 * b2);
-  const int r = blockIdx.x * HT + tid;
-  if (r < L) {
-    const double ur = H.Ur[(size_t)r + (size_t)k * H.ldp], ui = H.Ui[(size_t)r + (size_t)k * H.ldp];
-    const double tr = H.pr[r] - (alr * ur - ali * ui), ti = H.pi[r] - (alr * ui + ali * ur);
-    // t / conj(beta) = t beta / |beta|^2
-    H.Wr[(size_t)r + (size_t)k * H.ldp] = (tr * br - ti * bi) / b2;
-    H.Wi[(size_t)r + (size_t)k * H.ldp] = (tr * bi + ti * br) / b2;
+    if (do_x && r <= i) {
+      const double xr = axr - cr, xi = axi - ci;
+      if (r < i) { H.xr[r] = xr; H.xi[r] = xi; nrm = xr * xr + xi * xi; }
+      else H.d[i] = xr;
+    }
+    nrm = hwave_sum(nrm);
+    if (lane == 0 && do_x) pn_out[blockIdx.x] = nrm;
   }
 }
 
@@ -681,7 +672,6 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
   double* P2 = ctx.pool.get_t<double>("h.P2", (size_t)ldp * 4 * m);
   double* P3 = ctx.pool.get_t<double>("h.P3", (size_t)ldp * 4 * m);
   H.xr = ctx.pool.get_t<double>("h.xr", (size_t)ldp); H.xi = ctx.pool.get_t<double>("h.xi", (size_t)ldp);
-  H.pr = ctx.pool.get_t<double>("h.pr", (size_t)ldp); H.pi = ctx.pool.get_t<double>("h.pi", (size_t)ldp);
   H.beta = ctx.pool.get_t<double>("h.beta", (size_t)2 * n + 2);
   const int lde = (n + 3) / 4 * 4;
   H.d = ctx.pool.get_t<double>("h.d", (size_t)n);
@@ -689,8 +679,8 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
   const int nwg = ceil_div(n, 64) + 1;
   const int nt_max = ceil_div(n, HTL) + 1;
   const int npdc_max = ceil_div(n, PDR) + 1;
-  H.pn = ctx.pool.get_t<double>("h.pn", (size_t)nwg);
-  H.ps = ctx.pool.get_t<double>("h.ps", (size_t)2 * nwg);
+  H.pn = ctx.pool.get_t<double>("h.pn", (size_t)2 * nwg);                         // two parities
+  H.ps = ctx.pool.get_t<double>("h.ps", (size_t)nt_max * (nt_max + 1));            // 2 per mat-vec tile
   H.pd = ctx.pool.get_t<double>("h.pd", (size_t)npdc_max * HM * 4);
   H.yrr = ctx.pool.get_t<double>("h.yrr", (size_t)nt_max * ldp);
   H.yri = ctx.pool.get_t<double>("h.yri", (size_t)nt_max * ldp);
@@ -710,23 +700,33 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
 
   // ---- eigen_hrd: Hermitian -> real tridiagonal ---------------------------------------------------------------------
   const double t1 = hnow();
-  int k = 0, pend = 0, nparts_prev = 0;
+  // two launches per column: K1 (finish the previous column, form this one) and K3 (mat-vec + panel dots); the norm
+  // partials alternate between two buffers (K1 reads the previous column's while it writes this column's)
+  int k = 0, par = 0;
+  int Lp = 0, ntp = 0, npdcp = 0, npartsp = 0;     // the column that is waiting to be finished (Lp = 0: none)
+  double* pnb[2] = {H.pn, H.pn + nwg};
+  auto step = [&](int i, int do_x) {
+    const int rows = std::max(do_x ? i + 1 : 0, Lp);
+    H.pn = pnb[par ^ 1];
+    hipLaunchKernelGGL(h_step_kernel, dim3(ceil_div(rows, 64)), dim3(HT), 0, st, H, i, do_x, Lp, Lp ? k - 1 : 0, ntp, npdcp,
+                       npartsp, pnb[par]);
+    return ceil_div(rows, 64);
+  };
   for (int i = n - 1; i >= 1; --i) {
     const int L = i;
-    const int nb1 = ceil_div(i + 1, HT), nbl = ceil_div(L, HT);
-    hipLaunchKernelGGL(h_form_x_kernel, dim3(nb1), dim3(HT), 0, st, H, i, k, pend, nparts_prev);
+    const int nparts = step(i, 1);
     const int npdc = ceil_div(L, PDR);
     const int nt = ceil_div(L, HTL);
-    hipLaunchKernelGGL(h_hemv_kernel, dim3(k * npdc + nt * (nt + 1) / 2), dim3(HTH), 0, st, H, L, k, nt, npdc, 4, nb1);
-    const int nbc = ceil_div(L, 64);
-    hipLaunchKernelGGL(h_combine_kernel, dim3(nbc), dim3(HT), 0, st, H, L, k, nt, npdc, nb1);
-    pend = 1; nparts_prev = nbc;
+    H.pn = pnb[par];
+    hipLaunchKernelGGL(h_hemv_kernel, dim3(k * npdc + nt * (nt + 1) / 2), dim3(HTH), 0, st, H, L, k, nt, npdc, 4, nparts);
+    Lp = L; ntp = nt; npdcp = npdc; npartsp = nparts;
+    par ^= 1;
     ++k;
     if (k == m || i == 1) {
-      // trailing update of the remaining i x i block (both triangles), two real GEMMs with K = 4k; the pending v of
-      // this step is needed in memory first
-      hipLaunchKernelGGL(h_make_v_kernel, dim3(nbl), dim3(HT), 0, st, H, i, k - 1, nbc);
-      pend = 0;
+      // trailing update of the remaining i x i block (both triangles), two real GEMMs with K = 4k; the pending column
+      // is finished (u, v into the panel) first
+      (void)step(i - 1, 0);
+      Lp = 0;
       const int nr = i;
       hipLaunchKernelGGL(h_pack_kernel, dim3(ceil_div(nr, 256), k), dim3(256), 0, st, H, nr, k, P1, P2, P3);
       dgemm_dev(st, 'N', 'T', nr, nr, 4 * k, -1.0, P1, ldp, P3, ldp, 1.0, H.Ar, ld);
@@ -735,7 +735,7 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
       k = 0;
     }
   }
-  hipLaunchKernelGGL(h_form_x_kernel, dim3(1), dim3(HT), 0, st, H, 0, 0, 0, 0);   // d_0 = Re A(0,0)
+  (void)step(0, 1);   // d_0 = Re A(0,0)
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
   const double t2 = hnow();
 
