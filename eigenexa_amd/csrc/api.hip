@@ -207,6 +207,7 @@ int eigx_matdims_for_grid(int n, int x_procs, int y_procs, int m_forward, int m_
     const int64_t big = nmz > lnx ? nmz : lnx;
     lny = ceil_div64(big * nmw, lnx);
     if (lny < n2) lny = n2;
+    lnx = hbm_ld(lnx);                 // the solvers work in place on a(nx, *): column shift of 4 - 12 KiB (eigx_common.h)
   }
   // the default build of the reference takes the maximum with FS_get_matdims (src/eigen_libs.F:139-146,
   // src/FS_libs.F90:356-375), for every mode
@@ -235,7 +236,8 @@ int eigx_matdims_for_grid(int n, int x_procs, int y_procs, int m_forward, int m_
 // (src/eigen_libs0.F:1297-1343).  The contract that matters to callers is "allocate a(nx,ny),
 // z(nx,ny)"; we return extents >= the reference's (tests/test_host.py sweeps sizes and grids against a restatement
 // of the reference's formulas): nx = ceil(n/Px) rounded up to an odd multiple of 32 plus one more 64 step of
-// slack, ny from the same nmz/nmw formula.
+// slack -- and, where the reference nudges nx off A64FX cache aliasing, off the MI355X memory-channel aliasing instead
+// (hbm_ld, eigx_common.h) -- ny from the same nmz/nmw formula.
 int eigx_get_matdims(int n, int* nx, int* ny, int m_forward, int m_backward, char mode) {
   if (!g_ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
   return eigx_matdims_for_grid(n, g_ctx.grid.Px, g_ctx.grid.Py, m_forward, m_backward, mode, nx, ny);

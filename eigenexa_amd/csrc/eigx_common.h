@@ -38,7 +38,26 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // Leading dimension >= n that is an odd multiple of 32 doubles (256 B): column strides that are multiples of
 // large powers of two camp on a few HBM channels (measured: fp64 GEMM 60 -> 45 TFLOP/s at ld = 8192).  Same
 // rule as the reference's CSTAB_get_optdim (src/CSTAB.F:73-131) for a different memory system.
-static inline int pad_ld(int n) { int l = (n + 31) / 32; if ((l & 1) == 0) ++l; return l * 32; }
+// Leading dimensions (in doubles) of column-major device arrays that are streamed from HBM.
+// Measured on MI355X (tools/ld_scan.sh, profiles/r03_ld_scan.log): what matters is the byte shift between consecutive
+// columns modulo 16 KiB.  A shift of a few hundred bytes (the old "odd multiple of 32 doubles" rule: 256 B) keeps the
+// columns a wave walks through on the same few memory channels; 2 - 12 KiB spreads them.  N = 8192 band reduction:
+// ld 8224 -> 131.9 ms, 8256 -> 135.5, 8288 -> 129.6, 8448 -> 127.1, 8704 -> 126.5, 9216 -> 126.9 (reproducible to 0.2 ms).
+// Rule: from 2048 doubles on, ld mod 2048 in [512, 1536] (shift 4 - 12 KiB); below that the arrays live in L2 / MALL.
+static inline int hbm_ld(int l) {   // l: multiple of 32
+  if (l < 2048) return l;
+  const int m = l % 2048;
+  if (m < 512) return l + (512 - m);
+  if (m > 1536) return l + (2048 - m) + 512;
+  return l;
+}
+static inline int pad_ld(int n) {
+  static const int extra = [] { const char* e = getenv("EIGX_LD_EXTRA"); return e ? atoi(e) : 0; }();   // lab switch (doubles)
+  int l = (n + 31) / 32;
+  if (l * 32 >= 2048) return hbm_ld(l * 32) + extra;
+  if ((l & 1) == 0) ++l;
+  return l * 32 + extra;
+}
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // number of local indices l with global index l*P+p < n

@@ -24,6 +24,7 @@
 #include <cfloat>
 #include <chrono>
 #include <limits>
+#include <type_traits>
 #include <vector>
 
 namespace eigx {
@@ -31,6 +32,8 @@ namespace eigx {
 namespace {
 
 constexpr int HT = 256;      // threads per workgroup
+constexpr int HS = 512;      // threads of a step workgroup (K1): 64 rows x 8 waves
+constexpr int HSW = HS / 64;
 constexpr int HM = 128;      // max panel width (LDS arrays)
 constexpr int HTL = 128;     // tile edge of the Hermitian mat-vec
 constexpr int HTH = 256;     // threads of a mat-vec workgroup (4 waves x 32 tile columns, in units of 4 columns)
@@ -130,17 +133,14 @@ __global__ void h_fill_kernel(double* p, size_t n, double v) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
-// Reflector scalars of column i (L = i rows) from the norm partials of K1: every workgroup of the mat-vec and of the
-// combine kernel recomputes them in the same order (bit-identical everywhere), so no separate reflector kernel runs.
+// Reflector scalars of column i (L = i rows) from ||x||^2 (the norm partials of K1, added in one fixed order by every
+// workgroup of the mat-vec and of K1: bit-identical everywhere, so no separate reflector kernel runs) and the pivot.
 struct HRef { double nrm2, g, unr, uni, br, bi; };
-__device__ __forceinline__ HRef h_scalars(const HArgs& H, int L, int nparts, double* red /* >= 4 doubles */) {
-  double nr[1] = {0.0};
-  for (int q = threadIdx.x; q < nparts; q += HT) nr[0] += H.pn[q];
-  hblock_sum_w<1, HT / 64>(nr, red);
+// (anr, ani) = pivot x_{L-1}
+__device__ __forceinline__ HRef h_ref_of(double nrm2, double anr, double ani) {
   HRef f;
-  f.nrm2 = nr[0]; f.g = 0.0; f.unr = 0.0; f.uni = 0.0; f.br = 1.0; f.bi = 0.0;
+  f.nrm2 = nrm2; f.g = 0.0; f.unr = 0.0; f.uni = 0.0; f.br = 1.0; f.bi = 0.0;
   if (f.nrm2 != 0.0) {
-    const double anr = H.xr[L - 1], ani = H.xi[L - 1];
     const double mag = sqrt(f.nrm2);
     f.g = (anr >= 0.0) ? -mag : mag;
     f.unr = anr - f.g; f.uni = ani;
@@ -148,11 +148,12 @@ __device__ __forceinline__ HRef h_scalars(const HArgs& H, int L, int nparts, dou
   }
   return f;
 }
-// u_r = x_r, except the pivot row L-1 (x_{L-1} - g) ; zero vector for a trivial reflector
-__device__ __forceinline__ void h_u_of(const HArgs& H, const HRef& f, int L, int r, double& ur, double& ui) {
-  if (f.nrm2 == 0.0 || r >= L) { ur = 0.0; ui = 0.0; return; }
-  if (r == L - 1) { ur = f.unr; ui = f.uni; return; }
-  ur = H.xr[r]; ui = H.xi[r];
+// u_r = x_r, except the pivot row L-1 (x_{L-1} - g) ; zero vector for a trivial reflector.  (x_r, x_i) = x of row r,
+// requested by the caller before the scalars were known (rows >= L - 1: anything)
+__device__ __forceinline__ void h_u_of(const HRef& f, int L, int r, double x_r, double x_i, double& ur, double& ui) {
+  if (f.nrm2 == 0.0 || r >= L) { ur = 0.0; ui = 0.0; }
+  else if (r == L - 1) { ur = f.unr; ui = f.uni; }
+  else { ur = x_r; ui = x_i; }
 }
 
 __device__ __forceinline__ void h_paneldot_body(const HArgs& H, const HRef& f, int L, int k, int j, int c) {
@@ -161,7 +162,7 @@ __device__ __forceinline__ void h_paneldot_body(const HArgs& H, const HRef& f, i
   double v[4] = {0.0, 0.0, 0.0, 0.0};
   for (int r = c * PDR + threadIdx.x; r < r1; r += HTH) {
     double ur, ui;
-    h_u_of(H, f, L, r, ur, ui);
+    h_u_of(f, L, r, H.xr[r], H.xi[r], ur, ui);
     const double wr = H.Wr[(size_t)r + (size_t)j * H.ldp], wi = H.Wi[(size_t)r + (size_t)j * H.ldp];
     const double pr = H.Ur[(size_t)r + (size_t)j * H.ldp], pi = H.Ui[(size_t)r + (size_t)j * H.ldp];
     v[0] += wr * ur + wi * ui; v[1] += wr * ui - wi * ur;   // conj(w) u
@@ -253,16 +254,12 @@ __global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int 
   __shared__ double ucr[HTL], uci[HTL], urr[HTL], uri[HTL];
   __shared__ double part[HTH / 64][HTL][2];
   __shared__ double sred[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const HRef f = h_scalars(H, L, nparts, sred);
-  if (blockIdx.x == 0 && tid == 0) { H.beta[2 * L] = f.br; H.beta[2 * L + 1] = f.bi; H.e[L] = f.g; }   // column i = L
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: column offsets stay on the scalar unit
   // the first k * npdc workgroups of the launch are the panel-dot workgroups (column j, row chunk c)
-  if ((int)blockIdx.x < k * npdc) {
-    h_paneldot_body(H, f, L, k, (int)blockIdx.x % k, (int)blockIdx.x / k);
-    return;
-  }
+  const bool pdot = (int)blockIdx.x < k * npdc;
   // tile index -> (ty, tx), row-major over the upper block triangle
-  const int bid = (int)blockIdx.x - k * npdc;
+  const int bid = pdot ? 0 : (int)blockIdx.x - k * npdc;
   const float fn = 2.0f * (float)nt + 1.0f;
   int ty = (int)((fn - sqrtf(fn * fn - 8.0f * (float)bid)) * 0.5f);
   if (ty < 0) ty = 0;
@@ -286,22 +283,50 @@ __global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int 
       vi[j] = *reinterpret_cast<const hd2_t*>(H.Ai + (size_t)rc + (size_t)ccl * H.ld);
     }
   };
-  load4(av0r, av0i, 0);
-  if (tid < HTL) {
+  // Requests first, in the order they are needed: the norm partials and the pivot (reflector scalars), x at this
+  // thread's column / row of the tile (u), the first unit of the tile -- one round trip for the whole prologue
+  double nr[1] = {0.0};
+  for (int q = tid; q < nparts; q += HT) nr[0] += H.pn[q];
+  const double anr = H.xr[L - 1], ani = H.xi[L - 1];
+  const int myi = (tid < HTL) ? col0 + tid : row0 + tid - HTL;
+  const int myc = (myi < L) ? myi : L - 1;
+  const double mxr = H.xr[myc], mxi = H.xi[myc];
+  if (!pdot) load4(av0r, av0i, 0);
+  // reflector scalars of column i (L = i rows) from the norm partials of K1: every workgroup of the mat-vec and of K1
+  // recomputes them in the same order (bit-identical everywhere), so no separate reflector kernel runs
+  hblock_sum_w<1, HT / 64>(nr, sred);
+  const HRef f = h_ref_of(nr[0], anr, ani);
+  if (blockIdx.x == 0 && tid == 0) { H.beta[2 * L] = f.br; H.beta[2 * L + 1] = f.bi; H.e[L] = f.g; }   // column i = L
+  if (pdot) {
+    h_paneldot_body(H, f, L, k, (int)blockIdx.x % k, (int)blockIdx.x / k);
+    return;
+  }
+  {
     double a_, b_;
-    h_u_of(H, f, L, col0 + tid, a_, b_);
-    ucr[tid] = a_; uci[tid] = b_;
-  } else {
-    double a_, b_;
-    h_u_of(H, f, L, row0 + tid - HTL, a_, b_);
-    urr[tid - HTL] = a_; uri[tid - HTL] = b_;
+    h_u_of(f, L, myi, mxr, mxi, a_, b_);
+    if (tid < HTL) { ucr[tid] = a_; uci[tid] = b_; }
+    else { urr[tid - HTL] = a_; uri[tid - HTL] = b_; }
   }
   __syncthreads();
   const double mur0 = urr[l0], mui0 = uri[l0], mur1 = urr[l1], mui1 = uri[l1];   // u at my rows
   double sr0 = 0.0, si0 = 0.0, sr1 = 0.0, si1 = 0.0;   // row sums over the wave's 32 columns
   double sq[2] = {0.0, 0.0};                            // this tile's part of u^H q (K1 of the next column adds the tiles)
-  auto compute4 = [&](const hd2_t (&vr_)[4], const hd2_t (&vi_)[4], int g) {
+  // interior tiles (strictly above the diagonal, all rows and columns < L) need no masks: most tiles of a launch
+  const bool interior = !diag && row0 + HTL <= L && col0 + HTL <= L;
+  auto compute4 = [&](auto full_tag, const hd2_t (&vr_)[4], const hd2_t (&vi_)[4], int g) {
+    constexpr bool FULL = decltype(full_tag)::value;
     double cr[4], ci[4];
+    if constexpr (FULL) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cc = wc0 + g * 4 + j;
+        const double vr = ucr[cc], vi = uci[cc];
+        sr0 += vr_[j].x * vr - vi_[j].x * vi; si0 += vr_[j].x * vi + vi_[j].x * vr;
+        sr1 += vr_[j].y * vr - vi_[j].y * vi; si1 += vr_[j].y * vi + vi_[j].y * vr;
+        cr[j] = (vr_[j].x * mur0 + vi_[j].x * mui0) + (vr_[j].y * mur1 + vi_[j].y * mui1);
+        ci[j] = (vr_[j].x * mui0 - vi_[j].x * mur0) + (vr_[j].y * mui1 - vi_[j].y * mur1);
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int cc = wc0 + g * 4 + j, c = col0 + cc;
@@ -322,6 +347,7 @@ __global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int 
       cr[j] = (y0r * mur0 + y0i * mui0) + (y1r * mur1 + y1i * mui1);                   // conj(a) u(row)
       ci[j] = (y0r * mui0 - y0i * mur0) + (y1r * mui1 - y1i * mur1);
     }
+    }
     const double tcr = hcolsum4(cr, lane), tci = hcolsum4(ci, lane);
     if ((lane & 15) == 0) {
       const int j = ((lane >> 5) & 1) * 2 + ((lane >> 4) & 1);
@@ -334,13 +360,24 @@ __global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int 
     }
   };
   // software pipeline: av0 holds unit g (loaded one iteration ahead), av1 unit g + 1
+  if (interior) {
 #pragma unroll 1
-  for (int p = 0; p < npairs; ++p) {
-    const int g = 2 * p;
-    load4(av1r, av1i, g + 1);
-    compute4(av0r, av0i, g);
-    if (p + 1 < npairs) load4(av0r, av0i, g + 2);
-    compute4(av1r, av1i, g + 1);
+    for (int p = 0; p < npairs; ++p) {
+      const int g = 2 * p;
+      load4(av1r, av1i, g + 1);
+      compute4(std::true_type{}, av0r, av0i, g);
+      if (p + 1 < npairs) load4(av0r, av0i, g + 2);
+      compute4(std::true_type{}, av1r, av1i, g + 1);
+    }
+  } else {
+#pragma unroll 1
+    for (int p = 0; p < npairs; ++p) {
+      const int g = 2 * p;
+      load4(av1r, av1i, g + 1);
+      compute4(std::false_type{}, av0r, av0i, g);
+      if (p + 1 < npairs) load4(av0r, av0i, g + 2);
+      compute4(std::false_type{}, av1r, av1i, g + 1);
+    }
   }
   part[wave][l0][0] = sr0; part[wave][l0][1] = si0;
   part[wave][l1][0] = sr1; part[wave][l1][1] = si1;
@@ -365,122 +402,156 @@ __global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int 
 //   alpha = s / (2 beta),  v = (p - alpha u) / conj(beta)  -> W(:, kp);  u -> U(:, kp) and column Lp of A
 //   x = A_eff(0:i, i) = A(:, i) - sum_{j <= kp} [U_j conj(W(i,j)) + W_j conj(U(i,j))],  d_i = Re A_eff(i,i),  partial ||x||^2
 // s and row i of (p, u, v) are needed by every workgroup before its own rows: each workgroup reduces them itself, in the
-// same order (bit-identical everywhere).  64 rows per workgroup; wave q takes every fourth partial sum and every fourth
-// panel column of those rows (the chain of dependent loads per row, not the bytes, is what this kernel costs), the four
+// same order (bit-identical everywhere).  64 rows per workgroup of 8 waves; wave q takes every eighth partial sum and
+// every eighth panel column of those rows (the chain of dependent loads per row, not the bytes, is what this kernel
+// costs: everything is requested in one round trip before the first barrier), the
 // waves are combined through LDS.  x overwrites the previous x in place: a row is read and written by the one thread
 // that owns it, and the previous pivot row (= row i) is not part of the new x.
-__global__ __launch_bounds__(HT) void h_step_kernel(HArgs H, int i, int do_x, int Lp, int kp, int ntp, int npdcp,
+__global__ __launch_bounds__(HS) void h_step_kernel(HArgs H, int i, int do_x, int Lp, int kp, int ntp, int npdcp,
                                                     int npartsp, double* __restrict__ pn_out) {
   __shared__ double dwr[HM], dwi[HM], dur[HM], dui[HM];
   __shared__ double cwr[HM], cwi[HM], cur[HM], cui[HM];
-  __shared__ double comb[4][64][4];
-  __shared__ double sred[16];
+  __shared__ double comb[HSW][64][4];
+  __shared__ double sred[5 * HSW];
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
-  const bool prev = Lp > 0;
   const int r = blockIdx.x * 64 + lane;
-  // column i of A for my row: in flight during the whole prologue
-  double axr = 0.0, axi = 0.0;
-  if (do_x && q == 0 && r <= i) { axr = H.Ar[(size_t)r + (size_t)i * H.ld]; axi = H.Ai[(size_t)r + (size_t)i * H.ld]; }
-  HRef f;
-  f.nrm2 = 0.0; f.g = 0.0; f.unr = 0.0; f.uni = 0.0; f.br = 1.0; f.bi = 0.0;
-  double alr = 0.0, ali = 0.0, br = 1.0, bi = 0.0, b2 = 1.0;
-  if (prev) {
-    f = h_scalars(H, Lp, npartsp, sred);
-    br = f.br; bi = f.bi; b2 = br * br + bi * bi;
-    double v4[4] = {0.0, 0.0, 0.0, 0.0};       // s (2) and row i of p (2)
-    if (tid < kp) {
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      for (int c = 0; c < npdcp; ++c) {
-        const double* o = H.pd + ((size_t)c * HM + tid) * 4;
-        a0 += o[0]; a1 += o[1]; a2 += o[2]; a3 += o[3];
-      }
-      dwr[tid] = a0; dwi[tid] = a1; dur[tid] = a2; dui[tid] = a3;
-      v4[0] = -2.0 * (a2 * a0 + a3 * a1);      // -2 Re conj(du) dw
-      if (do_x) {
-        const double ur = H.Ur[(size_t)i + (size_t)tid * H.ldp], ui = H.Ui[(size_t)i + (size_t)tid * H.ldp];
-        const double wr = H.Wr[(size_t)i + (size_t)tid * H.ldp], wi = H.Wi[(size_t)i + (size_t)tid * H.ldp];
-        v4[2] = -((ur * a0 - ui * a1) + (wr * a2 - wi * a3));
-        v4[3] = -((ur * a1 + ui * a0) + (wr * a3 + wi * a2));
-        cwr[tid] = wr; cwi[tid] = -wi; cur[tid] = ur; cui[tid] = -ui;
-      }
+  if (Lp <= 0) {   // first column of a panel: nothing to finish, A_eff = A
+    if (q != 0) return;
+    double nrm = 0.0;
+    if (r <= i) {
+      const double xr = H.Ar[(size_t)r + (size_t)i * H.ld], xi = H.Ai[(size_t)r + (size_t)i * H.ld];
+      if (r < i) { H.xr[r] = xr; H.xi[r] = xi; nrm = xr * xr + xi * xi; }
+      else H.d[i] = xr;
     }
-    const int ntiles = ntp * (ntp + 1) / 2;
-    for (int t = tid; t < ntiles; t += HT) { v4[0] += H.ps[2 * t]; v4[1] += H.ps[2 * t + 1]; }
+    nrm = hwave_sum(nrm);
+    if (lane == 0) pn_out[blockIdx.x] = nrm;
+    return;
+  }
+  // ---- requests: everything the kernel needs from memory before the first barrier (one round trip for the common
+  // sizes; a straight-line version with every load unconditional and clamped was 2 % slower: more load instructions)
+  constexpr int PB = 6;                        // panel columns per wave that are requested up front (kp <= PB * HSW = 48)
+  constexpr int QB = 9;                        // mat-vec partials per wave and batch (one batch up to L = 9088)
+  const int rc = (r < Lp) ? r : Lp - 1;        // my row, clamped
+  double axr = 0.0, axi = 0.0, anr = 0.0, ani = 0.0, xpr = 0.0, xpi = 0.0;
+  if (q == 0) {
+    if (do_x && r <= i) { axr = H.Ar[(size_t)r + (size_t)i * H.ld]; axi = H.Ai[(size_t)r + (size_t)i * H.ld]; }
+    anr = H.xr[Lp - 1]; ani = H.xi[Lp - 1];
+    xpr = H.xr[rc]; xpi = H.xi[rc];
+  }
+  double v5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};    // ||x_prev||^2, s (2), row i of p (2)
+  if (tid < HT) for (int t = tid; t < npartsp; t += HT) v5[0] += H.pn[t];   // exactly the sum the mat-vec forms (the other waves add +0.0)
+  if (tid < 4 * kp) {   // panel dots: thread (column j, component) adds the chunks, eight requests at a time
+    const int j = tid >> 2, comp = tid & 3;
+    double a = 0.0;
+    for (int c0 = 0; c0 < npdcp; c0 += 8) {
+      double t8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t8[e] = H.pd[((size_t)((c0 + e < npdcp) ? c0 + e : npdcp - 1) * HM + j) * 4 + comp];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a += (c0 + e < npdcp) ? t8[e] : 0.0;
+    }
+    (comp == 0 ? dwr : comp == 1 ? dwi : comp == 2 ? dur : dui)[j] = a;
+  }
+  double rur = 0.0, rui = 0.0, rwr = 0.0, rwi = 0.0;   // row i of panel column tid
+  if (do_x && tid < kp) {
+    rur = H.Ur[(size_t)i + (size_t)tid * H.ldp]; rui = H.Ui[(size_t)i + (size_t)tid * H.ldp];
+    rwr = H.Wr[(size_t)i + (size_t)tid * H.ldp]; rwi = H.Wi[(size_t)i + (size_t)tid * H.ldp];
+    cwr[tid] = rwr; cwi[tid] = -rwi; cur[tid] = rur; cui[tid] = -rui;   // conj of row i of the panel
+  }
+  const int ntiles = ntp * (ntp + 1) / 2;
+  for (int t = tid; t < ntiles; t += HS) { v5[1] += H.ps[2 * t]; v5[2] += H.ps[2 * t + 1]; }
+  // partial u of row x: u <= R(x) -> column sums of tile (u, R); u > R -> row sums of tile (R, u-1)   (R = x / HTL)
+  auto part_r = [&](int u, int x) { return (u <= x / HTL) ? H.ycr[(size_t)u * H.ldp + x] : H.yrr[(size_t)(u - 1) * H.ldp + x]; };
+  auto part_i = [&](int u, int x) { return (u <= x / HTL) ? H.yci[(size_t)u * H.ldp + x] : H.yri[(size_t)(u - 1) * H.ldp + x]; };
+  if (do_x) for (int u = tid; u < ntp + 1; u += HS) { v5[3] += part_r(u, i); v5[4] += part_i(u, i); }
+  // wave q takes the panel columns j = q, q + HSW, ...; the first PB of them are requested here (a column past the end:
+  // clamped index, value dropped -- no load behind a branch)
+  double pur[PB], pui[PB], pwr[PB], pwi[PB];
+#pragma unroll
+  for (int e = 0; e < PB; ++e) {
+    const int j = q + e * HSW, jc = (j < kp) ? j : 0;
+    pur[e] = H.Ur[(size_t)rc + (size_t)jc * H.ldp]; pui[e] = H.Ui[(size_t)rc + (size_t)jc * H.ldp];
+    pwr[e] = H.Wr[(size_t)rc + (size_t)jc * H.ldp]; pwi[e] = H.Wi[(size_t)rc + (size_t)jc * H.ldp];
+  }
+  // and the partials u = q, q + HSW, ...
+  double pr = 0.0, pi = 0.0, cr = 0.0, ci = 0.0;
+  for (int u0 = q; u0 < ntp + 1; u0 += QB * HSW) {
+    double a[QB], b[QB];
+#pragma unroll
+    for (int e = 0; e < QB; ++e) {
+      const int u = u0 + e * HSW, uc = (u < ntp + 1) ? u : ntp;
+      a[e] = part_r(uc, rc); b[e] = part_i(uc, rc);
+    }
+#pragma unroll
+    for (int e = 0; e < QB; ++e) { const bool in = u0 + e * HSW < ntp + 1; pr += in ? a[e] : 0.0; pi += in ? b[e] : 0.0; }
+  }
+  __syncthreads();     // panel dots and row i of the panel are in LDS
+  if (tid < kp) {
+    const double a0 = dwr[tid], a1 = dwi[tid], a2 = dur[tid], a3 = dui[tid];
+    v5[1] += -2.0 * (a2 * a0 + a3 * a1);       // -2 Re conj(du) dw
     if (do_x) {
-      const int R = i / HTL;
-      for (int u = tid; u < ntp + 1; u += HT) {
-        v4[2] += (u <= R) ? H.ycr[(size_t)u * H.ldp + i] : H.yrr[(size_t)(u - 1) * H.ldp + i];
-        v4[3] += (u <= R) ? H.yci[(size_t)u * H.ldp + i] : H.yri[(size_t)(u - 1) * H.ldp + i];
-      }
-    }
-    hblock_sum<4>(v4, sred);
-    // alpha = s / (2 beta) = s conj(beta) / (2 |beta|^2)
-    alr = (v4[0] * br + v4[1] * bi) / (2.0 * b2); ali = (v4[1] * br - v4[0] * bi) / (2.0 * b2);
-    if (do_x && tid == kp) {   // row i of the column that is being finished: v(i), u(i)
-      double ur, ui;
-      h_u_of(H, f, Lp, i, ur, ui);
-      const double tr = v4[2] - (alr * ur - ali * ui), ti = v4[3] - (alr * ui + ali * ur);
-      cwr[kp] = (tr * br - ti * bi) / b2; cwi[kp] = -((tr * bi + ti * br) / b2);
-      cur[kp] = ur; cui[kp] = -ui;
+      v5[3] -= (rur * a0 - rui * a1) + (rwr * a2 - rwi * a3);
+      v5[4] -= (rur * a1 + rui * a0) + (rwr * a3 + rwi * a2);
     }
   }
-  __syncthreads();
-  double pr = 0.0, pi = 0.0, cr = 0.0, ci = 0.0;
-  if (prev && r < Lp) {
-    const int R = r / HTL;   // my tile row.  Partial u of the row: u <= R -> column sums of tile (u, R); u > R -> row sums of tile (R, u-1)
-    auto ldp_r = [&](int u) { return (u <= R) ? H.ycr[(size_t)u * H.ldp + r] : H.yrr[(size_t)(u - 1) * H.ldp + r]; };
-    auto ldp_i = [&](int u) { return (u <= R) ? H.yci[(size_t)u * H.ldp + r] : H.yri[(size_t)(u - 1) * H.ldp + r]; };
-    int u = q;
-    for (; u + 12 < ntp + 1; u += 16) {
-      double a[4], b[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { a[e] = ldp_r(u + 4 * e); b[e] = ldp_i(u + 4 * e); }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { pr += a[e]; pi += b[e]; }
-    }
-    for (; u < ntp + 1; u += 4) { pr += ldp_r(u); pi += ldp_i(u); }
-#pragma unroll 2
-    for (int j = q; j < kp; j += 4) {
-      const double ur = H.Ur[(size_t)r + (size_t)j * H.ldp], ui = H.Ui[(size_t)r + (size_t)j * H.ldp];
-      const double wr = H.Wr[(size_t)r + (size_t)j * H.ldp], wi = H.Wi[(size_t)r + (size_t)j * H.ldp];
+  {
+    auto apply = [&](int j, double ur, double ui, double wr, double wi) {
       pr -= (ur * dwr[j] - ui * dwi[j]) + (wr * dur[j] - wi * dui[j]);
       pi -= (ur * dwi[j] + ui * dwr[j]) + (wr * dui[j] + wi * dur[j]);
       if (do_x) {
         cr += (ur * cwr[j] - ui * cwi[j]) + (wr * cur[j] - wi * cui[j]);
         ci += (ur * cwi[j] + ui * cwr[j]) + (wr * cui[j] + wi * cur[j]);
       }
+    };
+#pragma unroll
+    for (int e = 0; e < PB; ++e) {
+      const int j = q + e * HSW;
+      if (j < kp) apply(j, pur[e], pui[e], pwr[e], pwi[e]);
     }
+    for (int j = q + PB * HSW; j < kp; j += HSW)     // wider panels only
+      apply(j, H.Ur[(size_t)rc + (size_t)j * H.ldp], H.Ui[(size_t)rc + (size_t)j * H.ldp], H.Wr[(size_t)rc + (size_t)j * H.ldp],
+            H.Wi[(size_t)rc + (size_t)j * H.ldp]);
   }
   comb[q][lane][0] = pr; comb[q][lane][1] = pi; comb[q][lane][2] = cr; comb[q][lane][3] = ci;
-  __syncthreads();
-  if (q == 0) {
-    double nrm = 0.0;
-    pr = (comb[0][lane][0] + comb[1][lane][0]) + (comb[2][lane][0] + comb[3][lane][0]);
-    pi = (comb[0][lane][1] + comb[1][lane][1]) + (comb[2][lane][1] + comb[3][lane][1]);
-    cr = (comb[0][lane][2] + comb[1][lane][2]) + (comb[2][lane][2] + comb[3][lane][2]);
-    ci = (comb[0][lane][3] + comb[1][lane][3]) + (comb[2][lane][3] + comb[3][lane][3]);
-    if (prev && r < Lp) {
-      double ur, ui;
-      h_u_of(H, f, Lp, r, ur, ui);
-      const double tr = pr - (alr * ur - ali * ui), ti = pi - (alr * ui + ali * ur);
-      const double wr = (tr * br - ti * bi) / b2, wi = (tr * bi + ti * br) / b2;   // t / conj(beta) = t beta / |beta|^2
-      H.Wr[(size_t)r + (size_t)kp * H.ldp] = wr; H.Wi[(size_t)r + (size_t)kp * H.ldp] = wi;
-      // the reflector goes into the panel and stays in column Lp of A (rows 0..Lp-1), as the reference leaves it
-      H.Ur[(size_t)r + (size_t)kp * H.ldp] = ur; H.Ui[(size_t)r + (size_t)kp * H.ldp] = ui;
-      H.Ar[(size_t)r + (size_t)Lp * H.ld] = ur; H.Ai[(size_t)r + (size_t)Lp * H.ld] = ui;
-      if (do_x) {
-        cr += (ur * cwr[kp] - ui * cwi[kp]) + (wr * cur[kp] - wi * cui[kp]);
-        ci += (ur * cwi[kp] + ui * cwr[kp]) + (wr * cui[kp] + wi * cur[kp]);
-      }
+  // the five scalars, added in the order the mat-vec uses (it recomputes the reflector scalars from the same
+  // partials and must get the same bits); its barriers also publish comb
+  hblock_sum_w<5, HSW>(v5, sred);
+  if (q != 0) return;
+  const HRef f = h_ref_of(v5[0], anr, ani);
+  const double br = f.br, bi = f.bi, b2 = br * br + bi * bi;
+  // alpha = s / (2 beta) = s conj(beta) / (2 |beta|^2);   t / conj(beta) = t beta / |beta|^2
+  const double alr = (v5[1] * br + v5[2] * bi) / (2.0 * b2), ali = (v5[2] * br - v5[1] * bi) / (2.0 * b2);
+  double nrm = 0.0;
+  pr = 0.0; pi = 0.0; cr = 0.0; ci = 0.0;
+#pragma unroll
+  for (int w = 0; w < HSW; ++w) { pr += comb[w][lane][0]; pi += comb[w][lane][1]; cr += comb[w][lane][2]; ci += comb[w][lane][3]; }
+  if (r < Lp) {
+    double ur, ui;
+    h_u_of(f, Lp, r, xpr, xpi, ur, ui);
+    const double tr = pr - (alr * ur - ali * ui), ti = pi - (alr * ui + ali * ur);
+    const double wr = (tr * br - ti * bi) / b2, wi = (tr * bi + ti * br) / b2;
+    H.Wr[(size_t)r + (size_t)kp * H.ldp] = wr; H.Wi[(size_t)r + (size_t)kp * H.ldp] = wi;
+    // the reflector goes into the panel and stays in column Lp of A (rows 0..Lp-1), as the reference leaves it
+    H.Ur[(size_t)r + (size_t)kp * H.ldp] = ur; H.Ui[(size_t)r + (size_t)kp * H.ldp] = ui;
+    H.Ar[(size_t)r + (size_t)Lp * H.ld] = ur; H.Ai[(size_t)r + (size_t)Lp * H.ld] = ui;
+    if (do_x) {
+      // row i of the column that is being finished: conj v(i), conj u(i)  (i = Lp - 1, the pivot row)
+      double uir, uii;
+      h_u_of(f, Lp, i, 0.0, 0.0, uir, uii);
+      const double sr = v5[3] - (alr * uir - ali * uii), si = v5[4] - (alr * uii + ali * uir);
+      const double cvr = (sr * br - si * bi) / b2, cvi = -((sr * bi + si * br) / b2);
+      const double cur_ = uir, cui_ = -uii;
+      cr += (ur * cvr - ui * cvi) + (wr * cur_ - wi * cui_);
+      ci += (ur * cvi + ui * cvr) + (wr * cui_ + wi * cur_);
     }
-    if (do_x && r <= i) {
-      const double xr = axr - cr, xi = axi - ci;
-      if (r < i) { H.xr[r] = xr; H.xi[r] = xi; nrm = xr * xr + xi * xi; }
-      else H.d[i] = xr;
-    }
-    nrm = hwave_sum(nrm);
-    if (lane == 0 && do_x) pn_out[blockIdx.x] = nrm;
   }
+  if (do_x && r <= i) {
+    const double xr = axr - cr, xi = axi - ci;
+    if (r < i) { H.xr[r] = xr; H.xi[r] = xi; nrm = xr * xr + xi * xi; }
+    else H.d[i] = xr;
+  }
+  nrm = hwave_sum(nrm);
+  if (lane == 0 && do_x) pn_out[blockIdx.x] = nrm;
 }
 
 // panel end: P1 = [Ur Ui Wr Wi], P2 = [Ui -Ur Wi -Wr], P3 = [Wr Wi Ur Ui]  (rows < nr, k columns each part)
@@ -663,7 +734,11 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
   HArgs H;
   H.n = n; H.ld = ld; H.ldp = ldp;
   H.Ar = ctx.pool.get_t<double>("h.Ar", (size_t)ld * n);
-  H.Ai = ctx.pool.get_t<double>("h.Ai", (size_t)ld * n);
+  // The two planes are streamed together at equal offsets; with plane sizes that are multiples of 16 KiB every pair of
+  // requests met on the same memory channel.  Half a period (+128 B) between them: reduction 488 -> 459 ms at N = 8192
+  // (tools/ab_herm_skew.sh: 0 -> 488, 272 -> 486, 784 -> 471, 1040 -> 459, 1552 -> 498, 4112 -> 492 ms, reproducible).
+  static const int plane_skew = [] { const char* e = getenv("EIGX_H_SKEW"); return e ? atoi(e) : 1040; }();   // doubles
+  H.Ai = ctx.pool.get_t<double>("h.Ai", (size_t)ld * n + plane_skew) + plane_skew;
   H.Ur = ctx.pool.get_t<double>("h.Ur", (size_t)ldp * m);
   H.Ui = ctx.pool.get_t<double>("h.Ui", (size_t)ldp * m);
   H.Wr = ctx.pool.get_t<double>("h.Wr", (size_t)ldp * m);
@@ -708,7 +783,7 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
   auto step = [&](int i, int do_x) {
     const int rows = std::max(do_x ? i + 1 : 0, Lp);
     H.pn = pnb[par ^ 1];
-    hipLaunchKernelGGL(h_step_kernel, dim3(ceil_div(rows, 64)), dim3(HT), 0, st, H, i, do_x, Lp, Lp ? k - 1 : 0, ntp, npdcp,
+    hipLaunchKernelGGL(h_step_kernel, dim3(ceil_div(rows, 64)), dim3(HS), 0, st, H, i, do_x, Lp, Lp ? k - 1 : 0, ntp, npdcp,
                        npartsp, pnb[par]);
     return ceil_div(rows, 64);
   };

@@ -13,7 +13,7 @@ if os.environ.get("EIGX_T256"): lib.eigx_tune(4, int(os.environ["EIGX_T256"]))
 if os.environ.get("EIGX_NT"): lib.eigx_tune(5, int(os.environ["EIGX_NT"]))
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-lda = n + (n & 1) + 2 + 30   # even, not a multiple of a large power of two
+lda = int(os.environ.get("EIGX_LDA", n + (n & 1) + 2 + 30))   # even, not a multiple of a large power of two
 R = torch.rand(n, lda, dtype=torch.float64, device=dev)
 d = torch.zeros(n, dtype=torch.float64, device=dev)
 e = torch.zeros(band * n, dtype=torch.float64, device=dev)
