@@ -113,7 +113,10 @@ int eigx_get_errinfo(int64_t* info);
 
 /* replaces eigen_get_matdims(n, nx, ny, m_forward, m_backward, mode) src/eigen_libs.F:106-148,
  * src/eigen_libs0.F:1254-1371.  Returns local array extents that are >= the reference's for the
- * same (n, grid) so existing callers' allocations stay valid; nx = ny = -1 if too large. */
+ * same (n, grid) so existing callers' allocations stay valid; nx = ny = -1 if too large.
+ * Mode 'O' (the default): where the reference nudges nx off A64FX cache-set aliasing (src/CSTAB.F:73-131), nx here is
+ * moved off MI355X memory-channel aliasing -- from 2048 on, nx mod 2048 lies in [512, 1536] (consecutive columns
+ * 4 - 12 KiB apart modulo 16 KiB); the solvers work in place on a(nx, *), and this is worth 2 - 9 % of a solve. */
 int eigx_get_matdims(int n, int* nx, int* ny, int m_forward, int m_backward, char mode);
 /* the same rule for an explicit x_procs x y_procs grid; pure arithmetic (usable before eigx_init, without a GPU) */
 int eigx_matdims_for_grid(int n, int x_procs, int y_procs, int m_forward, int m_backward, char mode, int* nx, int* ny);
