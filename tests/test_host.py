@@ -301,6 +301,29 @@ def test_matdims_not_smaller_than_reference():
                     assert nx.value >= (n + Px - 1) // Px and ny.value >= (n + Py - 1) // Py
 
 
+def test_matdims_leading_dimension_avoids_channel_aliasing():
+    """the nx that eigen_get_matdims recommends (mode 'O') puts consecutive columns 4 - 12 KiB apart
+    modulo 16 KiB from 2048 doubles on (nx mod 2048 in [512, 1536]), stays a multiple of 32 (16-byte column loads need it
+    even) and costs at most 1024 + 160 doubles over the local extent"""
+    import ctypes as C
+
+    from eigenexa_amd import _lib
+
+    lib = _lib.load()
+    for Px, Py in [(1, 1), (2, 2), (2, 4), (1, 8)]:
+        for n in [100, 2047, 2048, 3000, 4096, 8192, 10000, 12289, 16384, 20000, 32768, 40000, 65536]:
+            nx, ny = C.c_int(), C.c_int()
+            rc = lib.eigx_matdims_for_grid(n, Px, Py, 48, 128, b"O", C.byref(nx), C.byref(ny))
+            if rc == -3:
+                continue
+            assert rc == 0
+            n1 = (n + Px - 1) // Px
+            assert nx.value % 32 == 0 and nx.value >= n1
+            if nx.value >= 2048:
+                assert 512 <= nx.value % 2048 <= 1536, (n, Px, nx.value)
+            assert nx.value <= n1 + 1024 + 160, (n, Px, nx.value)
+
+
 # ------------------------------------------------- 2-D cyclic partition of the reduction step: index arithmetic on the CPU
 def _mg_nty(tx, T, Lc, Px, px, Py, py):
     """tiles of tile column tx of a rank's local block (band_reduce.hip mg_nty)"""
