@@ -1142,6 +1142,40 @@ def test_eigen_h_matches_oracle(gpu_lib, orc, n, m):
     assert a[0, 0].real > 0 and (n < 2 or a[1, 0].real >= 0)      # a(1,1) = flops, a(2,1) = seconds
 
 
+@pytest.mark.parametrize("n,m", [(9400, 48), (4500, 96)])
+def test_eigen_h_beyond_the_first_batches(gpu_lib, n, m):
+    """eigen_h at sizes where the step kernel's remainder loops run (more than 72 mat-vec partials per row above
+    L = 9088, more than 8 panel-dot chunks above L = 8192, more than 48 panel columns): residual, unitarity (the
+    reference's thresholds for the real solvers, benchmark/ev_test.f:181-204), trace and Frobenius norm of the spectrum --
+    all on the GPU, device API"""
+    import torch
+
+    dev = _dev()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + n)
+    B = torch.randn(n, n, dtype=torch.complex128, device=dev, generator=gen)
+    A = (B + B.conj().T) / 2
+    del B
+    at = A.T.contiguous().clone()          # at[j, i] = A(i, j): the column-major image
+    z = torch.zeros(n, n, dtype=torch.complex128, device=dev)
+    w = torch.zeros(n, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    assert gpu_lib.eigx_h_dev(n, n, at.data_ptr(), n, w.data_ptr(), z.data_ptr(), n, m, 128, b"A") == 0
+    del at
+    Z = z.T                                # Z[:, k] = eigenvector k
+    anorm = torch.linalg.norm(A).item()
+    res = torch.linalg.norm(A @ Z - Z * w[None, :]).item() / (n * EPS * anorm)
+    orth = torch.linalg.norm(Z.conj().T @ Z - torch.eye(n, dtype=torch.complex128, device=dev)).item() / (n * EPS)
+    assert res < GATE_RES and orth < GATE_ORTH, (res, orth)
+    wh = w.cpu().numpy()
+    assert np.all(np.diff(wh) >= 0)
+    tr = torch.diagonal(A).real.sum().item()
+    assert abs(wh.sum() - tr) < 1e-12 * n * max(1.0, np.abs(wh).max())
+    assert abs(np.sqrt((wh ** 2).sum()) - anorm) < 1e-12 * anorm
+    del A, z, Z
+    torch.cuda.empty_cache()
+
+
 def test_eigen_h_known_spectrum_and_modes(gpu_lib, orc):
     """A = D F D^H with the Frank matrix F and a unitary diagonal D has Frank's analytic spectrum
     (benchmark/mat_set.f:638-647); modes 'N' and 'X'; partial eigenvector sets; a real symmetric matrix passed as
