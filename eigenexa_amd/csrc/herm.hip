@@ -1,5 +1,5 @@
-// herm.hip -- eigen_h: complex Hermitian eigensolver, first version (one GPU; with more ranks the
-// cyclic blocks are gathered and every rank solves the replicated problem).
+// herm.hip -- eigen_h: complex Hermitian eigensolver.  One GPU; with more ranks the cyclic blocks are
+// gathered, every rank reduces the replicated problem, and the back-transformation is shared by eigenvector columns.
 //
 // Replaces eigen_h (src/eigen_h.F:30-322): eigen_scaling_h -> eigen_hrd (Hermitian -> REAL symmetric tridiagonal,
 // src/eigen_hrd.F:1-448) -> dc2 (the real tridiagonal D&C of dc.hip, unchanged) -> eigen_hrbakwyx (complex WY
@@ -679,10 +679,13 @@ double hnow() { return std::chrono::duration<double>(std::chrono::steady_clock::
 }  // namespace
 
 // a, z: device, interleaved complex(8), leading dimensions in complex elements
-// full (global) matrix on this rank's GPU.  With more than one rank every rank runs this on the same replicated input
-// (the D&C inside distributes its GEMMs over the ranks, everything else is redundant): correct, not yet scalable.
+// full (global) matrix on this rank's GPU.  With more than one rank every rank runs this on the same replicated input:
+// the reduction and the real tridiagonal D&C are redundant, the back-transformation (19 % of a solve at N = 8192) is
+// split by eigenvector columns and allgathered.  Correct; the reduction is what a sharded form still has to distribute.
+// bt_P, bt_p: several ranks that hold the same replicated problem share the back-transformation by eigenvector columns
+// (rank bt_p of bt_P takes the columns [bt_p * zc, (bt_p + 1) * zc), zc = ceil(nvec / bt_P)) and allgather the result
 static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb,
-                           char mode) {
+                           char mode, int bt_P = 1, int bt_p = 0) {
   if (!ctx.initialized) return EIGX_ERR_NOT_INITIALIZED;
   if (n <= 0) {
     fprintf(stderr, "[eigx] warning: non-positive dimension is invalid\n");   // src/eigen_h.F:91-94
@@ -821,8 +824,8 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
   if (!want_vec) {
     band_bisect_dev(ctx, n, H.d, H.e, lde, 1, w);
   } else {
-    Zr = ctx.pool.get_t<double>("h.Zr", (size_t)ldzp * n);
-    Zi = ctx.pool.get_t<double>("h.Zi", (size_t)ldzp * n);
+    Zr = ctx.pool.get_t<double>("h.Zr", (size_t)ldzp * (n + bt_P));   // room for bt_P column blocks of ceil(nvec / bt_P)
+    Zi = ctx.pool.get_t<double>("h.Zi", (size_t)ldzp * (n + bt_P));
     if (mode == 'S') {
       // Z = I (the first nvec columns), eigenvalues by bisection: the back-transformation then delivers the unitary
       // matrix of the reduction itself, Z^H A Z = T (src/eigen_h.F:207-210, eigen_identity src/eigen_identity.F)
@@ -875,8 +878,16 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
       dgemm_dev(st, 'T', 'N', 2 * nb, 2 * nb, rows, 1.0, Vs, lds, Vs, lds, 0.0, Gall + (size_t)b * 4 * HMB * HMB, 2 * HMB);
     }
     hipLaunchKernelGGL(h_tinv_kernel, dim3(nblk), dim3(HMB), shm, st, Gall, H.beta, 1, bw, n, Tall);
-    // phase B: apply the blocks in ascending order
-    for (int b = 0; b < nblk; ++b) {
+    // phase B: apply the blocks in ascending order -- to this rank's eigenvector columns
+    const int zc = ceil_div(nvec, bt_P);
+    const int c0 = (bt_p * zc < nvec) ? bt_p * zc : nvec;
+    const int cn = (c0 + zc <= nvec) ? zc : nvec - c0;
+    double* const Zr_all = Zr;
+    double* const Zi_all = Zi;
+    const int nvec_all = nvec;
+    Zr += (size_t)c0 * ldzp; Zi += (size_t)c0 * ldzp;
+    nvec = cn;
+    for (int b = 0; b < nblk && nvec > 0; ++b) {
       const int j0 = 1 + b * bw;
       const int nb = (j0 + bw <= n) ? bw : n - j0;
       const int rows = j0 + nb - 1;
@@ -897,6 +908,15 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
       hipLaunchKernelGGL(h_xstack_kernel, dim3(1, nvec), dim3(128), 0, st, Xr, Xi, nb, nvec, YA, YB);
       dgemm_dev(st, 'N', 'N', rows, nvec, 2 * nb, -1.0, Vs, lds, YA, 2 * HMB, 1.0, Zr, ldzp);
       dgemm_dev(st, 'N', 'N', rows, nvec, 2 * nb, -1.0, Vs, lds, YB, 2 * HMB, 1.0, Zi, ldzp);
+    }
+    nvec = nvec_all;
+    Zr = Zr_all; Zi = Zi_all;
+    if (bt_P > 1) {   // every rank gets every column block (the caller cuts its cyclic block out of the full matrix)
+      double* Gr = ctx.pool.get_t<double>("h.ZrG", (size_t)ldzp * zc * bt_P);
+      double* Gi = ctx.pool.get_t<double>("h.ZiG", (size_t)ldzp * zc * bt_P);
+      comm_allgather(ctx, COMM_WORLD, Zr + (size_t)bt_p * zc * ldzp, Gr, (size_t)zc * ldzp, st);
+      comm_allgather(ctx, COMM_WORLD, Zi + (size_t)bt_p * zc * ldzp, Gi, (size_t)zc * ldzp, st);
+      Zr = Gr; Zi = Gi;
     }
   }
   if (want_vec) hipLaunchKernelGGL(h_join_kernel, dim3(8, nvec), dim3(256), 0, st, Zr, Zi, ldzp, n, nvec, z, ldz);
@@ -980,7 +1000,9 @@ int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w,
   comm_allgather(ctx, COMM_WORLD, sendb, recvb, (size_t)2 * bx * by, st);
   hipLaunchKernelGGL(hz_cyclic_to_full_kernel, dim3(8, by, G.nranks), dim3(256), 0, st, recvb, bx, by, G.Px, G.Py,
                      G.row_major, n, Af, ldf);
-  const int rc = herm_solve_full(ctx, n, nvec, Af, ldf, w, Zf, ldf, mf, mb, mode);
+  int members[EIGX_MAXP], mine = 0;
+  const int np = comm_group(ctx, COMM_WORLD, members, &mine);
+  const int rc = herm_solve_full(ctx, n, nvec, Af, ldf, w, Zf, ldf, mf, mb, mode, np, mine);
   if (rc != EIGX_OK) return rc;
   if (want_vec) {
     const int nzc = local_count(nv, G.Py, G.py);
