@@ -9,8 +9,8 @@
 // fp64 MFMA GEMMs of gemm_f64.hip instead of a ZGEMM port:
 //   trailing update  A -= U W^H + W U^H :  Ar -= [Ur Ui Wr Wi][Wr Wi Ur Ui]^T ,  Ai -= [Ui -Ur Wi -Wr][Wr Wi Ur Ui]^T  (K = 4m)
 //   back-transform   Z -= V (T (V^H Z)), T = S^-H : 4 real GEMMs each for V^H Z, T Y and V X, 4 small ones for the Gram matrix
-// The reduction keeps both triangles of A up to date (the trailing update is a full GEMM), but the Hermitian mat-vec
-// streams only the upper triangle (64 x 64 tiles transposed through LDS).  Each column is formed lazily from the panel (dlatrd style), one column per step as the reference does:
+// The reduction keeps the upper triangle of A up to date (the trailing update computes the tiles that meet it), and the
+// Hermitian mat-vec streams only that triangle (128 x 128 register tiles).  Each column is formed lazily from the panel (dlatrd style), one column per step as the reference does:
 //   x = A_eff(0:L, i);  g = -sign(||x||, Re x_{L-1});  u = x, u_{L-1} -= g;  beta = -u_{L-1} g       (src/eigen_hrd_t4.F:40-95)
 //   q = A_eff u;  s = u^H q;  alpha = s / (2 beta);  v = (q - alpha u) / conj(beta)                 (src/eigen_hrd_t6_3.F:256-272)
 //   A_eff = A - U W^H - W U^H  (panel of m columns, applied every m steps)                          (src/eigen_hrd_t1.F:2-110)
@@ -801,14 +801,17 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
     par ^= 1;
     ++k;
     if (k == m || i == 1) {
-      // trailing update of the remaining i x i block (both triangles), two real GEMMs with K = 4k; the pending column
-      // is finished (u, v into the panel) first
+      // trailing update of the remaining i x i block, two real GEMMs with K = 4k; the pending column is finished
+      // (u, v into the panel) first
       (void)step(i - 1, 0);
       Lp = 0;
       const int nr = i;
       hipLaunchKernelGGL(h_pack_kernel, dim3(ceil_div(nr, 256), k), dim3(256), 0, st, H, nr, k, P1, P2, P3);
-      dgemm_dev(st, 'N', 'T', nr, nr, 4 * k, -1.0, P1, ldp, P3, ldp, 1.0, H.Ar, ld);
-      dgemm_dev(st, 'N', 'T', nr, nr, 4 * k, -1.0, P2, ldp, P3, ldp, 1.0, H.Ai, ld);
+      // only the tiles that meet the upper triangle: after the split nothing reads the strict lower triangle any more
+      // (K1 reads A(0:i, i), the mat-vec the tiles ty <= tx with the lower half of a diagonal tile masked, the
+      // back-transformation zeroes below the reflectors first)
+      dgemm_dev(st, 'N', 'T', nr, nr, 4 * k, -1.0, P1, ldp, P3, ldp, 1.0, H.Ar, ld, 1);
+      dgemm_dev(st, 'N', 'T', nr, nr, 4 * k, -1.0, P2, ldp, P3, ldp, 1.0, H.Ai, ld, 1);
       zero_panel();
       k = 0;
     }
