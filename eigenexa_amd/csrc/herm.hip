@@ -827,8 +827,11 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
   if (!want_vec) {
     band_bisect_dev(ctx, n, H.d, H.e, lde, 1, w);
   } else {
-    Zr = ctx.pool.get_t<double>("h.Zr", (size_t)ldzp * (n + bt_P));   // room for bt_P column blocks of ceil(nvec / bt_P)
-    Zi = ctx.pool.get_t<double>("h.Zi", (size_t)ldzp * (n + bt_P));
+    // both planes in one buffer (V^H Z is one batched product over them), room for bt_P column blocks of
+    // ceil(nvec / bt_P) each, the imaginary plane half a 16 KiB period off the real one's grid (as for A above)
+    const size_t zplane = (size_t)ldzp * (n + bt_P) + 1040;
+    Zr = ctx.pool.get_t<double>("h.Zri", 2 * zplane);
+    Zi = Zr + zplane;
     if (mode == 'S') {
       // Z = I (the first nvec columns), eigenvalues by bisection: the back-transformation then delivers the unitary
       // matrix of the reduction itself, Z^H A Z = T (src/eigen_h.F:207-210, eigen_identity src/eigen_identity.F)
@@ -858,8 +861,8 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
     const int nblk = ceil_div(n - 1, bw);
     double* Gall = ctx.pool.get_t<double>("h.Gall", (size_t)nblk * 4 * HMB * HMB);
     double* Tall = ctx.pool.get_t<double>("h.Tall", (size_t)nblk * 2 * HMB * HMB);
-    double* YA = ctx.pool.get_t<double>("h.YA", (size_t)2 * HMB * nvec);
-    double* YB = ctx.pool.get_t<double>("h.YB", (size_t)2 * HMB * nvec);
+    double* YA = ctx.pool.get_t<double>("h.YAB", (size_t)2 * 2 * HMB * nvec);
+    double* YB = YA + (size_t)2 * HMB * nvec;
     double* Yr = ctx.pool.get_t<double>("h.Yr", (size_t)HMB * nvec);
     double* Yi = ctx.pool.get_t<double>("h.Yi", (size_t)HMB * nvec);
     double* Xr = ctx.pool.get_t<double>("h.Xr", (size_t)HMB * nvec);
@@ -898,9 +901,10 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
       const double* Ti = Tr + (size_t)HMB * HMB;
       hipLaunchKernelGGL(h_stack_v_kernel, dim3(8, 2 * nb), dim3(256), 0, st, H.Ar + (size_t)j0 * ld, H.Ai + (size_t)j0 * ld,
                          ld, rows, nb, Vs, lds);
-      // Y = V^H Z from two passes: YA = Vs^T Zr, YB = Vs^T Zi
-      dgemm_dev(st, 'T', 'N', 2 * nb, nvec, rows, 1.0, Vs, lds, Zr, ldzp, 0.0, YA, 2 * HMB);
-      dgemm_dev(st, 'T', 'N', 2 * nb, nvec, rows, 1.0, Vs, lds, Zi, ldzp, 0.0, YB, 2 * HMB);
+      // Y = V^H Z from YA = Vs^T Zr, YB = Vs^T Zi: one batched launch (256 tiles: the LDS-ring kernel; two launches of
+      // 128 tiles each went to the 64 x 64 kernel)
+      dgemm_dev(st, 'T', 'N', 2 * nb, nvec, rows, 1.0, Vs, lds, Zr, ldzp, 0.0, YA, 2 * HMB, 0, nullptr, nullptr, nullptr, 2, 0,
+                (long)(Zi - Zr), (long)(YB - YA));
       hipLaunchKernelGGL(h_ycombine_kernel, dim3(1, nvec), dim3(128), 0, st, YA, YB, nb, nvec, Yr, Yi);
       // X = T Y : Xr = Tr Yr - Ti Yi ; Xi = Tr Yi + Ti Yr
       dgemm_dev(st, 'N', 'N', nb, nvec, nb, 1.0, Tr, HMB, Yr, HMB, 0.0, Xr, HMB);
