@@ -591,13 +591,13 @@ __global__ __launch_bounds__(HMB) void h_tinv_kernel(const double* __restrict__ 
   const double* Gr = Gall + (size_t)blockIdx.x * 4 * HMB * HMB;
   double* Tr = Tall + (size_t)blockIdx.x * 2 * HMB * HMB;
   double* Ti = Tr + (size_t)HMB * HMB;
-  // Gr = stacked Gram Vs^T Vs (2nb x 2nb, ld = 2 HMB; Gi unused): V^H V = (Vr^T Vr + Vi^T Vi) + i (Vr^T Vi - Vi^T Vr)
+  // Gr = [Vr^T Vr, Vr^T Vi; Vi^T Vr, Vi^T Vi] (ld = 2 HMB, second half at offset bw): V^H V = (Vr^T Vr + Vi^T Vi) + i (Vr^T Vi - Vi^T Vr)
   constexpr int LG = 2 * HMB;
   for (int t = threadIdx.x; t < nb * nb; t += HMB) {
     const int a = t % nb, b = t / nb;
     if (a > b) {
-      sr[a * (a + 1) / 2 + b] = Gr[a + b * LG] + Gr[(nb + a) + (nb + b) * LG];
-      si[a * (a + 1) / 2 + b] = Gr[a + (nb + b) * LG] - Gr[(nb + a) + b * LG];
+      sr[a * (a + 1) / 2 + b] = Gr[a + b * LG] + Gr[(bw + a) + (bw + b) * LG];
+      si[a * (a + 1) / 2 + b] = Gr[a + (bw + b) * LG] - Gr[(bw + a) + b * LG];
     }
     else if (a == b) { sr[a * (a + 1) / 2 + a] = beta[2 * (j0 + a)]; si[a * (a + 1) / 2 + a] = -beta[2 * (j0 + a) + 1]; }
   }
@@ -736,16 +736,16 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
   const int ldp = ld;
   HArgs H;
   H.n = n; H.ld = ld; H.ldp = ldp;
-  H.Ar = ctx.pool.get_t<double>("h.Ar", (size_t)ld * n);
+  H.Ar = ctx.pool.get_t<double>("h.Ar", (size_t)ld * (n + HMB));   // HMB columns of slack: the batched Gram products of phase A
   // The two planes are streamed together at equal offsets; with plane sizes that are multiples of 16 KiB every pair of
   // requests met on the same memory channel.  Half a period (+128 B) between them: reduction 488 -> 459 ms at N = 8192
   // (tools/ab_herm_skew.sh: 0 -> 488, 272 -> 486, 784 -> 471, 1040 -> 459, 1552 -> 498, 4112 -> 492 ms, reproducible).
   static const int plane_skew = [] { const char* e = getenv("EIGX_H_SKEW"); return e ? atoi(e) : 1040; }();   // doubles
-  H.Ai = ctx.pool.get_t<double>("h.Ai", (size_t)ld * n + plane_skew) + plane_skew;
-  H.Ur = ctx.pool.get_t<double>("h.Ur", (size_t)ldp * m);
-  H.Ui = ctx.pool.get_t<double>("h.Ui", (size_t)ldp * m);
-  H.Wr = ctx.pool.get_t<double>("h.Wr", (size_t)ldp * m);
-  H.Wi = ctx.pool.get_t<double>("h.Wi", (size_t)ldp * m);
+  H.Ai = ctx.pool.get_t<double>("h.Ai", (size_t)ld * (n + HMB) + plane_skew) + plane_skew;
+  H.Ur = ctx.pool.get_t<double>("h.UW", (size_t)4 * ldp * m);   // the four panel planes in one buffer (one fill per panel)
+  H.Ui = H.Ur + (size_t)ldp * m;
+  H.Wr = H.Ui + (size_t)ldp * m;
+  H.Wi = H.Wr + (size_t)ldp * m;
   double* P1 = ctx.pool.get_t<double>("h.P1", (size_t)ldp * 4 * m);
   double* P2 = ctx.pool.get_t<double>("h.P2", (size_t)ldp * 4 * m);
   double* P3 = ctx.pool.get_t<double>("h.P3", (size_t)ldp * 4 * m);
@@ -768,12 +768,7 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
   hipLaunchKernelGGL(h_split_kernel, dim3(8, n), dim3(256), 0, st, a, lda, n, H.Ar, H.Ai, ld);
   hipLaunchKernelGGL(h_fill_kernel, dim3(64), dim3(256), 0, st, H.e, (size_t)lde, 0.0);
   hipLaunchKernelGGL(h_fill_kernel, dim3(64), dim3(256), 0, st, H.beta, (size_t)2 * n + 2, 0.0);
-  auto zero_panel = [&]() {
-    hipLaunchKernelGGL(h_fill_kernel, dim3(256), dim3(256), 0, st, H.Ur, (size_t)ldp * m, 0.0);
-    hipLaunchKernelGGL(h_fill_kernel, dim3(256), dim3(256), 0, st, H.Ui, (size_t)ldp * m, 0.0);
-    hipLaunchKernelGGL(h_fill_kernel, dim3(256), dim3(256), 0, st, H.Wr, (size_t)ldp * m, 0.0);
-    hipLaunchKernelGGL(h_fill_kernel, dim3(256), dim3(256), 0, st, H.Wi, (size_t)ldp * m, 0.0);
-  };
+  auto zero_panel = [&]() { hipLaunchKernelGGL(h_fill_kernel, dim3(512), dim3(256), 0, st, H.Ur, (size_t)4 * ldp * m, 0.0); };
   zero_panel();
 
   // ---- eigen_hrd: Hermitian -> real tridiagonal ---------------------------------------------------------------------
@@ -817,6 +812,36 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
     }
   }
   (void)step(0, 1);   // d_0 = Re A(0,0)
+  // ---- back-transformation, phase A: the T factors of all blocks (they depend on the reflectors only).  V^H V of a
+  // block = (Vr^T Vr + Vi^T Vi) + i (Vr^T Vi - Vi^T Vr) from two batched launches over all blocks and both planes,
+  // straight from the reflector columns of A with K = n for every block (rows below a reflector are zero after
+  // h_zero_below; 64 separate products of 16 workgroups each took 14 ms at N = 8192), then every T = S^-H in one launch
+  // (a per-block single-workgroup kernel on the critical path cost 37 of 149 ms at N=8192).
+  int bw = mb <= 0 ? HMB : mb;
+  if (bw > HMB) bw = HMB;
+  const int lds = ld;
+  const int nblk = n > 1 ? ceil_div(n - 1, bw) : 1;
+  double* Tall = nullptr;
+  if (want_vec && n > 1) {
+    double* Gall = ctx.pool.get_t<double>("h.Gall", (size_t)nblk * 4 * HMB * HMB);
+    Tall = ctx.pool.get_t<double>("h.Tall", (size_t)nblk * 2 * HMB * HMB);
+    const size_t shm = (size_t)2 * (HMB * (HMB + 1) / 2) * sizeof(double);
+    static bool attr = false;
+    if (!attr) {
+      EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)h_tinv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      attr = true;
+    }
+    hipLaunchKernelGGL(h_zero_below_kernel, dim3(8, n), dim3(256), 0, st, H.Ar, H.Ai, ld, n, n);
+    // block b = columns 1 + b bw ... of A; G_b (ld 2 HMB) = [Vr^T Vr, Vr^T Vi; Vi^T Vr, Vi^T Vi] with the second half at
+    // offset bw.  The last block may be narrower: its product reads up to bw - 1 columns past the matrix (allocated,
+    // any content) into entries of G_b that nobody reads.
+    const long sblk = (long)bw * ld, sg = (long)4 * HMB * HMB;
+    for (int half = 0; half < 2; ++half)
+      dgemm_dev(st, 'T', 'N', bw, bw, n, 1.0, (half ? H.Ai : H.Ar) + (size_t)ld, ld, H.Ar + (size_t)ld, ld, 0.0,
+                Gall + (half ? bw : 0), 2 * HMB, 0, nullptr, nullptr, nullptr, nblk, sblk, sblk, sg, 2, 0, (long)(H.Ai - H.Ar),
+                (long)bw * 2 * HMB);
+    hipLaunchKernelGGL(h_tinv_kernel, dim3(nblk), dim3(HMB), shm, st, Gall, H.beta, 1, bw, n, Tall);
+  }
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
   const double t2 = hnow();
 
@@ -853,37 +878,13 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
 
   // ---- eigen_hrbakwyx: z = H_{n-1}^H ... H_1^H y in blocks of HMB reflectors -------------------------------------------
   if (want_vec && n > 1) {
-    int bw = mb <= 0 ? HMB : mb;
-    if (bw > HMB) bw = HMB;
-    hipLaunchKernelGGL(h_zero_below_kernel, dim3(8, n), dim3(256), 0, st, H.Ar, H.Ai, ld, n, n);
-    const int lds = ld;
-    double* Vs = ctx.pool.get_t<double>("h.Vs", (size_t)lds * 2 * HMB);
-    const int nblk = ceil_div(n - 1, bw);
-    double* Gall = ctx.pool.get_t<double>("h.Gall", (size_t)nblk * 4 * HMB * HMB);
-    double* Tall = ctx.pool.get_t<double>("h.Tall", (size_t)nblk * 2 * HMB * HMB);
     double* YA = ctx.pool.get_t<double>("h.YAB", (size_t)2 * 2 * HMB * nvec);
     double* YB = YA + (size_t)2 * HMB * nvec;
     double* Yr = ctx.pool.get_t<double>("h.Yr", (size_t)HMB * nvec);
     double* Yi = ctx.pool.get_t<double>("h.Yi", (size_t)HMB * nvec);
     double* Xr = ctx.pool.get_t<double>("h.Xr", (size_t)HMB * nvec);
     double* Xi = ctx.pool.get_t<double>("h.Xi", (size_t)HMB * nvec);
-    const size_t shm = (size_t)2 * (HMB * (HMB + 1) / 2) * sizeof(double);
-    static bool attr = false;
-    if (!attr) {
-      EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)h_tinv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-      attr = true;
-    }
-    // phase A: stacked Gram matrices Vs^T Vs of all blocks, then every T = S^-H in one launch (the T factors depend on
-    // the reflectors only; a per-block single-workgroup kernel on the critical path cost 37 of 149 ms at N=8192)
-    for (int b = 0; b < nblk; ++b) {
-      const int j0 = 1 + b * bw;
-      const int nb = (j0 + bw <= n) ? bw : n - j0;
-      const int rows = j0 + nb - 1;               // longest reflector of the block (column j has rows 0..j-1)
-      hipLaunchKernelGGL(h_stack_v_kernel, dim3(8, 2 * nb), dim3(256), 0, st, H.Ar + (size_t)j0 * ld, H.Ai + (size_t)j0 * ld,
-                         ld, rows, nb, Vs, lds);
-      dgemm_dev(st, 'T', 'N', 2 * nb, 2 * nb, rows, 1.0, Vs, lds, Vs, lds, 0.0, Gall + (size_t)b * 4 * HMB * HMB, 2 * HMB);
-    }
-    hipLaunchKernelGGL(h_tinv_kernel, dim3(nblk), dim3(HMB), shm, st, Gall, H.beta, 1, bw, n, Tall);
+    double* Vs = ctx.pool.get_t<double>("h.Vs", (size_t)lds * 2 * HMB);
     // phase B: apply the blocks in ascending order -- to this rank's eigenvector columns
     const int zc = ceil_div(nvec, bt_P);
     const int c0 = (bt_p * zc < nvec) ? bt_p * zc : nvec;
