@@ -156,11 +156,13 @@ __device__ __forceinline__ void h_u_of(const HRef& f, int L, int r, double x_r, 
   else { ur = x_r; ui = x_i; }
 }
 
+template <int NW>
 __device__ __forceinline__ void h_paneldot_body(const HArgs& H, const HRef& f, int L, int k, int j, int c) {
-  __shared__ double red[4 * (HTH / 64)];
+  __shared__ double red[4 * NW];
   const int r1 = (c * PDR + PDR < L) ? c * PDR + PDR : L;
   double v[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int r = c * PDR + threadIdx.x; r < r1; r += HTH) {
+  // the first four waves add the rows (the order of the sum does not depend on NW: further waves contribute +0.0)
+  for (int r = c * PDR + threadIdx.x; r < r1 && threadIdx.x < HTH; r += HTH) {
     double ur, ui;
     h_u_of(f, L, r, H.xr[r], H.xi[r], ur, ui);
     const double wr = H.Wr[(size_t)r + (size_t)j * H.ldp], wi = H.Wi[(size_t)r + (size_t)j * H.ldp];
@@ -168,7 +170,7 @@ __device__ __forceinline__ void h_paneldot_body(const HArgs& H, const HRef& f, i
     v[0] += wr * ur + wi * ui; v[1] += wr * ui - wi * ur;   // conj(w) u
     v[2] += pr * ur + pi * ui; v[3] += pr * ui - pi * ur;   // conj(U_j) u
   }
-  hblock_sum_w<4, HTH / 64>(v, red);
+  hblock_sum_w<4, NW>(v, red);
   if (threadIdx.x == 0) {
     double* o = H.pd + ((size_t)c * HM + j) * 4;
     o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
@@ -250,10 +252,14 @@ typedef double hd2_t __attribute__((ext_vector_type(2)));
 // the row pair (2 lane, 2 lane + 1) (16-byte loads).  Two units are in flight (register sets av0 / av1); the loop over
 // unit pairs is rolled with a trip count the compiler does not know (`npairs`, always 4), otherwise it hoists every load to
 // the top and the kernel needs all 256 VGPRs + AGPRs.
-__global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int nt, int npdc, int npairs, int nparts) {
+// NW = 4 or 8 waves per tile: with 8 a wave owns 16 tile columns (npairs = 2) and the chain of load round trips per tile is
+// half as long -- for small active sizes, where a launch has fewer tiles than the chip has CUs and its time is that chain
+// (11.7 us per launch below L = 2000 with 4 waves); one workgroup per CU then.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void h_hemv_kernel(HArgs H, int L, int k, int nt, int npdc, int npairs, int nparts) {
   __shared__ double ucr[HTL], uci[HTL], urr[HTL], uri[HTL];
-  __shared__ double part[HTH / 64][HTL][2];
-  __shared__ double sred[4];
+  __shared__ double part[NW][HTL][2];
+  __shared__ double sred[NW];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: column offsets stay on the scalar unit
   // the first k * npdc workgroups of the launch are the panel-dot workgroups (column j, row chunk c)
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int 
   const int l0 = 2 * lane, l1 = 2 * lane + 1;           // my rows inside the tile
   const int r0 = row0 + l0, r1 = row0 + l1;
   const int rc = (r0 < L) ? r0 : 0;
-  const int wc0 = wave * 32;                            // first tile column of this wave
+  const int wc0 = wave * (HTL / NW);                    // first tile column of this wave
   hd2_t av0r[4], av0i[4], av1r[4], av1i[4];
   auto load4 = [&](hd2_t (&vr)[4], hd2_t (&vi)[4], int g) {
 #pragma unroll
@@ -286,26 +292,26 @@ __global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int 
   // Requests first, in the order they are needed: the norm partials and the pivot (reflector scalars), x at this
   // thread's column / row of the tile (u), the first unit of the tile -- one round trip for the whole prologue
   double nr[1] = {0.0};
-  for (int q = tid; q < nparts; q += HT) nr[0] += H.pn[q];
+  if (tid < HT) for (int q = tid; q < nparts; q += HT) nr[0] += H.pn[q];   // the sum K1 forms (further waves add +0.0)
   const double anr = H.xr[L - 1], ani = H.xi[L - 1];
-  const int myi = (tid < HTL) ? col0 + tid : row0 + tid - HTL;
+  const int myi = (tid < HTL) ? col0 + tid : row0 + ((tid - HTL) & (HTL - 1));
   const int myc = (myi < L) ? myi : L - 1;
   const double mxr = H.xr[myc], mxi = H.xi[myc];
   if (!pdot) load4(av0r, av0i, 0);
   // reflector scalars of column i (L = i rows) from the norm partials of K1: every workgroup of the mat-vec and of K1
   // recomputes them in the same order (bit-identical everywhere), so no separate reflector kernel runs
-  hblock_sum_w<1, HT / 64>(nr, sred);
+  hblock_sum_w<1, NW>(nr, sred);
   const HRef f = h_ref_of(nr[0], anr, ani);
   if (blockIdx.x == 0 && tid == 0) { H.beta[2 * L] = f.br; H.beta[2 * L + 1] = f.bi; H.e[L] = f.g; }   // column i = L
   if (pdot) {
-    h_paneldot_body(H, f, L, k, (int)blockIdx.x % k, (int)blockIdx.x / k);
+    h_paneldot_body<NW>(H, f, L, k, (int)blockIdx.x % k, (int)blockIdx.x / k);
     return;
   }
   {
     double a_, b_;
     h_u_of(f, L, myi, mxr, mxi, a_, b_);
     if (tid < HTL) { ucr[tid] = a_; uci[tid] = b_; }
-    else { urr[tid - HTL] = a_; uri[tid - HTL] = b_; }
+    else if (tid < 2 * HTL) { urr[tid - HTL] = a_; uri[tid - HTL] = b_; }
   }
   __syncthreads();
   const double mur0 = urr[l0], mui0 = uri[l0], mur1 = urr[l1], mui1 = uri[l1];   // u at my rows
@@ -385,13 +391,13 @@ __global__ __launch_bounds__(HTH) void h_hemv_kernel(HArgs H, int L, int k, int 
   if (tid < HTL && row0 + tid < L) {
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-    for (int w = 0; w < HTH / 64; ++w) { a0 += part[w][tid][0]; a1 += part[w][tid][1]; }
+    for (int w = 0; w < NW; ++w) { a0 += part[w][tid][0]; a1 += part[w][tid][1]; }
     H.yrr[(size_t)tx * H.ldp + row0 + tid] = a0;
     H.yri[(size_t)tx * H.ldp + row0 + tid] = a1;
     sq[0] += a0 * urr[tid] + a1 * uri[tid];
     sq[1] += a1 * urr[tid] - a0 * uri[tid];
   }
-  hblock_sum_w<2, HTH / 64>(sq, &part[0][0][0]);
+  hblock_sum_w<2, NW>(sq, &part[0][0][0]);
   if (tid == 0) { H.ps[2 * bid] = sq[0]; H.ps[2 * bid + 1] = sq[1]; }
 }
 
@@ -775,6 +781,7 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
   const double t1 = hnow();
   // two launches per column: K1 (finish the previous column, form this one) and K3 (mat-vec + panel dots); the norm
   // partials alternate between two buffers (K1 reads the previous column's while it writes this column's)
+  static const int hemv8_nt = [] { const char* e = getenv("EIGX_H_HEMV8_NT"); return e ? atoi(e) : 22; }();   // lab switch
   int k = 0, par = 0;
   int Lp = 0, ntp = 0, npdcp = 0, npartsp = 0;     // the column that is waiting to be finished (Lp = 0: none)
   double* pnb[2] = {H.pn, H.pn + nwg};
@@ -791,7 +798,10 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
     const int npdc = ceil_div(L, PDR);
     const int nt = ceil_div(L, HTL);
     H.pn = pnb[par];
-    hipLaunchKernelGGL(h_hemv_kernel, dim3(k * npdc + nt * (nt + 1) / 2), dim3(HTH), 0, st, H, L, k, nt, npdc, 4, nparts);
+    if (nt <= hemv8_nt)   // few tiles (253 for nt = 22): 8 waves per tile, one workgroup per CU
+      hipLaunchKernelGGL(h_hemv_kernel<8>, dim3(k * npdc + nt * (nt + 1) / 2), dim3(512), 0, st, H, L, k, nt, npdc, 2, nparts);
+    else
+      hipLaunchKernelGGL(h_hemv_kernel<4>, dim3(k * npdc + nt * (nt + 1) / 2), dim3(HTH), 0, st, H, L, k, nt, npdc, 4, nparts);
     Lp = L; ntp = nt; npdcp = npdc; npartsp = nparts;
     par ^= 1;
     ++k;
