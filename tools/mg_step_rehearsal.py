@@ -31,7 +31,11 @@ lib.eigx_get_procs(C.byref(p_), C.byref(xp), C.byref(yp)); lib.eigx_get_id(C.byr
 Px, Py, px, py = xp.value, yp.value, xi.value - 1, yi.value - 1
 dev = torch.device("cuda:0")
 rows = np.arange(px, n, Px); cols = np.arange(py, n, Py)
-nx = (len(rows) + 63) // 64 * 64 + 34
+# leading dimension of the local block: what eigen_get_matdims recommends for this grid (EIGX_NX=old: the pre-round-3 choice)
+nx_c, ny_c = C.c_int(), C.c_int()
+lib.eigx_matdims_for_grid(n, Px, Py, mf, 128, b"O", C.byref(nx_c), C.byref(ny_c))
+nx = (len(rows) + 63) // 64 * 64 + 34 if os.environ.get("EIGX_NX") == "old" else max(nx_c.value, len(rows))
+print(f"local block {len(rows)} x {len(cols)}, leading dimension {nx}", flush=True)
 a = torch.zeros(len(cols) + 8, nx, dtype=torch.float64, device=dev)
 for c0 in range(0, len(cols), 1024):          # chunked: the generator makes (rows x chunk) temporaries
     blk = layout.random_symmetric_torch(n, dev, rows=rows, cols=cols[c0:c0 + 1024])
