@@ -1064,18 +1064,20 @@ __device__ __forceinline__ void kp_role(const RedArgs& R, const HouseScalars& hs
     }
     return;
   }
-  // panel dots: wave w owns panel columns kk0 .. kk0+3; lanes stride the chunk's rows, two row groups
-  // (20 loads) per batch
+  // panel dots: wave w owns panel columns kk0 .. kk0+3; lanes stride the chunk's rows, KPG row groups (10 loads each)
+  // per batch.  A/B at N = 8192 in alternating processes: 4 groups instead of 2 -> tridiagonal 213.5 -> 212.6 ms,
+  // pentadiagonal 126.4 -> 127.0 ms; the order of the sums does not depend on it.
+  constexpr int KPG = (NV == 1) ? 4 : 2;
   const int kk0 = cg * PD_COLS + wave * 4;
   if (kk0 >= k) return;
   const int rend = (rbase + pdr < L) ? rbase + pdr : L;
   double su[4][2], sw[4][2];
 #pragma unroll
   for (int c = 0; c < 4; ++c) { su[c][0] = su[c][1] = sw[c][0] = sw[c][1] = 0.0; }
-  for (int r0 = rbase + lane; r0 < rend; r0 += 128) {
-    double x0[2], x1[2], tu[2][4], tw[2][4];
+  for (int r0 = rbase + lane; r0 < rend; r0 += 64 * KPG) {
+    double x0[KPG], x1[KPG], tu[KPG][4], tw[KPG][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < KPG; ++j) {
       const int r = (r0 + 64 * j < rend) ? r0 + 64 * j : rbase;
       x0[j] = R.X[r];
       x1[j] = (NV == 2) ? R.X[ldp + r] : 0.0;
@@ -1087,7 +1089,7 @@ __device__ __forceinline__ void kp_role(const RedArgs& R, const HouseScalars& hs
       }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < KPG; ++j) {
       const int r = r0 + 64 * j;
       if (r < rend) {
         const double a = u_fix<NV>(hs, L, 0, r, x0[j], x1[j]);
