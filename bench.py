@@ -279,7 +279,9 @@ def main():
     torch.cuda.synchronize()
     for i in range(args.warmup):
         solve(a_bufs[i])
-    lib.eigx_profile(8)  # bracket every 8th SYMV launch and every trailing-update launch with HIP events
+    # bracket every 32nd SYMV launch and every trailing-update launch with HIP events: the events cost time themselves
+    # (N = 8192 reduction 126.4 ms without, 130.2 ms with every 8th launch bracketed), so the sample is kept sparse
+    lib.eigx_profile(32)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -418,7 +420,15 @@ def main():
     #   extra_s        configs[3]'s, N=32768 eigen_s (tridiagonal route) all eigenpairs
     #   extra_n65536   configs[4]'s, N=65536 eigenvalues only (mode 'N': reduction + bisection)
     def gen_big(n2):
-        lda2 = n2 + 34
+        # leading dimension as a caller of the reference API sizes it: eigen_get_matdims (channel-friendly since round 3,
+        # DESIGN.md section 2); beyond the reference's 32-bit guard (N = 65536) the same rule by hand
+        lda2 = ee.eigen_get_matdims(n2)[0]
+        if lda2 < n2:
+            lda2 = (n2 + 95) // 32 * 32
+            if lda2 % 2048 < 512:
+                lda2 += 512 - lda2 % 2048
+            elif lda2 % 2048 > 1536:
+                lda2 += 2048 - lda2 % 2048 + 512
         a2 = torch.empty(n2, lda2, dtype=torch.float64, device=dev)
         a2[:, n2:] = 0.0
         fro2 = 0.0

@@ -8,6 +8,7 @@ from eigenexa_amd import _lib
 n = int(sys.argv[1]); band = int(sys.argv[2]) if len(sys.argv) > 2 else 2; reps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 lib = _lib.load()
 _lib.check(lib.eigx_init(0), "eigx_init")
+if os.environ.get("EIGX_PROFILE_EVERY"): lib.eigx_profile(int(os.environ["EIGX_PROFILE_EVERY"]))   # the bench's per-launch events
 if os.environ.get("EIGX_T128"): lib.eigx_tune(3, int(os.environ["EIGX_T128"]))
 if os.environ.get("EIGX_T256"): lib.eigx_tune(4, int(os.environ["EIGX_T256"]))
 if os.environ.get("EIGX_NT"): lib.eigx_tune(5, int(os.environ["EIGX_NT"]))
