@@ -275,6 +275,11 @@ def main():
     def solve(a):
         rc = fn(n, n, a.data_ptr(), nx, w.data_ptr(), z.data_ptr(), nx, args.mf, 128, b"A")
         _lib.check(rc, "eigen_" + args.route)
+        if os.environ.get("EIGX_BENCH_VERBOSE"):   # lab: stage timers of every solve (warm-up included) on stderr
+            tv = np.zeros(16)
+            lib.eigx_get_timers(tv.ctypes.data_as(C.POINTER(C.c_double)))
+            print(f"[bench] solve: total {tv[0]*1e3:.1f} ms, reduction {tv[1]*1e3:.1f}, dc {tv[2]*1e3:.1f}, bt {tv[3]*1e3:.1f}",
+                  file=sys.stderr, flush=True)
 
     torch.cuda.synchronize()
     for i in range(args.warmup):
