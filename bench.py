@@ -446,7 +446,7 @@ def main():
             del blk
         return a2, lda2, fro2, tr2
 
-    def extra_block(n2, route, mode, mf2, warm):
+    def extra_block(n2, route, mode, mf2, warm, timed=1):
         fn2 = lib.eigx_sx_dev if route == "sx" else lib.eigx_s_dev
         a2, lda2, fro2, tr2 = gen_big(n2)
         nvec2 = n2 if mode == "A" else 0
@@ -457,22 +457,34 @@ def main():
             _lib.check(fn2(n2, nvec2, a2w.data_ptr(), lda2, w2.data_ptr(), z2.data_ptr(), lda2, mf2, 128, mode.encode()),
                        "eigen_" + route)                       # warm-up: workspace allocation (~26 GB) happens here
             del a2w
-        lib.eigx_profile(8)
-        torch.cuda.synchronize()
-        t0x = time.perf_counter()
-        _lib.check(fn2(n2, nvec2, a2.data_ptr(), lda2, w2.data_ptr(), z2.data_ptr(), lda2, mf2, 128, mode.encode()),
-                   "eigen_" + route)
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t0x
-        prof2 = read_prof()
-        lib.eigx_profile(0)
-        tm2 = np.zeros(16)
-        lib.eigx_get_timers(tm2.ctypes.data_as(C.POINTER(C.c_double)))
+        # `timed` solves, each with its own events; the block reports the fastest and lists all (the first ~40 s of work on
+        # a freshly acquired card run on the part's lower bandwidth level)
+        runs = []
+        for t_ in range(timed):
+            a_run = a2 if t_ == timed - 1 else a2.clone()      # the solver destroys its input
+            lib.eigx_profile(8)
+            torch.cuda.synchronize()
+            t0x = time.perf_counter()
+            _lib.check(fn2(n2, nvec2, a_run.data_ptr(), lda2, w2.data_ptr(), z2.data_ptr(), lda2, mf2, 128, mode.encode()),
+                       "eigen_" + route)
+            torch.cuda.synchronize()
+            dtx = time.perf_counter() - t0x
+            profx = read_prof()
+            lib.eigx_profile(0)
+            tmx = np.zeros(16)
+            lib.eigx_get_timers(tmx.ctypes.data_as(C.POINTER(C.c_double)))
+            runs.append((dtx, profx, tmx))
+            if a_run is not a2:
+                del a_run
+        dt2, prof2, tm2 = min(runs, key=lambda r_: r_[0])
         anorm2 = fro2 ** 0.5
         what = "all eigenpairs" if mode == "A" else "eigenvalues only (mode 'N': reduction + multi-section bisection)"
-        ex = {"workload": f"N={n2} random symmetric fp64, eigen_{route} {what}, m_forward={mf2}, ONE timed solve on this GPU "
+        ex = {"workload": f"N={n2} random symmetric fp64, eigen_{route} {what}, m_forward={mf2}, "
+                          + ("ONE timed solve" if timed == 1 else f"the fastest of {timed} timed solves (all in seconds_each)")
+                          + " on this GPU "
                           + ("after one warm-up solve" if warm else "without a warm-up solve (workspace allocation included)"),
-              "seconds": round(dt2, 3), "gflops": round(abs(float(tm2[12])) / dt2 / 1e9, 1),
+              "seconds": round(dt2, 3), "seconds_each": [round(r_[0], 3) for r_ in runs],
+              "gflops": round(abs(float(tm2[12])) / dt2 / 1e9, 1),
               "stage_ms": {"reduction": round(tm2[1] * 1e3, 1), "dc_or_bisection": round(tm2[2] * 1e3, 1),
                            "backtransform": round(tm2[3] * 1e3, 1)},
               "frobenius_error_over_anorm": abs(float(torch.linalg.norm(w2).item()) - anorm2) / anorm2,
@@ -486,11 +498,11 @@ def main():
     if world == 1 and not args.no_extra and n != 32768 and args.route == "sx":
         del a_bufs, z, w, A_loc_T
         torch.cuda.empty_cache()
-        for key, (n2, route2, mode2, mf2, warm2) in {"extra": (32768, "sx", "A", args.extra_mf, True),
-                                                     "extra_s": (32768, "s", "A", args.extra_mf, True),
-                                                     "extra_n65536": (65536, "sx", "N", args.extra_mf, False)}.items():
+        for key, (n2, route2, mode2, mf2, warm2, timed2) in {"extra": (32768, "sx", "A", args.extra_mf, True, 2),
+                                                             "extra_s": (32768, "s", "A", args.extra_mf, True, 1),
+                                                             "extra_n65536": (65536, "sx", "N", args.extra_mf, False, 1)}.items():
             try:
-                out[key] = extra_block(n2, route2, mode2, mf2, warm2)
+                out[key] = extra_block(n2, route2, mode2, mf2, warm2, timed2)
             except Exception as exc_x:   # an extra block never invalidates the main line
                 out[key] = {"error": str(exc_x)}
 
