@@ -246,7 +246,7 @@ __device__ __forceinline__ double hcolsum4(const double (&v)[4], int lane) {
 // 16-byte loads per thread, all issued before anything is consumed).  The same registers give the row sums
 // sum_c A(r,c) u(c)  (combined over the eight waves through LDS) and the column sums  sum_r conj(A(r,c)) u(r)  of the
 // mirrored lower-triangle block (halving butterfly over the lanes).  Row partials are indexed by tile column
-// (YR[tx][r]), column partials by tile row (YC[ty][c]); K4 adds the nt + 1 partials of a row in fixed order.
+// (YR[tx][r]), column partials by tile row (YC[ty][c]); K1 of the next column adds the nt + 1 partials of a row in fixed order.
 typedef double hd2_t __attribute__((ext_vector_type(2)));
 // 128 x 128 tile per 4-wave workgroup; wave w owns the tile columns [32w, 32w+32) as eight units of 4 columns, a lane owns
 // the row pair (2 lane, 2 lane + 1) (16-byte loads).  Two units are in flight (register sets av0 / av1); the loop over
