@@ -241,14 +241,14 @@ __device__ __forceinline__ double hcolsum4(const double (&v)[4], int lane) {
 }
 
 // K3: q = A(0:L, 0:L) u from the UPPER triangle only (half the HBM bytes of a GEMV over both triangles): one workgroup
-// of 8 waves per 128 x 128 tile (ty <= tx) of the upper block triangle, 1-D grid in row-major tile order.  Wave w owns the
-// tile columns [16w, 16w+16), a lane owns the row pair (2 lane, 2 lane + 1): the tile lives in registers (32 coalesced
-// 16-byte loads per thread, all issued before anything is consumed).  The same registers give the row sums
-// sum_c A(r,c) u(c)  (combined over the eight waves through LDS) and the column sums  sum_r conj(A(r,c)) u(r)  of the
-// mirrored lower-triangle block (halving butterfly over the lanes).  Row partials are indexed by tile column
-// (YR[tx][r]), column partials by tile row (YC[ty][c]); K1 of the next column adds the nt + 1 partials of a row in fixed order.
+// per 128 x 128 tile (ty <= tx) of the upper block triangle, 1-D grid in row-major tile order.  The registers that hold a
+// piece of the tile give the row sums  sum_c A(r,c) u(c)  (combined over the waves through LDS) and the column sums
+// sum_r conj(A(r,c)) u(r)  of the mirrored lower-triangle block (halving butterfly over the lanes).  Row partials are
+// indexed by tile column (YR[tx][r]), column partials by tile row (YC[ty][c]); K1 of the next column adds the nt + 1
+// partials of a row in fixed order.  Every tile also writes its part of u^H q.
 typedef double hd2_t __attribute__((ext_vector_type(2)));
-// 128 x 128 tile per 4-wave workgroup; wave w owns the tile columns [32w, 32w+32) as eight units of 4 columns, a lane owns
+// 128 x 128 tile per workgroup of NW = 4 waves; wave w owns the tile columns [32w, 32w+32) as eight units of 4 columns (NW = 8:
+// [16w, 16w+16), four units), a lane owns
 // the row pair (2 lane, 2 lane + 1) (16-byte loads).  Two units are in flight (register sets av0 / av1); the loop over
 // unit pairs is rolled with a trip count the compiler does not know (`npairs`, always 4), otherwise it hoists every load to
 // the top and the kernel needs all 256 VGPRs + AGPRs.
