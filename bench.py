@@ -235,6 +235,20 @@ def main():
         lib.eigx_profile_read(prof.ctypes.data_as(C.POINTER(C.c_double)))
         return prof
 
+    def pmc_traffic(nn, alg_per_launch):
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_symv_traffic.json")) as fh:
+                pm = json.load(fh)
+            if int(pm["n"]) != int(nn):
+                return {"traffic": None}
+            ratio = float(pm["traffic_over_algorithmic"])
+            return {"traffic": round(ratio * alg_per_launch, 1),
+                    "traffic_source": f"profiles/r03_symv_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                                      f"one N={nn} reduction (gfx950 correction of the guide applied), {ratio:.3f} x the algorithmic "
+                                      f"bytes; not collected in this run"}
+        except Exception:
+            return {"traffic": None}
+
     def roofline_blocks(prof, nn):
         out = {}
         if prof[0] > 0 and prof[2] > 0:
@@ -244,8 +258,9 @@ def main():
                 "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4),
                 # HBM-side bytes need PMC passes of their own (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside
-                # this process): not measured in this run -> null; the passes of the same command are under profiles/
-                "traffic": None,
+                # this process): taken from the committed passes of the same kernel at the same N when there are any
+                # (measured ratio to the algorithmic bytes x this run's algorithmic bytes per launch), else null
+                **pmc_traffic(nn, prof[1] / prof[0]),
                 "launches_sampled": int(prof[0]), "avg_launch_us": round(prof[2] / prof[0] * 1e6, 2),
                 "algorithmic_bytes_per_launch": round(prof[1] / prof[0], 1), "n": nn,
             }
