@@ -10,8 +10,9 @@ beforehand because the solver destroys `a`, exactly like the reference).  value 
 own model (4/3 N^3 + counted D&C GEMM flops + 2 nvec N^2, src/eigen_sx.F:165,:248,:285-296) / wall time.
 
   --gpus 1 : BASELINE.json configs[1], N=8192 random symmetric fp64 on one MI355X.  The line also carries an
-             `extra` block with ONE solve of configs[2]'s matrix (N=32768) on the same GPU, so that north_star's
-             "trailing update >= 70 % of the fp64 MFMA roofline at N=32768 on 1 GPU" is timed by the driver's run.
+             `extra` block with configs[2]'s matrix (N=32768) on the same GPU (the faster of two timed solves, both
+             listed), so that north_star's "trailing update >= 70 % of the fp64 MFMA roofline at N=32768 on 1 GPU" is
+             timed by the driver's run, and `extra_s` / `extra_n65536` with configs[3] / [4] (one timed solve each).
   --gpus N : BASELINE.json configs[2], N=32768 on the Px x Py grid of the N GPUs -- STRONG scaling (the matrix is
              fixed, `value` is the whole-job rate, the driver forms speed-ups from its own 1/2/4/8 runs).  A is
              distributed 2-D cyclically (nothing replicated), see DESIGN.md section 6.  A small sanity solve runs
