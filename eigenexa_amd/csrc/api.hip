@@ -345,7 +345,7 @@ int eigx_tune(int key, int value) {
   if (key == 9) return comm_set_bounce(value);
   if (key == 10) return set_symv_threshold(4, value);
   if (key == 11) return set_symv_threshold(5, value);   // branch-free pipelined form of the mat-vec up to this active size
-  if (key == 12) return set_symv_threshold(6, value);   // several GPUs: step exchange folded into the mat-vec launch (1) or kl_kernel (0)
+  if (key == 12) return set_symv_threshold(6, value);   // (removed in round 4: step exchange folded into the mat-vec launch; accepted, ignored)
   return -1;
 }
 

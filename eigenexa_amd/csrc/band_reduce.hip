@@ -68,18 +68,29 @@ struct RedArgs {
   double* d; double* e; int lde;
   int maxseg, maxrs, maxchunk, gp2_off, kdab_off;
   // multi-GPU (P > 1), 2-D cyclic like the reference (src/eigen_libs0.F:1825-2258): A is this rank's LOCAL block
-  // a(lda, *), local (li, lj) = global (li*Px + px, lj*Py + py); nothing of A is replicated.  The panel [U | W | U], the
-  // x vectors and every scalar are replicated (computed redundantly from bit-identical inputs).  Once per step every
-  // rank writes its locally reduced SYMV partial sums -- row sums of its local rows, column sums of its local
-  // columns, 3 bilinear scalars: one "step message" -- into every rank's step window (comm.hip); the consumer
-  // (K_A) adds the Py + Px contributions of a row in a fixed order.  This one exchange replaces the reference's
-  // allreduce over X, allreduce over Y and row->column transpose per column (src/eigen_prd_t2.F:179,:203,
-  // src/comm.F:1377-1528).
-  int P;
+  // a(lda, *), local (li, lj) = global (li*Px + px, lj*Py + py); nothing of A is replicated.  The per-row panel work of a
+  // step (finish W, form the next x: ka_kernel; panel dot products: K_P) is DISTRIBUTED: global rows are dealt to the
+  // ranks in groups of KA_ROWS = 16, row r belongs to rank (r / 16) % P at owned index ((r / 16) / P) * 16 + r % 16 --
+  // the reference forms v, u and the panel update for a rank's rows only as well (src/eigen_prd_t6_3.F:76-477,
+  // src/eigen_prd_t4x.F:215-224, src/eigen_prd_t5.F:69-266).  Two exchanges per step through peer windows (comm.hip):
+  //   Y  after the local mat-vec: kl_kernel sums the rank's tile partial sums and stores the sum of local row li /
+  //      column lj into the window of the row's OWNER only (rows of the next block columns: into everybody's), plus the
+  //      rank's share of the panel dots and 3 bilinear scalars into everybody's;
+  //   X  ka_kernel, for its own rows: adds the Py + Px contributions of a row in a fixed order, finishes W, forms the next
+  //      x, and stores both into everybody's window, plus the rank's Gram partial sums.
+  // They replace the reference's allreduces over X and Y and the row->column transpose per column
+  // (src/eigen_prd_t2.F:179,:203, src/comm.F:1377-1528; src/eigen_prd_t6_3.F:174,:296).  What stays replicated is
+  // O(L) per step: the reflector store [U | . | U] from x and the copy of the received W rows into the panel.
+  int P, me;
+  float invP;                     // 1 / P (owner of a row group without an integer division: exact for groups < 2^20)
   int Px, Py, px, py, row_major;
-  int nxs, nys;                   // padded maximal local extents = strides inside a step message
-  const double* MSG;              // my step window: message of source q, parity h at MSG + (h*P + q)*msg_stride
-  int msg_stride;                 // doubles per message: NB*(nxs + nys) + 8
+  int nxs, nys;                   // padded maximal local extents = strides inside a Y message
+  const double* MSG;              // my Y window: message of source q, parity h at MSG + h*ypar_stride + q*ysrc_stride
+  int msg_stride;                 // doubles per Y message: NB*(nxs + nys) + 8 + 2*NB*m
+  size_t ypar_stride; int ysrc_stride;
+  const double* XW;               // my X window: message of source q, parity h at XW + h*xpar_stride + q*xmsg_stride:
+  int xmsg_stride, nown;          //   [x_i | x_{i-1} | W_A | W_B](owned index, stride nown), then 8 doubles: Gram partial sums
+  size_t xpar_stride;
   const double* PAN; int ldpan;   // columns of the current panel gathered from their owners (global row order)
   const double* zero16;           // 16 bytes of zeros: where the mat-vec's loads of rows beyond the active block go (see load8)
   int abl;                        // EIGX_STAMPS diagnostic build only: ablation mask (timing experiments)
@@ -107,11 +118,9 @@ int g_ka_fit = 1;     // K_A (eigx_tune key 10): 1 = load batches matched to the
 int g_ka_wgs = 256;   // K_A (eigx_tune key 7): beyond 2 * this many row groups a workgroup takes several of them, ~this many workgroups
 int g_symv_t128 = 4500, g_symv_t256 = 40000;
 int g_symv_nt = 9000;
-// several GPUs: 1 = the step exchange runs inside the mat-vec launch (its last-arriving tiles reduce and push), 0 = as
-// kl_kernel behind it (EIGX_FOLD_KL, eigx_tune key 12).  Default 0: in the rehearsal of one rank of a 2 x 4 grid at
-// N = 32768 (tools/mg_step_rehearsal.py) the folded form made the mat-vec 23 us longer to save a 20-us kernel -- the last
-// tile's workgroup does a whole row block's and column block's reduction alone, on the critical path
-int g_fold_kl = 0;
+// (eigx_tune key 12, once EIGX_FOLD_KL: the Y exchange inside the mat-vec launch -- its last-arriving tiles reduced and pushed.
+// In the rehearsal of one rank of a 2 x 4 grid at N = 32768 it made the mat-vec 23 us longer to save a 20-us kernel: the last
+// tile's workgroup did a whole row block's and column block's reduction alone, on the critical path.  Removed in round 4.)
 int g_symv_unc = 9000;   // the fused mat-vec's branch-free pipelined form up to this active size (eigx_tune key 11)
 
 inline SymvGeom symv_geom(int L) {
@@ -196,6 +205,12 @@ __device__ __forceinline__ double sign_of(double mag, double s) { return s >= 0.
 __device__ __forceinline__ double ld_sys(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void st_sys(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
+// loads / stores of words that another workgroup of the SAME launch reads / wrote: agent scope, past the per-XCD L2s
+// (MI355X_MICROARCH.md, hand-off forms: sc1 stores, every storing wave drains, one agent-scope atomic add per workgroup,
+// the workgroup whose add came last reads with sc1 loads)
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // =================================================================================================
 // K_A : finish previous step (if has_prev) and form the next columns (ncols = 0,1,2).
 // Workgroup = 32 rows x 8 slices: slice ks handles panel columns kk = ks (mod 8) and SYMV partials
@@ -213,9 +228,13 @@ struct KAArgs {
   int k;          // panel fill to use for the new columns (= kprev+NB if has_prev)
   int rows;       // rows to cover: max(iprev+1, i+1)
   int nt_prev, lgT_prev;  // SYMV tiling of the previous step: tiles per dimension, log2(tile edge)
-  int par;                // multi-GPU: parity of the step messages that hold the previous step's SYMV partial sums
+  int par;                // multi-GPU: parity of the Y messages that hold the previous step's SYMV partial sums
   int pan_c0;             // multi-GPU: first global column held by the gathered panel R.PAN
-  StepWait wait;          // multi-GPU: wait for the step messages here instead of in a wait kernel (wait.n = 0: no)
+  StepWait wait;          // multi-GPU: wait for the Y messages here instead of in a wait kernel (wait.n = 0: no)
+  int nchunk_ab;          // multi-GPU: row chunks of the (replicated) reflector store = entries of the uA.uB partial sums
+  int xpar;               // multi-GPU: parity of the X message this launch writes
+  unsigned long long xepoch;   // ... and its epoch
+  const StepPeers* xp;    // ... and where it goes (device copy: keeps the kernel arguments of the one-GPU launches small)
   int G;                  // row groups (of KA_ROWS rows) per workgroup: the scalar work of a workgroup is done once, then
                           // its G row groups follow in a loop (the next group's loads in flight behind the current one)
 };
@@ -230,7 +249,47 @@ __device__ __forceinline__ const double* mg_partial(const RedArgs& R, int par, i
   if (t < R.Py) { qx = r % R.Px; qy = t; off = r / R.Px; stride = R.nxs; }
   else { qx = t - R.Py; qy = r % R.Py; off = NB * R.nxs + r / R.Py; stride = R.nys; }
   const int src = R.row_major ? qx * R.Py + qy : qx + qy * R.Px;
-  return R.MSG + ((size_t)par * R.P + src) * R.msg_stride + off;
+  return R.MSG + (size_t)par * R.ypar_stride + (size_t)src * R.ysrc_stride + off;
+}
+
+// multi-GPU: owner (world rank) and owned index of global row r -- groups of KA_ROWS rows dealt round-robin
+__device__ __forceinline__ void own_of(const RedArgs& R, int r, int& src, int& idx) {
+  const int g = r >> 4;
+  const int q = (int)(((float)g + 0.5f) * R.invP);   // g / P, exact (see RedArgs::invP)
+  src = g - q * R.P;
+  idx = (q << 4) | (r & 15);
+}
+static_assert(KA_ROWS == 16, "own_of assumes groups of 16 rows");
+// global row of owned index o on rank `me`
+__device__ __forceinline__ int own_row(const RedArgs& R, int o) { return (((o >> 4) * R.P + R.me) << 4) | (o & 15); }
+// x_i (v = 0) / x_{i-1} (v = 1) at global row r: one GPU from R.X; several GPUs from the owner's X message (parity xpar)
+template <bool MG>
+__device__ __forceinline__ double xget(const RedArgs& R, int xpar, int v, int r) {
+  if (!MG) return R.X[(size_t)v * R.ldp + r];
+  int s_, o_;
+  own_of(R, r, s_, o_);
+  return ld_sys(R.XW + (size_t)xpar * R.xpar_stride + (size_t)s_ * R.xmsg_stride + (size_t)v * R.nown + o_);
+}
+// bounded spin of a consumer kernel's prologue on the P arrival flags of a step message (lane q of the first wave waits for
+// rank q; a time-out sets the sticky error word and the solver reports it), then the workgroup barrier releases the rest
+__device__ __forceinline__ void step_wait_fused(const StepWait& W) {
+  const int tid = threadIdx.x;
+  if (tid < W.n) {
+    const unsigned long long* f = W.flag + (W.epoch & 1) * EIGX_MAXP + tid;
+    const long long t0 = wall_clock64();
+    if (__hip_atomic_load(W.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+      while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < W.epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__hip_atomic_load(W.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;   // a peer failed
+        if (wall_clock64() - t0 > W.limit_ticks) {
+          __hip_atomic_store(W.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+      }
+    }
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(W.ticks, (unsigned long long)(wall_clock64() - t0));
+  }
+  __syncthreads();
 }
 
 template <int NB, bool MG, bool LG, int RPBT, int SPBT, int KBT>
@@ -239,6 +298,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   __shared__ double kd[4][256];        // reduced panel-dot vectors: [UuA, WuA, UuB, WuB][kk]  (m <= 256)
   __shared__ double rowU[2][258], rowW[2][258];  // U(c, kk), W(c, kk) for the new block columns c
   __shared__ double slice[4][KA_ROWS][4];        // per-wave slice sums
+  __shared__ int lastw;                          // several GPUs: this workgroup publishes the X message
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int rr = tid & (KA_ROWS - 1), ks = tid / KA_ROWS;
@@ -259,28 +319,12 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   // VGPRs, two waves per SIMD) -- faster up to 512 groups (N = 8192: 143.7 against 146.8 ms per reduction); LG = true beyond
   // (N = 32768: 5.15 against 5.48 s).
   const int G = LG ? S.G : 1;
-  const int r = (blockIdx.x * G) * KA_ROWS + rr;      // row of group 0
+  // several GPUs: the workgroup's groups are groups of THIS rank (owned group og <-> global group og * P + me)
+  const int r = MG ? ((blockIdx.x * G) * R.P + R.me) * KA_ROWS + rr : (blockIdx.x * G) * KA_ROWS + rr;      // row of group 0
+  const int rstep = MG ? KA_ROWS * R.P : KA_ROWS;     // rows from a group of the workgroup to its next one
+  const StepPeers& XP = *S.xp;                        // (dereferenced on the several-GPU paths only)
   EIGX_STAMP_INIT
-  if (MG && S.wait.n > 0) {
-    // several GPUs, one per rank: lane q of the first wave waits for rank q's step message (bounded spin; a time-out
-    // sets the sticky error word and the solver reports it), the workgroup barrier releases the other waves
-    if (tid < S.wait.n) {
-      const unsigned long long* f = S.wait.flag + (S.wait.epoch & 1) * EIGX_MAXP + tid;
-      const long long t0 = wall_clock64();
-      if (__hip_atomic_load(S.wait.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < S.wait.epoch) {
-          __builtin_amdgcn_s_sleep(1);
-          if (__hip_atomic_load(S.wait.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;   // a peer failed
-          if (wall_clock64() - t0 > S.wait.limit_ticks) {
-            __hip_atomic_store(S.wait.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;
-          }
-        }
-      }
-      if (blockIdx.x == 0 && tid == 0) atomicAdd(S.wait.ticks, (unsigned long long)(wall_clock64() - t0));
-    }
-    __syncthreads();
-  }
+  if (MG && S.wait.n > 0) step_wait_fused(S.wait);
 
   // ============ phase 0: every load that depends on nothing computed in this kernel ==================
   // The kernel is a latency chain (a few hundred bytes per thread): ALL loads are issued first, in
@@ -295,7 +339,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   // SYMV partials per slice in the first batch: 10 (10 * KA_SL = 160 slots) or 5 (80 slots: every step of N <= 10000,
   // half the unconditional loads of that phase); several GPUs: one message entry per slice
   constexpr int RPB = MG ? 1 : RPBT;
-  constexpr int CHB = 4;                // K_P row chunks (pd_rows_for() never makes more)
+  constexpr int CHB = MG ? EIGX_MAXP : 4;   // K_P row chunks (pd_rows_for() never makes more); several GPUs: one share of the panel dots per rank
   constexpr int SPB = MG ? 8 : SPBT;    // folded SP rows per wave in the first batch (covers nt <= 8 * SPB - 1)
   struct RowRegs { double tu[KB], tw[KB], ta[RPB], tb[RPB], uA, uB, ai, aim; };   // what a thread loads for its row of a group
   RowRegs cur, nxt;
@@ -400,8 +444,15 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
     for (int j = 0; j < CHB; ++j) {
 #pragma unroll
       for (int q = 0; q < 2 * NB; ++q) {
-        const double* bk = R.KD + (size_t)((j < S.nchunk_prev ? j : 0) * 2 * NB + q) * m;   // uniform
-        kdl[q][j] = bk[(unsigned)tid];
+        if (!mg) {   // (compile-time)
+          const double* bk = R.KD + (size_t)((j < S.nchunk_prev ? j : 0) * 2 * NB + q) * m;   // uniform
+          kdl[q][j] = bk[(unsigned)tid];
+        } else {
+          // rank j's share (the rows it owns) from its Y message: behind the row / column sums and the 8 scalar slots
+          const double* bk = R.MSG + (size_t)S.par * R.ypar_stride + (size_t)(j < R.P ? j : 0) * R.ysrc_stride +
+                             NB * (R.nxs + R.nys) + 8 + q * m;
+          kdl[q][j] = ld_sys(bk + (tid < m ? tid : 0));
+        }
       }
     }
   }
@@ -426,12 +477,13 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
     }
   } else {
     // bilinear scalars: one message per rank
-    const double* b = R.MSG + ((size_t)S.par * R.P + (tid < R.P ? tid : 0)) * R.msg_stride + NB * (R.nxs + R.nys);
+    const double* b = R.MSG + (size_t)S.par * R.ypar_stride + (size_t)(tid < R.P ? tid : 0) * R.ysrc_stride + NB * (R.nxs + R.nys);
     spr[0][0] = ld_sys(b);
     spr[0][1] = ld_sys(b + (NB == 2 ? 1 : 0));
     spr[0][2] = ld_sys(b + (NB == 2 ? 2 : 0));
   }
-  abl = R.KD[R.kdab_off + (tid < S.nchunk_prev ? tid : 0)];
+  const int nch_ab = MG ? S.nchunk_ab : S.nchunk_prev;   // entries of the uA.uB partial sums (reflector-store chunks)
+  abl = R.KD[R.kdab_off + (tid < nch_ab ? tid : 0)];
   // P(c, a): rows c of the previous step's SYMV result for the new block columns
 #pragma unroll
   for (int cc = 0; cc < 2; ++cc) {
@@ -520,8 +572,8 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       }
     }
     if (NB == 2) {
-      v[6] = (tid < S.nchunk_prev) ? abl : 0.0;
-      for (int c = tid + 256; c < S.nchunk_prev; c += 256) v[6] += R.KD[R.kdab_off + c];
+      v[6] = (tid < nch_ab) ? abl : 0.0;
+      for (int c = tid + 256; c < nch_ab; c += 256) v[6] += R.KD[R.kdab_off + c];
     }
   }
   EIGX_STAMP(1);
@@ -597,10 +649,10 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   // ============ phase 3: the row groups of this workgroup ===============================================
   double gg[3] = {0.0, 0.0, 0.0};
   for (int g = 0; g < G; ++g) {
-    const int rg = r + g * KA_ROWS;
+    const int rg = r + g * rstep;
     const bool okg = rg < S.rows;
     const bool more = LG && (g + 1 < G);
-    if (more) load_rows(rg + KA_ROWS, nxt);        // the next group's loads travel behind this group's work
+    if (more) load_rows(rg + rstep, nxt);          // the next group's loads travel behind this group's work
     // my share of this row's SYMV partial sums
     double prA = 0.0, prB = 0.0;
     {
@@ -676,11 +728,12 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       for (int q = 0; q < 4; ++q) {
         pA += slice[q][rr][0]; pB += slice[q][rr][1]; x0 += slice[q][rr][2]; x1 += slice[q][rr][3];
       }
+      double wA = 0.0, wB = 0.0;
       if (hp) {
         const double uA = cur.uA, uB = cur.uB;
         const double yA = tm[0] * pA, yB = tm[1] * pA + tm[2] * pB;
-        double wA = yA - 0.5 * (uA * tm[3] + uB * tm[5]);
-        double wB = (NB == 2) ? yB - 0.5 * (uA * tm[4] + uB * tm[6]) : 0.0;
+        wA = yA - 0.5 * (uA * tm[3] + uB * tm[5]);
+        wB = (NB == 2) ? yB - 0.5 * (uA * tm[4] + uB * tm[6]) : 0.0;
         if (rg >= S.Lprev) { wA = 0.0; wB = 0.0; }
         Wp[(size_t)kp * ldp + rg] = wA;
         if (NB == 2) Wp[(size_t)(kp + 1) * ldp + rg] = wB;
@@ -693,31 +746,74 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
           }
         }
       }
+      double xi = 0.0, xim = 0.0;
       if (S.ncols > 0 && rg <= S.i) {
-        const double xi = cur.ai - x0;
-        R.X[rg] = xi;
-        double xim = 0.0;
+        xi = cur.ai - x0;
+        if (!MG) R.X[rg] = xi;
         if (S.ncols > 1 && rg <= S.i - 1) {
           xim = cur.aim - x1;
-          R.X[ldp + rg] = xim;
+          if (!MG) R.X[ldp + rg] = xim;
         }
         if (rg < S.L) { gg[0] += xi * xi; gg[1] += xi * xim; gg[2] += xim * xim; }
-        if (rg == S.i) R.d[S.i] = xi;
-        if (S.ncols > 1 && rg == S.i - 1) { R.e[S.i] = xi; R.d[S.i - 1] = xim; }  // e(i,1) = A_eff(i-1,i)
+        if (!MG) {   // (several GPUs: every rank takes d, e from the X messages -- symv_kernel's publisher, mg_tail_kernel)
+          if (rg == S.i) R.d[S.i] = xi;
+          if (S.ncols > 1 && rg == S.i - 1) { R.e[S.i] = xi; R.d[S.i - 1] = xim; }  // e(i,1) = A_eff(i-1,i)
+        }
+      }
+      if (MG) {
+        // my rows of the new x and of the finished W into every rank's X window: the 16 row lanes of the group write 128
+        // contiguous bytes per field and destination (write-through stores over xGMI)
+        const size_t off = (size_t)S.xpar * XP.parity_stride + (size_t)(((blockIdx.x * G + g) << 4) | rr);
+        for (int d_ = 0; d_ < XP.n; ++d_) {
+          double* q_ = XP.slot[d_] + off;
+          if (S.ncols > 0) { st_sys(q_, xi); if (NB == 2) st_sys(q_ + R.nown, xim); }
+          if (hp) { st_sys(q_ + 2 * (size_t)R.nown, wA); if (NB == 2) st_sys(q_ + 3 * (size_t)R.nown, wB); }
+        }
       }
     }
     if (more) {
       __syncthreads();                 // slice[] is written again by the next group
-      mask_rows(rg + KA_ROWS, nxt);
+      mask_rows(rg + rstep, nxt);
       cur = nxt;
     }
   }
-  if (S.ncols > 0 && wave == 0) {
+  if ((MG || S.ncols > 0) && wave == 0) {
     // Gram partials of the new columns over the rows above the block: x_i.x_i, x_i.x_{i-1}, x_{i-1}.x_{i-1}: one entry
     // per workgroup (the row threads of every group are lanes 0..15 of wave 0: no block reduction needed)
 #pragma unroll
     for (int q = 0; q < 3; ++q) gg[q] = wave_sum(gg[q]);
-    if (lane == 0) { R.GP[blockIdx.x * 3 + 0] = gg[0]; R.GP[blockIdx.x * 3 + 1] = gg[1]; R.GP[blockIdx.x * 3 + 2] = gg[2]; }
+    if (lane == 0) {
+      if (MG) { st_agent(&R.GP[blockIdx.x * 3 + 0], gg[0]); st_agent(&R.GP[blockIdx.x * 3 + 1], gg[1]); st_agent(&R.GP[blockIdx.x * 3 + 2], gg[2]); }
+      else { R.GP[blockIdx.x * 3 + 0] = gg[0]; R.GP[blockIdx.x * 3 + 1] = gg[1]; R.GP[blockIdx.x * 3 + 2] = gg[2]; }
+    }
+  }
+  if (MG) {
+    // Publish the X message: every storing wave waits for its write-through stores to be acknowledged, the barrier collects
+    // the waves, one agent-scope add counts the workgroup; the workgroup whose add came last sums the rank's Gram partial
+    // sums in a fixed order (whoever it is), appends them to the message and raises the flag on every rank (the only store
+    // with a system-scope release) -- the protocol of kl_publish, self-tested at init (comm.hip st_step_push_kernel).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned tk = atomicAdd(XP.counter, 1u);
+      lastw = (tk + 1u == gridDim.x);
+      if (lastw) *XP.counter = 0;
+    }
+    __syncthreads();
+    if (lastw) {
+      double g3[3] = {0.0, 0.0, 0.0};
+      for (int q = tid; q < (int)gridDim.x; q += 256) {
+        g3[0] += ld_agent(&R.GP[3 * q]); g3[1] += ld_agent(&R.GP[3 * q + 1]); g3[2] += ld_agent(&R.GP[3 * q + 2]);
+      }
+      block_sum_multi<3>(g3, red);
+      if (tid < 3) {
+        const size_t off = (size_t)S.xpar * XP.parity_stride + 4 * (size_t)R.nown + tid;
+        for (int d_ = 0; d_ < XP.n; ++d_) st_sys(XP.slot[d_] + off, g3[tid]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the Gram stores and the flag stores are the first wave's)
+      if (tid < XP.n && XP.flag[tid])
+        __hip_atomic_store(XP.flag[tid] + S.xpar * EIGX_MAXP, S.xepoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   EIGX_STAMP(4);
 #ifdef EIGX_STAMPS
@@ -746,6 +842,12 @@ struct KBArgs { int i, L, nt, ngp, k, ncg, toprows, pdr, npd;
   // ntc tile columns; the last (clipped) tile column has nty_last tiles and comes first in the grid; tile column
   // tx < ntc - 1 has slope*tx + c1 tiles when Px divides Py (slope = Py / Px), otherwise slope = 0 and the kernel counts
   int Lr, Lc, ntc, nty_last, slope, c1;
+  // several GPUs: the panel dots run over the rows THIS rank owns (nown_L of them below L, chunks of pdr owned indices:
+  // npd x ncg workgroups), the reflector store over all rows (npd_s chunks of pdr_s rows behind them); the store chunks
+  // also copy the W columns [wk, wk + NV) that the previous ka_kernel launches sent (wk < 0: nothing to copy)
+  int nown_L, npd_s, pdr_s, wk;
+  int xpar;            // parity of the X message that holds this step's x (and the W columns wk..)
+  StepWait xwait;      // wait for that message in the prologue (xwait.n = 0: a wait kernel ran, or stream order)
 };
 
 // tiles of tile column tx of the local block (T-row tile ty exists iff its first global row <= the last global
@@ -757,40 +859,30 @@ __host__ __device__ inline int mg_nty(int tx, int T, int Lc, int Px, int px, int
 }
 
 // K_L (multi-GPU only): reduce this rank's SYMV partials over its tiles -- row sums of the local rows, column sums
-// of the local columns, bilinear scalars -- and WRITE the result into every rank's step window (system-scope stores
-// over xGMI; the ranks of a node are all directly linked), then publish the step's flag on every rank.
+// of the local columns, bilinear scalars, its share of the panel dots -- and WRITE the result into the step windows
+// (system-scope stores over xGMI; the ranks of a node are all directly linked): a row's / column's sum goes to the rank
+// that owns that global row for the panel work, everything else to every rank; then publish the step's flag on every rank.
 struct KLArgs {
   int L, Lr, Lc, T, ntc, nbr, par;
   unsigned long long epoch;
   StepPeers peers;
-  // folded form (the reduce + push runs inside the mat-vec launch, see symv_kernel): counters [tile rows | tile columns |
-  // tiles | pushes], all zero between launches; tiles of the launch; tile rows that hold at least one tile
-  // second level of the panel dots (several GPUs, kl_kernel form): the mat-vec launch's K_P workgroups take short row
-  // chunks (the local tile stream is 1/P of one GPU's, a 4-chunk K_P would outlast it) and write kd2; kl_kernel's extra
-  // workgroup sums the npd2 chunks into the one-chunk array that K_A reads
-  const double* kd2; int npd2, kdab2_off, kfill;
-  unsigned* cnt;
-  int cnt_cols, ntiles, ntr, total, fold;
-  int fence;   // 1: every pushing workgroup runs a system-scope fence behind its stores (EIGX_STEP_FENCE=1); 0: see kl_publish   // total = pushes of a launch: tile rows + tile columns that hold tiles, + 1
+  // second level of the panel dots: the mat-vec launch's K_P workgroups take short chunks of the rank's rows and write kd2;
+  // kl_kernel's extra workgroups sum the npd2 chunks and send the rank's share to everybody
+  const double* kd2; int npd2, kfill;
+  int fence;   // 1: every pushing workgroup runs a system-scope fence behind its stores (EIGX_STEP_FENCE=1); 0: see kl_publish
 };
 
-// loads / stores of partial sums that another workgroup of the SAME launch reads / wrote (folded form): agent scope,
-// past the per-XCD L2s (MI355X_MICROARCH.md, hand-off forms: sc1 stores, every storing wave drains, one agent-scope
-// atomic add per workgroup, the workgroup whose add came last reads with sc1 loads)
-__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 // one chunk of 64 local rows (rows = true) or 64 local columns starting at l0: sum this rank's tile partial sums of
-// each and write the result into every rank's step window.  Wave q takes every fourth partial sum (up to ~64 of them sit
-// behind a cold L2: one thread per row walking them one after the other is a chain of memory round trips), the four
-// waves are combined through LDS in a fixed order.  AG: the partial sums were written by other workgroups of this launch.
-template <int NB, bool AG>
+// each and write the result into the step window of the row's owner (of every rank for the rows of the next block
+// columns, L-1 and L-2: every rank needs P(c, :) of those, see ka_kernel).  Wave q takes every fourth partial sum (up to
+// ~64 of them sit behind a cold L2: one thread per row walking them one after the other is a chain of memory round trips),
+// the four waves are combined through LDS in a fixed order.
+template <int NB>
 __device__ __forceinline__ void kl_chunk(const RedArgs& R, const KLArgs& K, bool rows, int l0, double (*comb)[64][2]) {
   const int ldp = R.ldp;
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int T = K.T;
   const int l = l0 + lane;
-  auto ld = [&](const double* p) { return AG ? ld_agent(p) : *p; };
   double pA = 0.0, pB = 0.0;
   // this lane's partial sums: tile index t0, t0 + 4, ... < tend of the row's / column's partial-sum array P (stride
   // NB * ldp per tile).  They sit behind a cold L2 (written by tiles on other XCDs): ALL loads of a batch of 16 per vector
@@ -817,8 +909,8 @@ __device__ __forceinline__ void kl_chunk(const RedArgs& R, const KLArgs& K, bool
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int t = (tb + 4 * e < tend) ? tb + 4 * e : tb;
-      a[e] = ld(&P[((size_t)t * NB + 0) * ldp + lc]);
-      b[e] = (NB == 2) ? ld(&P[((size_t)t * NB + 1) * ldp + lc]) : 0.0;
+      a[e] = P[((size_t)t * NB + 0) * ldp + lc];
+      b[e] = (NB == 2) ? P[((size_t)t * NB + 1) * ldp + lc] : 0.0;
     }
     asm volatile("" ::: "memory");   // every load of the batch issued
 #pragma unroll
@@ -831,21 +923,27 @@ __device__ __forceinline__ void kl_chunk(const RedArgs& R, const KLArgs& K, bool
   comb[q][lane][0] = pA; comb[q][lane][1] = pB;
   __syncthreads();
   const size_t pbase = (size_t)K.par * K.peers.parity_stride;
-  if (q == 0 && l < (rows ? K.Lr : K.Lc)) {
+  if (q == 0 && act) {
     const double sA = (comb[0][lane][0] + comb[1][lane][0]) + (comb[2][lane][0] + comb[3][lane][0]);
     const double sB = (comb[0][lane][1] + comb[1][lane][1]) + (comb[2][lane][1] + comb[3][lane][1]);
     const size_t off = pbase + (rows ? 0 : (size_t)NB * R.nxs) + l;
     const int stv = rows ? R.nxs : R.nys;
+    const int gidx = rows ? l * R.Px + R.px : l * R.Py + R.py;     // global row this sum belongs to
+    int own, oi;
+    own_of(R, gidx, own, oi);
+    const bool all = (gidx >= K.L - 2);                            // rows of the next block columns (gidx < L here)
     for (int d = 0; d < K.peers.n; ++d) {
-      st_sys(K.peers.slot[d] + off, sA);
-      if (NB == 2) st_sys(K.peers.slot[d] + off + stv, sB);
+      if (K.peers.n == 1 || all || d == own) {                     // (n == 1: collective form, one local send buffer)
+        st_sys(K.peers.slot[d] + off, sA);
+        if (NB == 2) st_sys(K.peers.slot[d] + off + stv, sB);
+      }
     }
   }
   __syncthreads();   // comb is reused by the caller's next chunk
 }
 
 // the three bilinear scalars of this rank: sum over its tiles, written into every rank's step window
-template <int NB, bool AG>
+template <int NB>
 __device__ __forceinline__ void kl_scalars(const RedArgs& R, const KLArgs& K, double* red) {
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   double v[3] = {0.0, 0.0, 0.0};
@@ -854,34 +952,13 @@ __device__ __forceinline__ void kl_scalars(const RedArgs& R, const KLArgs& K, do
     const int nty = mg_nty(tx, K.T, K.Lc, R.Px, R.px, R.Py, R.py);
     for (int ty = lane; ty < nty; ty += 64) {
       const double* sp = R.SP + ((size_t)ty * R.maxseg + tx) * 3;
-      if (AG) { v[0] += ld_agent(sp); v[1] += ld_agent(sp + 1); v[2] += ld_agent(sp + 2); }
-      else { v[0] += sp[0]; v[1] += sp[1]; v[2] += sp[2]; }
+      v[0] += sp[0]; v[1] += sp[1]; v[2] += sp[2];
     }
   }
   block_sum_multi<3>(v, red);
   if (threadIdx.x < 3) {
     const size_t off = (size_t)K.par * K.peers.parity_stride + (size_t)NB * (R.nxs + R.nys) + threadIdx.x;
     for (int d = 0; d < K.peers.n; ++d) st_sys(K.peers.slot[d] + off, v[threadIdx.x]);
-  }
-}
-
-// zeros for the rows / columns of this rank that no tile covers (row blocks beyond the last tile row, tile columns
-// without tiles: they exist for tiny local blocks), so that the peers never read a stale entry of an older step
-template <int NB>
-__device__ __forceinline__ void kl_zero_uncovered(const RedArgs& R, const KLArgs& K) {
-  const size_t pbase = (size_t)K.par * K.peers.parity_stride;
-  for (int l = K.ntr * K.T + threadIdx.x; l < K.Lr; l += 256)
-    for (int d = 0; d < K.peers.n; ++d) {
-      st_sys(K.peers.slot[d] + pbase + l, 0.0);
-      if (NB == 2) st_sys(K.peers.slot[d] + pbase + R.nxs + l, 0.0);
-    }
-  for (int tx = 0; tx < K.ntc; ++tx) {
-    if (mg_nty(tx, K.T, K.Lc, R.Px, R.px, R.Py, R.py) > 0) continue;
-    for (int l = tx * K.T + threadIdx.x; l < (tx + 1) * K.T && l < K.Lc; l += 256)
-      for (int d = 0; d < K.peers.n; ++d) {
-        st_sys(K.peers.slot[d] + pbase + (size_t)NB * R.nxs + l, 0.0);
-        if (NB == 2) st_sys(K.peers.slot[d] + pbase + (size_t)NB * R.nxs + R.nys + l, 0.0);
-      }
   }
 }
 
@@ -915,12 +992,13 @@ __global__ __launch_bounds__(256) void kl_kernel(RedArgs R, KLArgs K) {
   __shared__ double comb[4][64][2];
   __shared__ double red[16];
   __shared__ int last;
-  if (K.npd2 > 0 && (int)blockIdx.x >= (int)gridDim.x - 2 * NB) {
-    // panel dots, second level: one workgroup per kind q; entry (q, panel column kk) = sum over the row chunks in chunk
-    // order (deterministic), ALL chunk loads of a thread in one batch (<= 4 P + 4 = 36 chunks: one memory round trip)
+  if ((int)blockIdx.x >= (int)gridDim.x - 2 * NB) {
+    // panel dots, second level: one workgroup per kind q; entry (q, panel column kk) = sum over this rank's row chunks in
+    // chunk order (deterministic), ALL chunk loads of a thread in one batch (<= 12 chunks: one memory round trip); the
+    // rank's share goes into every rank's window (ka_kernel adds the P shares in rank order)
     const int m = R.m, tid = threadIdx.x;
     const int q = (int)blockIdx.x - ((int)gridDim.x - 2 * NB);
-    constexpr int MAXC = 4 * EIGX_MAXP + 4;
+    constexpr int MAXC = 12;
     if (tid < K.kfill) {
       double v[MAXC];
 #pragma unroll
@@ -929,18 +1007,13 @@ __global__ __launch_bounds__(256) void kl_kernel(RedArgs R, KLArgs K) {
       double acc = 0.0;
 #pragma unroll
       for (int e = 0; e < MAXC; ++e) acc += (e < K.npd2) ? v[e] : 0.0;
-      R.KD[(size_t)q * m + tid] = acc;
-    }
-    if (NB == 2 && q == 1 && (tid >> 6) == 3) {   // uA.uB: one lane per chunk (<= 36), one wave reduction
-      const int lane = tid & 63;
-      double ab = (lane < K.npd2) ? K.kd2[K.kdab2_off + lane] : 0.0;
-      ab = wave_sum(ab);
-      if (lane == 0) R.KD[R.kdab_off] = ab;
+      const size_t off = (size_t)K.par * K.peers.parity_stride + (size_t)NB * (R.nxs + R.nys) + 8 + (size_t)q * m + tid;
+      for (int d = 0; d < K.peers.n; ++d) st_sys(K.peers.slot[d] + off, acc);
     }
   } else {
     const bool rows = (int)blockIdx.x < K.nbr;
-    kl_chunk<NB, false>(R, K, rows, (rows ? blockIdx.x : blockIdx.x - K.nbr) * 64, comb);
-    if (blockIdx.x == 0) kl_scalars<NB, false>(R, K, red);
+    kl_chunk<NB>(R, K, rows, (rows ? blockIdx.x : blockIdx.x - K.nbr) * 64, comb);
+    if (blockIdx.x == 0) kl_scalars<NB>(R, K, red);   // (rows / columns that no tile covers get explicit zeros above: tend = 0)
   }
   // every storing wave drains its stores; the last workgroup to arrive publishes the flag on every rank
   kl_publish(K, K.peers.counter, 1u, gridDim.x, &last);
@@ -956,11 +1029,10 @@ __global__ __launch_bounds__(256) void kl_kernel(RedArgs R, KLArgs K) {
 // (more than 3/4 of the column's weight in the pivot row) the sum is taken explicitly instead -- same
 // order in every workgroup, so the replicas stay bit-identical either way.
 struct HouseScalars { double sA, sB, betaA, betaB, gammaB, eL1; };
-template <int NV>
+template <int NV, bool MG = false>
 __device__ __forceinline__ HouseScalars house_scalars(const RedArgs& R, int ngp, int L, const double (&gpt)[2][3], double x0L,
-                                                      double x1L, double x0P, double x1P, double* red) {
+                                                      double x1L, double x0P, double x1P, double* red, int xpar = 0) {
   const int tid = threadIdx.x;
-  const int ldp = R.ldp;
   const int pivB = L - 2;
   double sA, sB = 0.0, betaA, betaB = 0.0, gammaB = 0.0, eL1 = 0.0;
   {
@@ -993,7 +1065,7 @@ __device__ __forceinline__ HouseScalars house_scalars(const RedArgs& R, int ngp,
       if (!(hB >= 0.25 * gv[2])) {
         double h[1] = {0.0};
         for (int j = tid; j < L - 1; j += 256) {
-          const double t = R.X[ldp + j] - gammaB * R.X[j];
+          const double t = xget<MG>(R, xpar, 1, j) - gammaB * xget<MG>(R, xpar, 0, j);
           h[0] += t * t;
         }
         block_sum_multi<1>(h, red);
@@ -1021,10 +1093,12 @@ __device__ __forceinline__ double u_fix(const HouseScalars& h, int L, int a, int
 
 // K_P role of a mat-vec launch: panel dot products U^T u, W^T u over one row chunk (cg < ncg: panel columns
 // [cg*PD_COLS, +PD_COLS)), or (cg == ncg) the reflector store into the panel (both U copies), into `a`, and the
-// partial uA.uB of the chunk.
+// partial uA.uB of the chunk.  Several GPUs (B = the launch's arguments): the dots run over the rows this rank owns
+// (chunks of owned indices; the P shares are added by ka_kernel), the store over all rows -- it also copies the W columns
+// that the owners sent with this step's x into the local panel, so that [U | W | U] stays complete on every rank.
 template <int NV, bool MG>
-__device__ __forceinline__ void kp_role(const RedArgs& R, const HouseScalars& hs, int i, int L, int k, int ncg, int toprows,
-                                        int pdr, int chunk, int cg, double* red) {
+__device__ __forceinline__ void kp_role(const RedArgs& R, const KBArgs& B, const HouseScalars& hs, int i, int L, int k, int ncg,
+                                        int toprows, int pdr, int chunk, int cg, double* red) {
   // No LDS staging: u_A, u_B are recomputed from the x vectors (L2-hot) next to every U/W load, so the
   // chunk length is free and there are never more than 4 row chunks to re-reduce in K_A.
   const int m = R.m;
@@ -1039,8 +1113,21 @@ __device__ __forceinline__ void kp_role(const RedArgs& R, const HouseScalars& hs
     double ab[1] = {0.0};
     const int rend = (rbase + pdr < toprows) ? rbase + pdr : toprows;
     for (int r = rbase + tid; r < rend; r += 256) {
-      const double x0 = R.X[r];
-      const double x1 = (NV == 2) ? R.X[ldp + r] : 0.0;
+      double x0, x1 = 0.0;
+      if (MG) {
+        int s_, o_;
+        own_of(R, r, s_, o_);
+        const double* xm = R.XW + (size_t)B.xpar * R.xpar_stride + (size_t)s_ * R.xmsg_stride + o_;
+        x0 = ld_sys(xm);
+        if (NV == 2) x1 = ld_sys(xm + R.nown);
+        if (B.wk >= 0) {   // rows of the W columns that the previous ka_kernel finished, from their owners
+          Wp[(size_t)B.wk * ldp + r] = ld_sys(xm + 2 * (size_t)R.nown);
+          if (NV == 2) Wp[(size_t)(B.wk + 1) * ldp + r] = ld_sys(xm + 3 * (size_t)R.nown);
+        }
+      } else {
+        x0 = R.X[r];
+        if (NV == 2) x1 = R.X[ldp + r];
+      }
       const double uA = u_fix<NV>(hs, L, 0, r, x0, x1);
       const double uB = (NV == 2) ? u_fix<NV>(hs, L, NV - 1, r, x0, x1) : 0.0;
       Up[(size_t)k * ldp + r] = uA;
@@ -1067,10 +1154,15 @@ __device__ __forceinline__ void kp_role(const RedArgs& R, const HouseScalars& hs
   // panel dots: wave w owns panel columns kk0 .. kk0+3; lanes stride the chunk's rows, KPG row groups (10 loads each)
   // per batch.  A/B at N = 8192 in alternating processes: 4 groups instead of 2 -> tridiagonal 213.5 -> 212.6 ms,
   // pentadiagonal 126.4 -> 127.0 ms; the order of the sums does not depend on it.
+  // Several GPUs: the row index runs over this rank's owned indices o (global row own_row(o), ascending with o; x from the
+  // rank's own slot of the X window, contiguous in o), rend = the owned rows below L.
   constexpr int KPG = (NV == 1) ? 4 : 2;
   const int kk0 = cg * PD_COLS + wave * 4;
   if (kk0 >= k) return;
-  const int rend = (rbase + pdr < L) ? rbase + pdr : L;
+  const int Lrows = MG ? B.nown_L : L;
+  const int rend = (rbase + pdr < Lrows) ? rbase + pdr : Lrows;
+  const double* xme = MG ? R.XW + (size_t)B.xpar * R.xpar_stride + (size_t)R.me * R.xmsg_stride : R.X;
+  const int xst = MG ? R.nown : ldp;
   double su[4][2], sw[4][2];
 #pragma unroll
   for (int c = 0; c < 4; ++c) { su[c][0] = su[c][1] = sw[c][0] = sw[c][1] = 0.0; }
@@ -1078,9 +1170,10 @@ __device__ __forceinline__ void kp_role(const RedArgs& R, const HouseScalars& hs
     double x0[KPG], x1[KPG], tu[KPG][4], tw[KPG][4];
 #pragma unroll
     for (int j = 0; j < KPG; ++j) {
-      const int r = (r0 + 64 * j < rend) ? r0 + 64 * j : rbase;
-      x0[j] = R.X[r];
-      x1[j] = (NV == 2) ? R.X[ldp + r] : 0.0;
+      const int ro = (r0 + 64 * j < rend) ? r0 + 64 * j : rbase;
+      const int r = MG ? own_row(R, ro) : ro;
+      x0[j] = MG ? ld_sys(xme + ro) : xme[ro];
+      x1[j] = (NV == 2) ? (MG ? ld_sys(xme + xst + ro) : xme[xst + ro]) : 0.0;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int kk = (kk0 + c < k) ? kk0 + c : kk0;
@@ -1090,8 +1183,9 @@ __device__ __forceinline__ void kp_role(const RedArgs& R, const HouseScalars& hs
     }
 #pragma unroll
     for (int j = 0; j < KPG; ++j) {
-      const int r = r0 + 64 * j;
-      if (r < rend) {
+      const int ro = r0 + 64 * j;
+      if (ro < rend) {
+        const int r = MG ? own_row(R, ro) : ro;
         const double a = u_fix<NV>(hs, L, 0, r, x0[j], x1[j]);
         const double b = (NV == 2) ? u_fix<NV>(hs, L, NV - 1, r, x0[j], x1[j]) : 0.0;
 #pragma unroll
@@ -1128,7 +1222,7 @@ template <int K> struct IC { static constexpr int value = K; };
 // processes: 4751 ms against 5326 ms with the pipeline -- more requests in flight per CU than the memory system likes);
 // the launch picks by active size (g_symv_unc, eigx_tune key 14).
 template <int NV, int RB, bool NTL, bool MG, bool UNC>
-__global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B, KLArgs K) {
+__global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   constexpr int T = 128 * RB;
   // NTL: non-temporal A loads, chosen by the launch for triangles far beyond L2 + Infinity Cache (g_symv_nt)
   constexpr int DYN = 4 * NV * T;
@@ -1139,8 +1233,10 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B, KLArgs K
   const int L = B.L, i = B.i;
   // 1-D grid: the K_P workgroups [chunk][column group 0..ncg], then the nt(nt+1)/2 tiles of the upper block triangle
   // (row-major): no empty workgroups for the lower triangle
-  const int nkp = B.npd * (B.ncg + 1);
+  // (several GPUs: npd x ncg dot workgroups over the rank's own rows, then npd_s store workgroups over all rows)
+  const int nkp = MG ? B.npd * B.ncg + B.npd_s : B.npd * (B.ncg + 1);
   const bool panel_role = (int)blockIdx.x < nkp;     // K_P first: its workgroups are the long ones at small L
+  if (MG && B.xwait.n > 0) step_wait_fused(B.xwait); // this step's x (X message) must be in: here, or a wait kernel ran
   const int bid = (int)blockIdx.x - nkp;
   int tyv = 0, txv = 0;
   if (!panel_role && MG) {
@@ -1184,6 +1280,10 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B, KLArgs K
     while ((ty + 1) * B.nt - (ty + 1) * ty / 2 <= bid) ++ty;
     tyv = ty;
     txv = ty + (bid - (ty * B.nt - ty * (ty - 1) / 2));
+  } else if (MG) {
+    const int q = blockIdx.x, nd = B.npd * B.ncg;
+    if (q < nd) { tyv = B.nt + q / B.ncg; txv = q - (q / B.ncg) * B.ncg; }   // dots: (row chunk of owned rows, column group)
+    else { tyv = B.nt + (q - nd); txv = B.ncg; }                             // store: row chunk of all rows
   } else {
     const int q = blockIdx.x;
     tyv = B.nt + q / (B.ncg + 1);   // nt + row chunk
@@ -1207,13 +1307,20 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B, KLArgs K
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int q = (tid + 256 * j < B.ngp) ? tid + 256 * j : 0;
-    gpt[j][0] = R.GP[3 * q];
-    if (NV == 2) { gpt[j][1] = R.GP[3 * q + 1]; gpt[j][2] = R.GP[3 * q + 2]; }
+    if (!MG) {
+      gpt[j][0] = R.GP[3 * q];
+      if (NV == 2) { gpt[j][1] = R.GP[3 * q + 1]; gpt[j][2] = R.GP[3 * q + 2]; }
+    } else {
+      // several GPUs: one triple per rank (B.ngp = P), behind the four row fields of its X message
+      const double* gq = R.XW + (size_t)B.xpar * R.xpar_stride + (size_t)q * R.xmsg_stride + 4 * (size_t)R.nown;
+      gpt[j][0] = ld_sys(gq);
+      if (NV == 2) { gpt[j][1] = ld_sys(gq + 1); gpt[j][2] = ld_sys(gq + 2); }
+    }
   }
-  const double x0L = R.X[L - 1];
-  const double x1L = (NV == 2) ? R.X[ldp + L - 1] : 0.0;
-  const double x1P = (NV == 2 && pivB >= 0) ? R.X[ldp + pivB] : 0.0;
-  const double x0P = (NV == 2 && pivB >= 0) ? R.X[pivB] : 0.0;
+  const double x0L = xget<MG>(R, B.xpar, 0, L - 1);
+  const double x1L = (NV == 2) ? xget<MG>(R, B.xpar, 1, L - 1) : 0.0;
+  const double x1P = (NV == 2 && pivB >= 0) ? xget<MG>(R, B.xpar, 1, pivB) : 0.0;
+  const double x0P = (NV == 2 && pivB >= 0) ? xget<MG>(R, B.xpar, 0, pivB) : 0.0;
   asm volatile("" ::: "memory");
   double craw[NV][(T + 255) / 256];       // raw x at the tile's columns (thread t -> column t, t+256)
   double rraw[NV][RB][2];                 // raw x at this lane's rows
@@ -1224,8 +1331,8 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B, KLArgs K
       const int c = col0 + tid + 256 * q;
       const bool ok = (tid + 256 * q < T) && c < Lc;
       const int gc = ok ? gcol(c) : 0;
-      craw[0][q] = ok ? R.X[gc] : 0.0;
-      if (NV == 2) craw[NV - 1][q] = ok ? R.X[ldp + gc] : 0.0;
+      craw[0][q] = ok ? xget<MG>(R, B.xpar, 0, gc) : 0.0;
+      if (NV == 2) craw[NV - 1][q] = ok ? xget<MG>(R, B.xpar, 1, gc) : 0.0;
     }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -1234,8 +1341,8 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B, KLArgs K
       for (int h = 0; h < 2; ++h) {
         const bool ok = r0 + h < Lr;
         const int gr = ok ? grow(r0 + h) : 0;
-        rraw[0][rb][h] = ok ? R.X[gr] : 0.0;
-        if (NV == 2) rraw[NV - 1][rb][h] = ok ? R.X[ldp + gr] : 0.0;
+        rraw[0][rb][h] = ok ? xget<MG>(R, B.xpar, 0, gr) : 0.0;
+        if (NV == 2) rraw[NV - 1][rb][h] = ok ? xget<MG>(R, B.xpar, 1, gr) : 0.0;
       }
     }
     {
@@ -1271,7 +1378,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B, KLArgs K
   // order in every workgroup, so the replicas stay bit-identical either way.
   double sA, sB = 0.0, betaA, betaB = 0.0, gammaB = 0.0, eL1 = 0.0;
   {
-    HouseScalars hs = house_scalars<NV>(R, B.ngp, L, gpt, x0L, x1L, x0P, x1P, red);
+    HouseScalars hs = house_scalars<NV, MG>(R, B.ngp, L, gpt, x0L, x1L, x0P, x1P, red, B.xpar);
     sA = hs.sA; sB = hs.sB; betaA = hs.betaA; betaB = hs.betaB; gammaB = hs.gammaB; eL1 = hs.eL1;
   }
   // the store-role panel workgroup of chunk 0 publishes the scalars (it exists on every rank)
@@ -1284,6 +1391,11 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B, KLArgs K
       R.e[R.lde + i] = sA;                       // e(i,2)   = T(i-2,i)
       R.e[i - 1] = eL1;                          // e(i-1,1) = T(i-2,i-1)
       if (i - 1 >= 2) R.e[R.lde + i - 1] = sB;   // e(i-1,2) = T(i-3,i-1)
+    }
+    if (MG) {
+      // several GPUs: the diagonal block of the band that ka_kernel writes on one GPU, on every rank from the X message
+      R.d[i] = xget<MG>(R, B.xpar, 0, i);
+      if (NV == 2) { R.e[i] = xget<MG>(R, B.xpar, 0, i - 1); R.d[i - 1] = xget<MG>(R, B.xpar, 1, i - 1); }   // e(i,1) = A_eff(i-1,i)
     }
   }
   // u_A(j) = x0(j) - [j == pivA] sA ;  u_B(j) = x1'(j) - [j == pivB] sB, u_B(L-1) = 0 ;
@@ -1298,7 +1410,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B, KLArgs K
     // ================================================================ K_P
     HouseScalars hs;
     hs.sA = sA; hs.sB = sB; hs.betaA = betaA; hs.betaB = betaB; hs.gammaB = gammaB; hs.eL1 = eL1;
-    kp_role<NV, MG>(R, hs, i, L, B.k, B.ncg, B.toprows, B.pdr, ty - B.nt, tx, red);
+    kp_role<NV, MG>(R, B, hs, i, L, B.k, B.ncg, B.toprows, (MG && tx == B.ncg) ? B.pdr_s : B.pdr, ty - B.nt, tx, red);
     return;
   }
 
@@ -1433,8 +1545,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B, KLArgs K
         if (c < Lc) {
 #pragma unroll
           for (int a = 0; a < NV; ++a) {
-            double* q_ = &R.YC[((size_t)ty * NV + a) * ldp + c];
-            if (MG && K.fold) st_agent(q_, fin[a]); else *q_ = fin[a];   // (folded exchange: read by another workgroup of this launch)
+            R.YC[((size_t)ty * NV + a) * ldp + c] = fin[a];
           }
           const double ua = ucs[tc0 + j];
           sp[0] += ua * fin[0];
@@ -1532,8 +1643,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B, KLArgs K
       for (int a = 0; a < NV; ++a) {
         const double s = (yrs[((size_t)0 * NV + a) * T + t] + yrs[((size_t)1 * NV + a) * T + t]) +
                          (yrs[((size_t)2 * NV + a) * T + t] + yrs[((size_t)3 * NV + a) * T + t]);
-        double* q_ = &R.YR[((size_t)tx * NV + a) * ldp + r];
-        if (MG && K.fold) st_agent(q_, s); else *q_ = s;
+        R.YR[((size_t)tx * NV + a) * ldp + r] = s;
       }
     }
   }
@@ -1547,55 +1657,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B, KLArgs K
   if (!EIGX_ABL(512)) block_sum_multi<3>(sp, red);
   if (tid == 0) {
     const size_t w = (size_t)ty * R.maxseg + tx;
-    if (MG && K.fold) { st_agent(&R.SP[w * 3 + 0], sp[0]); st_agent(&R.SP[w * 3 + 1], sp[1]); st_agent(&R.SP[w * 3 + 2], sp[2]); }
-    else { R.SP[w * 3 + 0] = sp[0]; R.SP[w * 3 + 1] = sp[1]; R.SP[w * 3 + 2] = sp[2]; }
-  }
-  if (MG && K.fold) {
-    // ---- folded step exchange (several GPUs): the LAST tile to finish of a tile row reduces that row block's row sums
-    // over the rank's tiles and writes them into every rank's step window; the same per tile column; the last tile of the
-    // launch adds the bilinear scalars (and zeros for whatever no tile covers); the last of these pushes publishes the
-    // step's flag on every rank.  What was a kernel of its own behind the mat-vec (kl_kernel: launch + ~4 us) now
-    // overlaps the stream of the other tiles; only the last tile's share is on the critical path.
-    // Hand-off between workgroups of one launch (MI355X_MICROARCH.md): agent-scope stores above, every storing wave
-    // drains, barrier, ONE agent-scope atomic add per counter; the workgroup whose add came last reads with agent-scope loads.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int* lastf = reinterpret_cast<int*>(red);         // [0] row block, [1] column block, [2] whole launch, [3] publisher
-    if (tid == 0) {
-      const long g0 = (long)ty * T * R.Px + R.px;
-      const long cneed = g0 > R.py ? (g0 - R.py + R.Py - 1) / R.Py : 0;
-      const unsigned nrow = (cneed <= K.Lc - 1) ? (unsigned)(K.ntc - (int)(cneed / T)) : 0u;   // tiles of tile row ty
-      const unsigned ncol = (unsigned)mg_nty(tx, T, K.Lc, R.Px, R.px, R.Py, R.py);             // tiles of tile column tx
-      unsigned* cr = K.cnt + ty;
-      unsigned* cc = K.cnt + K.cnt_cols + tx;
-      unsigned* ct = K.cnt + 2 * K.cnt_cols;
-      lastf[0] = (atomicAdd(cr, 1u) + 1u == nrow);
-      lastf[1] = (atomicAdd(cc, 1u) + 1u == ncol);
-      lastf[2] = (atomicAdd(ct, 1u) + 1u == (unsigned)K.ntiles);
-      if (lastf[0]) *cr = 0;
-      if (lastf[1]) *cc = 0;
-      if (lastf[2]) *ct = 0;
-    }
-    __syncthreads();
-    const bool lrow = lastf[0] != 0, lcol = lastf[1] != 0, lall = lastf[2] != 0;
-    __syncthreads();
-    if (!(lrow || lcol || lall)) return;
-    double (*comb)[64][2] = reinterpret_cast<double (*)[64][2]>(dyn);   // the tile's LDS is free now
-    unsigned mine = 0;
-    if (lrow) {
-      for (int l0 = row0; l0 < row0 + T && l0 < K.Lr; l0 += 64) kl_chunk<NV, true>(R, K, true, l0, comb);
-      ++mine;
-    }
-    if (lcol) {
-      for (int l0 = col0; l0 < col0 + T && l0 < K.Lc; l0 += 64) kl_chunk<NV, true>(R, K, false, l0, comb);
-      ++mine;
-    }
-    if (lall) {
-      kl_scalars<NV, true>(R, K, red + 8);
-      kl_zero_uncovered<NV>(R, K);
-      ++mine;
-    }
-    kl_publish(K, K.cnt + 2 * K.cnt_cols + 1, mine, (unsigned)K.total, lastf + 3);
+    R.SP[w * 3 + 0] = sp[0]; R.SP[w * 3 + 1] = sp[1]; R.SP[w * 3 + 2] = sp[2];
   }
   EIGX_STAMP(11);
   if (R.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) atomicAdd(&R.dbg[15], 1ull);
@@ -1645,6 +1707,31 @@ __global__ void unpack_panel_kernel(const double* __restrict__ recv, size_t coun
   }
 }
 
+// several GPUs, once per panel: the W columns [wk, wk + NB) that the panel-closing ka_kernel finished, rows < rows, from
+// their owners' X messages (parity xpar) into the local panel -- the trailing update needs the complete [U | W | U]
+template <int NB>
+__global__ void mg_wcopy_kernel(RedArgs R, int xpar, int wk, int rows, StepWait W) {
+  if (W.n > 0) step_wait_fused(W);
+  double* Wp = R.UW + (size_t)R.ldp * R.m;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+    int s_, o_;
+    own_of(R, r, s_, o_);
+    const double* xm = R.XW + (size_t)xpar * R.xpar_stride + (size_t)s_ * R.xmsg_stride + o_;
+    Wp[(size_t)wk * R.ldp + r] = ld_sys(xm + 2 * (size_t)R.nown);
+    if (NB == 2) Wp[(size_t)(wk + 1) * R.ldp + r] = ld_sys(xm + 3 * (size_t)R.nown);
+  }
+}
+// several GPUs, once per reduction: the last diagonal block (the final ka_kernel formed its <= NB columns, no mat-vec
+// follows that would publish them): d(i), and for two columns e(i,1) = A_eff(i-1,i), d(i-1)
+template <int NB>
+__global__ void mg_tail_kernel(RedArgs R, int xpar, int i, int ncols, StepWait W) {
+  if (W.n > 0) step_wait_fused(W);
+  if (threadIdx.x == 0 && ncols > 0) {
+    R.d[i] = xget<true>(R, xpar, 0, i);
+    if (ncols > 1) { R.e[i] = xget<true>(R, xpar, 0, i - 1); R.d[i - 1] = xget<true>(R, xpar, 1, i - 1); }
+  }
+}
+
 template <int NB>
 void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double* e, int lde, int m) {
   hipStream_t st = ctx.stream;
@@ -1657,11 +1744,16 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   RedArgs R;
   R.A = A; R.lda = lda; R.n = n; R.ldp = ldp; R.m = m;
   R.d = d; R.e = e; R.lde = lde;
-  R.P = G.nranks; R.Px = G.Px; R.Py = G.Py; R.px = G.px; R.py = G.py; R.row_major = G.row_major;
+  R.P = G.nranks; R.me = G.rank; R.invP = 1.0f / (float)G.nranks;
+  R.Px = G.Px; R.Py = G.Py; R.px = G.px; R.py = G.py; R.row_major = G.row_major;
   R.nxs = (ceil_div(n, G.Px) + 7) / 8 * 8;
   R.nys = (ceil_div(n, G.Py) + 7) / 8 * 8;
-  R.msg_stride = NB * (R.nxs + R.nys) + 8;
-  R.MSG = nullptr; R.PAN = nullptr; R.ldpan = ldp;
+  R.msg_stride = NB * (R.nxs + R.nys) + 8 + 2 * NB * m;          // Y: row sums | column sums | 8 scalar slots | share of the panel dots
+  R.ypar_stride = (size_t)G.nranks * R.msg_stride; R.ysrc_stride = R.msg_stride;
+  R.nown = ceil_div(ceil_div(n, KA_ROWS), G.nranks) * KA_ROWS;   // rows a rank can own (groups of KA_ROWS dealt round-robin)
+  R.xmsg_stride = 4 * R.nown + 8;                                // X: x_i | x_{i-1} | W_A | W_B (owned rows) | Gram partial sums
+  R.xpar_stride = (size_t)G.nranks * R.xmsg_stride;
+  R.MSG = nullptr; R.XW = nullptr; R.PAN = nullptr; R.ldpan = ldp;
   int maxseg = 0;
   if (!mg) {
     for (int L = n; L >= 1; --L) {  // nt is not monotone in L: scan
@@ -1693,10 +1785,14 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   }
   R.kdab_off = R.maxchunk * 2 * NB * m;
   R.KD = ctx.pool.get_t<double>("red.KD", (size_t)R.kdab_off + R.maxchunk + 8 + 512);   // + slack: K_A loads kk < 256 unclamped
-  // several GPUs: first-level panel dots of up to 4 P + 4 short row chunks (see KLArgs)
-  const int maxchunk2 = 4 * G.nranks + 4;
+  // several GPUs: first-level panel dots of up to 12 chunks of the rank's own rows (kl_kernel sums them and sends the
+  // rank's share to everybody), then the uA.uB partial sums of up to 4 P + 4 chunks of the replicated reflector store
+  const int maxchunk2 = 12;
   const int kdab2_off = maxchunk2 * 2 * NB * m;
-  double* KD2 = mg ? ctx.pool.get_t<double>("red.KD2", (size_t)kdab2_off + maxchunk2 + 8) : nullptr;
+  if (mg) {
+    R.KD = ctx.pool.get_t<double>("red.KD2", (size_t)kdab2_off + 4 * G.nranks + 4 + 8 + 512);
+    R.kdab_off = kdab2_off;
+  }
   const size_t sp_count = (size_t)(maxseg * maxseg) * 3 + 8;
   R.SP = ctx.pool.get_t<double>("red.SP", sp_count);
   const int maxgp = (n + KA_ROWS - 1) / KA_ROWS + 2;
@@ -1711,9 +1807,10 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   EIGX_HIP_CHECK(hipMemsetAsync(R.dbg, 0, 32 * sizeof(unsigned long long), st));
 #endif
   // ---- multi-GPU state: step window, gathered panel, compact panels ------------------------------------------
-  StepPeers peers;
-  unsigned* step_cnt = nullptr;          // folded step exchange: arrival counters [tile rows | tile columns | tiles | pushes]
-  unsigned long long epoch = 0;          // epoch of the step message that the NEXT K_A consumes
+  StepPeers peers, xpeers;
+  StepPeers* xp_dev = nullptr;
+  unsigned long long epoch = 0;          // epoch of the Y message that the NEXT K_A consumes
+  unsigned long long xepoch = 0;         // epoch of the X message that the last K_A launch wrote
   PeerBuf* panr = nullptr;               // receive window of the panel gather: [rank][mloc_max][nxs]
   double *pan = nullptr, *pan_send = nullptr, *UWr = nullptr, *UWc = nullptr;
   // a gathered panel holds the m columns of the next panel and, when fewer than NB + 1 columns would remain below it,
@@ -1723,8 +1820,14 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   const size_t pan_count = (size_t)mloc_max * R.nxs;
   const int ldr = pad_ld(R.nxs + 2), ldc = pad_ld(R.nys + 2);
   if (mg) {
-    R.MSG = comm_step_window(ctx, (size_t)R.msg_stride, &peers);
-    epoch = comm_step_epoch_base(ctx, (unsigned long long)(n / NB + 2));
+    R.MSG = comm_step_window(ctx, 0, (size_t)R.msg_stride, &peers);
+    R.ysrc_stride = (int)peers.src_stride;
+    R.XW = comm_step_window(ctx, 1, (size_t)R.xmsg_stride, &xpeers);
+    epoch = comm_step_epoch_base(ctx, 0, (unsigned long long)(n / NB + 2));
+    xepoch = comm_step_epoch_base(ctx, 1, (unsigned long long)(n / NB + n / m + 8));
+    xp_dev = ctx.pool.get_t<StepPeers>("red.xpeers", 1);
+    EIGX_HIP_CHECK(hipMemcpyAsync(xp_dev, &xpeers, sizeof(StepPeers), hipMemcpyHostToDevice, st));
+    EIGX_HIP_CHECK(hipStreamSynchronize(st));   // (xpeers lives on this stack frame; once per reduction)
     panr = comm_buffer(ctx, "red.panr", (size_t)G.nranks * pan_count * sizeof(double));
     pan = ctx.pool.get_t<double>("red.pan", (size_t)ldp * (m + NB));
     pan_send = ctx.pool.get_t<double>("red.pansend", pan_count);
@@ -1732,8 +1835,6 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     UWc = ctx.pool.get_t<double>("red.UWc", (size_t)ldc * 2 * m);
     R.PAN = pan;
     EIGX_HIP_CHECK(hipMemsetAsync(pan_send, 0, pan_count * sizeof(double), st));
-    step_cnt = ctx.pool.get_t<unsigned>("red.cnt", (size_t)2 * maxseg + 8);
-    EIGX_HIP_CHECK(hipMemsetAsync(step_cnt, 0, ((size_t)2 * maxseg + 8) * sizeof(unsigned), st));
   }
   // gather the panel columns [clo, chi], rows < chi + 1, from their owners into `pan` (enqueued on stream s)
   auto gather_panel = [&](int clo, int chi, hipStream_t s, CommChannel ch) {
@@ -1789,10 +1890,46 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   S.has_prev = 0; S.iprev = 0; S.Lprev = 0; S.kprev = 0; S.nchunk_prev = 0; S.nt_prev = 0; S.lgT_prev = 7;
   S.par = 0; S.pan_c0 = 0; S.G = 1;
   S.wait.n = 0; S.wait.flag = nullptr; S.wait.err = nullptr; S.wait.ticks = nullptr; S.wait.limit_ticks = 0; S.wait.epoch = 0;
+  S.nchunk_ab = 0; S.xpar = 0; S.xepoch = 0; S.xp = xp_dev;
+  const StepWait no_wait = S.wait;
   const bool fuse_wait = mg && comm_step_wait_fused(ctx);
-  const bool step_coll = mg && comm_step_collective(ctx);
-  if (const char* ef = getenv("EIGX_FOLD_KL")) g_fold_kl = atoi(ef);
-  const int step_fence = (getenv("EIGX_STEP_FENCE") && atoi(getenv("EIGX_STEP_FENCE")) != 0) ? 1 : 0;   // per-step exchange as an allgather (RCCL / emulated)
+  const bool step_coll = mg && comm_step_collective(ctx);   // per-step exchanges as allgathers (RCCL / emulated)
+  const int step_fence = (getenv("EIGX_STEP_FENCE") && atoi(getenv("EIGX_STEP_FENCE")) != 0) ? 1 : 0;
+  // several GPUs: K_A runs over this rank's row groups only: workgroups / groups per workgroup for the groups below `rows`
+  auto ka_grid = [&](int rows, int& Gout) {
+    const int ng = (rows + KA_ROWS - 1) / KA_ROWS;
+    const int own = mg ? local_count(ng, G.nranks, G.rank) : ng;
+    Gout = (own > 2 * g_ka_wgs) ? (own + g_ka_wgs - 1) / g_ka_wgs : 1;
+    const int nwg = (own + Gout - 1) / Gout;
+    return nwg > 0 ? nwg : 1;
+  };
+  // rows below L that this rank owns (they come first in its owned index order)
+  auto own_count = [&](int L) {
+    const int gfull = L / KA_ROWS, rem = L % KA_ROWS;
+    return local_count(gfull, G.nranks, G.rank) * KA_ROWS + ((rem > 0 && gfull % G.nranks == G.rank) ? rem : 0);
+  };
+  // several GPUs: the next K_A launch writes X message xepoch + 1; behind it (collective form) the allgather that delivers it
+  int wk_last = -1;                       // W columns that the last K_A launch finished (-1: none), for the next mat-vec's copy
+  int last_ka_i = -1, last_ka_ncols = 0;
+  auto ka_mg_begin = [&](KAArgs& K) {
+    if (!mg) return;
+    ++xepoch;
+    K.xpar = (int)(xepoch & 1); K.xepoch = xepoch; K.xp = xp_dev;
+    wk_last = K.has_prev ? K.kprev : -1;
+    last_ka_i = K.i; last_ka_ncols = K.ncols;
+  };
+  auto ka_mg_end = [&](const KAArgs& K) {
+    if (mg && step_coll) comm_step_allgather(ctx, 1, xpeers.slot[0], K.xpar, st);
+  };
+  // consumer side of the X message: a StepWait for the kernel's prologue, or a wait kernel in front of it (then n = 0)
+  auto x_wait = [&](int prof_kind) -> StepWait {
+    if (!mg || step_coll) return no_wait;
+    if (fuse_wait) return comm_step_wait_args(ctx, 1, xepoch);
+    if (prof_kind >= 0) ctx.prof_begin(prof_kind, 0.0, st);
+    comm_step_wait(ctx, 1, xepoch, st);
+    if (prof_kind >= 0) ctx.prof_end(st);
+    return no_wait;
+  };
   int k = 0;        // panel fill
   int i = n - 1;    // top column of the current block
   if (mg) {
@@ -1816,41 +1953,51 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     if (S.has_prev && S.iprev + 1 > S.rows) S.rows = S.iprev + 1;
     // row groups per workgroup: one wave per SIMD at most (1024 SIMDs = 256 workgroups of 4 waves); the scalar work
     // of a workgroup is done once for all its groups
-    const int ngroups = (S.rows + KA_ROWS - 1) / KA_ROWS;
-    S.G = (ngroups > 2 * g_ka_wgs) ? (ngroups + g_ka_wgs - 1) / g_ka_wgs : 1;
-    const int nb_ka = (ngroups + S.G - 1) / S.G;
+    const int nb_ka = ka_grid(S.rows, S.G);
     if (S.rows > 0 && (S.has_prev || ncols > 0)) {
-      // the previous step's messages of every rank must be in: a wait kernel, or the wait folded into K_A's prologue
+      // the previous step's Y messages of every rank must be in: a wait kernel, or the wait folded into K_A's prologue
       S.wait.n = 0;
       if (mg && S.has_prev && !step_coll) {
-        if (fuse_wait) S.wait = comm_step_wait_args(ctx, epoch);
+        if (fuse_wait) S.wait = comm_step_wait_args(ctx, 0, epoch);
         else {
           if (prof_step) ctx.prof_begin(3, 0.0, st);
-          comm_step_wait(ctx, epoch, st);
+          comm_step_wait(ctx, 0, epoch, st);
           if (prof_step) ctx.prof_end(st);
         }
       }
+      ka_mg_begin(S);
       if (prof_step) ctx.prof_begin(4, 0.0, st);
       launch_ka(nb_ka, S);
+      ka_mg_end(S);
       if (prof_step) ctx.prof_end(st);
-      prof_step = false;
       S.wait.n = 0;
     }
-    if (!do_step) break;
+    if (!do_step) { prof_step = false; break; }
     KBArgs B;
     B.i = i; B.L = L; B.k = k;
     B.ncg = (k + PD_COLS - 1) / PD_COLS;
     B.toprows = i + 1;
     B.pdr = pd_rows_for(B.toprows);
-    // several GPUs, kl_kernel form of the exchange: 4 P chunks (>= 512 rows each), reduced a second time by kl_kernel
-    const bool kd_two_level = mg && !g_fold_kl;
-    if (kd_two_level) {
-      int r_ = ((B.toprows + 4 * G.nranks - 1) / (4 * G.nranks) + 63) / 64 * 64;
+    B.nown_L = 0; B.npd_s = 0; B.pdr_s = 0; B.wk = -1; B.xpar = 0; B.xwait = no_wait;
+    int npd = (B.toprows + B.pdr - 1) / B.pdr;
+    if (mg) {
+      // several GPUs: the panel dots over the rank's own rows below L in <= 8 chunks (>= 512 rows each; kl_kernel adds
+      // them up and sends the share), the reflector store over all rows in <= 4 P chunks (the local tile stream is 1 / P of
+      // one GPU's: a long K_P chunk would outlast it)
+      B.nown_L = own_count(L);
+      int r_ = ((B.nown_L + 7) / 8 + 63) / 64 * 64;
       B.pdr = r_ < 512 ? 512 : r_;
+      npd = (B.nown_L + B.pdr - 1) / B.pdr;
+      r_ = ((B.toprows + 4 * G.nranks - 1) / (4 * G.nranks) + 63) / 64 * 64;
+      B.pdr_s = r_ < 512 ? 512 : r_;
+      B.npd_s = (B.toprows + B.pdr_s - 1) / B.pdr_s;
+      B.wk = wk_last;
+      B.xpar = (int)(xepoch & 1);
+      B.xwait = x_wait(prof_step ? 5 : -1);
     }
-    const int npd = (B.toprows + B.pdr - 1) / B.pdr;
+    prof_step = false;
     B.npd = npd;
-    B.ngp = nb_ka;
+    B.ngp = mg ? G.nranks : nb_ka;
     B.Lr = L; B.Lc = L; B.ntc = 0; B.nty_last = 0; B.slope = 0; B.c1 = 0;
     int T, ntiles;
     if (!mg) {
@@ -1875,13 +2022,13 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       }
     }
     B.ng = T / 32;
-    const int gx = ntiles + npd * (B.ncg + 1);               // + K_P workgroups
+    const int gx = ntiles + (mg ? npd * B.ncg + B.npd_s : npd * (B.ncg + 1));   // + K_P workgroups
     const bool prof = ctx.prof_stride > 0 && (n_symv % ctx.prof_stride) == 0;
     if (prof) ctx.prof_begin(0, 8.0 * ((double)L * (L + 1) / 2) / R.P, st);  // this rank's share of the triangle
     const bool nt_loads = (mg ? sqrt((double)B.Lr * B.Lc) : (double)L) > g_symv_nt;
     const bool unc = (mg ? sqrt((double)B.Lr * B.Lc) : (double)L) <= g_symv_unc;   // latency-bound sizes: the true two-unit pipeline
-    // several GPUs: the step exchange -- reduce this rank's tile partial sums, write them into every rank's window,
-    // publish the flag -- folded into the mat-vec launch (its last-arriving tiles do it) or as kl_kernel behind it
+    // several GPUs: the Y exchange behind the mat-vec -- kl_kernel reduces this rank's tile partial sums, writes them into
+    // the owners' windows and publishes the flag
     KLArgs KL;
     memset(&KL, 0, sizeof(KL));
     if (mg) {
@@ -1891,26 +2038,15 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       KL.par = (int)(epoch & 1);
       KL.epoch = epoch;
       KL.peers = peers;
-      KL.cnt = step_cnt; KL.cnt_cols = maxseg; KL.ntiles = ntiles;
-      int ntr = 0, ncovc = 0;
-      for (int tx = 0; tx < B.ntc; ++tx) {
-        const int c = mg_nty(tx, T, B.Lc, G.Px, G.px, G.Py, G.py);
-        if (c > ntr) ntr = c;
-        if (c > 0) ++ncovc;
-      }
-      KL.ntr = ntr; KL.total = ntr + ncovc + 1;
-      KL.fold = (g_fold_kl && ntiles > 0) ? 1 : 0;   // a rank without tiles at this step has nobody to do it: kl_kernel
-      if (kd_two_level) { KL.kd2 = KD2; KL.npd2 = npd; KL.kdab2_off = kdab2_off; KL.kfill = k; }
+      KL.kd2 = R.KD; KL.npd2 = npd; KL.kfill = k;
       KL.fence = step_fence;
     }
-    RedArgs RS = R;                    // what the mat-vec launch sees: two-level panel dots write the first level
-    if (kd_two_level) { RS.KD = KD2; RS.kdab_off = kdab2_off; }
 #define EIGX_SYMV(RBv, NTv)                                                                                         \
   do {                                                                                                              \
-    if (mg && unc) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true, true>), dim3(gx), dim3(256), 0, st, RS, B, KL);   \
-    else if (mg) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true, false>), dim3(gx), dim3(256), 0, st, RS, B, KL);    \
-    else if (unc) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false, true>), dim3(gx), dim3(256), 0, st, R, B, KL);   \
-    else hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false, false>), dim3(gx), dim3(256), 0, st, R, B, KL);           \
+    if (mg && unc) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true, true>), dim3(gx), dim3(256), 0, st, R, B);   \
+    else if (mg) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true, false>), dim3(gx), dim3(256), 0, st, R, B);    \
+    else if (unc) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false, true>), dim3(gx), dim3(256), 0, st, R, B);   \
+    else hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false, false>), dim3(gx), dim3(256), 0, st, R, B);           \
   } while (0)
     if (T == 128) EIGX_SYMV(1, false);
     else if (T == 256 && !nt_loads) EIGX_SYMV(2, false);
@@ -1922,8 +2058,8 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     if (mg) {
       const int nbc = ceil_div(B.Lc > 0 ? B.Lc : 1, 64);
       if (prof) ctx.prof_begin(2, 8.0 * R.msg_stride, st);
-      if (!KL.fold) hipLaunchKernelGGL((kl_kernel<NB>), dim3(KL.nbr + nbc + (KL.npd2 > 0 ? 2 * NB : 0)), dim3(256), 0, st, R, KL);
-      if (step_coll) comm_step_allgather(ctx, peers.slot[0], KL.par, st);
+      hipLaunchKernelGGL((kl_kernel<NB>), dim3(KL.nbr + nbc + 2 * NB), dim3(256), 0, st, R, KL);
+      if (step_coll) comm_step_allgather(ctx, 0, peers.slot[0], KL.par, st);
       if (prof) ctx.prof_end(st);
       prof_step = prof;
       S.par = KL.par;
@@ -1932,7 +2068,8 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     ++n_symv;
     // bookkeeping for the next K_A
     S.has_prev = 1; S.iprev = i; S.Lprev = L; S.kprev = k;
-    S.nchunk_prev = kd_two_level ? 1 : npd;
+    S.nchunk_prev = mg ? G.nranks : npd;   // shares of the panel dots that the next K_A adds: one per rank / one per K_P row chunk
+    S.nchunk_ab = mg ? B.npd_s : npd;
     S.nt_prev = B.nt; S.lgT_prev = (T == 128) ? 7 : (T == 256 ? 8 : 9);
     k += NB;
     i -= NB;
@@ -1941,15 +2078,22 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       KAArgs F = S;
       prof_step = false;   // (the panel-closing K_A is not part of the sampled step breakdown)
       F.ncols = 0; F.i = i; F.L = 0; F.k = k; F.rows = S.iprev + 1;
-      const int fgroups = (F.rows + KA_ROWS - 1) / KA_ROWS;
-      F.G = (fgroups > 2 * g_ka_wgs) ? (fgroups + g_ka_wgs - 1) / g_ka_wgs : 1;
-      const int nb_kf = (fgroups + F.G - 1) / F.G;
+      const int nb_kf = ka_grid(F.rows, F.G);
       F.wait.n = 0;
       if (mg && !step_coll) {
-        if (fuse_wait) F.wait = comm_step_wait_args(ctx, epoch);
-        else comm_step_wait(ctx, epoch, st);
+        if (fuse_wait) F.wait = comm_step_wait_args(ctx, 0, epoch);
+        else comm_step_wait(ctx, 0, epoch, st);
       }
+      ka_mg_begin(F);
       launch_ka(nb_kf, F);
+      ka_mg_end(F);
+      if (mg) {
+        // the last W columns of the panel, finished by their owners just now, into the local panel (all rows)
+        const StepWait xw = x_wait(-1);
+        hipLaunchKernelGGL((mg_wcopy_kernel<NB>), dim3(ceil_div(F.rows, 256) < 64 ? ceil_div(F.rows, 256) : 64), dim3(256), 0, st, R,
+                           F.xpar, F.kprev, F.rows, xw);
+        wk_last = -1;
+      }
       const int nr = i + 1;
       if (ctx.prof_stride > 0) ctx.prof_begin(1, 2.0 * (double)nr * nr * m / R.P, st);
       if (!mg) {
@@ -1989,6 +2133,11 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       k = 0;
     }
   }
+  if (mg && last_ka_ncols > 0) {
+    // the last <= NB columns: no mat-vec follows whose publisher would take d, e from the X message
+    const StepWait xw = x_wait(-1);
+    hipLaunchKernelGGL((mg_tail_kernel<NB>), dim3(1), dim3(64), 0, st, R, (int)(xepoch & 1), last_ka_i, last_ka_ncols, xw);
+  }
   if (getenv("EIGX_TRACE_ENQUEUE")) {
     const double te = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     EIGX_HIP_CHECK(hipStreamSynchronize(st));
@@ -2017,7 +2166,7 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
 
 int set_symv_threshold(int which, int v) {
   if (which == 5) { const int old = g_symv_unc; g_symv_unc = v; return old; }
-  if (which == 6) { const int old = g_fold_kl; g_fold_kl = v; return old; }
+  if (which == 6) return 0;   // (removed: folded step exchange)
   int& t = (which == 4) ? g_ka_fit : (which == 3) ? g_ka_wgs : (which == 2) ? g_symv_nt : (which ? g_symv_t256 : g_symv_t128);
   const int old = t; t = v; return old;
 }

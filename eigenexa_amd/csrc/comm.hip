@@ -153,13 +153,13 @@ struct CommState {
   double st_ipc_us = 0.0, st_step_us = 0.0, st_rccl_us = 0.0;
   // peer-mapped flag block + local bookkeeping words
   PeerBuf flags;
-  unsigned long long epoch[CH_COUNT] = {0, 0, 0, 0};
+  unsigned long long epoch[CH_COUNT] = {0, 0, 0, 0, 0, 0};
   unsigned* counters = nullptr;          // [CH_COUNT] last-workgroup tickets (device)
   int* err_dev = nullptr;                // sticky device-side failure word (a bounded spin ran out)
   unsigned long long* ticks_dev = nullptr;   // accumulated 100 MHz ticks spent in waits / pushes
   std::map<std::string, PeerBuf> bufs;
   std::vector<PeerBuf> retired;          // outgrown buffers: stay mapped until comm_free
-  size_t step_msg = 0;
+  size_t step_msg[2] = {0, 0};   // doubles per message of the two step windows (Y, X)
   double rccl_seconds = 0.0;
   std::vector<hipEvent_t> tev;           // event pairs around RCCL calls
   size_t tev_used = 0;
@@ -712,10 +712,18 @@ int comm_init(Context& ctx, const void* uid) {
   cs->in_selftest = true;
   if (cs->ipc) {
     int my_ok = 1;
-    // (1) bulk protocol: ready handshake + push kernel + flag + wait kernel, world all-gather, every round checked
+    // Every board round of this block -- the two collective allocations and the two votes -- is made by EVERY rank whatever
+    // it has seen locally: checksum errors are local to the receiver, and a rank that skipped a round would pair its next
+    // message with the others' current one (garbage verdicts, or a 120-s stall).  Only kernel rounds are skipped.
+    // EIGX_SELFTEST_FAIL=ipc makes this leg report failure; with EIGX_SELFTEST_FAIL_RANK=r on rank r alone (tests).
+    const char* fail_rank = getenv("EIGX_SELFTEST_FAIL_RANK");
+    const bool forced_ipc = force_fail && strcmp(force_fail, "ipc") == 0 && (!fail_rank || atoi(fail_rank) == cs->me);
     cs->rccl = false;
     PeerBuf* w = comm_buffer(ctx, "comm.selftest", (size_t)EIGX_MAXP * cnt * sizeof(double));
+    StepPeers sp;
+    double* win = comm_step_window(ctx, 0, cnt, &sp);
     if (!w->mapped || cs->failed) my_ok = 0;
+    // (1) bulk protocol: ready handshake + push kernel + flag + wait kernel, world all-gather, every round checked
     const double t0 = now_s();
     for (int r = 1; my_ok && r <= rounds; ++r) {
       hipLaunchKernelGGL(st_fill_kernel, dim3(4), dim3(256), 0, ts, sendb, cnt, cs->me, r);
@@ -724,33 +732,34 @@ int comm_init(Context& ctx, const void* uid) {
     }
     cs->st_ipc_rounds = my_ok ? rounds : 0;
     cs->st_ipc_errors = my_ok ? (int)read_errs(0) : 1;
+    if (forced_ipc && fail_rank) cs->st_ipc_errors += 1;     // (test hook: checksum errors seen by this rank only)
     cs->st_ipc_us = rounds > 0 ? (now_s() - t0) * 1e6 / rounds : 0.0;
+    if (cs->st_ipc_errors != 0 || cs->failed) my_ok = 0;
+    bool bulk_good = false;
+    if (!vote(my_ok, &bulk_good)) { (void)hipFree(errs); (void)hipFree(sendb); (void)hipStreamDestroy(ts); return give_up("bootstrap exchange timed out"); }
     // (2) step protocol: system-scope stores straight into every rank's step window, epoch flags, parity double
-    // buffering, no ready handshake -- the per-step exchange of the reduction in miniature
-    if (my_ok && cs->st_ipc_errors == 0 && !cs->failed) {
-      StepPeers sp;
-      double* win = comm_step_window(ctx, cnt, &sp);
-      if (cs->failed) my_ok = 0;
+    // buffering, no ready handshake -- the per-step exchanges of the reduction in miniature.  Run by all ranks or none.
+    if (bulk_good) {
       StStepArgs A;
       A.n = cs->P; A.rank = cs->me; A.count = cnt; A.parity_stride = sp.parity_stride; A.counter = sp.counter;
       A.fence = (getenv("EIGX_STEP_FENCE") && atoi(getenv("EIGX_STEP_FENCE")) != 0) ? 1 : 0;
       for (int q = 0; q < EIGX_MAXP; ++q) { A.slot[q] = sp.slot[q]; A.flag[q] = sp.flag[q]; }
-      const u64 base = comm_step_epoch_base(ctx, (u64)rounds + 2);
+      const u64 base = comm_step_epoch_base(ctx, 0, (u64)rounds + 2);
       const double t1 = now_s();
-      for (int r = 1; my_ok && r <= rounds; ++r) {
+      for (int r = 1; r <= rounds; ++r) {
         A.round = r; A.epoch = base + r;
         hipLaunchKernelGGL(st_step_push_kernel, dim3(4), dim3(256), 0, ts, A);
-        comm_step_wait(ctx, A.epoch, ts);
+        comm_step_wait(ctx, 0, A.epoch, ts);
         hipLaunchKernelGGL(st_check_kernel, dim3(8), dim3(256), 0, ts, (const double*)(win + (A.epoch & 1) * sp.parity_stride), cnt, cnt,
                            cs->P, Mw, r, errs + 1);
       }
-      cs->st_step_rounds = my_ok ? rounds : 0;
-      cs->st_step_errors = my_ok ? (int)read_errs(1) : 1;
+      cs->st_step_rounds = rounds;
+      cs->st_step_errors = (int)read_errs(1);
       cs->st_step_us = rounds > 0 ? (now_s() - t1) * 1e6 / rounds : 0.0;
     }
-    if (cs->st_ipc_errors != 0 || (cs->st_step_rounds > 0 && cs->st_step_errors != 0) || cs->failed) my_ok = 0;
+    if (!bulk_good || cs->st_ipc_errors != 0 || (cs->st_step_rounds > 0 && cs->st_step_errors != 0) || cs->failed) my_ok = 0;
     if (my_ok && comm_failed(ctx)) my_ok = 0;
-    if (force_fail && strcmp(force_fail, "ipc") == 0) my_ok = 0;
+    if (forced_ipc) my_ok = 0;
     if (!my_ok && cs->me == 0)
       fprintf(stderr, "[eigx] transport self-test: peer windows FAILED (bulk errors %d, step errors %d%s)\n", cs->st_ipc_errors,
               cs->st_step_errors, (force_fail && strcmp(force_fail, "ipc") == 0) ? ", forced by EIGX_SELFTEST_FAIL" : "");
@@ -804,10 +813,12 @@ int comm_init(Context& ctx, const void* uid) {
   cs->rccl_ok = rccl_good;
 
   // ---- the ladder: peer windows -> RCCL -> (caller falls back to independent replicas) -----------------------------
-  // Default = the transport that every multi-rank test runs: peer windows for the per-step exchange AND the bulk
-  // collectives, wait kernels.  RCCL takes over what the peer windows cannot do (failed mapping / failed self-test) or
-  // what the environment asks for: EIGX_BULK=rccl (bulk collectives), EIGX_STEP=coll (per-step exchange as an allgather:
-  // ncclAllGather on a node, the same group semantics emulated over the peer windows when ranks share a card).
+  // Per-step exchanges: peer windows (kernel stores into the peers' HBM + epoch flags) when they passed the self-test,
+  // otherwise -- or with EIGX_STEP=coll -- allgathers (ncclAllGather on a node, the same group semantics emulated over
+  // the peer windows when ranks share a card).  Bulk collectives (panel gather, reflector gather, the all-to-alls): RCCL
+  // wherever its communicators exist and passed the self-test, i.e. on a node with one rank per GPU -- windows of N^2/P
+  // doubles are then never peer-mapped (comm_buffer) --, the peer windows where RCCL cannot run (ranks sharing a card:
+  // every multi-rank test) or where EIGX_BULK=ipc asks for them.
   if (!cs->ipc && !cs->rccl_ok) {
     fprintf(stderr, "[eigx] rank %d: neither peer windows (hipIpc) nor RCCL are usable between the ranks\n", cs->me);
     comm_free(ctx);
@@ -815,7 +826,7 @@ int comm_init(Context& ctx, const void* uid) {
   }
   const char* want_bulk = getenv("EIGX_BULK");
   const char* want_step = getenv("EIGX_STEP");
-  cs->rccl = cs->rccl_ok && (!cs->ipc || (want_bulk && strcmp(want_bulk, "rccl") == 0));
+  cs->rccl = cs->rccl_ok && !(cs->ipc && want_bulk && strcmp(want_bulk, "ipc") == 0);
   cs->step_coll = !cs->ipc || (want_step && strcmp(want_step, "coll") == 0);
   if (getenv("EIGX_TRACE_COMM") && cs->me == 0) {
     char info[1536];
@@ -829,8 +840,7 @@ int comm_info(const Context& ctx, char* buf, int len) {
   const CommState* cs = ctx.comm;
   if (!buf || len <= 0) return EIGX_ERR_BAD_ARG;
   if (!cs) { snprintf(buf, (size_t)len, "{\"ranks\": 1}"); return EIGX_OK; }
-  const char* e = getenv("EIGX_FUSE_WAIT");
-  const bool fused = e && atoi(e) != 0 && !cs->step_coll;
+  const bool fused = comm_step_wait_fused(ctx);
   snprintf(buf, (size_t)len,
            "{\"ranks\": %d, \"shared_device\": %s, \"peer_windows\": %s, \"rccl\": %s, \"step_exchange\": \"%s\", "
            "\"step_wait\": \"%s\", \"bulk\": \"%s\", \"selftest\": {\"ipc_rounds\": %d, \"ipc_errors\": %d, \"ipc_us_per_round\": %.1f, "
@@ -839,7 +849,7 @@ int comm_info(const Context& ctx, char* buf, int len) {
            "\"small_bytes_sent\": %.0f, \"allreduces\": %.0f, \"allreduce_bytes_sent\": %.0f, \"large_exchanges\": %.0f, \"large_bytes_sent\": %.0f}}",
            cs->P, cs->shared_device ? "true" : "false", cs->ipc ? "true" : "false", cs->rccl_ok ? "true" : "false",
            cs->step_coll ? (cs->rccl ? "allgather (RCCL)" : "allgather (peer-window emulation)") : "peer writes (hipIpc windows, kernel stores over xGMI)",
-           cs->step_coll ? "stream order" : (fused ? "fused into ka_kernel" : "wait kernel"), cs->rccl ? "rccl" : "peer windows",
+           cs->step_coll ? "stream order" : (fused ? "fused into the consumer kernels" : "wait kernel"), cs->rccl ? "rccl" : "peer windows",
            cs->st_ipc_rounds, cs->st_ipc_errors, cs->st_ipc_us, cs->st_step_rounds, cs->st_step_errors, cs->st_step_us,
            cs->st_rccl_checks, cs->st_rccl_errors, cs->st_rccl_us, cs->st_calls[0], cs->st_bytes[0], cs->st_calls[1], cs->st_bytes[1],
            cs->st_calls[2], cs->st_bytes[2], cs->st_calls[3], cs->st_bytes[3]);
@@ -906,7 +916,7 @@ PeerBuf* comm_buffer(Context& ctx, const std::string& name, size_t bytes) {
     b.mapped = true;
     return &b;
   }
-  const bool map = cs->ipc && (!cs->rccl || (name == "comm.step" && !cs->step_coll));
+  const bool map = cs->ipc && (!cs->rccl || ((name == "comm.step" || name == "comm.stepx") && !cs->step_coll));
   b.local = map ? alloc_window(want) : nullptr;
   const bool window_ok = b.local != nullptr;      // false with map: no fine-grained memory -> reported as a failed mapping below
   if (!b.local) EIGX_HIP_CHECK(hipMalloc((void**)&b.local, want));
@@ -981,7 +991,7 @@ void comm_exchange(Context& ctx, CommGroup grp, const double* send, size_t send_
     return;
   }
   if (cs->failed) return;
-  if (ch != CH_STEP2) { cs->st_calls[1] += 1.0; cs->st_bytes[1] += 8.0 * (double)count * (n - 1); }
+  if (ch != CH_STEP2 && ch != CH_STEPX2) { cs->st_calls[1] += 1.0; cs->st_bytes[1] += 8.0 * (double)count * (n - 1); }
   if (cs->rccl) {
     rccl_time_begin(cs, s);
     if (send_stride == 0) {
@@ -1150,27 +1160,38 @@ void comm_exchange_big(Context& ctx, CommGroup grp, const double* send, size_t s
   }
 }
 
-// ---- per-step exchange ---------------------------------------------------------------------------------------
-double* comm_step_window(Context& ctx, size_t msg_doubles, StepPeers* peers) {
+// ---- per-step exchanges (two windows: 0 = Y on CH_STEP, 1 = X on CH_STEPX; see eigx_comm.h) ---------------------------
+static const char* step_name(int which) { return which ? "comm.stepx" : "comm.step"; }
+static int step_channel(int which) { return which ? CH_STEPX : CH_STEP; }
+
+double* comm_step_window(Context& ctx, int which, size_t msg_doubles, StepPeers* peers) {
   CommState* cs = ctx.comm;
-  PeerBuf* w = comm_buffer(ctx, "comm.step", (size_t)2 * cs->P * msg_doubles * sizeof(double));
-  cs->step_msg = msg_doubles;
+  PeerBuf* w = comm_buffer(ctx, step_name(which), (size_t)2 * cs->P * msg_doubles * sizeof(double));
+  cs->step_msg[which] = msg_doubles;
+  const int ch = step_channel(which);
   peers->n = cs->P;
   peers->parity_stride = (size_t)cs->P * msg_doubles;
-  peers->counter = cs->counters + CH_STEP;
+  peers->src_stride = msg_doubles;
+  peers->counter = cs->counters + ch;
   for (int q = 0; q < EIGX_MAXP; ++q) { peers->slot[q] = nullptr; peers->flag[q] = nullptr; }
   if (cs->step_coll) {
-    // collective form: the producer writes its message into a local send buffer (comm_step_send) and
-    // comm_step_allgather moves it; nothing is stored into a peer by the producer kernel
-    double* sendb = ctx.pool.get_t<double>("comm.stepsend", msg_doubles + 8);
+    // collective form: the producer writes its message into a local send buffer and comm_step_allgather moves it;
+    // nothing is stored into a peer by the producer kernel
+    double* sendb = ctx.pool.get_t<double>(which ? "comm.stepxsend" : "comm.stepsend", msg_doubles + 8);
     peers->n = 1;
     peers->parity_stride = 0;
     peers->slot[0] = sendb;
     return w->local;
   }
+  // Loopback lab mode.  X: this rank writes its message once per "peer", into the slot of each source of its own window
+  // (as many stores as on a node; every source's x / W then reads as this rank's).  Y: the row and column sums go to ONE
+  // destination each (the row's owner), so all sources alias one message area (src_stride 0) -- every entry a consumer
+  // reads has then been written in this step, with one store as on a node.
+  if (cs->loop && which == 0) peers->src_stride = 0;
   for (int q = 0; q < cs->P; ++q) {
-    peers->slot[q] = (w->mapped ? w->peer[q] : w->local) + (size_t)sig_idx(cs, q) * msg_doubles;
-    peers->flag[q] = flag_word(cs->flags.mapped ? cs->flags.peer[q] : cs->flags.local, CH_STEP, 0, sig_idx(cs, q));
+    const size_t so = (cs->loop && which == 0) ? 0 : (size_t)sig_idx(cs, q) * msg_doubles;
+    peers->slot[q] = (w->mapped ? w->peer[q] : w->local) + so;
+    peers->flag[q] = flag_word(cs->flags.mapped ? cs->flags.peer[q] : cs->flags.local, ch, 0, sig_idx(cs, q));
   }
   if (!w->mapped) comm_fail(cs, "the per-step exchange needs peer windows (hipIpc) between the ranks");
   return w->local;
@@ -1178,57 +1199,63 @@ double* comm_step_window(Context& ctx, size_t msg_doubles, StepPeers* peers) {
 
 bool comm_step_collective(const Context& ctx) { return ctx.comm && ctx.comm->step_coll; }
 
-// collective form of the per-step exchange (the north_star's literal "allgather / allreduce on RCCL", src/comm.F:1192-1247
+// collective form of a per-step exchange (the north_star's literal "allgather / allreduce on RCCL", src/comm.F:1192-1247
 // reduce_dbl): every rank's message of msg_doubles lands in every rank's step window at the given parity; the consumer
 // adds the contributions in rank order as with the peer-write form, so the replicated results stay bit-identical.
 // Enqueued on s; the consumer kernel follows in stream order (no wait kernel).
-void comm_step_allgather(Context& ctx, const double* sendmsg, int parity, hipStream_t s) {
+void comm_step_allgather(Context& ctx, int which, const double* sendmsg, int parity, hipStream_t s) {
   CommState* cs = ctx.comm;
   if (cs->failed) return;
-  PeerBuf* w = &cs->bufs["comm.step"];
-  const size_t off = (size_t)parity * cs->P * cs->step_msg;
+  PeerBuf* w = &cs->bufs[step_name(which)];
+  const size_t msg = cs->step_msg[which];
+  const size_t off = (size_t)parity * cs->P * msg;
   if (cs->rccl) {
     rccl_time_begin(cs, s);
-    EIGX_NCCL_TRY(cs, api.AllGather(sendmsg, w->local + off, cs->step_msg, kNcclFloat64, cs->world, s));
+    EIGX_NCCL_TRY(cs, api.AllGather(sendmsg, w->local + off, msg, kNcclFloat64, cs->world, s));
     rccl_time_end(cs, s);
     return;
   }
-  comm_exchange(ctx, COMM_WORLD, sendmsg, 0, w, off, cs->step_msg, s, CH_STEP2);
+  comm_exchange(ctx, COMM_WORLD, sendmsg, 0, w, off, msg, s, which ? CH_STEPX2 : CH_STEP2);
 }
 
-unsigned long long comm_step_epoch_base(Context& ctx, unsigned long long nsteps) {
+unsigned long long comm_step_epoch_base(Context& ctx, int which, unsigned long long nmsg) {
   CommState* cs = ctx.comm;
-  const u64 base = cs->epoch[CH_STEP];
-  cs->epoch[CH_STEP] += nsteps;
-  // (an upper bound of the steps of the reduction that follows; every step sends one message to each of the P - 1 peers)
-  cs->st_calls[0] += (double)nsteps; cs->st_bytes[0] += 8.0 * (double)cs->step_msg * (double)nsteps * (cs->P - 1);
+  const int ch = step_channel(which);
+  const u64 base = cs->epoch[ch];
+  cs->epoch[ch] += nmsg;
+  // (an upper bound of the messages that follow; each goes to the P - 1 peers: Y in pieces -- every row sum to one
+  // owner --, X whole)
+  cs->st_calls[0] += (double)nmsg;
+  cs->st_bytes[0] += 8.0 * (double)cs->step_msg[which] * (double)nmsg * (which ? (cs->P - 1) : 1.0);
   return base;
 }
 
 bool comm_step_wait_fused(const Context& ctx) {
   const CommState* cs = ctx.comm;
   if (!cs || cs->step_coll) return false;
-  // Opt-in (EIGX_FUSE_WAIT=1).  The default is the wait kernel: it is the form every multi-rank test and rehearsal
-  // runs; the fused spin has only run in small tests on a shared card and gets switched on by default only after a
-  // run on physically separate GPUs has passed tests/mg_worker.py with it.
+  // The consumer kernels (ka_kernel, the mat-vec launch) spin on the flags in their prologue instead of running behind a
+  // one-wave wait kernel: the default when every rank has its own GPU (a rank's spinning workgroups then only share the
+  // card with its own side-stream kernels, which never wait for them); on a shared card (tests) and in the loopback lab
+  // the wait kernel, unless EIGX_FUSE_WAIT says otherwise.
   const char* e = getenv("EIGX_FUSE_WAIT");
-  return e && atoi(e) != 0;
+  if (e) return atoi(e) != 0;
+  return !cs->shared_device && !cs->loop;
 }
-StepWait comm_step_wait_args(Context& ctx, unsigned long long epoch) {
+StepWait comm_step_wait_args(Context& ctx, int which, unsigned long long epoch) {
   CommState* cs = ctx.comm;
   StepWait w;
-  w.flag = (const u64*)cs->flags.local + flag_index(CH_STEP, 0, 0);
+  w.flag = (const u64*)cs->flags.local + flag_index(step_channel(which), 0, 0);
   w.err = cs->err_dev; w.ticks = cs->ticks_dev; w.limit_ticks = limit_ticks(cs);
   w.epoch = epoch; w.n = cs->P;
   return w;
 }
 
-void comm_step_wait(Context& ctx, unsigned long long epoch, hipStream_t s) {
+void comm_step_wait(Context& ctx, int which, unsigned long long epoch, hipStream_t s) {
   CommState* cs = ctx.comm;
   WaitArgs W;
   W.n = cs->P; W.epoch = epoch; W.err = cs->err_dev; W.ticks = cs->ticks_dev; W.limit_ticks = limit_ticks(cs);
   const int kind = (int)(epoch & 1);
-  for (int q = 0; q < cs->P; ++q) W.flag[q] = flag_word(cs->flags.local, CH_STEP, kind, q);
+  for (int q = 0; q < cs->P; ++q) W.flag[q] = flag_word(cs->flags.local, step_channel(which), kind, q);
   hipLaunchKernelGGL(wait_kernel, dim3(1), dim3(64), 0, s, W);
 }
 

@@ -29,7 +29,7 @@ struct PeerBuf {
 enum CommGroup { COMM_WORLD = 0, COMM_X = 1, COMM_Y = 2 };
 
 // flag channels: one per (stream, purpose) so that operations in flight on different streams never share an epoch
-enum CommChannel { CH_STEP = 0, CH_BULK = 1, CH_SIDE = 2, CH_STEP2 = 3, CH_COUNT = 4 };
+enum CommChannel { CH_STEP = 0, CH_BULK = 1, CH_SIDE = 2, CH_STEP2 = 3, CH_STEPX = 4, CH_STEPX2 = 5, CH_COUNT = 6 };
 
 struct CommState;
 
@@ -62,26 +62,33 @@ void comm_exchange_big(Context& ctx, CommGroup grp, const double* send, size_t s
                        hipStream_t s);
 int comm_set_bounce(int doubles);
 
-// ---- per-step exchange of the reduction (channel CH_STEP, double-buffered by step parity) ---------------------
-// View handed to the producer kernel (band_reduce.hip kl_kernel): where rank `me`'s message of the given parity lives
-// in every rank's window, and which flag word announces it.
+// ---- per-step exchanges of the reduction (double-buffered by message parity) -------------------------------------
+// Two windows, one flag channel each.  which = 0 ("Y", CH_STEP): after the local mat-vec every rank sends the sums of its
+// local rows / columns to the rank that OWNS the row for the panel work (band_reduce.hip: rows are dealt to the ranks in
+// groups of 16), plus its share of the panel dot products and three scalars to everybody.  which = 1 ("X", CH_STEPX): the
+// owner finishes W and the next x for its rows and sends them to everybody.  (The reference does the same two rounds per
+// column with allreduces over X and Y: src/eigen_prd_t2.F:179,:203 and src/eigen_prd_t6_3.F:174,:296.)
+// View handed to the producer kernel: where rank `me`'s message of the given parity lives in every rank's window, and
+// which flag word announces it.
 struct StepPeers {
   double* slot[EIGX_MAXP];                 // slot[q] = start of my message area (parity 0) in rank q's window
   unsigned long long* flag[EIGX_MAXP];     // flag[q] = my arrival flag (parity 0) in rank q's flag block; parity 1 at +EIGX_MAXP
   size_t parity_stride;                    // doubles between the parity-0 and parity-1 message areas
+  size_t src_stride;                       // doubles between the messages of two sources in a window (reader side)
   unsigned* counter;                       // local last-workgroup counter
   int n;                                   // ranks
 };
-// (re)allocates the step window for messages of msg_doubles each; returns my window (all sources, both parities):
-// message of source q, parity p at  win + (p * P + q) * msg_doubles
-double* comm_step_window(Context& ctx, size_t msg_doubles, StepPeers* peers);
-// one-wave kernel on s: wait until every rank's message of step `epoch` (1-based) has arrived
-void comm_step_wait(Context& ctx, unsigned long long epoch, hipStream_t s);
-// The same wait folded into the consumer kernel's prologue (saves the wait kernel's launch): allowed when no two ranks
-// share a GPU -- on a shared card thousands of spinning consumer workgroups could keep the producers off the CUs --
-// or when EIGX_FUSE_WAIT=1 asks for it (tests at sizes whose grids leave room).  n = 0: nothing to wait for.
+// (re)allocates the step window `which` for messages of msg_doubles each; returns my window (all sources, both parities):
+// message of source q, parity p at  win + p * parity_stride + q * src_stride
+double* comm_step_window(Context& ctx, int which, size_t msg_doubles, StepPeers* peers);
+// one-wave kernel on s: wait until every rank's message `epoch` (1-based) of window `which` has arrived
+void comm_step_wait(Context& ctx, int which, unsigned long long epoch, hipStream_t s);
+// The same wait folded into the consumer kernel's prologue (saves the wait kernel's launch): the default when every rank
+// has its own GPU -- on a shared card thousands of spinning consumer workgroups could keep the producers off the CUs --
+// or when EIGX_FUSE_WAIT=1 asks for it (tests at sizes whose grids leave room); EIGX_FUSE_WAIT=0 forces the wait kernel.
+// n = 0: nothing to wait for.
 struct StepWait {
-  const unsigned long long* flag;   // my flag block of the step channel: parity p, source q at flag[p * EIGX_MAXP + q]
+  const unsigned long long* flag;   // my flag block of the channel: parity p, source q at flag[p * EIGX_MAXP + q]
   int* err;
   unsigned long long* ticks;
   long long limit_ticks;
@@ -89,17 +96,18 @@ struct StepWait {
   int n;
 };
 bool comm_step_wait_fused(const Context& ctx);
-StepWait comm_step_wait_args(Context& ctx, unsigned long long epoch);
-// Collective form of the per-step exchange (selected when the peer windows are not usable, or by EIGX_STEP=coll):
+StepWait comm_step_wait_args(Context& ctx, int which, unsigned long long epoch);
+// Collective form of the per-step exchanges (selected when the peer windows are not usable, or by EIGX_STEP=coll):
 // the producer kernel writes its message into peers.slot[0] (a local send buffer; peers.n == 1, no flags) and
 // comm_step_allgather delivers every rank's message into every rank's step window at the given parity --
 // ncclAllGather over the world communicator on a node, the same group semantics through the peer windows when ranks
 // share a card.  The consumer follows in stream order.
 bool comm_step_collective(const Context& ctx);
-void comm_step_allgather(Context& ctx, const double* sendmsg, int parity, hipStream_t s);
+void comm_step_allgather(Context& ctx, int which, const double* sendmsg, int parity, hipStream_t s);
 // JSON description of the transports in use and of the init-time self-test (eigx_comm_info)
 int comm_info(const Context& ctx, char* buf, int len);
-// first epoch number of the next reduction (epochs are monotone over the life of the communicator)
-unsigned long long comm_step_epoch_base(Context& ctx, unsigned long long nsteps);
+// first epoch number of the next reduction's messages in window `which` (epochs are monotone over the life of the
+// communicator); nmsg = an upper bound of the messages that follow
+unsigned long long comm_step_epoch_base(Context& ctx, int which, unsigned long long nmsg);
 
 }  // namespace eigx

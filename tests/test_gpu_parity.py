@@ -584,14 +584,11 @@ def test_multi_rank_collective_step_exchange(world, n, route, dims):
     _run_multi_rank(world, n, route, 0, dims, {"EIGX_STEP": "coll", "EIGX_EXPECT_STEP": "allgather"})
 
 
-@pytest.mark.parametrize("world,n,route,dims", [(2, 300, "sx", ""), (4, 517, "s", ""), (4, 700, "sx", "1x4"), (4, 5, "s", ""),
-                                                (5, 7, "sx", "1x5")])
-def test_multi_rank_step_exchange_folded_into_the_mat_vec(world, n, route, dims):
-    """the step exchange (reduce this rank's tile partial sums, write them into every rank's window, publish the flag)
-    inside the mat-vec launch (EIGX_FOLD_KL=1: the last tile to finish of a tile row / tile column does that block, agent-scope
-    hand-off between workgroups of one launch) instead of kl_kernel behind it (the default, which every other multi-rank
-    test runs; ranks without tiles at a step use kl_kernel in the folded form as well)"""
-    _run_multi_rank(world, n, route, 0, dims, {"EIGX_FOLD_KL": "1"})
+def test_multi_rank_selftest_errors_on_one_rank_only():
+    """checksum errors of the init-time self-test are local to the receiver: ONE rank sees them (forced), every rank still
+    makes the same board rounds, the verdict is agreed on and -- with no other transport on a shared card -- eigx_init_multi
+    fails on every rank at once (a rank that skipped rounds would pair its vote with the others' buffer handles)"""
+    _run_multi_rank(3, 64, "initfail", 0, "", {"EIGX_SELFTEST_FAIL": "ipc", "EIGX_SELFTEST_FAIL_RANK": "1"})
 
 
 def test_multi_rank_default_rung_is_peer_writes():

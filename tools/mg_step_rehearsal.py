@@ -1,7 +1,8 @@
 """Lab: ONE rank of a P-rank grid alone on the GPU (EIGX_LOOPBACK: every peer window is the rank's own memory, it signals
-on behalf of every source), so that the complete per-rank kernel sequence of the multi-GPU reduction -- local mat-vec with
-the folded exchange, wait, the replicated ka_kernel, panel gathers, local trailing update -- runs at the TRUE local sizes of
-that grid on an otherwise idle card and can be timed.  The numbers computed are meaningless (the other ranks' messages are
+on behalf of every source), so that the complete per-rank kernel sequence of the multi-GPU reduction -- local mat-vec + the
+rank's share of the panel dots, kl_kernel (sums to the row owners), ka_kernel over the rank's own rows (x, W to everybody),
+the waits, panel gathers, local trailing update -- runs at the TRUE local sizes of that grid on an otherwise idle card and
+can be timed.  The numbers computed are meaningless (the other ranks' messages are
 copies of this rank's own); xGMI latency and link bandwidth are not part of it.
 usage: mg_step_rehearsal.py P rank N [band=2] [mf=256] [PxxPy]        (run under rocprofv3 --kernel-trace for durations)"""
 import ctypes as C
@@ -51,11 +52,12 @@ for rep in range(2):                           # first pass allocates the worksp
     t0 = time.perf_counter()
     rc = lib.eigx_band_reduce_dev(n, a.data_ptr(), nx, d.data_ptr(), e.data_ptr(), n, mf, band)
     dt = time.perf_counter() - t0
-    kinds = np.zeros(15)
-    lib.eigx_profile_read_kinds(kinds.ctypes.data_as(C.POINTER(C.c_double)), 5)
+    kinds = np.zeros(18)
+    lib.eigx_profile_read_kinds(kinds.ctypes.data_as(C.POINTER(C.c_double)), 6)
     lib.eigx_profile(0)
     steps = n // band
     us = lambda k: kinds[3 * k + 2] / max(kinds[3 * k], 1) * 1e6
     print(f"rank {rank} ({px},{py}) of {Px}x{Py}, N={n} band={band} mf={mf} rep {rep}: rc {rc}, reduction {dt*1e3:.1f} ms = {dt/steps*1e6:.2f} us per step "
-          f"over {steps} steps; sampled averages over the whole reduction (HIP events, us): mat-vec + folded exchange {us(0):.2f}, "
-          f"exchange kernel {us(2):.2f}, wait {us(3):.2f}, ka {us(4):.2f}, trailing update {us(1):.1f} x {int(kinds[3])}", flush=True)
+          f"over {steps} steps; sampled averages over the whole reduction (HIP events, us): mat-vec + K_P {us(0):.2f}, "
+          f"kl (sums to owners) {us(2):.2f}, wait Y {us(3):.2f}, ka (own rows) {us(4):.2f}, wait X {us(5):.2f}, "
+          f"trailing update {us(1):.1f} x {int(kinds[3])}; d, e finite: {bool(torch.isfinite(d).all() and torch.isfinite(e).all())}", flush=True)
