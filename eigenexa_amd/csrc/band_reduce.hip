@@ -41,9 +41,10 @@ namespace {
 static inline int pd_rows_for(int toprows) { int r = ((toprows + 3) / 4 + 63) / 64 * 64; return r < 512 ? 512 : r; }
 #ifdef EIGX_STAMPS
 #define EIGX_ABL(bit) (R.abl & (bit))
-#define EIGX_STAMP(slot) do { if (R.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) { \
+// (stamp_me: the workgroup in the middle of its role's range takes the stamps)
+#define EIGX_STAMP(slot) do { if (R.dbg && threadIdx.x == 0 && stamp_me) { \
   const unsigned long long _t = __builtin_amdgcn_s_memtime(); atomicAdd(&R.dbg[slot], _t - stamp_prev); stamp_prev = _t; } } while (0)
-#define EIGX_STAMP_INIT unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#define EIGX_STAMP_INIT const bool stamp_me = (bid == nblocks / 2); unsigned long long stamp_prev = __builtin_amdgcn_s_memtime(); (void)stamp_me;
 #else
 #define EIGX_ABL(bit) false
 #define EIGX_STAMP(slot) do {} while (0)
@@ -234,7 +235,6 @@ struct KAArgs {
   int nchunk_ab;          // multi-GPU: row chunks of the (replicated) reflector store = entries of the uA.uB partial sums
   int xpar;               // multi-GPU: parity of the X message this launch writes
   unsigned long long xepoch;   // ... and its epoch
-  const StepPeers* xp;    // ... and where it goes (device copy: keeps the kernel arguments of the one-GPU launches small)
   int G;                  // row groups (of KA_ROWS rows) per workgroup: the scalar work of a workgroup is done once, then
                           // its G row groups follow in a loop (the next group's loads in flight behind the current one)
 };
@@ -271,15 +271,20 @@ __device__ __forceinline__ double xget(const RedArgs& R, int xpar, int v, int r)
   return ld_sys(R.XW + (size_t)xpar * R.xpar_stride + (size_t)s_ * R.xmsg_stride + (size_t)v * R.nown + o_);
 }
 // bounded spin of a consumer kernel's prologue on the P arrival flags of a step message (lane q of the first wave waits for
-// rank q; a time-out sets the sticky error word and the solver reports it), then the workgroup barrier releases the rest
-__device__ __forceinline__ void step_wait_fused(const StepWait& W) {
+// rank q; a time-out sets the sticky error word and the solver reports it), then the workgroup barrier releases the rest.
+// The polls are RELAXED system-scope loads: an acquire load invalidates caches at every look (~1.7 us each), and in the
+// one-launch-per-step form hundreds of waiting workgroups doing that evicted the working set of the roles still computing
+// (N = 32768 on 2 x 4, rehearsal of one rank: 95 us per step with acquire polls, 67 us with relaxed ones; a second level
+// of local gate words with one system-scope poller per role gained nothing on top and was dropped).  Every byte of a
+// message is read with system-scope loads that bypass the caches, so no acquire is needed behind the flag either.
+__device__ __forceinline__ void step_wait_fused(const StepWait& W, bool first_block) {
   const int tid = threadIdx.x;
   if (tid < W.n) {
     const unsigned long long* f = W.flag + (W.epoch & 1) * EIGX_MAXP + tid;
     const long long t0 = wall_clock64();
     if (__hip_atomic_load(W.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
-      while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < W.epoch) {
-        __builtin_amdgcn_s_sleep(1);
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < W.epoch) {
+        for (int z = 0; z < W.naps; ++z) __builtin_amdgcn_s_sleep(2);   // (~60 ns each)
         if (__hip_atomic_load(W.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;   // a peer failed
         if (wall_clock64() - t0 > W.limit_ticks) {
           __hip_atomic_store(W.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -287,13 +292,14 @@ __device__ __forceinline__ void step_wait_fused(const StepWait& W) {
         }
       }
     }
-    if (blockIdx.x == 0 && tid == 0) atomicAdd(W.ticks, (unsigned long long)(wall_clock64() - t0));
+    if (first_block && tid == 0) atomicAdd(W.ticks, (unsigned long long)(wall_clock64() - t0));
   }
   __syncthreads();
 }
 
+// (role body: workgroup `bid` of `nblocks`; XPp = where the X message goes, several GPUs only)
 template <int NB, bool MG, bool LG, int RPBT, int SPBT, int KBT>
-__global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
+__device__ __forceinline__ void ka_body(const RedArgs& R, const KAArgs& S, const StepPeers* XPp, const int bid, const int nblocks) {
   __shared__ double red[64];
   __shared__ double kd[4][256];        // reduced panel-dot vectors: [UuA, WuA, UuB, WuB][kk]  (m <= 256)
   __shared__ double rowU[2][258], rowW[2][258];  // U(c, kk), W(c, kk) for the new block columns c
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   const int kp = hp ? S.kprev : 0;
   const int kloop = hp ? S.kprev : S.k;
   const int kold = hp ? S.kprev : S.k;  // panel slots that are final in memory
-  // The workgroup owns the row groups blockIdx.x * G + g, g = 0 .. G-1 (KA_ROWS rows each).  Everything that does not
+  // The workgroup owns the row groups bid * G + g, g = 0 .. G-1 (KA_ROWS rows each).  Everything that does not
   // depend on the row -- ~85 % of the kernel's instructions: the re-reduction of the tile / panel partial sums, the 2x2
   // algebra, the LDS tables -- is done ONCE per workgroup; with one row group per workgroup the chip ran that overhead
   // 2 (N = 8192) to 8 (N = 32768) times per SIMD, and the PMC counters show the kernel issue-bound there.
@@ -320,11 +326,10 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   // (N = 32768: 5.15 against 5.48 s).
   const int G = LG ? S.G : 1;
   // several GPUs: the workgroup's groups are groups of THIS rank (owned group og <-> global group og * P + me)
-  const int r = MG ? ((blockIdx.x * G) * R.P + R.me) * KA_ROWS + rr : (blockIdx.x * G) * KA_ROWS + rr;      // row of group 0
+  const int r = MG ? ((bid * G) * R.P + R.me) * KA_ROWS + rr : (bid * G) * KA_ROWS + rr;      // row of group 0
   const int rstep = MG ? KA_ROWS * R.P : KA_ROWS;     // rows from a group of the workgroup to its next one
-  const StepPeers& XP = *S.xp;                        // (dereferenced on the several-GPU paths only)
+  const StepPeers& XP = *XPp;                         // (dereferenced on the several-GPU paths only)
   EIGX_STAMP_INIT
-  if (MG && S.wait.n > 0) step_wait_fused(S.wait);
 
   // ============ phase 0: every load that depends on nothing computed in this kernel ==================
   // The kernel is a latency chain (a few hundred bytes per thread): ALL loads are issued first, in
@@ -368,32 +373,10 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   // per-lane address arithmetic with clamps was most of it.  The buffers are padded so that unclamped slots stay
   // inside the allocation (band_reduce_impl).
   // row loads of one row group (this thread's row rg of it): unconditional, clamped / padded addresses
-  auto load_rows = [&](int rg, RowRegs& Q) {
+  // the row's share of the previous mat-vec's result: partial sums (one GPU) / message entries (several GPUs)
+  auto load_rows_msg = [&](int rg, RowRegs& Q) {
     const bool ok = rg < S.rows;
     const bool okp = hp && ok && rg < S.Lprev;
-    {
-      const unsigned voff = (unsigned)ks * (unsigned)ldp + (unsigned)(ok ? rg : 0);
-#pragma unroll
-      for (int j = 0; j < KB; ++j) {
-        // uniform; batches beyond the panel fill re-read batch 0 (same cache lines) instead of touching new memory
-        const int jb = (j * KA_SL < kloop) ? j * KA_SL : 0;
-        const double* bu = Up + (size_t)jb * ldp;
-        const double* bw = Wp + (size_t)jb * ldp;
-        Q.tu[j] = bu[voff];
-        Q.tw[j] = bw[voff];
-      }
-    }
-    {
-      const int ic0 = S.i, ic1 = (S.i > 0) ? S.i - 1 : 0;
-      // column i of the (lazily updated) matrix: from A itself, or from the gathered panel on several GPUs
-      const double* ci = mg ? R.PAN + (size_t)((ic0 > S.pan_c0 ? ic0 : S.pan_c0) - S.pan_c0) * R.ldpan : R.A + (size_t)ic0 * R.lda;
-      const double* cm = mg ? R.PAN + (size_t)((ic1 > S.pan_c0 ? ic1 : S.pan_c0) - S.pan_c0) * R.ldpan : R.A + (size_t)ic1 * R.lda;
-      Q.ai = ci[(rg <= ic0) ? rg : ic0];
-      Q.aim = cm[(rg <= ic1) ? rg : ic1];
-      const int rc = ok ? rg : 0;
-      Q.uA = Up[(size_t)kp * ldp + rc];
-      Q.uB = Up[(size_t)(kp + (NB == 2 ? 1 : 0)) * ldp + rc];
-    }
     // SYMV partial sums of the row: t-th partial, t in [0, nt]: t <= ty -> column result of tile row t
     // (column r of tile (t, ty)); t > ty -> row result of tile column t-1 (row r of tile (ty, t-1))
     if (!mg) {   // (compile-time)  one GPU: slot t of the unified array Y = YC (see band_reduce_impl)
@@ -417,6 +400,34 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       for (int j = 1; j < RPB; ++j) { Q.ta[j] = 0.0; Q.tb[j] = 0.0; }
     }
   };
+  // (with_msg = false: the row's local data only -- what a several-GPU launch requests BEFORE it waits for the messages)
+  auto load_rows = [&](int rg, RowRegs& Q, bool with_msg = true) {
+    const bool ok = rg < S.rows;
+    {
+      const unsigned voff = (unsigned)ks * (unsigned)ldp + (unsigned)(ok ? rg : 0);
+#pragma unroll
+      for (int j = 0; j < KB; ++j) {
+        // uniform; batches beyond the panel fill re-read batch 0 (same cache lines) instead of touching new memory
+        const int jb = (j * KA_SL < kloop) ? j * KA_SL : 0;
+        const double* bu = Up + (size_t)jb * ldp;
+        const double* bw = Wp + (size_t)jb * ldp;
+        Q.tu[j] = bu[voff];
+        Q.tw[j] = bw[voff];
+      }
+    }
+    {
+      const int ic0 = S.i, ic1 = (S.i > 0) ? S.i - 1 : 0;
+      // column i of the (lazily updated) matrix: from A itself, or from the gathered panel on several GPUs
+      const double* ci = mg ? R.PAN + (size_t)((ic0 > S.pan_c0 ? ic0 : S.pan_c0) - S.pan_c0) * R.ldpan : R.A + (size_t)ic0 * R.lda;
+      const double* cm = mg ? R.PAN + (size_t)((ic1 > S.pan_c0 ? ic1 : S.pan_c0) - S.pan_c0) * R.ldpan : R.A + (size_t)ic1 * R.lda;
+      Q.ai = ci[(rg <= ic0) ? rg : ic0];
+      Q.aim = cm[(rg <= ic1) ? rg : ic1];
+      const int rc = ok ? rg : 0;
+      Q.uA = Up[(size_t)kp * ldp + rc];
+      Q.uB = Up[(size_t)(kp + (NB == 2 ? 1 : 0)) * ldp + rc];
+    }
+    if (with_msg) load_rows_msg(rg, Q);
+  };
   // masks of the row data (consume side): entries loaded from clamped addresses for rows / steps that have none
   auto mask_rows = [&](int rg, RowRegs& Q) {
     const bool ok = rg < S.rows;
@@ -427,7 +438,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
 #pragma unroll
     for (int j = 0; j < RPB; ++j) { if (!hp || (!mg && !(j * KA_SL < nt + 1)) || (mg && j > 0)) { Q.ta[j] = 0.0; Q.tb[j] = 0.0; } }
   };
-  load_rows(r, cur);
+  load_rows(r, cur, !(MG && S.wait.n > 0));
   {
     const int kku = (tid < S.k) ? tid : 0;
     const int ic0 = S.i, ic1 = (S.i > 0) ? S.i - 1 : 0;
@@ -438,6 +449,13 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
   }
   bA = R.sc[SC_BETA_A];
   bB = R.sc[SC_BETA_B];
+  if (MG && S.wait.n > 0) {
+    // several GPUs, wait folded into this kernel: everything above is local data (panel rows, the next block columns,
+    // scalars) and travels while the first wave polls the arrival flags of the Y messages; what follows reads them
+    step_wait_fused(S.wait, bid == 0);
+    EIGX_STAMP(5);
+    load_rows_msg(r, cur);
+  }
   // panel dots: thread kk = tid (< kp <= 256) sums entry (kind, kk) over the K_P row chunks
   {
 #pragma unroll
@@ -763,7 +781,7 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       if (MG) {
         // my rows of the new x and of the finished W into every rank's X window: the 16 row lanes of the group write 128
         // contiguous bytes per field and destination (write-through stores over xGMI)
-        const size_t off = (size_t)S.xpar * XP.parity_stride + (size_t)(((blockIdx.x * G + g) << 4) | rr);
+        const size_t off = (size_t)S.xpar * XP.parity_stride + (size_t)(((bid * G + g) << 4) | rr);
         for (int d_ = 0; d_ < XP.n; ++d_) {
           double* q_ = XP.slot[d_] + off;
           if (S.ncols > 0) { st_sys(q_, xi); if (NB == 2) st_sys(q_ + R.nown, xim); }
@@ -783,8 +801,8 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) gg[q] = wave_sum(gg[q]);
     if (lane == 0) {
-      if (MG) { st_agent(&R.GP[blockIdx.x * 3 + 0], gg[0]); st_agent(&R.GP[blockIdx.x * 3 + 1], gg[1]); st_agent(&R.GP[blockIdx.x * 3 + 2], gg[2]); }
-      else { R.GP[blockIdx.x * 3 + 0] = gg[0]; R.GP[blockIdx.x * 3 + 1] = gg[1]; R.GP[blockIdx.x * 3 + 2] = gg[2]; }
+      if (MG) { st_agent(&R.GP[bid * 3 + 0], gg[0]); st_agent(&R.GP[bid * 3 + 1], gg[1]); st_agent(&R.GP[bid * 3 + 2], gg[2]); }
+      else { R.GP[bid * 3 + 0] = gg[0]; R.GP[bid * 3 + 1] = gg[1]; R.GP[bid * 3 + 2] = gg[2]; }
     }
   }
   if (MG) {
@@ -792,17 +810,19 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
     // the waves, one agent-scope add counts the workgroup; the workgroup whose add came last sums the rank's Gram partial
     // sums in a fixed order (whoever it is), appends them to the message and raises the flag on every rank (the only store
     // with a system-scope release) -- the protocol of kl_publish, self-tested at init (comm.hip st_step_push_kernel).
+    EIGX_STAMP(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    EIGX_STAMP(12);
     if (tid == 0) {
       const unsigned tk = atomicAdd(XP.counter, 1u);
-      lastw = (tk + 1u == gridDim.x);
+      lastw = (tk + 1u == (unsigned)nblocks);
       if (lastw) *XP.counter = 0;
     }
     __syncthreads();
     if (lastw) {
       double g3[3] = {0.0, 0.0, 0.0};
-      for (int q = tid; q < (int)gridDim.x; q += 256) {
+      for (int q = tid; q < nblocks; q += 256) {
         g3[0] += ld_agent(&R.GP[3 * q]); g3[1] += ld_agent(&R.GP[3 * q + 1]); g3[2] += ld_agent(&R.GP[3 * q + 2]);
       }
       block_sum_multi<3>(g3, red);
@@ -813,12 +833,20 @@ __global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the Gram stores and the flag stores are the first wave's)
       if (tid < XP.n && XP.flag[tid])
         __hip_atomic_store(XP.flag[tid] + S.xpar * EIGX_MAXP, S.xepoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef EIGX_STAMPS
+      if (R.dbg && tid == 0) { atomicAdd(&R.dbg[13], __builtin_amdgcn_s_memtime() - stamp_prev); atomicAdd(&R.dbg[14], 1ull); }
+#endif
     }
   }
   EIGX_STAMP(4);
 #ifdef EIGX_STAMPS
-  if (R.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) atomicAdd(&R.dbg[7], 1ull);
+  if (R.dbg && threadIdx.x == 0 && stamp_me) atomicAdd(&R.dbg[7], 1ull);
 #endif
+}
+
+template <int NB, bool MG, bool LG, int RPBT, int SPBT, int KBT>
+__global__ __launch_bounds__(256) void ka_kernel(RedArgs R, KAArgs S) {
+  ka_body<NB, MG, LG, RPBT, SPBT, KBT>(R, S, nullptr, blockIdx.x, gridDim.x);
 }
 
 // =================================================================================================
@@ -986,18 +1014,19 @@ __device__ __forceinline__ void kl_publish(const KLArgs& K, unsigned* counter, u
     __hip_atomic_store(K.peers.flag[threadIdx.x] + K.par * EIGX_MAXP, K.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// (role body of the step launch: workgroup `bid` of `nblocks` = local rows / 64 + local columns / 64 + 2 NB)
 template <int NB>
-__global__ __launch_bounds__(256) void kl_kernel(RedArgs R, KLArgs K) {
+__device__ __forceinline__ void kl_body(const RedArgs& R, const KLArgs& K, const int bid, const int nblocks) {
   // 64 rows (columns) per workgroup
   __shared__ double comb[4][64][2];
   __shared__ double red[16];
   __shared__ int last;
-  if ((int)blockIdx.x >= (int)gridDim.x - 2 * NB) {
+  if (bid >= nblocks - 2 * NB) {
     // panel dots, second level: one workgroup per kind q; entry (q, panel column kk) = sum over this rank's row chunks in
     // chunk order (deterministic), ALL chunk loads of a thread in one batch (<= 12 chunks: one memory round trip); the
     // rank's share goes into every rank's window (ka_kernel adds the P shares in rank order)
     const int m = R.m, tid = threadIdx.x;
-    const int q = (int)blockIdx.x - ((int)gridDim.x - 2 * NB);
+    const int q = bid - (nblocks - 2 * NB);
     constexpr int MAXC = 12;
     if (tid < K.kfill) {
       double v[MAXC];
@@ -1011,12 +1040,12 @@ __global__ __launch_bounds__(256) void kl_kernel(RedArgs R, KLArgs K) {
       for (int d = 0; d < K.peers.n; ++d) st_sys(K.peers.slot[d] + off, acc);
     }
   } else {
-    const bool rows = (int)blockIdx.x < K.nbr;
-    kl_chunk<NB>(R, K, rows, (rows ? blockIdx.x : blockIdx.x - K.nbr) * 64, comb);
-    if (blockIdx.x == 0) kl_scalars<NB>(R, K, red);   // (rows / columns that no tile covers get explicit zeros above: tend = 0)
+    const bool rows = bid < K.nbr;
+    kl_chunk<NB>(R, K, rows, (rows ? bid : bid - K.nbr) * 64, comb);
+    if (bid == 0) kl_scalars<NB>(R, K, red);   // (rows / columns that no tile covers get explicit zeros above: tend = 0)
   }
   // every storing wave drains its stores; the last workgroup to arrive publishes the flag on every rank
-  kl_publish(K, K.peers.counter, 1u, gridDim.x, &last);
+  kl_publish(K, K.peers.counter, 1u, (unsigned)nblocks, &last);
 }
 
 // Reflector scalars of a step, computed by EVERY workgroup of the mat-vec launch in the same order (bit-identical
@@ -1178,7 +1207,10 @@ __device__ __forceinline__ void kp_role(const RedArgs& R, const KBArgs& B, const
       for (int c = 0; c < 4; ++c) {
         const int kk = (kk0 + c < k) ? kk0 + c : kk0;
         tu[j][c] = Up[(size_t)kk * ldp + r];
-        tw[j][c] = Wp[(size_t)kk * ldp + r];
+        // several GPUs: the W columns that the ka role of THIS launch finished (its plain stores into the panel are not
+        // visible across the XCDs before the launch ends) come from the rank's own slot of the X message like x itself
+        if (MG && B.wk >= 0 && kk >= B.wk && kk < B.wk + NV) tw[j][c] = ld_sys(xme + (size_t)(2 + kk - B.wk) * xst + ro);
+        else tw[j][c] = Wp[(size_t)kk * ldp + r];
       }
     }
 #pragma unroll
@@ -1222,7 +1254,7 @@ template <int K> struct IC { static constexpr int value = K; };
 // processes: 4751 ms against 5326 ms with the pipeline -- more requests in flight per CU than the memory system likes);
 // the launch picks by active size (g_symv_unc, eigx_tune key 14).
 template <int NV, int RB, bool NTL, bool MG, bool UNC>
-__global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
+__device__ __forceinline__ void symv_body(const RedArgs& R, const KBArgs& B, const int bid0, const int nblocks) {
   constexpr int T = 128 * RB;
   // NTL: non-temporal A loads, chosen by the launch for triangles far beyond L2 + Infinity Cache (g_symv_nt)
   constexpr int DYN = 4 * NV * T;
@@ -1235,9 +1267,9 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   // (row-major): no empty workgroups for the lower triangle
   // (several GPUs: npd x ncg dot workgroups over the rank's own rows, then npd_s store workgroups over all rows)
   const int nkp = MG ? B.npd * B.ncg + B.npd_s : B.npd * (B.ncg + 1);
-  const bool panel_role = (int)blockIdx.x < nkp;     // K_P first: its workgroups are the long ones at small L
-  if (MG && B.xwait.n > 0) step_wait_fused(B.xwait); // this step's x (X message) must be in: here, or a wait kernel ran
-  const int bid = (int)blockIdx.x - nkp;
+  const bool panel_role = bid0 < nkp;     // K_P first: its workgroups are the long ones at small L
+  if (MG && B.xwait.n > 0) step_wait_fused(B.xwait, bid0 == 0); // this step's x (X message) must be in: here, or a wait kernel ran
+  const int bid = bid0 - nkp;
   int tyv = 0, txv = 0;
   if (!panel_role && MG) {
     // multi-GPU: tiles of the LOCAL block a(Lr, Lc) that touch the global upper triangle.  Grid order: the tiles of
@@ -1281,11 +1313,11 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
     tyv = ty;
     txv = ty + (bid - (ty * B.nt - ty * (ty - 1) / 2));
   } else if (MG) {
-    const int q = blockIdx.x, nd = B.npd * B.ncg;
+    const int q = bid0, nd = B.npd * B.ncg;
     if (q < nd) { tyv = B.nt + q / B.ncg; txv = q - (q / B.ncg) * B.ncg; }   // dots: (row chunk of owned rows, column group)
     else { tyv = B.nt + (q - nd); txv = B.ncg; }                             // store: row chunk of all rows
   } else {
-    const int q = blockIdx.x;
+    const int q = bid0;
     tyv = B.nt + q / (B.ncg + 1);   // nt + row chunk
     txv = q - (q / (B.ncg + 1)) * (B.ncg + 1);   // column group
   }
@@ -1298,7 +1330,9 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   const int Lr = MG ? B.Lr : L, Lc = MG ? B.Lc : L;
   auto grow = [&](int lr) { return MG ? lr * R.Px + R.px : lr; };
   auto gcol = [&](int lc) { return MG ? lc * R.Py + R.py : lc; };
-  EIGX_STAMP_INIT
+#ifdef EIGX_STAMPS
+  const bool stamp_me = (bid0 == nblocks / 2); unsigned long long stamp_prev = __builtin_amdgcn_s_memtime(); (void)stamp_me;
+#endif
   const int wcol0 = wave * (T / 4);       // first tile column of this wave
   // Loads that feed the reflector scalars go FIRST (vmcnt retires in order: behind the A-tile loads below they
   // would make the scalar phase wait for HBM); the empty asm keeps the compiler from sinking them.
@@ -1366,7 +1400,7 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
   }
 
 #ifdef EIGX_STAMPS
-  if (!panel_role) { if (R.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); atomicAdd(&R.dbg[8], _t - stamp_prev); stamp_prev = _t; } }
+  if (!panel_role) { if (R.dbg && threadIdx.x == 0 && stamp_me) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); atomicAdd(&R.dbg[8], _t - stamp_prev); stamp_prev = _t; } }
 #endif
   // ---- reflector scalars (every workgroup, same order) -------------------------------------------
   // NV = 1: s = -sign(||x||, x_piv), beta = ||x||^2 - s x_piv from the Gram partials of K_A.
@@ -1660,9 +1694,38 @@ __global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
     R.SP[w * 3 + 0] = sp[0]; R.SP[w * 3 + 1] = sp[1]; R.SP[w * 3 + 2] = sp[2];
   }
   EIGX_STAMP(11);
-  if (R.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) atomicAdd(&R.dbg[15], 1ull);
+#ifdef EIGX_STAMPS
+  if (R.dbg && threadIdx.x == 0 && stamp_me) atomicAdd(&R.dbg[15], 1ull);
+#endif
 }
 
+template <int NV, int RB, bool NTL, bool MG, bool UNC>
+__global__ __launch_bounds__(256) void symv_kernel(RedArgs R, KBArgs B) {
+  symv_body<NV, RB, NTL, MG, UNC>(R, B, blockIdx.x, gridDim.x);
+}
+
+// Several GPUs: ONE launch per step.  Roles in dispatch order (a 1-D grid is dispatched in workgroup order, so a role never
+// waits for a workgroup that could be kept off the CUs by a later one):
+//   [0, nkl)          kl_body of the PREVIOUS step: sums of this rank's tile partial sums to the row owners (Y message);
+//   [nkl, nkl + nka)  ka_body: spins until every rank's Y message is in, finishes W and forms x for this rank's rows,
+//                     sends them to everybody (X message);
+//   the rest          symv_body of THIS step (K_P workgroups, then tiles): spins until every rank's X message is in.
+// Between the ranks the order is enforced by the flags, inside a rank by the flags as well (its own messages count): what
+// kl reads (the previous launch's partial sums) is complete at the launch boundary and is not overwritten before the X
+// flags -- which follow the Y flags, which this rank raises after its last kl workgroup has read.  Against three launches
+// with a wait each, this saves two launch boundaries per step and lets the consumers' local prologue loads run while
+// they wait.  With wait kernels (ranks sharing a card: tests) or the collective exchanges the same kernel is launched
+// role by role (the other counts zero).
+struct MGStep { int nkl, nka; StepPeers xpeers; };
+template <int NV, int RB, bool NTL, bool UNC>
+__global__ __launch_bounds__(256) void mg_step_kernel(RedArgs R, KLArgs KL, KAArgs S, KBArgs B, MGStep M) {
+  int bid = blockIdx.x;
+  if (bid < M.nkl) { kl_body<NV>(R, KL, bid, M.nkl); return; }
+  bid -= M.nkl;
+  if (bid < M.nka) { ka_body<NV, true, false, 1, 8, 8>(R, S, &M.xpeers, bid, M.nka); return; }
+  bid -= M.nka;
+  symv_body<NV, RB, NTL, true, UNC>(R, B, bid, (int)gridDim.x - M.nkl - M.nka);
+}
 
 // zero-fill helper
 __global__ void fill_kernel(double* p, size_t n, double v) {
@@ -1711,7 +1774,7 @@ __global__ void unpack_panel_kernel(const double* __restrict__ recv, size_t coun
 // their owners' X messages (parity xpar) into the local panel -- the trailing update needs the complete [U | W | U]
 template <int NB>
 __global__ void mg_wcopy_kernel(RedArgs R, int xpar, int wk, int rows, StepWait W) {
-  if (W.n > 0) step_wait_fused(W);
+  if (W.n > 0) step_wait_fused(W, blockIdx.x == 0);
   double* Wp = R.UW + (size_t)R.ldp * R.m;
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
     int s_, o_;
@@ -1725,7 +1788,7 @@ __global__ void mg_wcopy_kernel(RedArgs R, int xpar, int wk, int rows, StepWait 
 // follows that would publish them): d(i), and for two columns e(i,1) = A_eff(i-1,i), d(i-1)
 template <int NB>
 __global__ void mg_tail_kernel(RedArgs R, int xpar, int i, int ncols, StepWait W) {
-  if (W.n > 0) step_wait_fused(W);
+  if (W.n > 0) step_wait_fused(W, blockIdx.x == 0);
   if (threadIdx.x == 0 && ncols > 0) {
     R.d[i] = xget<true>(R, xpar, 0, i);
     if (ncols > 1) { R.e[i] = xget<true>(R, xpar, 0, i - 1); R.d[i - 1] = xget<true>(R, xpar, 1, i - 1); }
@@ -1808,7 +1871,6 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
 #endif
   // ---- multi-GPU state: step window, gathered panel, compact panels ------------------------------------------
   StepPeers peers, xpeers;
-  StepPeers* xp_dev = nullptr;
   unsigned long long epoch = 0;          // epoch of the Y message that the NEXT K_A consumes
   unsigned long long xepoch = 0;         // epoch of the X message that the last K_A launch wrote
   PeerBuf* panr = nullptr;               // receive window of the panel gather: [rank][mloc_max][nxs]
@@ -1825,9 +1887,6 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     R.XW = comm_step_window(ctx, 1, (size_t)R.xmsg_stride, &xpeers);
     epoch = comm_step_epoch_base(ctx, 0, (unsigned long long)(n / NB + 2));
     xepoch = comm_step_epoch_base(ctx, 1, (unsigned long long)(n / NB + n / m + 8));
-    xp_dev = ctx.pool.get_t<StepPeers>("red.xpeers", 1);
-    EIGX_HIP_CHECK(hipMemcpyAsync(xp_dev, &xpeers, sizeof(StepPeers), hipMemcpyHostToDevice, st));
-    EIGX_HIP_CHECK(hipStreamSynchronize(st));   // (xpeers lives on this stack frame; once per reduction)
     panr = comm_buffer(ctx, "red.panr", (size_t)G.nranks * pan_count * sizeof(double));
     pan = ctx.pool.get_t<double>("red.pan", (size_t)ldp * (m + NB));
     pan_send = ctx.pool.get_t<double>("red.pansend", pan_count);
@@ -1863,44 +1922,43 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   // ka_kernel's first batches of loads are unconditional (clamped), so their sizes are template parameters matched to
   // the step: partial sums of a row (nt + 1 slots: 1 / 2 / 3 / 5 / 10 batches of KA_SL = 16), folded rows of tile
   // scalars (nt <= 15 / 31 / 63: 2 / 4 / 8 per wave), panel columns (k <= 32 / 64 / more: 2 / 4 / 8 per slice)
-  auto launch_ka = [&](int nwg, const KAArgs& K) {
+  auto launch_ka = [&](int nwg, const KAArgs& K) {   // (one GPU)
     const bool fit = g_ka_fit != 0;
     const int nslot = fit ? K.nt_prev + 1 : 1 << 30, ntp = fit ? K.nt_prev : 1 << 30;
     const int kk = fit ? (K.has_prev ? K.kprev : K.k) : 1 << 30;
-#define EIGX_KA3(MGV, RPBV, SPBV, KBV)                                                                                  \
+#define EIGX_KA3(RPBV, SPBV, KBV)                                                                                        \
     do {                                                                                                                \
-      if (K.G > 1) hipLaunchKernelGGL((ka_kernel<NB, MGV, true, RPBV, SPBV, KBV>), dim3(nwg), dim3(256), 0, st, R, K);   \
-      else hipLaunchKernelGGL((ka_kernel<NB, MGV, false, RPBV, SPBV, KBV>), dim3(nwg), dim3(256), 0, st, R, K);          \
+      if (K.G > 1) hipLaunchKernelGGL((ka_kernel<NB, false, true, RPBV, SPBV, KBV>), dim3(nwg), dim3(256), 0, st, R, K); \
+      else hipLaunchKernelGGL((ka_kernel<NB, false, false, RPBV, SPBV, KBV>), dim3(nwg), dim3(256), 0, st, R, K);        \
     } while (0)
-#define EIGX_KA2(MGV, RPBV, SPBV)                                                                                       \
+#define EIGX_KA2(RPBV, SPBV)                                                                                             \
     do {                                                                                                                \
-      if (kk <= 2 * KA_SL) EIGX_KA3(MGV, RPBV, SPBV, 2);                                                                \
-      else if (kk <= 4 * KA_SL) EIGX_KA3(MGV, RPBV, SPBV, 4);                                                           \
-      else EIGX_KA3(MGV, RPBV, SPBV, 8);                                                                                \
+      if (kk <= 2 * KA_SL) EIGX_KA3(RPBV, SPBV, 2);                                                                      \
+      else if (kk <= 4 * KA_SL) EIGX_KA3(RPBV, SPBV, 4);                                                                 \
+      else EIGX_KA3(RPBV, SPBV, 8);                                                                                      \
     } while (0)
-    if (mg) EIGX_KA2(true, 1, 8);
-    else if (nslot <= 1 * KA_SL && ntp <= 15) EIGX_KA2(false, 1, 2);
-    else if (nslot <= 2 * KA_SL && ntp <= 31) EIGX_KA2(false, 2, 4);
-    else if (nslot <= 3 * KA_SL) EIGX_KA2(false, 3, 8);
-    else if (nslot <= 5 * KA_SL) EIGX_KA2(false, 5, 8);
-    else EIGX_KA2(false, 10, 8);
+    if (nslot <= 1 * KA_SL && ntp <= 15) EIGX_KA2(1, 2);
+    else if (nslot <= 2 * KA_SL && ntp <= 31) EIGX_KA2(2, 4);
+    else if (nslot <= 3 * KA_SL) EIGX_KA2(3, 8);
+    else if (nslot <= 5 * KA_SL) EIGX_KA2(5, 8);
+    else EIGX_KA2(10, 8);
 #undef EIGX_KA2
 #undef EIGX_KA3
   };
   S.has_prev = 0; S.iprev = 0; S.Lprev = 0; S.kprev = 0; S.nchunk_prev = 0; S.nt_prev = 0; S.lgT_prev = 7;
   S.par = 0; S.pan_c0 = 0; S.G = 1;
-  S.wait.n = 0; S.wait.flag = nullptr; S.wait.err = nullptr; S.wait.ticks = nullptr; S.wait.limit_ticks = 0; S.wait.epoch = 0;
-  S.nchunk_ab = 0; S.xpar = 0; S.xepoch = 0; S.xp = xp_dev;
+  S.wait.n = 0; S.wait.flag = nullptr; S.wait.err = nullptr; S.wait.ticks = nullptr; S.wait.limit_ticks = 0; S.wait.epoch = 0; S.wait.naps = 1;
+  S.nchunk_ab = 0; S.xpar = 0; S.xepoch = 0;
   const StepWait no_wait = S.wait;
   const bool fuse_wait = mg && comm_step_wait_fused(ctx);
   const bool step_coll = mg && comm_step_collective(ctx);   // per-step exchanges as allgathers (RCCL / emulated)
   const int step_fence = (getenv("EIGX_STEP_FENCE") && atoi(getenv("EIGX_STEP_FENCE")) != 0) ? 1 : 0;
-  // several GPUs: K_A runs over this rank's row groups only: workgroups / groups per workgroup for the groups below `rows`
+  // K_A's grid.  Several GPUs: K_A runs over this rank's row groups only, one group per workgroup
   auto ka_grid = [&](int rows, int& Gout) {
     const int ng = (rows + KA_ROWS - 1) / KA_ROWS;
-    const int own = mg ? local_count(ng, G.nranks, G.rank) : ng;
-    Gout = (own > 2 * g_ka_wgs) ? (own + g_ka_wgs - 1) / g_ka_wgs : 1;
-    const int nwg = (own + Gout - 1) / Gout;
+    if (mg) { Gout = 1; const int own = local_count(ng, G.nranks, G.rank); return own > 0 ? own : 1; }
+    Gout = (ng > 2 * g_ka_wgs) ? (ng + g_ka_wgs - 1) / g_ka_wgs : 1;
+    const int nwg = (ng + Gout - 1) / Gout;
     return nwg > 0 ? nwg : 1;
   };
   // rows below L that this rank owns (they come first in its owned index order)
@@ -1908,23 +1966,72 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     const int gfull = L / KA_ROWS, rem = L % KA_ROWS;
     return local_count(gfull, G.nranks, G.rank) * KA_ROWS + ((rem > 0 && gfull % G.nranks == G.rank) ? rem : 0);
   };
-  // several GPUs: the next K_A launch writes X message xepoch + 1; behind it (collective form) the allgather that delivers it
+  // ---- several GPUs: the step launch (mg_step_kernel) with whatever roles are due --------------------------------
+  // fuse_wait (every rank on its own GPU): one launch per step, [kl of the previous step | K_A | mat-vec], the consumers
+  // spin on the flags in their prologues.  Otherwise (ranks sharing a card: wait kernels; collective exchanges) the roles
+  // are launched one by one with the wait kernel / allgather between them.
+  // polls of a spinning consumer: naps of ~60 ns between two looks at the flags (lab knob EIGX_SPIN_NAPS="ka,x"; with
+  // relaxed polls 1 .. 64 naps all give the same time within 2 %)
+  int naps_ka = 1, naps_x = 2;
+  if (const char* e = getenv("EIGX_SPIN_NAPS")) { if (sscanf(e, "%d,%d", &naps_ka, &naps_x) < 2) naps_x = naps_ka; }
+  MGStep MS;
+  memset(&MS, 0, sizeof(MS));
+  MS.xpeers = xpeers;
+  KLArgs KLnone;
+  memset(&KLnone, 0, sizeof(KLnone));
+  KBArgs Bnone;
+  memset(&Bnone, 0, sizeof(Bnone));
+  Bnone.xwait = no_wait;
+  // symv_T: tile edge of the mat-vec role (0: no mat-vec in this launch)
+  auto launch_roles = [&](int nkl, const KLArgs& KLa, int nka, const KAArgs& Ka, int nsymv, const KBArgs& Ba, int symv_T, bool nt_loads, bool unc) {
+    MGStep M = MS;
+    M.nkl = nkl; M.nka = nka;
+    const int gx = nkl + nka + nsymv;
+    if (gx <= 0) return;
+#define EIGX_STEP(RBv, NTv)                                                                                             \
+  do {                                                                                                                  \
+    if (unc) hipLaunchKernelGGL((mg_step_kernel<NB, RBv, NTv, true>), dim3(gx), dim3(256), 0, st, R, KLa, Ka, Ba, M);    \
+    else hipLaunchKernelGGL((mg_step_kernel<NB, RBv, NTv, false>), dim3(gx), dim3(256), 0, st, R, KLa, Ka, Ba, M);       \
+  } while (0)
+    if (symv_T == 0) hipLaunchKernelGGL((mg_step_kernel<NB, 1, false, true>), dim3(gx), dim3(256), 0, st, R, KLa, Ka, Ba, M);
+    else if (symv_T == 128) EIGX_STEP(1, false);
+    else if (symv_T == 256 && !nt_loads) EIGX_STEP(2, false);
+    else if (symv_T == 256) EIGX_STEP(2, true);
+    else if (!nt_loads) EIGX_STEP(4, false);
+    else EIGX_STEP(4, true);
+#undef EIGX_STEP
+  };
   int wk_last = -1;                       // W columns that the last K_A launch finished (-1: none), for the next mat-vec's copy
   int last_ka_i = -1, last_ka_ncols = 0;
+  bool kl_pending = false;                // fuse_wait: the last mat-vec's kl role rides in the next launch
+  KLArgs KLp = KLnone;
+  int nkl_p = 0;
+  // a K_A launch writes X message ++xepoch
   auto ka_mg_begin = [&](KAArgs& K) {
-    if (!mg) return;
     ++xepoch;
-    K.xpar = (int)(xepoch & 1); K.xepoch = xepoch; K.xp = xp_dev;
+    K.xpar = (int)(xepoch & 1); K.xepoch = xepoch;
     wk_last = K.has_prev ? K.kprev : -1;
     last_ka_i = K.i; last_ka_ncols = K.ncols;
+    K.wait = (fuse_wait && K.has_prev) ? comm_step_wait_args(ctx, 0, epoch) : no_wait;
+    K.wait.naps = naps_ka;
   };
-  auto ka_mg_end = [&](const KAArgs& K) {
-    if (mg && step_coll) comm_step_allgather(ctx, 1, xpeers.slot[0], K.xpar, st);
+  // roles one by one (no fused waits): [kl] was launched behind its mat-vec; here: wait / allgather Y, then [K_A]
+  auto ka_mg_alone = [&](int nwg, const KAArgs& K, bool prof_it) {
+    if (K.has_prev && !step_coll) {
+      if (prof_it) ctx.prof_begin(3, 0.0, st);
+      comm_step_wait(ctx, 0, epoch, st);
+      if (prof_it) ctx.prof_end(st);
+    }
+    if (prof_it) ctx.prof_begin(4, 0.0, st);
+    launch_roles(0, KLnone, nwg, K, 0, Bnone, 0, false, true);
+    if (step_coll) comm_step_allgather(ctx, 1, xpeers.slot[0], K.xpar, st);
+    if (prof_it) ctx.prof_end(st);
   };
-  // consumer side of the X message: a StepWait for the kernel's prologue, or a wait kernel in front of it (then n = 0)
+  // consumer side of the X message outside the step launch: a StepWait for the kernel's prologue, or a wait kernel in
+  // front of it (then n = 0)
   auto x_wait = [&](int prof_kind) -> StepWait {
     if (!mg || step_coll) return no_wait;
-    if (fuse_wait) return comm_step_wait_args(ctx, 1, xepoch);
+    if (fuse_wait) { StepWait w = comm_step_wait_args(ctx, 1, xepoch); w.naps = naps_x; return w; }
     if (prof_kind >= 0) ctx.prof_begin(prof_kind, 0.0, st);
     comm_step_wait(ctx, 1, xepoch, st);
     if (prof_kind >= 0) ctx.prof_end(st);
@@ -1954,25 +2061,21 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     // row groups per workgroup: one wave per SIMD at most (1024 SIMDs = 256 workgroups of 4 waves); the scalar work
     // of a workgroup is done once for all its groups
     const int nb_ka = ka_grid(S.rows, S.G);
-    if (S.rows > 0 && (S.has_prev || ncols > 0)) {
-      // the previous step's Y messages of every rank must be in: a wait kernel, or the wait folded into K_A's prologue
-      S.wait.n = 0;
-      if (mg && S.has_prev && !step_coll) {
-        if (fuse_wait) S.wait = comm_step_wait_args(ctx, 0, epoch);
-        else {
-          if (prof_step) ctx.prof_begin(3, 0.0, st);
-          comm_step_wait(ctx, 0, epoch, st);
-          if (prof_step) ctx.prof_end(st);
-        }
-      }
-      ka_mg_begin(S);
-      if (prof_step) ctx.prof_begin(4, 0.0, st);
+    const bool need_ka = S.rows > 0 && (S.has_prev || ncols > 0);
+    bool ka_held = false;      // several GPUs, fuse_wait: K_A rides in the step launch below
+    if (need_ka && !mg) {
       launch_ka(nb_ka, S);
-      ka_mg_end(S);
-      if (prof_step) ctx.prof_end(st);
-      S.wait.n = 0;
+    } else if (need_ka) {
+      ka_mg_begin(S);
+      if (fuse_wait) ka_held = true;
+      else ka_mg_alone(nb_ka, S, prof_step);
     }
-    if (!do_step) { prof_step = false; break; }
+    if (!do_step) {
+      if (ka_held) launch_roles(kl_pending ? nkl_p : 0, KLp, nb_ka, S, 0, Bnone, 0, false, true);
+      kl_pending = false;
+      prof_step = false;
+      break;
+    }
     KBArgs B;
     B.i = i; B.L = L; B.k = k;
     B.ncg = (k + PD_COLS - 1) / PD_COLS;
@@ -1981,8 +2084,8 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     B.nown_L = 0; B.npd_s = 0; B.pdr_s = 0; B.wk = -1; B.xpar = 0; B.xwait = no_wait;
     int npd = (B.toprows + B.pdr - 1) / B.pdr;
     if (mg) {
-      // several GPUs: the panel dots over the rank's own rows below L in <= 8 chunks (>= 512 rows each; kl_kernel adds
-      // them up and sends the share), the reflector store over all rows in <= 4 P chunks (the local tile stream is 1 / P of
+      // several GPUs: the panel dots over the rank's own rows below L in <= 8 chunks (>= 512 rows each; kl adds them up
+      // and sends the share), the reflector store over all rows in <= 4 P chunks (the local tile stream is 1 / P of
       // one GPU's: a long K_P chunk would outlast it)
       B.nown_L = own_count(L);
       int r_ = ((B.nown_L + 7) / 8 + 63) / 64 * 64;
@@ -2027,11 +2130,29 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     if (prof) ctx.prof_begin(0, 8.0 * ((double)L * (L + 1) / 2) / R.P, st);  // this rank's share of the triangle
     const bool nt_loads = (mg ? sqrt((double)B.Lr * B.Lc) : (double)L) > g_symv_nt;
     const bool unc = (mg ? sqrt((double)B.Lr * B.Lc) : (double)L) <= g_symv_unc;   // latency-bound sizes: the true two-unit pipeline
-    // several GPUs: the Y exchange behind the mat-vec -- kl_kernel reduces this rank's tile partial sums, writes them into
-    // the owners' windows and publishes the flag
-    KLArgs KL;
-    memset(&KL, 0, sizeof(KL));
-    if (mg) {
+    if (!mg) {
+#define EIGX_SYMV(RBv, NTv)                                                                                         \
+  do {                                                                                                              \
+    if (unc) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false, true>), dim3(gx), dim3(256), 0, st, R, B);        \
+    else hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false, false>), dim3(gx), dim3(256), 0, st, R, B);           \
+  } while (0)
+      if (T == 128) EIGX_SYMV(1, false);
+      else if (T == 256 && !nt_loads) EIGX_SYMV(2, false);
+      else if (T == 256) EIGX_SYMV(2, true);
+      else if (!nt_loads) EIGX_SYMV(4, false);
+      else EIGX_SYMV(4, true);
+#undef EIGX_SYMV
+      if (prof) ctx.prof_end(st);
+    } else {
+      // the step launch: [kl of the previous step | K_A | this mat-vec] (fuse_wait), or the mat-vec alone
+      if (ka_held) launch_roles(kl_pending ? nkl_p : 0, KLp, nb_ka, S, gx, B, T, nt_loads, unc);
+      else launch_roles(0, KLnone, 0, S, gx, B, T, nt_loads, unc);
+      kl_pending = false;
+      if (prof) ctx.prof_end(st);
+      // the Y exchange behind the mat-vec: kl reduces this rank's tile partial sums, writes them into the owners' windows
+      // and publishes the flag -- in the next launch (fuse_wait) or right away
+      KLArgs KL;
+      memset(&KL, 0, sizeof(KL));
       ++epoch;
       KL.L = L; KL.Lr = B.Lr; KL.Lc = B.Lc; KL.T = T; KL.ntc = B.ntc;
       KL.nbr = ceil_div(B.Lr > 0 ? B.Lr : 1, 64);
@@ -2040,28 +2161,15 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       KL.peers = peers;
       KL.kd2 = R.KD; KL.npd2 = npd; KL.kfill = k;
       KL.fence = step_fence;
-    }
-#define EIGX_SYMV(RBv, NTv)                                                                                         \
-  do {                                                                                                              \
-    if (mg && unc) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true, true>), dim3(gx), dim3(256), 0, st, R, B);   \
-    else if (mg) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, true, false>), dim3(gx), dim3(256), 0, st, R, B);    \
-    else if (unc) hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false, true>), dim3(gx), dim3(256), 0, st, R, B);   \
-    else hipLaunchKernelGGL((symv_kernel<NB, RBv, NTv, false, false>), dim3(gx), dim3(256), 0, st, R, B);           \
-  } while (0)
-    if (T == 128) EIGX_SYMV(1, false);
-    else if (T == 256 && !nt_loads) EIGX_SYMV(2, false);
-    else if (T == 256) EIGX_SYMV(2, true);
-    else if (!nt_loads) EIGX_SYMV(4, false);
-    else EIGX_SYMV(4, true);
-#undef EIGX_SYMV
-    if (prof) ctx.prof_end(st);
-    if (mg) {
-      const int nbc = ceil_div(B.Lc > 0 ? B.Lc : 1, 64);
-      if (prof) ctx.prof_begin(2, 8.0 * R.msg_stride, st);
-      hipLaunchKernelGGL((kl_kernel<NB>), dim3(KL.nbr + nbc + 2 * NB), dim3(256), 0, st, R, KL);
-      if (step_coll) comm_step_allgather(ctx, 0, peers.slot[0], KL.par, st);
-      if (prof) ctx.prof_end(st);
-      prof_step = prof;
+      const int nkl = KL.nbr + ceil_div(B.Lc > 0 ? B.Lc : 1, 64) + 2 * NB;
+      if (fuse_wait) { kl_pending = true; KLp = KL; nkl_p = nkl; }
+      else {
+        if (prof) ctx.prof_begin(2, 8.0 * R.msg_stride, st);
+        launch_roles(nkl, KL, 0, S, 0, Bnone, 0, false, true);
+        if (step_coll) comm_step_allgather(ctx, 0, peers.slot[0], KL.par, st);
+        if (prof) ctx.prof_end(st);
+      }
+      prof_step = prof && !fuse_wait;
       S.par = KL.par;
     }
     t_symv_bytes += 8.0 * ((double)L * (L + 1) / 2);
@@ -2080,14 +2188,12 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       F.ncols = 0; F.i = i; F.L = 0; F.k = k; F.rows = S.iprev + 1;
       const int nb_kf = ka_grid(F.rows, F.G);
       F.wait.n = 0;
-      if (mg && !step_coll) {
-        if (fuse_wait) F.wait = comm_step_wait_args(ctx, 0, epoch);
-        else comm_step_wait(ctx, 0, epoch, st);
-      }
-      ka_mg_begin(F);
-      launch_ka(nb_kf, F);
-      ka_mg_end(F);
-      if (mg) {
+      if (!mg) launch_ka(nb_kf, F);
+      else {
+        ka_mg_begin(F);
+        if (fuse_wait) launch_roles(kl_pending ? nkl_p : 0, KLp, nb_kf, F, 0, Bnone, 0, false, true);
+        else ka_mg_alone(nb_kf, F, false);
+        kl_pending = false;
         // the last W columns of the panel, finished by their owners just now, into the local panel (all rows)
         const StepWait xw = x_wait(-1);
         hipLaunchKernelGGL((mg_wcopy_kernel<NB>), dim3(ceil_div(F.rows, 256) < 64 ? ceil_div(F.rows, 256) : 64), dim3(256), 0, st, R,
@@ -2149,6 +2255,8 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     unsigned long long h[32];
     EIGX_HIP_CHECK(hipStreamSynchronize(st));
     EIGX_HIP_CHECK(hipMemcpy(h, R.dbg, sizeof(h), hipMemcpyDeviceToHost));
+    if (mg) fprintf(stderr, "[eigx stamps] K_A several GPUs: wait %.0f | to the end of the pushes %.0f, drain + barrier %.0f | last arriver (from its previous stamp "
+                    "to the flag store) %.0f x %llu\n", (double)h[5] / h[7], (double)h[6] / h[7], (double)h[12] / h[7], (double)h[13] / (h[14] ? h[14] : 1), h[14]);
     fprintf(stderr, "[eigx stamps] NB=%d n=%d K_A launches %llu: avg cycles issue %.0f consume %.0f reduce %.0f rows %.0f tail %.0f | SYMV %llu: "
             "entry %.0f scalars %.0f stream %.0f tail %.0f\n", NB, n, h[7], (double)h[0] / h[7], (double)h[1] / h[7], (double)h[2] / h[7],
             (double)h[3] / h[7], (double)h[4] / h[7], h[15], (double)h[8] / (h[15] ? h[15] : 1), (double)h[9] / (h[15] ? h[15] : 1),

@@ -251,7 +251,8 @@ typedef unsigned long long u64;
 __device__ __forceinline__ bool spin_until(const u64* flag, u64 epoch, int* err, long long limit_ticks) {
   if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
   const long long t0 = wall_clock64();
-  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+  // (relaxed polls, one acquire at the end: an acquire load invalidates caches at every look)
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
     __builtin_amdgcn_s_sleep(1);
     // a peer that failed (or this rank's host) sets the failure word: leave at once
     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
@@ -260,6 +261,7 @@ __device__ __forceinline__ bool spin_until(const u64* flag, u64 epoch, int* err,
       return false;
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   return true;
 }
 
@@ -1246,7 +1248,7 @@ StepWait comm_step_wait_args(Context& ctx, int which, unsigned long long epoch) 
   StepWait w;
   w.flag = (const u64*)cs->flags.local + flag_index(step_channel(which), 0, 0);
   w.err = cs->err_dev; w.ticks = cs->ticks_dev; w.limit_ticks = limit_ticks(cs);
-  w.epoch = epoch; w.n = cs->P;
+  w.epoch = epoch; w.n = cs->P; w.naps = 1;
   return w;
 }
 

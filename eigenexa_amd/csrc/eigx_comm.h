@@ -94,6 +94,7 @@ struct StepWait {
   long long limit_ticks;
   unsigned long long epoch;
   int n;
+  int naps;                         // ~60-ns naps between two polls
 };
 bool comm_step_wait_fused(const Context& ctx);
 StepWait comm_step_wait_args(Context& ctx, int which, unsigned long long epoch);

@@ -55,7 +55,27 @@ struct GemmArgs {
   int tri_gb;          // gemm2 tri mode: tile-block edge of the XCD-aware order
   int tn_lo, tn_hi;    // tri mode: only tile columns tn_lo <= tn < tn_hi are updated (look-ahead split of the trailing update)
   int c_stream;        // gemm2: C tiles with non-temporal loads / stores (tuning hook, eigx_tune key 6)
+  // gemm2, tri mode 2 (rectangular local block of a 2-D cyclic distribution): the launch holds only the tiles of the
+  // active region.  Tile rows in groups of rg_h; group q covers tile columns [rg_c0[q], rg_c1) and starts at position
+  // rg_start[q] of the tile list (rg_start[nrg] = total); 0 groups: the full rectangle is launched (older form).
+  int nrg, rg_h, rg_c1;
+  unsigned rg_magic;   // floor(2^32 / Py) + 1: x / Py == umulhi(x, rg_magic) for the x < 2^22 that occur (Py > 1)
 };
+// tri mode 2: first tile column of row group q = the tile column that holds the first local column whose global index
+// reaches the first global row of the group, clipped to the launch's column window [tn_lo, rg_c1]
+__host__ __device__ inline int tri2_c0(const GemmArgs& g, int q, int tiles_n) {
+  const long grow_min = (long)q * g.rg_h * 128 * g.Px + g.px;
+  const unsigned x = grow_min > g.py ? (unsigned)(grow_min - g.py + g.Py - 1) : 0u;
+#ifdef __HIP_DEVICE_COMPILE__
+  const unsigned lc = (g.Py == 1) ? x : __umulhi(x, g.rg_magic);
+#else
+  const unsigned lc = (g.Py == 1) ? x : (unsigned)(((unsigned long long)x * g.rg_magic) >> 32);
+#endif
+  int c = (lc > (unsigned)(g.N - 1)) ? tiles_n : (int)(lc >> 7);
+  if (c < g.tn_lo) c = g.tn_lo;
+  if (c > g.rg_c1) c = g.rg_c1;
+  return c;
+}
 typedef double d2s_t __attribute__((ext_vector_type(2)));
 
 // column indices (gather map) of the slab starting at k0 for this thread's NL elements
@@ -391,6 +411,32 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmArgs g) {
     tm = bi * GB + (w % GB);
     tn = bj * GB + (w / GB);
     if (tm >= tiles_m || tn >= tiles_n) return;
+  } else if (g.tri_mode == 2 && g.nrg > 0) {
+    // only the active region was launched: same order as the full mode below (row groups, columns inside a group, a
+    // contiguous share of the list per XCD), but a group's columns start where its first tile row reaches the global
+    // diagonal.  The full rectangle's list is empty in its lower half, so its contiguous shares left the XCDs that got
+    // the bottom row groups idle (24 TFLOP/s per rank on a 2 x 4 grid at N = 32768 against 60 on one GPU).
+    int o = blockIdx.x;
+    {
+      const int ntiles = (int)gridDim.x;
+      const int q = ntiles >> 3, r = ntiles & 7, xcd = o & 7;
+      o = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (o >> 3);
+    }
+    // the row group that holds position o of the list (uniform scalar loop, <= 32 short iterations)
+    int rg = 0, st0 = 0, c0 = 0;
+    for (int q = 0; q < g.nrg; ++q) {
+      const int c = tri2_c0(g, q, tiles_n);
+      const int rws = (tiles_m - q * g.rg_h < g.rg_h) ? tiles_m - q * g.rg_h : g.rg_h;
+      const int cnt = rws * (g.rg_c1 - c);
+      rg = q; c0 = c;
+      if (o < st0 + cnt) break;
+      st0 += cnt;
+    }
+    const int rem = o - st0;
+    const int rows = (tiles_m - rg * g.rg_h < g.rg_h) ? tiles_m - rg * g.rg_h : g.rg_h;
+    const int tc = rem / rows;
+    tn = c0 + tc;
+    tm = rg * g.rg_h + rem - tc * rows;
   } else {
     const int ntiles = tiles_m * tiles_n;
     int o = blockIdx.x;
@@ -603,6 +649,7 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
   g.sA2 = strideA2; g.sB2 = strideB2; g.sC2 = strideC2;
   g.ownP = ownP; g.ownp = ownp; g.tri_gb = 1;
   g.tn_lo = tn_lo; g.tn_hi = tn_hi;
+  g.nrg = 0; g.rg_h = 8; g.rg_c1 = 0; g.rg_magic = 0;
   g.c_stream = (tri_mode != 0 && g_gemm_cstream) ? 1 : 0;
   g.Px = grid ? grid->Px : 1; g.px = grid ? grid->px : 0;
   g.Py = grid ? grid->Py : 1; g.py = grid ? grid->py : 0;
@@ -620,6 +667,22 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
         const int nb = ceil_div(t, g.tri_gb);
         const int nblk = nb * (nb + 1) / 2;
         gx2 = 8 * ceil_div(nblk, 8) * g.tri_gb * g.tri_gb;
+      }
+      if (tri_mode == 2 && batch == 1 && batch2 == 1 && ownP == 1) {
+        // active region of the local block: tile (tm, tn) holds an element on or above the global diagonal iff the first
+        // global row of tile row tm <= the last global column of tile column tn; the window [tn_lo, tn_hi) cuts columns
+        const int tiles_m = ceil_div(M, 128), tiles_n = ceil_div(N, 128);
+        g.rg_h = (tiles_m <= 256) ? 8 : ceil_div(tiles_m, 32);
+        g.nrg = ceil_div(tiles_m, g.rg_h);
+        g.rg_c1 = tiles_n < tn_hi ? tiles_n : tn_hi;
+        g.rg_magic = (unsigned)(((1ull << 32) / (unsigned long long)g.Py) + 1ull);
+        int total = 0;
+        for (int q = 0; q < g.nrg; ++q) {
+          const int rows = (tiles_m - q * g.rg_h < g.rg_h) ? tiles_m - q * g.rg_h : g.rg_h;
+          total += rows * (g.rg_c1 - tri2_c0(g, q, tiles_n));
+        }
+        if (total == 0) return;
+        gx2 = total;
       }
       dim3 grd2(gx2, batch, batch2), blk2(256);
       const size_t shmem2 = (size_t)4 * G2_STAGE * sizeof(double);

@@ -392,11 +392,13 @@ def test_multi_rank_modes_and_partial_spectrum(world, n, route, dims):
     _run_multi_rank(world, n, route, 0, dims)
 
 
-@pytest.mark.parametrize("world,n,route,dims", [(2, 700, "sx", ""), (4, 900, "s", "")])
-def test_multi_rank_row_group_loop(world, n, route, dims):
-    """ka_kernel's loop form (one workgroup, several row groups: what runs beyond 512 row groups, i.e. N > 8192) forced
-    at a small size on the process grid (eigx_tune key 7 = 4 workgroups), with the wait folded into the kernel"""
-    _run_multi_rank(world, n, route, 0, dims, {"EIGX_TEST_TUNE": "7=4", "EIGX_FUSE_WAIT": "1"})
+@pytest.mark.parametrize("world,n,route,dims", [(2, 700, "sx", ""), (4, 900, "s", ""), (3, 260, "sx", ""), (4, 5, "s", ""), (5, 7, "sx", "1x5")])
+def test_multi_rank_one_launch_per_step(world, n, route, dims):
+    """the form that runs when every rank has its own GPU (EIGX_FUSE_WAIT=1 forces it on the shared card): ONE launch per
+    reduction step, roles [kl of the previous step | ka_kernel over the rank's own rows | mat-vec] dispatched in that order,
+    the consumers spin on the arrival flags in their prologues (no wait kernels); tiny grids with ranks that own no rows or
+    hold no tiles included"""
+    _run_multi_rank(world, n, route, 0, dims, {"EIGX_FUSE_WAIT": "1"})
 
 
 @pytest.mark.parametrize("world,n,route,dims,chunk", [(2, 333, "sx", "", 64), (4, 517, "s", "", 64), (3, 260, "sx", "", 128),
@@ -566,13 +568,6 @@ def test_ka_load_batch_sizes_do_not_change_the_result(gpu_lib, band, n, m):
 def test_multi_rank_error_behaviour_and_scaling(world, n, route, dims):
     """NaN / Inf input, matrices scaled by 1e+-200 and a NaN-poisoned strict lower triangle on the process grid"""
     _run_multi_rank(world, n, route, 0, dims)
-
-
-@pytest.mark.parametrize("world,n,route,dims", [(2, 300, "sx", ""), (4, 517, "s", ""), (4, 700, "sx", "1x4")])
-def test_multi_rank_wait_folded_into_consumer(world, n, route, dims):
-    """the per-step wait inside ka_kernel's prologue instead of a wait kernel -- the form used when every rank owns a GPU;
-    forced here (EIGX_FUSE_WAIT=1) at sizes whose grids leave the shared card room for the producers"""
-    _run_multi_rank(world, n, route, 0, dims, {"EIGX_FUSE_WAIT": "1"})
 
 
 @pytest.mark.parametrize("world,n,route,dims", [(2, 300, "sx", ""), (4, 517, "s", ""), (4, 700, "sx", "1x4"), (3, 260, "sx", "")])
