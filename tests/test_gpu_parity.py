@@ -13,6 +13,10 @@ GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "known_a
 GATE_RES = GOLD["gates"]["residual"]
 GATE_ORTH = GOLD["gates"]["orthogonality"]
 EPS = np.finfo(np.float64).eps
+# element-wise bounds of the band-reduction parity tests, as multiples of n max|A|: ~10 x / 20 x the worst case measured
+# on MI355X (the PARITY-MARGIN lines the tests print under -s; profiles/r04_parity_margins.log: 8.8e-14 and 2.4e-16)
+TRD_ELEMENT_TOL = 1e-12
+SIMILARITY_TOL = 5e-15
 
 
 def _dev():
@@ -94,12 +98,16 @@ def test_tridiagonal_matches_oracle(gpu_lib, orc, n, m):
     d = torch.zeros(n, dtype=torch.float64, device=_dev())
     e = torch.zeros(n, dtype=torch.float64, device=_dev())
     assert gpu_lib.eigx_band_reduce_dev(n, a.data_ptr(), lda, d.data_ptr(), e.data_ptr(), n, m, 1) == 0
-    # single entries of T are not backward-stable quantities (errors accumulate along the n-1 similarity
-    # steps); 1e-9 ||A|| element-wise, while the spectrum of T is held to 1e-13 n ||A||
+    # single entries of T are not backward-stable quantities (errors accumulate along the n-1 similarity steps, and the
+    # two implementations order their sums differently).  Measured on MI355X (profiles/r04_parity_margins.log): the largest
+    # element-wise difference over these cases is 8.8e-14 * n * max|A| (n = 64); the bound is ~10 x the measured worst case.
+    # A wrong low-order term in ka_kernel shows at 1e-3 .. 1e-8 of this scale.
     scale = np.abs(A).max() * n
     dg, eg = d.cpu().numpy(), e.cpu().numpy()
-    assert np.abs(dg - do).max() < 1e-9 * scale
-    assert np.abs(np.abs(eg) - np.abs(eo[0])).max() < 1e-9 * scale
+    err_d = np.abs(dg - do).max() / scale
+    err_e = np.abs(np.abs(eg) - np.abs(eo[0])).max() / scale
+    print(f"PARITY-MARGIN tridiagonal n={n} m={m}: |d - d_oracle| = {err_d:.2e}, ||e| - |e_oracle|| = {err_e:.2e}  (x n max|A|)")
+    assert err_d < TRD_ELEMENT_TOL and err_e < TRD_ELEMENT_TOL
     wr = np.linalg.eigvalsh(A)
     assert np.abs(np.linalg.eigvalsh(_band_matrix(dg, eg.reshape(1, n), 1)) - wr).max() < 1e-13 * n * np.abs(wr).max()
 
@@ -118,6 +126,34 @@ def test_pentadiagonal_is_similarity(gpu_lib, n, m):
     T = _band_matrix(d.cpu().numpy(), e.cpu().numpy().reshape(2, n), 2)
     wr = np.linalg.eigvalsh(A)
     assert np.abs(np.linalg.eigvalsh(T) - wr).max() < 1e-13 * n * np.abs(wr).max()
+
+
+@pytest.mark.parametrize("band", [1, 2])
+@pytest.mark.parametrize("n,m,mb", [(64, 16, 32), (201, 32, 128), (513, 48, 128), (700, 128, 128), (1300, 128, 128)])
+def test_band_is_the_reflectors_similarity_elementwise(gpu_lib, band, n, m, mb):
+    """stronger than the spectrum: with Q = H_n ... H_1 applied to the identity by the real back-transformation
+    (mode 'S' of src/eigen_sx.F:200-240 does exactly this), Q^T A Q must BE the band matrix (d, e) element by element --
+    every entry outside the band zero, every entry inside equal -- to a few n eps ||A||.  The pentadiagonal is not unique
+    (the oracle's differs by 2x2 block rotations), but the pair (T, Q) that the reduction leaves is: a wrong
+    term anywhere in ka_kernel / K_P / the trailing update breaks this identity at the size of the term."""
+    import torch
+    from eigenexa_amd import layout
+
+    A = layout.random_symmetric(n, seed=21 + band)
+    a, lda = _to_colmajor(A)
+    d = torch.zeros(n, dtype=torch.float64, device=_dev())
+    e = torch.zeros(2 * n, dtype=torch.float64, device=_dev())
+    assert gpu_lib.eigx_band_reduce_dev(n, a.data_ptr(), lda, d.data_ptr(), e.data_ptr(), n, m, band) == 0
+    z = torch.zeros(n, lda, dtype=torch.float64, device=_dev())
+    z[:, :n] = torch.eye(n, dtype=torch.float64, device=_dev())
+    assert gpu_lib.eigx_trbak_dev(n, n, a.data_ptr(), lda, z.data_ptr(), lda, e.data_ptr(), n, mb, band) == 0
+    Q = z[:, :n].T.cpu().numpy()             # column j = Q e_j
+    T = _band_matrix(d.cpu().numpy(), e.cpu().numpy().reshape(2, n)[:band], band)
+    anorm = np.abs(A).max() * n
+    err_sim = np.abs(Q.T @ A @ Q - T).max() / anorm
+    err_orth = np.abs(Q.T @ Q - np.eye(n)).max()
+    print(f"PARITY-MARGIN similarity band={band} n={n} m={m}: |Q^T A Q - T| = {err_sim:.2e} (x n max|A|), |Q^T Q - I| = {err_orth:.2e}")
+    assert err_sim < SIMILARITY_TOL and err_orth < 50 * n * EPS
 
 
 # ------------------------------------------------------------------------------------------- D&C
