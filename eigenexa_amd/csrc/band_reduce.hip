@@ -33,6 +33,13 @@
 #include <chrono>
 #include <cstring>
 
+// Floating-point contraction by SOURCE FORM only (a * b + c written in one expression becomes an fma, nothing is fused
+// across statements): the same source then rounds the same way in every template instantiation and role of these kernels.
+// With the default "fast" mode the compiler decides per instantiation; after the round-4 refactor of the kernels into role
+// bodies the two load forms of the mat-vec (UNC) stopped being bit-identical (test_symv_load_forms_are_bit_identical), and
+// the replicas of the multi-GPU path rely on identical rounding on every rank.
+#pragma clang fp contract(on)
+
 namespace eigx {
 
 namespace {

@@ -261,6 +261,23 @@ def random_symmetric(n, seed=20240807, rows=None, cols=None):
         return r(i, j) + r(j, i).T
 
 
+def random_hermitian(n, seed=20240807, rows=None, cols=None):
+    """the matrix family of the reference's eigen_h driver (benchmark_h/mat_set_h.f:36-64): S with real and imaginary parts
+    uniform in [-1/2, 1/2) (real on the diagonal), A = S + S^H.  The reference draws S from the compiler's RNG seeded with
+    the rank id; here from the counter-based generator of random_symmetric() at the global indices (layout-independent)."""
+    i = (np.arange(n) if rows is None else np.asarray(rows)).astype(np.uint64)
+    j = (np.arange(n) if cols is None else np.asarray(cols)).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        def u(ii, jj, plane):
+            key = (ii[:, None] * np.uint64(n) + jj[None, :]) + np.uint64(seed + plane) * np.uint64(0x9E3779B97F4A7C15)
+            return (_mix64(key) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0) - 0.5
+
+        def s(ii, jj):
+            im = np.where(ii[:, None] == jj[None, :], 0.0, u(ii, jj, 1))
+            return u(ii, jj, 0) + 1j * im
+        return s(i, j) + s(j, i).conj().T
+
+
 def accuracy_metrics(A, w, Z):
     """the reference's three gates: residual ||AZ-ZW||_F/(N eps ||A||_F) (< 768), orthogonality
     ||Z^T Z - I||_F/(N eps) (< 8)  (benchmark/ev_test.f:181-204)."""

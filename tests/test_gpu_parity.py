@@ -1079,19 +1079,23 @@ def test_large_n_eigenvalues_only_invariants(gpu_lib):
     _spectrum_invariants(w.cpu().numpy(), tr, fro2, n)
 
 
-@pytest.mark.parametrize("route,mf", [("sx", 128), ("sx", 256), ("s", 128)])
-def test_baseline_config_n32768_all_eigenpairs(gpu_lib, route, mf):
+@pytest.mark.parametrize("route,mf,ld", [("sx", 128, "n+34"), ("sx", 256, "matdims"), ("s", 128, "n+34")])
+def test_baseline_config_n32768_all_eigenpairs(gpu_lib, route, mf, ld):
     """BASELINE.json configs[2] (N=32768 random symmetric, eigen_sx) and configs[3] (N=32768 eigen_s: eigen_trd +
     trbakwy4), all eigenpairs, at the full size on this one GPU (the 8-GPU partition of the same solve is covered by
     test_multi_rank_solver_on_one_gpu at sizes the ranks of one card can hold): the complete gates of
     benchmark/ev_test.f:181-204 through GPU matmuls -- ||AZ-ZW||_F/(N eps ||A||_F) < 768, ||Z^T Z - I||_F/(N eps) < 8,
     north_star's ||AZ-ZW||/||A|| <= 1e-12 N -- plus trace / Frobenius invariants and sortedness.  m_forward = 256 is the
-    panel width of bench.py's `extra` block (the one quoted for the trailing update's share of the MFMA peak)."""
+    panel width of bench.py's `extra` block (the one quoted for the trailing update's share of the MFMA peak); that case runs
+    on the extents eigen_get_matdims recommends (what a caller of the reference API allocates, and what bench.py times),
+    the others on lda = n + 34 (a leading dimension of the slow kind: few bytes of shift between columns)."""
     import torch
+    import eigenexa_amd as ee
 
     n = 32768
     dev = _dev()
-    lda = n + 34
+    lda = ee.eigen_get_matdims(n)[0] if ld == "matdims" else n + 34
+    assert lda >= n
     a, tr, fro2 = _random_symmetric_dev(n, lda)
     A = a[:, :n].clone()                         # A is symmetric: the row-major view of the column-major copy is A itself
     w = torch.zeros(n, dtype=torch.float64, device=dev)
@@ -1168,6 +1172,36 @@ def test_eigen_h_matches_oracle(gpu_lib, orc, n, m):
     res, orth = _herm_check(A, w, z)
     assert res < GATE_RES and orth < GATE_ORTH, (res, orth)
     assert a[0, 0].real > 0 and (n < 2 or a[1, 0].real >= 0)      # a(1,1) = flops, a(2,1) = seconds
+
+
+@pytest.mark.parametrize("n", [1000, 2048])
+def test_eigen_h_reference_driver_checks(gpu_lib, n):
+    """the two checks of the reference's own eigen_h driver on its matrix family (benchmark_h/mat_set_h.f:36-64:
+    A = S + S^H, S uniform in [-1/2, 1/2)^2, real diagonal): (1) the "Repro test" of benchmark_h/bench_eigen_h.f:100-127 --
+    two solves of the same input give max(w - w_) = 0 and max(z - z_) = 0, bit for bit; (2) the comparison with PZHEEVD
+    (:234-270; LAPACK zheevd here): same eigenvalues, and eigenvectors that pass the residual / unitarity gates; sizes of
+    benchmark_h/check_h.sh's small sweep"""
+    import eigenexa_amd as ee
+    from eigenexa_amd import layout
+
+    ee.eigen_init()
+    A = layout.random_hermitian(n)
+    assert np.abs(A - A.conj().T).max() == 0.0 and np.abs(A.imag.diagonal()).max() == 0.0
+    out = []
+    for _ in range(2):
+        a = np.asfortranarray(np.triu(A))
+        z = np.zeros((n, n), dtype=np.complex128, order="F")
+        w = np.zeros(n)
+        ee.eigen_h(n, n, a, n, w, z, n)
+        assert ee.api.last_status() == 0
+        out.append((w.copy(), z.copy()))
+    assert np.array_equal(out[0][0], out[1][0]), np.abs(out[0][0] - out[1][0]).max()      # Repro test : max(w-w_) = 0
+    assert np.array_equal(out[0][1], out[1][1]), np.abs(out[0][1] - out[1][1]).max()      # Repro test : max(z-z_) = 0
+    w, z = out[0]
+    wl = np.linalg.eigvalsh(A)                                                            # zheevd-class reference
+    assert np.abs(w - wl).max() < 1e-13 * n * np.abs(wl).max()
+    res, orth = _herm_check(A, w, z)
+    assert res < GATE_RES and orth < GATE_ORTH, (res, orth)
 
 
 @pytest.mark.parametrize("n,m", [(9400, 48), (4500, 96)])
