@@ -515,32 +515,6 @@ def main():
         torch.cuda.empty_cache()
         return ex
 
-    # ---- cpu_baseline: the OpenMP oracle on the headline configuration itself (N = the GPU line's N: ~105 s on 16 cores at
-    # N = 8192).  It runs on a host thread WHILE the GPU works through the extra blocks below (ctypes releases the GIL; two
-    # cores stay free for the launch loops of those solves), after the timed main line, so neither timing sees the other.
-    cpu_thread = None
-    cpu_result = {}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import threading
-        from oracle import orc
-
-        nc = args.cpu_n or n
-        all_cores = int(os.environ.get("EIGX_CPU_CORES", 0)) or min(orc.host_cores(), 16 * max(1, torch.cuda.device_count()))
-        beside_gpu = not args.no_extra and n != 32768 and args.route == "sx"
-        cores = orc.set_threads(max(1, all_cores - 2) if beside_gpu else all_cores)
-
-        def cpu_leg():
-            try:
-                Ac = layout.random_symmetric(nc)
-                t0c = time.perf_counter()
-                _, _, stats, st_ = orc.eigen(Ac, args.route)
-                cpu_result.update(tc=time.perf_counter() - t0c, stats=stats, st=st_, nc=nc, cores=cores, beside_gpu=beside_gpu)
-            except Exception as exc_c:   # reported in the line, never fatal
-                cpu_result.update(error=str(exc_c))
-
-        cpu_thread = threading.Thread(target=cpu_leg, name="cpu_baseline")
-        cpu_thread.start()
-
     if world == 1 and not args.no_extra and n != 32768 and args.route == "sx":
         del a_bufs, z, w, A_loc_T
         torch.cuda.empty_cache()
@@ -553,25 +527,31 @@ def main():
                 out[key] = {"error": str(exc_x)}
 
     if rank == 0:
-        if cpu_thread is not None:
-            cpu_thread.join()
-            if "error" in cpu_result:
-                out["cpu_baseline"] = {"error": cpu_result["error"]}
-            else:
-                tc, stats, st, nc, cores = (cpu_result[k_] for k_ in ("tc", "stats", "st", "nc", "cores"))
-                out["cpu_baseline"] = {
-                    "value": round(abs(stats[0]) / tc / 1e9, 3), "unit": "GFLOP/s", "cores": cores,
-                    "kind": "port", "n": nc,
-                    "sample": f"oracle/eigx_oracle.c eigen_{args.route} (unblocked C restatement, its O(N^3) loops threaded with "
-                              f"OpenMP over {cores} host cores of this box; the only CPU code that can run on the GPU box) on the "
-                              f"GPU line's own configuration" + ("" if nc == n else f" scaled down to N={nc} (--cpu-n)") +
-                              f": N={nc}, the same generator, all eigenpairs, ONE solve, {tc:.1f} s (reduction {st[0]:.1f} s, "
-                              f"D&C {st[1]:.1f} s, back-transform {st[2]:.1f} s)" +
-                              (", on a host thread while the GPU ran the extra blocks (two cores left to their launch loops)"
-                               if cpu_result["beside_gpu"] else "") +
-                              "; the reference's own MPI CPU path (another box) is in reference_published",
-                    "reference_published": REFERENCE_PUBLISHED,
-                }
+        if world == 1 and not args.no_cpu_baseline:
+            # cpu_baseline: the OpenMP oracle on the headline configuration itself (N = the GPU line's N), after all GPU work,
+            # alone on the host cores (beside the GPU's extra blocks its busy-waiting OpenMP barriers and the HIP runtime's
+            # threads starved each other under the box's CPU quota: the run was killed after 7 silent minutes)
+            from oracle import orc
+
+            nc = args.cpu_n or n
+            cores = orc.set_threads(int(os.environ.get("EIGX_CPU_CORES", 0)) or min(orc.host_cores(), 16 * max(1, torch.cuda.device_count())))
+            print(f"[bench] GPU part done; cpu_baseline: oracle eigen_{args.route} at N={nc} on {cores} host cores "
+                  f"(~100 s at N=8192 on 16 cores) ...", file=sys.stderr, flush=True)
+            Ac = layout.random_symmetric(nc)
+            t0c = time.perf_counter()
+            _, _, stats, st = orc.eigen(Ac, args.route)
+            tc = time.perf_counter() - t0c
+            out["cpu_baseline"] = {
+                "value": round(abs(stats[0]) / tc / 1e9, 3), "unit": "GFLOP/s", "cores": cores,
+                "kind": "port", "n": nc,
+                "sample": f"oracle/eigx_oracle.c eigen_{args.route} (unblocked C restatement, its O(N^3) loops threaded with "
+                          f"OpenMP over {cores} host cores of this box; the only CPU code that can run on the GPU box) on the "
+                          f"GPU line's own configuration" + ("" if nc == n else f" scaled down to N={nc} (--cpu-n)") +
+                          f": N={nc}, the same generator, all eigenpairs, ONE solve, {tc:.1f} s (reduction {st[0]:.1f} s, "
+                          f"D&C {st[1]:.1f} s, back-transform {st[2]:.1f} s); the reference's own MPI CPU path (another box) "
+                          f"is in reference_published",
+                "reference_published": REFERENCE_PUBLISHED,
+            }
         print(json.dumps(out), flush=True)
     lib.eigx_free()
     if dist is not None:

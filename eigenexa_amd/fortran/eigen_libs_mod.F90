@@ -101,6 +101,10 @@ module eigen_libs_mod
       import :: c_int
       integer(c_int), value :: i, nnod, inod
     end function
+    integer(c_int) function eigx_get_timers(out16) bind(C, name="eigx_get_timers")
+      import :: c_int, c_double
+      real(c_double), intent(out) :: out16(16)
+    end function eigx_get_timers
     integer(c_int) function eigx_sx(n, nvec, a, lda, w, z, ldz, mf, mb, mode) bind(C, name="eigx_sx")
       import :: c_int, c_double, c_char
       integer(c_int), value :: n, nvec, lda, ldz, mf, mb
@@ -552,6 +556,7 @@ contains
     if (present(m_backward)) mb = m_backward
     if (present(mode)) md = mode(1:1)
     rc = eigx_sx(n, nvec, a, lda, w, z, ldz, mf, mb, md)   ! no status argument in the reference
+    call timer_print_lines(n, nvec, md, 'TRD-BLK ')
   end subroutine eigen_sx
 
   !> eigen_s(n, nvec, a, lda, w, z, ldz, m_forward, m_backward, mode)   (src/eigen_libs.F:150-202)
@@ -568,7 +573,34 @@ contains
     if (present(m_backward)) mb = m_backward
     if (present(mode)) md = mode(1:1)
     rc = eigx_s(n, nvec, a, lda, w, z, ldz, mf, mb, md)
+    call timer_print_lines(n, nvec, md, 'TRD-BLK ')
   end subroutine eigen_s
+
+  !> The reference's per-stage report of a TIMER_PRINT=1 build (src/eigen_sx.F:167-174, :225-232, :252-258, format 10000 at
+  !> :304; src/eigen_FS.F likewise): one line per stage on rank 1 -- name, n, seconds, flops of the reference's model, GFLOPS.
+  !> Here a run-time switch: EIGX_TIMER_PRINT=1 in the environment.
+  subroutine timer_print_lines(n, nvec, md, first)
+    integer, intent(in) :: n, nvec
+    character(kind=c_char), intent(in) :: md
+    character(len=8), intent(in) :: first
+    character(len=8) :: val
+    integer :: st, rc, procs, xp, yp, id, xi, yi
+    real(c_double) :: tm(16), r1, r2, r3
+    call get_environment_variable('EIGX_TIMER_PRINT', val, status=st)
+    if (st /= 0) return
+    if (len_trim(val) == 0 .or. val(1:1) == '0') return
+    call eigen_get_id(id, xi, yi)
+    if (id /= 1) return
+    rc = eigx_get_timers(tm)
+    r1 = dble(n)**3 * 4 / 3
+    r2 = tm(12)
+    r3 = 2 * dble(abs(nvec)) * dble(n)**2
+    if (tm(2) > 0d0) print 10000, first, n, tm(2), r1, 1d-9 * r1 / tm(2), "GFLOPS"
+    if (tm(3) > 0d0) print 10000, "D&C     ", n, tm(3), r2, 1d-9 * r2 / tm(3), "GFLOPS"
+    if (tm(4) > 0d0 .and. md /= 'N' .and. md /= 'n') print 10000, "TRDBAK  ", n, tm(4), r3, 1d-9 * r3 / tm(4), "GFLOPS"
+    flush(6)
+10000 format (X, A8, I8, 3E25.16e2, X, A)
+  end subroutine timer_print_lines
 
   !> eigen_s0: the reference's classic tridiagonal driver (src/eigen_s.F:30-307); eigen_s dispatches to it or to
   !> eigen_FS by process count -- one implementation serves both here

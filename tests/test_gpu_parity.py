@@ -1329,15 +1329,23 @@ def test_fortran_caller_over_iso_c_binding(gpu_lib):
         if not os.path.exists("/opt/rocm/lib/llvm/bin/flang"):
             pytest.skip("no flang in this image")
         subprocess.check_call(["bash", os.path.join(root, "eigenexa_amd", "fortran", "build.sh")])
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, EIGX_TIMER_PRINT="1"))
     assert out.returncode == 0, out.stdout + out.stderr
     errs = {}
+    stages = []
     for line in out.stdout.splitlines():
         if "max rel eigenvalue error" in line:
             name = line.split()[0]
             errs[name] = float(line.split("=")[2].split()[0])
+        f = line.split()
+        if len(f) >= 6 and f[-1] == "GFLOPS":                  # the reference's TIMER_PRINT lines (src/eigen_sx.F:167-174, :304)
+            stages.append((" ".join(f[:-5]), int(f[-5]), float(f[-4]), float(f[-3]), float(f[-2])))
     assert set(errs) == {"eigen_sx", "eigen_s", "eigen_h"}, out.stdout
     assert all(v < 1e-8 for v in errs.values()), errs      # cond(Frank, n=1000) ~ 1.6e6
+    # EIGX_TIMER_PRINT=1: eigen_sx and eigen_s each report TRD-BLK, D&C, TRDBAK with seconds, model flops and their ratio
+    assert [s_[0] for s_ in stages] == ["TRD-BLK", "D&C", "TRDBAK"] * 2, out.stdout
+    for name, n_, sec, flops, gf in stages:
+        assert sec > 0 and flops > 0 and abs(gf - 1e-9 * flops / sec) <= 1e-9 * gf, (name, sec, flops, gf)
 
 
 @pytest.mark.parametrize("np_", [1, 2, 4])
