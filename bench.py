@@ -74,6 +74,21 @@ def spawn_ranks(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     worst = 0
     deadline = None
+    import signal
+
+    def leave(signum, _frame):     # an interrupted launcher takes its ranks with it (exact PIDs it started)
+        for p_ in procs:
+            p_.terminate()
+        t_end = time.time() + 10.0
+        for p_ in procs:
+            try:
+                p_.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p_.kill()
+        sys.exit(128 + signum)
+
+    signal.signal(signal.SIGINT, leave)
+    signal.signal(signal.SIGTERM, leave)
     while procs:
         for p_ in list(procs):
             rc = p_.poll()
@@ -244,10 +259,13 @@ def main():
             if int(pm["n"]) != int(nn):
                 return {"traffic": None}
             ratio = float(pm["traffic_over_algorithmic"])
-            return {"traffic": round(ratio * alg_per_launch, 1),
+            # nothing of this is measured in THIS run: `traffic` stays null, the committed PMC passes are quoted beside it
+            return {"traffic": None,
+                    "traffic_from_profile": round(ratio * alg_per_launch, 1),
                     "traffic_source": f"profiles/r03_symv_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
-                                      f"one N={nn} reduction (gfx950 correction of the guide applied), {ratio:.3f} x the algorithmic "
-                                      f"bytes; not collected in this run"}
+                                      f"one N={nn} reduction of round 3's kernel (gfx950 correction of the guide applied), {ratio:.3f} x "
+                                      f"the algorithmic bytes; the mat-vec's tiling and loads are unchanged since, but it was not "
+                                      f"collected in this run"}
         except Exception:
             return {"traffic": None}
 
@@ -302,7 +320,7 @@ def main():
     for i in range(args.warmup):
         solve(a_bufs[i])
     # bracket every 32nd SYMV launch and every trailing-update launch with HIP events: the events cost time themselves
-    # (N = 8192 reduction 126.4 ms without, 130.2 ms with every 8th launch bracketed), so the sample is kept sparse
+    # (N = 8192 reduction 126.4 ms without, 130.2 ms with every 32nd launch bracketed), so the sample is kept sparse
     lib.eigx_profile(32)
     barrier()
     t0 = time.perf_counter()

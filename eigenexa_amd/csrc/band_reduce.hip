@@ -1259,7 +1259,7 @@ template <int K> struct IC { static constexpr int value = K; };
 // wave-uniform branches and every use waits for everything in flight.  The first form wins where the launch is latency-bound
 // (N = 8192: reduction 133.3 -> 131.0 ms), the second where it is bandwidth-bound (N = 32768, same box, alternating
 // processes: 4751 ms against 5326 ms with the pipeline -- more requests in flight per CU than the memory system likes);
-// the launch picks by active size (g_symv_unc, eigx_tune key 14).
+// the launch picks by active size (g_symv_unc, eigx_tune key 11).
 template <int NV, int RB, bool NTL, bool MG, bool UNC>
 __device__ __forceinline__ void symv_body(const RedArgs& R, const KBArgs& B, const int bid0, const int nblocks) {
   constexpr int T = 128 * RB;

@@ -107,6 +107,19 @@ struct Context {
 
 extern Context g_ctx;
 
+// A nested one-GPU solve inside a multi-rank entry point (gathered, replicated problems: KMATH_EIGEN_GEV, eigen_h) runs with
+// the one-rank grid; the guard puts the caller's grid back on EVERY way out -- a workspace allocation that fails inside
+// the nested solve unwinds through here (DeviceAllocError), and a rank left on the one-rank grid would believe
+// nranks == 1 while its communicator is still multi-rank.
+struct GridSwap {
+  Context& c;
+  Grid saved;
+  explicit GridSwap(Context& ctx) : c(ctx), saved(ctx.grid) { c.grid = Grid(); }
+  ~GridSwap() { c.grid = saved; }
+  GridSwap(const GridSwap&) = delete;
+  GridSwap& operator=(const GridSwap&) = delete;
+};
+
 void comm_report_failure(Context& ctx, const char* what);   // comm.hip: sets this rank's and every peer's sticky failure word (P > 1)
 
 // C-ABI boundary guard of the solver entry points: a failed workspace allocation becomes an error code

@@ -876,10 +876,8 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
     } else {
       // multi-rank callers reach this point with the gathered (replicated) problem: the real tridiagonal D&C runs
       // replicated too (its distributed form delivers column blocks, which only the real solvers consume)
-      const Grid saved = ctx.grid;
-      ctx.grid = Grid();
+      GridSwap one_rank(ctx);
       band_dc_dev(ctx, n, nvec, H.d, H.e, lde, 1, w, Zr, ldzp);
-      ctx.grid = saved;
     }
     if (mode == 'X') band_bisect_dev(ctx, n, H.d, H.e, lde, 1, w);
     hipLaunchKernelGGL(h_fill_kernel, dim3(1024), dim3(256), 0, st, Zi, (size_t)ldzp * nvec, 0.0);

@@ -545,9 +545,11 @@ static int gev_dev_mg(Context& ctx, int n, double* a, int lda, double* b, int ld
   }
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
   if (comm_failed(ctx)) return EIGX_ERR_INTERNAL;
-  ctx.grid = Grid();                       // the replicated problem runs the one-GPU sequence on every rank
-  const int rc = gev_dev(ctx, n, Af, ldf, Bf, ldf, w, Zf, ldf);
-  ctx.grid = G;
+  int rc;
+  {
+    GridSwap one_rank(ctx);                // the replicated problem runs the one-GPU sequence on every rank
+    rc = gev_dev(ctx, n, Af, ldf, Bf, ldf, w, Zf, ldf);
+  }
   if (rc != EIGX_OK) return rc;
   if (nloc_r > 0 && nloc_c > 0) {
     double* const dst[3] = {z, a, b};
