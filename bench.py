@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--no-extra", action="store_true", help="--gpus 1: skip the extra N=32768 / N=65536 solves")
     ap.add_argument("--cpu-n", type=int, default=0, help="size of the cpu_baseline solve (OpenMP oracle on the host cores); "
                     "0 = the GPU line's N (the headline configuration)")
-    ap.add_argument("--mf", type=int, default=64, help="m_forward (panel width) of the main line (reference default 48; N=8192 reduction on one box: 132.8 / 132.0 / 132.6 / 133.7 ms for 48 / 64 / 96 / 128)")
+    ap.add_argument("--mf", type=int, default=0, help="m_forward (panel width) of the main line; default 64 on one GPU (reference default 48; N=8192 reduction on one box: 132.8 / 132.0 / 132.6 / 133.7 ms for 48 / 64 / 96 / 128), 128 on several (N=32768: what the per-rank rehearsal was tuned with)")
     ap.add_argument("--extra-mf", type=int, default=256, help="m_forward of the extra N=32768 solve (K = 512 slabs for the trailing update)")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of the distributed solve")
     ap.add_argument("--weak", action="store_true", help="N>1: weak scaling, N = size*sqrt(P) (size defaults to 8192)")
@@ -123,6 +123,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.mf <= 0:
+        args.mf = 64 if world == 1 else 128
     if args.gpus != world:
         # a line that says n_gpus = world while the caller asked for --gpus N would void a scaling run
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE = {world}: launch with `python bench.py --gpus N` (spawns the ranks "

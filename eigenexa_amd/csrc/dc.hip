@@ -38,7 +38,7 @@ namespace eigx {
 
 namespace {
 
-constexpr int LEAF = 64;
+constexpr int LEAF = 32;
 
 // ================================================================================================
 // leaves: cyclic Jacobi with round-robin pairing, one workgroup per leaf
