@@ -841,7 +841,12 @@ __device__ __forceinline__ void ka_body(const RedArgs& R, const KAArgs& S, const
       if (tid < XP.n && XP.flag[tid])
         __hip_atomic_store(XP.flag[tid] + S.xpar * EIGX_MAXP, S.xepoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef EIGX_STAMPS
-      if (R.dbg && tid == 0) { atomicAdd(&R.dbg[13], __builtin_amdgcn_s_memtime() - stamp_prev); atomicAdd(&R.dbg[14], 1ull); }
+      if (R.dbg && tid == 0) {
+        atomicAdd(&R.dbg[13], __builtin_amdgcn_s_memtime() - stamp_prev); atomicAdd(&R.dbg[14], 1ull);
+        const unsigned long long t0 = __hip_atomic_load(&R.dbg[20], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long dt = (unsigned long long)wall_clock64() - t0;
+        if (t0 != 0 && dt < 100000ull) atomicAdd(&R.dbg[23], dt);
+      }
 #endif
     }
   }
@@ -1053,6 +1058,13 @@ __device__ __forceinline__ void kl_body(const RedArgs& R, const KLArgs& K, const
   }
   // every storing wave drains its stores; the last workgroup to arrive publishes the flag on every rank
   kl_publish(K, K.peers.counter, 1u, (unsigned)nblocks, &last);
+#ifdef EIGX_STAMPS
+  if (R.dbg && last && threadIdx.x == 0) {
+    const unsigned long long t0 = __hip_atomic_load(&R.dbg[20], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long dt = (unsigned long long)wall_clock64() - t0;
+    if (t0 != 0 && dt < 100000ull) atomicAdd(&R.dbg[22], dt);
+  }
+#endif
 }
 
 // Reflector scalars of a step, computed by EVERY workgroup of the mat-vec launch in the same order (bit-identical
@@ -1727,6 +1739,15 @@ struct MGStep { int nkl, nka; StepPeers xpeers; };
 template <int NV, int RB, bool NTL, bool UNC>
 __global__ __launch_bounds__(256) void mg_step_kernel(RedArgs R, KLArgs KL, KAArgs S, KBArgs B, MGStep M) {
   int bid = blockIdx.x;
+#ifdef EIGX_STAMPS
+  if (R.dbg && bid == 0 && threadIdx.x == 0 && M.nkl > 0 && M.nka > 0 && (int)gridDim.x > M.nkl + M.nka) {
+    // timeline of a full step launch on the 100-MHz wall clock: workgroup 0's entry time; its distance to the previous one
+    const unsigned long long t = (unsigned long long)wall_clock64();
+    const unsigned long long prev = R.dbg[20];
+    if (prev != 0 && t - prev < 100000ull) { atomicAdd(&R.dbg[21], t - prev); atomicAdd(&R.dbg[24], 1ull); }
+    __hip_atomic_store(&R.dbg[20], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#endif
   if (bid < M.nkl) { kl_body<NV>(R, KL, bid, M.nkl); return; }
   bid -= M.nkl;
   if (bid < M.nka) { ka_body<NV, true, false, 1, 8, 8>(R, S, &M.xpeers, bid, M.nka); return; }
@@ -2262,6 +2283,9 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     unsigned long long h[32];
     EIGX_HIP_CHECK(hipStreamSynchronize(st));
     EIGX_HIP_CHECK(hipMemcpy(h, R.dbg, sizeof(h), hipMemcpyDeviceToHost));
+    if (mg && h[24]) fprintf(stderr, "[eigx stamps] step launch timeline (100-MHz clock, averages over %llu full launches, from workgroup 0's entry): Y flags "
+                             "raised at %.2f us, X flags at %.2f us, next launch's workgroup 0 enters at %.2f us\n", h[24], 0.01 * h[22] / h[24],
+                             0.01 * h[23] / h[24], 0.01 * h[21] / h[24]);
     if (mg) fprintf(stderr, "[eigx stamps] K_A several GPUs: wait %.0f | to the end of the pushes %.0f, drain + barrier %.0f | last arriver (from its previous stamp "
                     "to the flag store) %.0f x %llu\n", (double)h[5] / h[7], (double)h[6] / h[7], (double)h[12] / h[7], (double)h[13] / (h[14] ? h[14] : 1), h[14]);
     fprintf(stderr, "[eigx stamps] NB=%d n=%d K_A launches %llu: avg cycles issue %.0f consume %.0f reduce %.0f rows %.0f tail %.0f | SYMV %llu: "
