@@ -337,6 +337,16 @@ __device__ __forceinline__ void ka_body(const RedArgs& R, const KAArgs& S, const
   const int rstep = MG ? KA_ROWS * R.P : KA_ROWS;     // rows from a group of the workgroup to its next one
   const StepPeers& XP = *XPp;                         // (dereferenced on the several-GPU paths only)
   EIGX_STAMP_INIT
+#ifdef EIGX_STAMPS
+#define EIGX_TL(slot) do { if (MG && R.dbg && threadIdx.x == 0 && stamp_me) { const unsigned long long t0_ = __hip_atomic_load(&R.dbg[20], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    const unsigned long long dt_ = (unsigned long long)wall_clock64() - t0_; if (t0_ != 0 && dt_ < 100000ull) atomicAdd(&R.dbg[slot], dt_); } } while (0)
+#else
+#define EIGX_TL(slot) do {} while (0)
+#endif
+  EIGX_TL(26);   // (timeline: this workgroup's entry)
+#ifdef EIGX_STAMPS
+  const unsigned long long clk_w0 = (unsigned long long)wall_clock64(), clk_m0 = __builtin_amdgcn_s_memtime();
+#endif
 
   // ============ phase 0: every load that depends on nothing computed in this kernel ==================
   // The kernel is a latency chain (a few hundred bytes per thread): ALL loads are issued first, in
@@ -461,6 +471,7 @@ __device__ __forceinline__ void ka_body(const RedArgs& R, const KAArgs& S, const
     // scalars) and travels while the first wave polls the arrival flags of the Y messages; what follows reads them
     step_wait_fused(S.wait, bid == 0);
     EIGX_STAMP(5);
+    EIGX_TL(27);   // (timeline: Y flags seen)
     load_rows_msg(r, cur);
   }
   // panel dots: thread kk = tid (< kp <= 256) sums entry (kind, kk) over the K_P row chunks
@@ -818,13 +829,28 @@ __device__ __forceinline__ void ka_body(const RedArgs& R, const KAArgs& S, const
     // sums in a fixed order (whoever it is), appends them to the message and raises the flag on every rank (the only store
     // with a system-scope release) -- the protocol of kl_publish, self-tested at init (comm.hip st_step_push_kernel).
     EIGX_STAMP(6);
+    EIGX_TL(28);   // (timeline: pushes issued)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     EIGX_STAMP(12);
+    // arrival: a fire-and-forget add (a RETURNING device-scope atomic costs its whole round trip, 2.7 us in the stamps, on
+    // the last arriver's path); the role's first workgroup watches the counter with relaxed loads and publishes
     if (tid == 0) {
-      const unsigned tk = atomicAdd(XP.counter, 1u);
-      lastw = (tk + 1u == (unsigned)nblocks);
-      if (lastw) *XP.counter = 0;
+      __hip_atomic_fetch_add(XP.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      lastw = 0;
+      if (bid == 0) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(XP.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nblocks) {
+          __builtin_amdgcn_s_sleep(1);
+          if (wall_clock64() - t0 > 200000000ll) break;     // (2 s: never on a healthy run; the consumers' bounded waits report)
+        }
+        __hip_atomic_store(XP.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lastw = 1;
+#ifdef EIGX_STAMPS
+        if (R.dbg) { const unsigned long long t0_ = __hip_atomic_load(&R.dbg[20], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long dt_ = (unsigned long long)wall_clock64() - t0_; if (t0_ != 0 && dt_ < 100000ull) atomicAdd(&R.dbg[29], dt_); }
+#endif
+      }
     }
     __syncthreads();
     if (lastw) {
@@ -852,6 +878,9 @@ __device__ __forceinline__ void ka_body(const RedArgs& R, const KAArgs& S, const
   }
   EIGX_STAMP(4);
 #ifdef EIGX_STAMPS
+  if (R.dbg && threadIdx.x == 0 && stamp_me) {   // shader clock of this workgroup's lifetime: s_memtime ticks per 10-ns wall tick
+    atomicAdd(&R.dbg[30], (unsigned long long)wall_clock64() - clk_w0); atomicAdd(&R.dbg[31], __builtin_amdgcn_s_memtime() - clk_m0);
+  }
   if (R.dbg && threadIdx.x == 0 && stamp_me) atomicAdd(&R.dbg[7], 1ull);
 #endif
 }
@@ -912,19 +941,22 @@ struct KLArgs {
   int fence;   // 1: every pushing workgroup runs a system-scope fence behind its stores (EIGX_STEP_FENCE=1); 0: see kl_publish
 };
 
-// one chunk of 64 local rows (rows = true) or 64 local columns starting at l0: sum this rank's tile partial sums of
+// one chunk of KL_ROWS = 128 local rows (rows = true) or local columns starting at l0: sum this rank's tile partial sums of
 // each and write the result into the step window of the row's owner (of every rank for the rows of the next block
-// columns, L-1 and L-2: every rank needs P(c, :) of those, see ka_kernel).  Wave q takes every fourth partial sum (up to
-// ~64 of them sit behind a cold L2: one thread per row walking them one after the other is a chain of memory round trips),
-// the four waves are combined through LDS in a fixed order.
+// columns, L-1 and L-2: every rank needs P(c, :) of those, see ka_kernel).  Half q of the workgroup takes every second
+// partial sum of a row (up to ~64 of them sit behind a cold L2: one thread per row walking them one after the other is a
+// chain of memory round trips), the two halves are combined through LDS in a fixed order.  128 rows per workgroup (round
+// 4; was 64 with four quarters): at N = 32768 on 2 x 4 the kl and ka roles of a step launch then fit the chip together
+// (196 + 256 workgroups of 512 slots), so every ka workgroup has its local data in flight while kl still runs.
+constexpr int KL_ROWS = 128;
 template <int NB>
-__device__ __forceinline__ void kl_chunk(const RedArgs& R, const KLArgs& K, bool rows, int l0, double (*comb)[64][2]) {
+__device__ __forceinline__ void kl_chunk(const RedArgs& R, const KLArgs& K, bool rows, int l0, double (*comb)[KL_ROWS][2]) {
   const int ldp = R.ldp;
-  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int lane = threadIdx.x & (KL_ROWS - 1), q = threadIdx.x / KL_ROWS;    // q = 0, 1
   const int T = K.T;
   const int l = l0 + lane;
   double pA = 0.0, pB = 0.0;
-  // this lane's partial sums: tile index t0, t0 + 4, ... < tend of the row's / column's partial-sum array P (stride
+  // this thread's partial sums: tile index t0, t0 + 2, ... < tend of the row's / column's partial-sum array P (stride
   // NB * ldp per tile).  They sit behind a cold L2 (written by tiles on other XCDs): ALL loads of a batch of 16 per vector
   // are issued before the first add -- clamped indices, masked afterwards -- so a row costs one memory round trip, not
   // one per tile (the earlier loop with a serial remainder took ~20 us per launch at 32-64 tiles per row).
@@ -944,18 +976,18 @@ __device__ __forceinline__ void kl_chunk(const RedArgs& R, const KLArgs& K, bool
     }
   }
   const int lc = act ? l : 0;
-  for (int tb = t0; tb < tend; tb += 64) {
+  for (int tb = t0; tb < tend; tb += 32) {
     double a[16], b[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int t = (tb + 4 * e < tend) ? tb + 4 * e : tb;
+      const int t = (tb + 2 * e < tend) ? tb + 2 * e : tb;
       a[e] = P[((size_t)t * NB + 0) * ldp + lc];
       b[e] = (NB == 2) ? P[((size_t)t * NB + 1) * ldp + lc] : 0.0;
     }
     asm volatile("" ::: "memory");   // every load of the batch issued
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const bool ok = tb + 4 * e < tend;
+      const bool ok = tb + 2 * e < tend;
       pA += ok ? a[e] : 0.0;
       pB += ok ? b[e] : 0.0;
     }
@@ -964,8 +996,8 @@ __device__ __forceinline__ void kl_chunk(const RedArgs& R, const KLArgs& K, bool
   __syncthreads();
   const size_t pbase = (size_t)K.par * K.peers.parity_stride;
   if (q == 0 && act) {
-    const double sA = (comb[0][lane][0] + comb[1][lane][0]) + (comb[2][lane][0] + comb[3][lane][0]);
-    const double sB = (comb[0][lane][1] + comb[1][lane][1]) + (comb[2][lane][1] + comb[3][lane][1]);
+    const double sA = comb[0][lane][0] + comb[1][lane][0];
+    const double sB = comb[0][lane][1] + comb[1][lane][1];
     const size_t off = pbase + (rows ? 0 : (size_t)NB * R.nxs) + l;
     const int stv = rows ? R.nxs : R.nys;
     const int gidx = rows ? l * R.Px + R.px : l * R.Py + R.py;     // global row this sum belongs to
@@ -1002,8 +1034,8 @@ __device__ __forceinline__ void kl_scalars(const RedArgs& R, const KLArgs& K, do
   }
 }
 
-// after a workgroup's pushes: drain, count, and let the workgroup that completes the count publish the step's flag on
-// every rank (`mine` pushes of `total` expected; the counter returns to zero for the next launch)
+// after a workgroup's pushes: drain, count, and let the role's watching workgroup publish the step's flag on every rank
+// once the count is complete (the counter returns to zero for the next launch)
 // The payload stores are system-scope write-through stores (st_sys): each storing wave waits until they are acknowledged
 // (vmcnt(0)), the workgroup barrier collects the waves, ONE agent-scope add counts the workgroup, and only the publishing
 // workgroup's flag store carries a system-scope release.  A system-scope fence in EVERY pushing workgroup (the earlier
@@ -1011,14 +1043,23 @@ __device__ __forceinline__ void kl_scalars(const RedArgs& R, const KLArgs& K, do
 // the whole launch -- several hundred times per step: 20-38 us per launch in the rehearsal of one rank at N = 32768.  The
 // init-time self-test (comm.hip, st_step_push_kernel) runs this very protocol with checksummed payloads before the solver
 // relies on it.
-__device__ __forceinline__ void kl_publish(const KLArgs& K, unsigned* counter, unsigned mine, unsigned total, int* lastw) {
+__device__ __forceinline__ void kl_publish(const KLArgs& K, unsigned* counter, bool watcher, unsigned total, int* lastw) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (K.fence) __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned tk = atomicAdd(counter, mine);
-    *lastw = (tk + mine == total);
-    if (*lastw) *counter = 0;
+    // (fire-and-forget add + a watching workgroup: see ka_body)
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *lastw = 0;
+    if (watcher) {
+      const long long t0 = wall_clock64();
+      while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > 200000000ll) break;
+      }
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *lastw = 1;
+    }
   }
   __syncthreads();
   // (collective form of the exchange: one local destination, no flag -- comm_step_allgather follows in stream order)
@@ -1026,11 +1067,11 @@ __device__ __forceinline__ void kl_publish(const KLArgs& K, unsigned* counter, u
     __hip_atomic_store(K.peers.flag[threadIdx.x] + K.par * EIGX_MAXP, K.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// (role body of the step launch: workgroup `bid` of `nblocks` = local rows / 64 + local columns / 64 + 2 NB)
+// (role body of the step launch: workgroup `bid` of `nblocks` = local rows / KL_ROWS + local columns / KL_ROWS + 2 NB)
 template <int NB>
 __device__ __forceinline__ void kl_body(const RedArgs& R, const KLArgs& K, const int bid, const int nblocks) {
-  // 64 rows (columns) per workgroup
-  __shared__ double comb[4][64][2];
+  // KL_ROWS rows (columns) per workgroup
+  __shared__ double comb[2][KL_ROWS][2];
   __shared__ double red[16];
   __shared__ int last;
   if (bid >= nblocks - 2 * NB) {
@@ -1053,11 +1094,11 @@ __device__ __forceinline__ void kl_body(const RedArgs& R, const KLArgs& K, const
     }
   } else {
     const bool rows = bid < K.nbr;
-    kl_chunk<NB>(R, K, rows, (rows ? bid : bid - K.nbr) * 64, comb);
+    kl_chunk<NB>(R, K, rows, (rows ? bid : bid - K.nbr) * KL_ROWS, comb);
     if (bid == 0) kl_scalars<NB>(R, K, red);   // (rows / columns that no tile covers get explicit zeros above: tend = 0)
   }
   // every storing wave drains its stores; the last workgroup to arrive publishes the flag on every rank
-  kl_publish(K, K.peers.counter, 1u, (unsigned)nblocks, &last);
+  kl_publish(K, K.peers.counter, bid == 0, (unsigned)nblocks, &last);
 #ifdef EIGX_STAMPS
   if (R.dbg && last && threadIdx.x == 0) {
     const unsigned long long t0 = __hip_atomic_load(&R.dbg[20], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2183,13 +2224,13 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       memset(&KL, 0, sizeof(KL));
       ++epoch;
       KL.L = L; KL.Lr = B.Lr; KL.Lc = B.Lc; KL.T = T; KL.ntc = B.ntc;
-      KL.nbr = ceil_div(B.Lr > 0 ? B.Lr : 1, 64);
+      KL.nbr = ceil_div(B.Lr > 0 ? B.Lr : 1, KL_ROWS);
       KL.par = (int)(epoch & 1);
       KL.epoch = epoch;
       KL.peers = peers;
       KL.kd2 = R.KD; KL.npd2 = npd; KL.kfill = k;
       KL.fence = step_fence;
-      const int nkl = KL.nbr + ceil_div(B.Lc > 0 ? B.Lc : 1, 64) + 2 * NB;
+      const int nkl = KL.nbr + ceil_div(B.Lc > 0 ? B.Lc : 1, KL_ROWS) + 2 * NB;
       if (fuse_wait) { kl_pending = true; KLp = KL; nkl_p = nkl; }
       else {
         if (prof) ctx.prof_begin(2, 8.0 * R.msg_stride, st);
@@ -2286,6 +2327,10 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     if (mg && h[24]) fprintf(stderr, "[eigx stamps] step launch timeline (100-MHz clock, averages over %llu full launches, from workgroup 0's entry): Y flags "
                              "raised at %.2f us, X flags at %.2f us, next launch's workgroup 0 enters at %.2f us\n", h[24], 0.01 * h[22] / h[24],
                              0.01 * h[23] / h[24], 0.01 * h[21] / h[24]);
+    if (h[30]) fprintf(stderr, "[eigx stamps] K_A workgroup in the middle: %.2f us of wall clock per launch, %.0f s_memtime ticks: %.0f MHz\n",
+                       0.01 * h[30] / h[7], (double)h[31] / h[7], (double)h[31] / (0.01 * h[30]));
+    if (mg && h[24]) fprintf(stderr, "[eigx stamps] ka role, workgroup in the middle: enters at %.2f us, sees the Y flags at %.2f, has issued its pushes at %.2f; "
+                             "the watcher sees the count complete at %.2f us\n", 0.01 * h[26] / h[7], 0.01 * h[27] / h[7], 0.01 * h[28] / h[7], 0.01 * h[29] / h[14]);
     if (mg) fprintf(stderr, "[eigx stamps] K_A several GPUs: wait %.0f | to the end of the pushes %.0f, drain + barrier %.0f | last arriver (from its previous stamp "
                     "to the flag store) %.0f x %llu\n", (double)h[5] / h[7], (double)h[6] / h[7], (double)h[12] / h[7], (double)h[13] / (h[14] ? h[14] : 1), h[14]);
     fprintf(stderr, "[eigx stamps] NB=%d n=%d K_A launches %llu: avg cycles issue %.0f consume %.0f reduce %.0f rows %.0f tail %.0f | SYMV %llu: "
