@@ -404,6 +404,109 @@ def test_step_partition_covers_the_upper_triangle(Px, Py):
         assert np.allclose(y, A @ u, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("Px,Py,row_major", [(1, 2, 0), (2, 1, 0), (2, 2, 0), (1, 3, 0), (2, 3, 1), (3, 2, 0), (1, 5, 0), (2, 4, 0), (2, 4, 1),
+                                              (4, 2, 0), (1, 8, 0), (8, 1, 0), (1, 7, 0)])
+def test_owner_directed_step_exchange(Px, Py, row_major):
+    """Round 4's distribution of the per-step panel work, restated with numpy from the kernels' index formulas
+    (band_reduce.hip: own_of / own_row, kl_chunk's destinations, mg_partial, the X message layout), for every grid up to
+    8 ranks -- the 2 x 4 grid of the 8-GPU node included, which the one-GPU box cannot host.  Rows are dealt to the ranks in
+    groups of 16: row r belongs to world rank (r // 16) % P at owned index ((r // 16) // P) * 16 + r % 16.
+    Checks: (a) the owner map is a bijection onto [0, rows owned) per rank, ascending with the row, and the float
+    reciprocal the GPU uses for g // P is exact; (b) Y: every rank sends the sum of local row li (column lj) to the owner of
+    its global row only (rows L-1, L-2 to everybody) at the offsets mg_partial reads, and the owner, adding its Py + Px
+    entries, gets A_sym u for exactly its rows -- nobody reads an entry that was not written in this step; (c) the shares
+    of the panel dots over the ranks' own rows add up to the full dot products; (d) X: the owners' x, W rows at their
+    owned indices reassemble the full vectors on every rank; (e) the rows below L that a rank owns come first in its
+    owned order (what K_P's dot role and the host's own_count assume)."""
+    P = Px * Py
+    rng = np.random.default_rng(7)
+    KA = 16
+
+    def world(qx, qy):
+        return qx * Py + qy if row_major else qx + qy * Px
+
+    inv = np.float32(1.0) / np.float32(P)
+    for L in (1, 2, 15, 16, 17, 33, 130, 257, 1000):
+        n = L + 5                                    # the window strides come from n, the step works on rows < L
+        nxs = (-(-n // Px) + 7) // 8 * 8
+        nys = (-(-n // Py) + 7) // 8 * 8
+        nown = -(-(-(-n // KA)) // P) * KA
+        r = np.arange(n)
+        g = r // KA
+        own = g % P
+        oidx = (g // P) * KA + r % KA
+        # (a) exact float division, bijection, order
+        q32 = ((g.astype(np.float32) + np.float32(0.5)) * inv).astype(np.int64)
+        assert (q32 == g // P).all()
+        for me in range(P):
+            mine = r[own == me]
+            assert (oidx[own == me] == np.arange(len(mine))).all() or len(mine) == 0 or \
+                (np.diff(oidx[own == me]) > 0).all()                     # ascending with the row
+            assert oidx[own == me].max(initial=-1) < nown
+            # own_row inverts it
+            o = oidx[own == me]
+            assert ((((o // KA) * P + me) * KA) + o % KA == mine).all()
+            # (e) rows below L come first: count = full groups below L owned + the partial group if mine
+            gfull, rem = L // KA, L % KA
+            cnt = len([gg for gg in range(gfull) if gg % P == me]) * KA + (rem if (rem and gfull % P == me) else 0)
+            below = oidx[(own == me) & (r < L)]
+            assert len(below) == cnt and (np.sort(below) == np.arange(cnt)).all()
+        # (b) the Y exchange of one step
+        A = rng.standard_normal((L, L))
+        A = A + A.T
+        u = rng.standard_normal(L)
+        # window of destination d: [source][NB=1 row sums: nxs | column sums: nys], NaN = never written this step
+        win = np.full((P, P, nxs + nys), np.nan)
+        for px in range(Px):
+            for py in range(Py):
+                src = world(px, py)
+                rows = np.arange(px, L, Px)
+                cols = np.arange(py, L, Py)
+                blk = A[np.ix_(rows, cols)]
+                strict = rows[:, None] < cols[None, :]
+                upper = rows[:, None] <= cols[None, :]
+                rsum = (blk * strict) @ u[cols] if len(cols) else np.zeros(len(rows))
+                csum = (blk * upper).T @ u[rows] if len(rows) else np.zeros(len(cols))
+                for li, gr in enumerate(rows):
+                    dests = range(P) if gr >= L - 2 else [own[gr]]
+                    for d in dests:
+                        win[d, src, li] = rsum[li]
+                for lj, gc in enumerate(cols):
+                    dests = range(P) if gc >= L - 2 else [own[gc]]
+                    for d in dests:
+                        win[d, src, nxs + lj] = csum[lj]
+        y = A @ u
+        for me in range(P):
+            for gr in r[(own == me) & (r < L)]:
+                acc = 0.0
+                for t in range(Py + Px):                                  # mg_partial
+                    if t < Py:
+                        qx, qy, off = gr % Px, t, gr // Px
+                    else:
+                        qx, qy, off = t - Py, gr % Py, nxs + gr // Py
+                    v = win[me, world(qx, qy), off]
+                    assert not np.isnan(v), (L, me, gr, t)
+                    acc += v
+                assert abs(acc - y[gr]) <= 1e-12 * (1 + abs(y[gr]))
+            for c in (L - 1, L - 2):                                      # P(c, :) of the next block columns: on every rank
+                if c < 0:
+                    continue
+                acc = sum(win[me, world(c % Px, t), c // Px] for t in range(Py)) + \
+                    sum(win[me, world(t, c % Py), nxs + c // Py] for t in range(Px))
+                assert abs(acc - y[c]) <= 1e-12 * (1 + abs(y[c]))
+        # (c) panel dots: shares over the ranks' own rows
+        U = rng.standard_normal((L, 5))
+        shares = [U[(own[:L] == me), :].T @ u[own[:L] == me] for me in range(P)]
+        assert np.allclose(sum(shares), U.T @ u, rtol=1e-12, atol=1e-12)
+        # (d) X: owners' rows at their owned indices reassemble the vector
+        x = rng.standard_normal(L)
+        msg = np.full((P, nown), np.nan)
+        for me in range(P):
+            sel = (own[:L] == me)
+            msg[me, oidx[:L][sel]] = x[sel]
+        assert (msg[own[:L], oidx[:L]] == x).all()
+
+
 def test_matrix_market_reader(tmp_path):
     """matrix types -1 / -2 of the reference driver (benchmark/mat_set.f:218-330, mat_dim_get :461-533): coordinate
     triples of a symmetric matrix, comment lines, Fortran D exponents"""
