@@ -102,6 +102,7 @@ struct RedArgs {
   const double* PAN; int ldpan;   // columns of the current panel gathered from their owners (global row order)
   const double* zero16;           // 16 bytes of zeros: where the mat-vec's loads of rows beyond the active block go (see load8)
   int abl;                        // EIGX_STAMPS diagnostic build only: ablation mask (timing experiments)
+  int stamp_i;                    // EIGX_STAMPS diagnostic build only: the step (top column i) whose roles record per-workgroup times
   unsigned long long* dbg;        // EIGX_STAMPS diagnostic build only: accumulated s_memtime stamps
 };
 
@@ -345,6 +346,12 @@ __device__ __forceinline__ void ka_body(const RedArgs& R, const KAArgs& S, const
 #endif
   EIGX_TL(26);   // (timeline: this workgroup's entry)
 #ifdef EIGX_STAMPS
+#define EIGX_PW(base) do { if (MG && R.dbg && threadIdx.x == 0 && S.i == R.stamp_i && bid < 1024) R.dbg[(base) + bid] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define EIGX_PW(base) do {} while (0)
+#endif
+  EIGX_PW(64);
+#ifdef EIGX_STAMPS
   const unsigned long long clk_w0 = (unsigned long long)wall_clock64(), clk_m0 = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -472,6 +479,7 @@ __device__ __forceinline__ void ka_body(const RedArgs& R, const KAArgs& S, const
     step_wait_fused(S.wait, bid == 0);
     EIGX_STAMP(5);
     EIGX_TL(27);   // (timeline: Y flags seen)
+    EIGX_PW(1088);
     load_rows_msg(r, cur);
   }
   // panel dots: thread kk = tid (< kp <= 256) sums entry (kind, kk) over the K_P row chunks
@@ -830,6 +838,7 @@ __device__ __forceinline__ void ka_body(const RedArgs& R, const KAArgs& S, const
     // with a system-scope release) -- the protocol of kl_publish, self-tested at init (comm.hip st_step_push_kernel).
     EIGX_STAMP(6);
     EIGX_TL(28);   // (timeline: pushes issued)
+    EIGX_PW(2112);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     EIGX_STAMP(12);
@@ -846,6 +855,9 @@ __device__ __forceinline__ void ka_body(const RedArgs& R, const KAArgs& S, const
         }
         __hip_atomic_store(XP.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         lastw = 1;
+#ifdef EIGX_STAMPS
+        if (R.dbg && S.i == R.stamp_i) R.dbg[3904] = (unsigned long long)wall_clock64();
+#endif
 #ifdef EIGX_STAMPS
         if (R.dbg) { const unsigned long long t0_ = __hip_atomic_load(&R.dbg[20], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const unsigned long long dt_ = (unsigned long long)wall_clock64() - t0_; if (t0_ != 0 && dt_ < 100000ull) atomicAdd(&R.dbg[29], dt_); }
@@ -867,6 +879,7 @@ __device__ __forceinline__ void ka_body(const RedArgs& R, const KAArgs& S, const
       if (tid < XP.n && XP.flag[tid])
         __hip_atomic_store(XP.flag[tid] + S.xpar * EIGX_MAXP, S.xepoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef EIGX_STAMPS
+      if (R.dbg && tid == 0 && S.i == R.stamp_i) R.dbg[3905] = (unsigned long long)wall_clock64();
       if (R.dbg && tid == 0) {
         atomicAdd(&R.dbg[13], __builtin_amdgcn_s_memtime() - stamp_prev); atomicAdd(&R.dbg[14], 1ull);
         const unsigned long long t0 = __hip_atomic_load(&R.dbg[20], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -938,6 +951,7 @@ struct KLArgs {
   // second level of the panel dots: the mat-vec launch's K_P workgroups take short chunks of the rank's rows and write kd2;
   // kl_kernel's extra workgroups sum the npd2 chunks and send the rank's share to everybody
   const double* kd2; int npd2, kfill;
+  int ntr;     // tile rows that hold at least one tile (= the largest mg_nty over the tile columns)
   int fence;   // 1: every pushing workgroup runs a system-scope fence behind its stores (EIGX_STEP_FENCE=1); 0: see kl_publish
 };
 
@@ -950,7 +964,7 @@ struct KLArgs {
 // (196 + 256 workgroups of 512 slots), so every ka workgroup has its local data in flight while kl still runs.
 constexpr int KL_ROWS = 128;
 template <int NB>
-__device__ __forceinline__ void kl_chunk(const RedArgs& R, const KLArgs& K, bool rows, int l0, double (*comb)[KL_ROWS][2]) {
+__device__ __forceinline__ void kl_chunk(const RedArgs& R, const KLArgs& K, bool rows, int l0, double (*comb)[KL_ROWS][2], int kl_bid = 0) {
   const int ldp = R.ldp;
   const int lane = threadIdx.x & (KL_ROWS - 1), q = threadIdx.x / KL_ROWS;    // q = 0, 1
   const int T = K.T;
@@ -960,6 +974,12 @@ __device__ __forceinline__ void kl_chunk(const RedArgs& R, const KLArgs& K, bool
   // NB * ldp per tile).  They sit behind a cold L2 (written by tiles on other XCDs): ALL loads of a batch of 16 per vector
   // are issued before the first add -- clamped indices, masked afterwards -- so a row costs one memory round trip, not
   // one per tile (the earlier loop with a serial remainder took ~20 us per launch at 32-64 tiles per row).
+#ifdef EIGX_STAMPS
+#define EIGX_KLW(base) do { if (R.dbg && threadIdx.x == 0 && K.L == R.stamp_i - 1 && kl_bid < 256) R.dbg[(base) + kl_bid] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define EIGX_KLW(base) do {} while (0)
+#endif
+  EIGX_KLW(3136);
   const bool act = rows ? (l < K.Lr) : (l < K.Lc);
   const double* P = rows ? R.YR : R.YC;
   int t0 = q, tend = 0;
@@ -994,6 +1014,7 @@ __device__ __forceinline__ void kl_chunk(const RedArgs& R, const KLArgs& K, bool
   }
   comb[q][lane][0] = pA; comb[q][lane][1] = pB;
   __syncthreads();
+  EIGX_KLW(3392);
   const size_t pbase = (size_t)K.par * K.peers.parity_stride;
   if (q == 0 && act) {
     const double sA = comb[0][lane][0] + comb[1][lane][0];
@@ -1014,17 +1035,33 @@ __device__ __forceinline__ void kl_chunk(const RedArgs& R, const KLArgs& K, bool
   __syncthreads();   // comb is reused by the caller's next chunk
 }
 
-// the three bilinear scalars of this rank: sum over its tiles, written into every rank's step window
+// the three bilinear scalars of this rank: sum over its tiles, written into every rank's step window.  A workgroup of its
+// own (round 4: as a side job of the first row chunk's workgroup its serial walk over the tile columns -- a memory round
+// trip each -- kept that one workgroup busy for 8.7 us while the other ~200 had drained their stores after 4.6: the Y
+// flags went up at ~10 us).  Wave q takes the tile columns q, q + 4, ...; ALL loads of up to 16 of them are issued before
+// the first add (clamped indices, masked afterwards); lane = tile row.
 template <int NB>
 __device__ __forceinline__ void kl_scalars(const RedArgs& R, const KLArgs& K, double* red) {
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   double v[3] = {0.0, 0.0, 0.0};
-  // every tile of this rank: tile column tx holds mg_nty(tx) tiles
-  for (int tx = q; tx < K.ntc; tx += 4) {
-    const int nty = mg_nty(tx, K.T, K.Lc, R.Px, R.px, R.Py, R.py);
-    for (int ty = lane; ty < nty; ty += 64) {
-      const double* sp = R.SP + ((size_t)ty * R.maxseg + tx) * 3;
-      v[0] += sp[0]; v[1] += sp[1]; v[2] += sp[2];
+  for (int ty0 = 0; ty0 < K.ntr; ty0 += 64) {
+    const int ty = ty0 + lane;
+    for (int tb = q; tb < K.ntc; tb += 64) {
+      double a[16][3];
+      bool ok[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int tx = tb + 4 * e;
+        const int txc = tx < K.ntc ? tx : tb;
+        ok[e] = tx < K.ntc && ty < mg_nty(txc, K.T, K.Lc, R.Px, R.px, R.Py, R.py);
+        const double* sp = R.SP + ((size_t)(ok[e] ? ty : 0) * R.maxseg + txc) * 3;
+        a[e][0] = sp[0]; a[e][1] = sp[1]; a[e][2] = sp[2];
+      }
+      asm volatile("" ::: "memory");   // every load of the batch issued
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        v[0] += ok[e] ? a[e][0] : 0.0; v[1] += ok[e] ? a[e][1] : 0.0; v[2] += ok[e] ? a[e][2] : 0.0;
+      }
     }
   }
   block_sum_multi<3>(v, red);
@@ -1067,19 +1104,21 @@ __device__ __forceinline__ void kl_publish(const KLArgs& K, unsigned* counter, b
     __hip_atomic_store(K.peers.flag[threadIdx.x] + K.par * EIGX_MAXP, K.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// (role body of the step launch: workgroup `bid` of `nblocks` = local rows / KL_ROWS + local columns / KL_ROWS + 2 NB)
+// (role body of the step launch: workgroup `bid` of `nblocks` = local rows / KL_ROWS + local columns / KL_ROWS + 2 NB + 1)
 template <int NB>
 __device__ __forceinline__ void kl_body(const RedArgs& R, const KLArgs& K, const int bid, const int nblocks) {
   // KL_ROWS rows (columns) per workgroup
   __shared__ double comb[2][KL_ROWS][2];
   __shared__ double red[16];
   __shared__ int last;
-  if (bid >= nblocks - 2 * NB) {
+  if (bid == nblocks - 1) {
+    kl_scalars<NB>(R, K, red);
+  } else if (bid >= nblocks - 1 - 2 * NB) {
     // panel dots, second level: one workgroup per kind q; entry (q, panel column kk) = sum over this rank's row chunks in
     // chunk order (deterministic), ALL chunk loads of a thread in one batch (<= 12 chunks: one memory round trip); the
     // rank's share goes into every rank's window (ka_kernel adds the P shares in rank order)
     const int m = R.m, tid = threadIdx.x;
-    const int q = bid - (nblocks - 2 * NB);
+    const int q = bid - (nblocks - 1 - 2 * NB);
     constexpr int MAXC = 12;
     if (tid < K.kfill) {
       double v[MAXC];
@@ -1094,10 +1133,13 @@ __device__ __forceinline__ void kl_body(const RedArgs& R, const KLArgs& K, const
     }
   } else {
     const bool rows = bid < K.nbr;
-    kl_chunk<NB>(R, K, rows, (rows ? bid : bid - K.nbr) * KL_ROWS, comb);
-    if (bid == 0) kl_scalars<NB>(R, K, red);   // (rows / columns that no tile covers get explicit zeros above: tend = 0)
+    kl_chunk<NB>(R, K, rows, (rows ? bid : bid - K.nbr) * KL_ROWS, comb, bid);
+    // (rows / columns that no tile covers get explicit zeros above: tend = 0)
   }
   // every storing wave drains its stores; the last workgroup to arrive publishes the flag on every rank
+#ifdef EIGX_STAMPS
+  { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const int kl_bid = bid; EIGX_KLW(3648); }
+#endif
   kl_publish(K, K.peers.counter, bid == 0, (unsigned)nblocks, &last);
 #ifdef EIGX_STAMPS
   if (R.dbg && last && threadIdx.x == 0) {
@@ -1328,7 +1370,13 @@ __device__ __forceinline__ void symv_body(const RedArgs& R, const KBArgs& B, con
   // (several GPUs: npd x ncg dot workgroups over the rank's own rows, then npd_s store workgroups over all rows)
   const int nkp = MG ? B.npd * B.ncg + B.npd_s : B.npd * (B.ncg + 1);
   const bool panel_role = bid0 < nkp;     // K_P first: its workgroups are the long ones at small L
-  if (MG && B.xwait.n > 0) step_wait_fused(B.xwait, bid0 == 0); // this step's x (X message) must be in: here, or a wait kernel ran
+  if (MG && B.xwait.n > 0) step_wait_fused(B.xwait, bid0 == 0);
+#ifdef EIGX_STAMPS
+  if (MG && R.dbg && threadIdx.x == 0 && B.i == R.stamp_i) {
+    const unsigned long long t_ = (unsigned long long)wall_clock64();
+    atomicMax(&R.dbg[3907], t_); atomicMax(&R.dbg[3906], ~t_);
+  }
+#endif // this step's x (X message) must be in: here, or a wait kernel ran
   const int bid = bid0 - nkp;
   int tyv = 0, txv = 0;
   if (!panel_role && MG) {
@@ -1756,6 +1804,10 @@ __device__ __forceinline__ void symv_body(const RedArgs& R, const KBArgs& B, con
   EIGX_STAMP(11);
 #ifdef EIGX_STAMPS
   if (R.dbg && threadIdx.x == 0 && stamp_me) atomicAdd(&R.dbg[15], 1ull);
+  if (MG && R.dbg && threadIdx.x == 0 && B.i == R.stamp_i) {
+    const unsigned long long t_ = (unsigned long long)wall_clock64();
+    atomicMax(&R.dbg[3908], t_); atomicMax(&R.dbg[3909], ~t_); atomicAdd(&R.dbg[3910], 1ull);
+  }
 #endif
 }
 
@@ -1934,9 +1986,10 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
   R.zero16 = R.sc + SC_COUNT;             // zero-filled below with the scalars, never written afterwards
   R.dbg = nullptr;
   R.abl = getenv("EIGX_ABL") ? atoi(getenv("EIGX_ABL")) : 0;
+  R.stamp_i = getenv("EIGX_STAMP_I") ? atoi(getenv("EIGX_STAMP_I")) : -1;
 #ifdef EIGX_STAMPS
-  R.dbg = ctx.pool.get_t<unsigned long long>("red.dbg", 32);
-  EIGX_HIP_CHECK(hipMemsetAsync(R.dbg, 0, 32 * sizeof(unsigned long long), st));
+  R.dbg = ctx.pool.get_t<unsigned long long>("red.dbg", 4096);
+  EIGX_HIP_CHECK(hipMemsetAsync(R.dbg, 0, 4096 * sizeof(unsigned long long), st));
 #endif
   // ---- multi-GPU state: step window, gathered panel, compact panels ------------------------------------------
   StepPeers peers, xpeers;
@@ -2230,7 +2283,9 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
       KL.peers = peers;
       KL.kd2 = R.KD; KL.npd2 = npd; KL.kfill = k;
       KL.fence = step_fence;
-      const int nkl = KL.nbr + ceil_div(B.Lc > 0 ? B.Lc : 1, KL_ROWS) + 2 * NB;
+      KL.ntr = 0;
+      for (int tx = 0; tx < B.ntc; ++tx) { const int c_ = mg_nty(tx, T, B.Lc, G.Px, G.px, G.Py, G.py); if (c_ > KL.ntr) KL.ntr = c_; }
+      const int nkl = KL.nbr + ceil_div(B.Lc > 0 ? B.Lc : 1, KL_ROWS) + 2 * NB + 1;   // + the scalar workgroup
       if (fuse_wait) { kl_pending = true; KLp = KL; nkl_p = nkl; }
       else {
         if (prof) ctx.prof_begin(2, 8.0 * R.msg_stride, st);
@@ -2327,6 +2382,22 @@ void band_reduce_impl(Context& ctx, int n, double* A, int lda, double* d, double
     if (mg && h[24]) fprintf(stderr, "[eigx stamps] step launch timeline (100-MHz clock, averages over %llu full launches, from workgroup 0's entry): Y flags "
                              "raised at %.2f us, X flags at %.2f us, next launch's workgroup 0 enters at %.2f us\n", h[24], 0.01 * h[22] / h[24],
                              0.01 * h[23] / h[24], 0.01 * h[21] / h[24]);
+    if (R.stamp_i >= 0 && mg) {
+      // one sampled step (EIGX_STAMP_I = its top column): per-workgroup times of the three roles on the 100-MHz clock
+      std::vector<unsigned long long> big(4096);
+      EIGX_HIP_CHECK(hipMemcpy(big.data(), R.dbg, 4096 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      unsigned long long t0 = ~0ull; int nw = 0, nk = 0;
+      for (int b = 0; b < 256; ++b) if (big[3136 + b]) { ++nk; if (big[3136 + b] < t0) t0 = big[3136 + b]; }
+      for (int b = 0; b < 1024; ++b) if (big[64 + b]) { ++nw; if (big[64 + b] < t0) t0 = big[64 + b]; }
+      double mk[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+      for (int b = 0; b < nk; ++b) for (int q = 0; q < 3; ++q) { const double v = 0.01 * (big[3136 + 256 * q + b] - t0); if (v > mk[q]) mk[q] = v; }
+      for (int b = 0; b < nw; ++b) for (int q = 0; q < 3; ++q) { const double v = 0.01 * (big[64 + 1024 * q + b] - t0); if (v > mx[q]) mx[q] = v; }
+      fprintf(stderr, "[eigx stamps] step with top column %d, us after the launch's first workgroup: kl role (%d workgroups) latest entry %.2f, partial sums in %.2f, "
+              "stores drained %.2f | ka role (%d) latest entry %.2f, Y seen %.2f, pushes issued %.2f; count complete %.2f, X flags stored %.2f | mat-vec role "
+              "(%llu tiles): X seen first %.2f last %.2f, tile ends first %.2f last %.2f\n", R.stamp_i, nk, mk[0], mk[1], mk[2], nw, mx[0], mx[1], mx[2],
+              0.01 * (big[3904] - t0), 0.01 * (big[3905] - t0), big[3910], 0.01 * (~big[3906] - t0), 0.01 * (big[3907] - t0), 0.01 * (~big[3909] - t0),
+              0.01 * (big[3908] - t0));
+    }
     if (h[30]) fprintf(stderr, "[eigx stamps] K_A workgroup in the middle: %.2f us of wall clock per launch, %.0f s_memtime ticks: %.0f MHz\n",
                        0.01 * h[30] / h[7], (double)h[31] / h[7], (double)h[31] / (0.01 * h[30]));
     if (mg && h[24]) fprintf(stderr, "[eigx stamps] ka role, workgroup in the middle: enters at %.2f us, sees the Y flags at %.2f, has issued its pushes at %.2f; "
