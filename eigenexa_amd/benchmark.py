@@ -45,6 +45,7 @@ MATRIX_TEXT = {
     0: "(Frank matrix)", 1: "(Toeplitz matrix)", 2: "(Random matrix)", 3: "(Frank matrix 2)",
     4: "(W: 0, 1, ..., n-1)", 5: "(W: sin(PAI*5*i/(n-1)+EPS^1/4)^3)", 6: "(W: MOD(i,5)+MOD(i,2))",
     7: "(W: same as Frank matrix)", 8: "(W: Uniform Distribution, [0,1))", 9: "(W: Gauss Distribution, m=0,s=1)",
+    10: "(W: Read from the data file 'W.dat')",
     -1: "(Read from the data file 'A.mtx')", -2: "(Read from the data file 'B.mtx')",
 }
 EPS = np.finfo(np.float64).eps

@@ -164,8 +164,17 @@ def spectrum(n, mtype, seed=7):
     if mtype == 7:
         return frank_eigenvalues(n)
     if mtype == 10:
-        # benchmark/W.dat (the spectrum file of the KMATH_EIGEN_GEV driver, benchmark/KMATH_EIGEN_GEV_main.f:57-58):
-        # its k-th entry is 10 + sin(k-1) printed with six significant digits (checked against all 100000 entries)
+        # benchmark/W.dat (matrix type 10 of the driver, benchmark/mat_set.f:205-216, :714-729; also the spectrum file of the
+        # KMATH_EIGEN_GEV driver, benchmark/KMATH_EIGEN_GEV_main.f:57-58).  A 'W.dat' in the working directory is read as
+        # the reference reads it (free format, the first n numbers); without one the file's content is regenerated: its
+        # k-th entry is 10 + sin(k-1) printed with six significant digits (checked against all 100000 entries)
+        import os
+
+        if os.path.exists("W.dat"):
+            vals = np.array(open("W.dat").read().split()[:n], dtype=np.float64)
+            if len(vals) < n:
+                raise ValueError(f"W.dat holds {len(vals)} numbers, matrix type 10 needs {n}")
+            return vals
         v = 10.0 + np.sin(i - 1.0)
         return np.where(v >= 10.0, np.round(v, 4), np.round(v, 5))
     rng = np.random.default_rng(seed)

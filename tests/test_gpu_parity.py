@@ -925,8 +925,10 @@ def test_benchmark_driver_check_sweep(gpu_lib, tmp_path):
         for t in (0, 2):
             for s in (0, 1):
                 lines.append(f"{n} {n} 48 128 1 {t} {s} 1")
+    # ... other modes / matrix types, incl. type 10 (the spectrum file W.dat, benchmark/mat_set.f:205-216, :714-729; without a
+    # W.dat in the working directory its content is regenerated: 10 + sin(k - 1) to six digits)
     lines += ["300 300 48 128 0 0 0 1", "300 300 48 128 2 3 1 1", "200 50 48 128 1 4 0 1", "257 257 48 128 1 6 1 1",
-              "-1 0 0 0 0 0 0 0"]
+              "333 333 48 128 1 10 0 1", "200 200 48 128 1 10 1 1", "-1 0 0 0 0 0 0 0"]
     p = tmp_path / "IN-check"
     p.write_text("\n".join(lines) + "\n")
     log = []

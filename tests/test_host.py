@@ -507,6 +507,24 @@ def test_owner_directed_step_exchange(Px, Py, row_major):
         assert (msg[own[:L], oidx[:L]] == x).all()
 
 
+def test_matrix_type_10_reads_w_dat(tmp_path, monkeypatch):
+    """matrix type 10 of the reference driver (benchmark/mat_set.f:205-216, :714-729): the spectrum comes from the file
+    'W.dat' in the working directory (free format, first n numbers); without the file its content is regenerated
+    (10 + sin(k - 1) printed with six significant digits -- the formula was checked against all 100000 entries)"""
+    from eigenexa_amd import layout
+
+    monkeypatch.chdir(tmp_path)
+    gen = layout.spectrum(50, 10)
+    assert gen[0] == 10.0 and abs(gen[1] - 10.8415) < 1e-12 and abs(gen[4] - 9.2432) < 1e-12    # W.dat lines 1, 2, 5
+    (tmp_path / "W.dat").write_text("\n".join(f"{1.5 + 0.25 * k}" for k in range(60)) + "\n")
+    got = layout.spectrum(40, 10)
+    assert len(got) == 40 and got[0] == 1.5 and got[39] == 1.5 + 0.25 * 39
+    A, lam = layout.reference_matrix(40, 10)
+    assert np.abs(np.linalg.eigvalsh(A) - lam).max() < 1e-13 * 40
+    with pytest.raises(ValueError):
+        layout.spectrum(100, 10)
+
+
 def test_matrix_market_reader(tmp_path):
     """matrix types -1 / -2 of the reference driver (benchmark/mat_set.f:218-330, mat_dim_get :461-533): coordinate
     triples of a symmetric matrix, comment lines, Fortran D exponents"""
