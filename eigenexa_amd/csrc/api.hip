@@ -99,6 +99,15 @@ int eigx_init_multi(int device, int rank, int nranks, const void* uid, char orde
     EIGX_HIP_CHECK(hipEventCreateWithFlags(&g_ctx.aux_ev[q], hipEventDisableTiming));
   EIGX_HIP_CHECK(hipEventCreateWithFlags(&g_ctx.bt_ev, hipEventDisableTiming));
   EIGX_HIP_CHECK(hipEventCreateWithFlags(&g_ctx.dc_ev, hipEventDisableTiming));
+  {
+    // highest priority: its own hardware queue (the plain streams share four), and the small latency-bound kernels of the
+    // next D&C pass get CU slots while the current pass's product fills the chip
+    int prio_lo = 0, prio_hi = 0;
+    EIGX_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    EIGX_HIP_CHECK(hipStreamCreateWithPriority(&g_ctx.dc_stream, hipStreamNonBlocking, prio_hi));
+  }
+  EIGX_HIP_CHECK(hipEventCreateWithFlags(&g_ctx.dc_b_ev, hipEventDisableTiming));
+  EIGX_HIP_CHECK(hipEventCreateWithFlags(&g_ctx.dc_z_ev, hipEventDisableTiming));
   g_ctx.initialized = true;
   g_ctx.errinfo = 0;
   return EIGX_OK;
@@ -117,6 +126,9 @@ int eigx_free(void) {
   for (int q = 0; q <= Context::kAux; ++q) EIGX_HIP_CHECK(hipEventDestroy(g_ctx.aux_ev[q]));
   EIGX_HIP_CHECK(hipEventDestroy(g_ctx.bt_ev));
   EIGX_HIP_CHECK(hipEventDestroy(g_ctx.dc_ev));
+  EIGX_HIP_CHECK(hipStreamDestroy(g_ctx.dc_stream));
+  EIGX_HIP_CHECK(hipEventDestroy(g_ctx.dc_b_ev));
+  EIGX_HIP_CHECK(hipEventDestroy(g_ctx.dc_z_ev));
   g_ctx = Context();
   return EIGX_OK;
 }
@@ -346,6 +358,8 @@ int eigx_tune(int key, int value) {
   if (key == 10) return set_symv_threshold(4, value);
   if (key == 11) return set_symv_threshold(5, value);   // branch-free pipelined form of the mat-vec up to this active size
   if (key == 12) return set_symv_threshold(6, value);   // (removed in round 4: step exchange folded into the mat-vec launch; accepted, ignored)
+  if (key == 15) return set_dc_pipe(value);    // D&C on one GPU: next pass's deflation / secular equations under this pass's product
+  if (key == 16) return set_dc_batch(value);   // D&C on one GPU: one product launch per low height
   return -1;
 }
 

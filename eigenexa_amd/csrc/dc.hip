@@ -43,21 +43,24 @@ constexpr int LEAF = 32;
 // ================================================================================================
 // leaves: cyclic Jacobi with round-robin pairing, one workgroup per leaf
 // ================================================================================================
-__global__ __launch_bounds__(256) void jacobi_leaf_kernel(const double* __restrict__ d,
-                                                          const double* __restrict__ e, int lde, int band,
-                                                          const int* __restrict__ leaf_off,
-                                                          const int* __restrict__ leaf_n, double* __restrict__ D,
-                                                          double* __restrict__ Q, int ldq, int r0, int r1) {
+// One WAVE per leaf (64-thread workgroups: the barriers below cost nothing, every CU runs several leaves side by side).
+// Round 4: the 256-thread form spent its time in three workgroup barriers per round of <= 16 rotations (1.3 ms for the
+// 256 leaves of N = 8192).
+constexpr int LEAF_T = 64;
+__global__ __launch_bounds__(LEAF_T) void jacobi_leaf_kernel(const double* __restrict__ d,
+                                                             const double* __restrict__ e, int lde, int band,
+                                                             const int* __restrict__ leaf_off,
+                                                             const int* __restrict__ leaf_n, double* __restrict__ D,
+                                                             double* __restrict__ Q, int ldq, int r0, int r1) {
   __shared__ double A[LEAF][LEAF + 1];
   __shared__ double V[LEAF][LEAF + 1];
   __shared__ double cs[LEAF / 2][2];
   __shared__ int pq[LEAF / 2][2];
-  __shared__ int nrot;
-  __shared__ double anorm_s;
   __shared__ int perm[LEAF];
   const int tid = threadIdx.x;
   const int off = leaf_off[blockIdx.x], m = leaf_n[blockIdx.x];
-  for (int idx = tid; idx < LEAF * LEAF; idx += 256) {
+  double mx = 0.0;
+  for (int idx = tid; idx < LEAF * LEAF; idx += LEAF_T) {
     const int r = idx / LEAF, c = idx % LEAF;
     double v = 0.0;
     if (r < m && c < m) {
@@ -68,97 +71,121 @@ __global__ __launch_bounds__(256) void jacobi_leaf_kernel(const double* __restri
     }
     A[r][c] = v;
     V[r][c] = (r == c) ? 1.0 : 0.0;
+    mx = fmax(mx, fabs(v));
   }
-  if (tid == 0) anorm_s = 0.0;
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
   __syncthreads();
-  {
-    double mx = 0.0;
-    for (int idx = tid; idx < m * m; idx += 256) mx = fmax(mx, fabs(A[idx / m][idx % m]));
-    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
-    if ((tid & 63) == 0) atomicMax((unsigned long long*)&anorm_s, (unsigned long long)__double_as_longlong(mx));
-  }
-  __syncthreads();
-  const double thr = 2e-18 * anorm_s;
+  const double thr = 2e-18 * mx;
+  const double isc = (mx > 0.0) ? ldexp(1.0, -ilogb(mx)) : 1.0;   // the rotation angle is scale-free: keeps dd^2 + b^2 in range
   const int m2 = m + (m & 1);
   const int np = m2 / 2;
+  // Thread layout of the update phases: lane -> (row/column index k = tid & 31, pairs t = (tid >> 5) + 2 it, it < 8).  All
+  // loads of a phase are issued before its first store (the pairs of a round touch disjoint rows / columns), so a phase
+  // costs one LDS round trip instead of one per pair: a leaf is a single wave with nothing else to hide latency behind.
+  const int kk = tid & (LEAF - 1), th = tid >> 5;
+  const bool kact = kk < m;
   for (int sweep = 0; sweep < 40; ++sweep) {
-    if (tid == 0) nrot = 0;
-    __syncthreads();
+    int nrot = 0;
     for (int rnd = 0; rnd < m2 - 1; ++rnd) {
+      bool rot = false;
       if (tid < np) {
         int p, q;
         if (tid == 0) { p = m2 - 1; q = rnd; }
-        else { p = (rnd + tid) % (m2 - 1); q = (rnd - tid + (m2 - 1)) % (m2 - 1); }
+        else {
+          p = rnd + tid; if (p >= m2 - 1) p -= m2 - 1;
+          q = rnd - tid; if (q < 0) q += m2 - 1;
+        }
         if (p > q) { const int t = p; p = q; q = t; }
         double c = 1.0, s = 0.0;
         if (q < m) {
           const double apq = A[p][q];
           if (fabs(apq) > thr) {
-            const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
-            const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            c = 1.0 / sqrt(t * t + 1.0);
-            s = t * c;
-            atomicAdd(&nrot, 1);
+            // half-angle form with two reciprocal square roots (hardware estimate + two Newton steps each) instead of
+            // three divisions and two square roots: dd = a_qq - a_pp, b = 2 a_pq, r = sqrt(dd^2 + b^2),
+            // c = sqrt((1 + |dd|/r)/2), s = sign(dd b) |b| / (2 r c)   (tan of the smaller rotation angle, as before)
+            const double dd_ = (A[q][q] - A[p][p]) * isc, b = 2.0 * apq * isc;
+            const double x = dd_ * dd_ + b * b;
+            double ir = __builtin_amdgcn_rsq(x);
+            ir = ir * (1.5 - 0.5 * x * ir * ir);
+            ir = ir * (1.5 - 0.5 * x * ir * ir);
+            const double c2 = 0.5 + 0.5 * fabs(dd_) * ir;     // in [0.5, 1]
+            double ic = __builtin_amdgcn_rsq(c2);
+            ic = ic * (1.5 - 0.5 * c2 * ic * ic);
+            ic = ic * (1.5 - 0.5 * c2 * ic * ic);
+            c = c2 * ic;
+            s = 0.5 * b * ir * ic;
+            if (dd_ < 0.0) s = -s;
+            rot = true;
           }
         }
         cs[tid][0] = c; cs[tid][1] = s;
         pq[tid][0] = p; pq[tid][1] = q;
       }
+      const bool any = __ballot(rot) != 0ull;
       __syncthreads();
+      if (!any) continue;   // wave-uniform: nothing to rotate in this round
+      ++nrot;
       // columns: A <- A J, V <- V J
-      for (int idx = tid; idx < np * m; idx += 256) {
-        const int t = idx / m, k = idx - t * m;
-        const double c = cs[t][0], s = cs[t][1];
-        if (s != 0.0) {
-          const int p = pq[t][0], q = pq[t][1];
-          const double akp = A[k][p], akq = A[k][q];
-          A[k][p] = c * akp - s * akq;
-          A[k][q] = s * akp + c * akq;
-          const double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = c * vkp - s * vkq;
-          V[k][q] = s * vkp + c * vkq;
+      {
+        double c_[8], s_[8], a0[8], a1[8], v0[8], v1[8];
+        int p_[8], q_[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int t = th + 2 * it;
+          const bool on = kact && t < np;
+          c_[it] = on ? cs[t][0] : 1.0; s_[it] = on ? cs[t][1] : 0.0;
+          p_[it] = on ? pq[t][0] : 0; q_[it] = on ? pq[t][1] : 0;
         }
-      }
-      __syncthreads();
-      // rows: A <- J^T A
-      for (int idx = tid; idx < np * m; idx += 256) {
-        const int t = idx / m, k = idx - t * m;
-        const double c = cs[t][0], s = cs[t][1];
-        if (s != 0.0) {
-          const int p = pq[t][0], q = pq[t][1];
-          const double apk = A[p][k], aqk = A[q][k];
-          A[p][k] = c * apk - s * aqk;
-          A[q][k] = s * apk + c * aqk;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          a0[it] = A[kk][p_[it]]; a1[it] = A[kk][q_[it]];
+          v0[it] = V[kk][p_[it]]; v1[it] = V[kk][q_[it]];
         }
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+          if (s_[it] != 0.0) {
+            A[kk][p_[it]] = c_[it] * a0[it] - s_[it] * a1[it];
+            A[kk][q_[it]] = s_[it] * a0[it] + c_[it] * a1[it];
+            V[kk][p_[it]] = c_[it] * v0[it] - s_[it] * v1[it];
+            V[kk][q_[it]] = s_[it] * v0[it] + c_[it] * v1[it];
+          }
+        __syncthreads();
+        // rows: A <- J^T A
+#pragma unroll
+        for (int it = 0; it < 8; ++it) { a0[it] = A[p_[it]][kk]; a1[it] = A[q_[it]][kk]; }
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+          if (s_[it] != 0.0) {
+            A[p_[it]][kk] = c_[it] * a0[it] - s_[it] * a1[it];
+            A[q_[it]][kk] = s_[it] * a0[it] + c_[it] * a1[it];
+          }
       }
       __syncthreads();
     }
-    if (nrot == 0) break;
-    __syncthreads();
+    if (nrot == 0) break;   // wave-uniform
   }
-  if (tid == 0) {
-    for (int j = 0; j < m; ++j) perm[j] = j;
-    for (int j = 1; j < m; ++j) {  // insertion sort by eigenvalue
-      const int pj = perm[j];
-      const double v = A[pj][pj];
-      int t = j - 1;
-      while (t >= 0 && A[perm[t]][perm[t]] > v) { perm[t + 1] = perm[t]; --t; }
-      perm[t + 1] = pj;
+  // ascending order by rank counting (ties by index)
+  if (tid < m) {
+    const double v = A[tid][tid];
+    int rank = 0;
+    for (int i = 0; i < m; ++i) {
+      const double u = A[i][i];
+      rank += (u < v || (u == v && i < tid)) ? 1 : 0;
     }
+    perm[rank] = tid;
+    D[off + rank] = v;
   }
-  __syncthreads();
-  for (int j = tid; j < m; j += 256) D[off + j] = A[perm[j]][perm[j]];
   __syncthreads();
   // one Newton-Schulz step V <- V - V (V^T V - I)/2 : removes the O(sqrt(#rotations) eps) loss of
   // orthogonality that the rotation products accumulate (A is free now and holds E = V^T V - I)
-  for (int idx = tid; idx < m * m; idx += 256) {
+  for (int idx = tid; idx < m * m; idx += LEAF_T) {
     const int r = idx / m, c = idx - r * m;
     double acc = 0.0;
     for (int k = 0; k < m; ++k) acc += V[k][r] * V[k][c];
     A[r][c] = acc - (r == c ? 1.0 : 0.0);
   }
   __syncthreads();
-  for (int idx = tid; idx < m * m; idx += 256) {
+  for (int idx = tid; idx < m * m; idx += LEAF_T) {
     const int j = idx / m, r = idx - j * m;
     const int pj = perm[j];
     double acc = 0.0;
@@ -176,6 +203,10 @@ struct MergeDev {
   int rot_beg, rot_end;
   double rho;
   double wv[4];  // weights of rows off+n1-band .. off+n1+band-1 in z = Q^T w
+  // z of the NEXT pass, formed ahead of this pass's product (znext kernels): its rows that lie inside this merge
+  int zr_n, zr_pad;
+  int zr_row[4];
+  double zr_w[4];
 };
 
 __global__ void zgather_kernel(const MergeDev* __restrict__ md, int band, const double* __restrict__ Q, int ldq,
@@ -206,6 +237,62 @@ __global__ void rotate_kernel(const MergeDev* __restrict__ md, const int* __rest
     row[cp] = c * x + s * y;
     row[cj] = c * y - s * x;
   }
+}
+
+// ---- z of the next pass ahead of this pass's product (one GPU) -----------------------------------------------------
+// The next pass needs z' = Q'^T w' with Q' = this pass's result, a few rows of it only: Q'(r, off+j) = sum_i Q(r, nd_i) U(i,j)
+// for the K roots, Q'(r, dst) = Q(r, src) for the deflated columns.  So z'(off+j) = sum_i y_i U(i,j) with
+// y_i = sum_t w'_t Q(row_t, nd_i): a K x K mat-vec on the eigenvector rows S'(j,i) = U(i,j) that exists BEFORE the
+// O(n K^2) product.  With it the host deflates the next pass, and the device solves its secular equations, while the
+// product runs (the reference overlaps nothing here: PDLAED2 -> PDLAED3 -> PDGEMM in sequence, src/my_pdlaed1.F:225-341).
+// Two-phase and deterministic like the eigenvector norms: partial sums per chunk of ZN_IC poles, then a fixed-order sum.
+constexpr int ZN_IC = 256;
+__global__ __launch_bounds__(256) void znext1_kernel(const MergeDev* __restrict__ md, const int* __restrict__ nd,
+                                                     const double* __restrict__ Qa, int ldq, const double* __restrict__ S,
+                                                     int lds, double* __restrict__ zp, int ldn) {
+  __shared__ double ys[ZN_IC];
+  __shared__ double part[4][64];
+  const MergeDev M = md[blockIdx.z];
+  const int K = M.K;
+  if ((int)(blockIdx.x * 64) >= K || (int)(blockIdx.y * ZN_IC) >= K) return;
+  const int i0 = blockIdx.y * ZN_IC;
+  const int i1 = (i0 + ZN_IC < K) ? i0 + ZN_IC : K;
+  {
+    const int i = i0 + threadIdx.x;
+    double y = 0.0;
+    if (i < i1) {
+      const double* col = Qa + (size_t)nd[M.off + i] * ldq;
+      for (int t = 0; t < M.zr_n; ++t) y += M.zr_w[t] * col[M.zr_row[t]];
+    }
+    ys[threadIdx.x] = y;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const bool act = j < K;
+  const double* Sp = S + (size_t)M.off * lds + M.off + j;
+  double acc = 0.0;
+  if (act)
+    for (int i = i0 + wave; i < i1; i += 4) acc += ys[i - i0] * Sp[(size_t)i * lds];
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && act)
+    zp[(size_t)blockIdx.y * ldn + M.off + j] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+__global__ void znext2_kernel(const MergeDev* __restrict__ md, const int* __restrict__ dsrc, const double* __restrict__ Qa,
+                              int ldq, const double* __restrict__ zp, int ldn, double* __restrict__ z) {
+  const MergeDev M = md[blockIdx.y];
+  const int jj = blockIdx.x * blockDim.x + threadIdx.x;
+  if (jj >= M.nm) return;
+  double v = 0.0;
+  if (jj < M.K) {
+    const int nch = (M.K + ZN_IC - 1) / ZN_IC;
+    for (int c = 0; c < nch; ++c) v += zp[(size_t)c * ldn + M.off + jj];
+  } else {
+    const double* col = Qa + (size_t)dsrc[M.off + jj] * ldq;   // deflated: the column is copied as it is
+    for (int t = 0; t < M.zr_n; ++t) v += M.zr_w[t] * col[M.zr_row[t]];
+  }
+  z[M.off + jj] = v;
 }
 
 // row-block exchange of the multi-GPU D&C: pack rows [r0, r0+nr) of Q(:, 0:n) / unpack all ranks' blocks
@@ -558,6 +645,7 @@ __global__ void final_permute_kernel(const int* __restrict__ perm, const double*
 struct Node {
   int off, n;
   int left = -1, right = -1;  // children (node indices), -1 for a leaf
+  int parent = -1;
   int height = 0;
   int n1 = 0;
   double sig[2] = {0, 0};
@@ -626,21 +714,56 @@ struct HostDC {
     const int l = build(off, n1);
     const int r = build(off + n1, nn - n1);
     nodes[id].left = l; nodes[id].right = r;
+    nodes[l].parent = id; nodes[r].parent = id;
     nodes[id].height = 1 + std::max(nodes[l].height, nodes[r].height);
     return id;
   }
 };
 
-// host deflation of one merge (DLAED2 logic).  Works on global-index arrays.
-struct DeflOut {
-  int K = 0;
-  double rho = 0.0;
-};
+// Index order of d[0..nm) by (value, index).  The eigenvalues of a merge arrive as a handful of ascending runs (each
+// child: its roots in order, then its deflated values, nearly in order), so this is a natural merge sort: find the runs,
+// merge them pairwise; many runs (heavy deflation with reordering) fall back to std::sort.  Same order as sorting the
+// (value, index) pairs, which is what every rank of a process grid must agree on.
+void sort_index_runs(const double* d, int nm, std::vector<int>& idx, std::vector<int>& tmp, std::vector<int>& bounds) {
+  idx.resize(nm);
+  for (int i = 0; i < nm; ++i) idx[i] = i;
+  bounds.clear();
+  bounds.push_back(0);
+  for (int i = 1; i < nm; ++i)
+    if (d[i] < d[i - 1]) bounds.push_back(i);
+  bounds.push_back(nm);
+  auto cmp = [d](int a, int b) { return d[a] < d[b] || (d[a] == d[b] && a < b); };
+  int nr = (int)bounds.size() - 1;
+  if (nr > 16) { std::sort(idx.begin(), idx.end(), cmp); return; }
+  tmp.resize(nm);
+  while (nr > 1) {
+    int w = 0;
+    for (int r = 0; r < nr; r += 2) {
+      if (r + 1 < nr)
+        std::merge(idx.begin() + bounds[r], idx.begin() + bounds[r + 1], idx.begin() + bounds[r + 1], idx.begin() + bounds[r + 2],
+                   tmp.begin() + bounds[r], cmp);
+      else
+        std::copy(idx.begin() + bounds[r], idx.begin() + bounds[r + 1], tmp.begin() + bounds[r]);
+      bounds[w++] = bounds[r];
+    }
+    bounds[w] = nm;
+    nr = w;
+    idx.swap(tmp);
+  }
+}
 
 }  // namespace
 
 // several GPUs: width of the chunk buffer in which eigenvector rows are regenerated (eigx_tune key 8; the tests lower it so
 // that the chunk-by-chunk path of the big merges runs at small sizes)
+// lab switches (eigx_tune keys 15, 16): pipelined passes / one product launch per low height on one GPU
+int g_dc_pipe = 1, g_dc_batch = 1, g_dc_side_min = 1024;
+int set_dc_pipe(int v) {   // 0 / 1: off / on; v >= 2: merges larger than v use the side stream
+  const int old = g_dc_pipe;
+  if (v >= 2) g_dc_side_min = v; else g_dc_pipe = v ? 1 : 0;
+  return old;
+}
+int set_dc_batch(int v) { const int old = g_dc_batch; g_dc_batch = v ? 1 : 0; return old; }
 int g_dc_chunk = 2048;
 int set_dc_chunk(int v) {
   const int old = g_dc_chunk;
@@ -705,6 +828,8 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   const int maxh = H.nodes[root].height;
 
   // ---- device workspace --------------------------------------------------------------------------
+  // One GPU: the passes are pipelined (see znext1_kernel) -- two arenas and two S buffers alternate from pass to pass.
+  const bool pipe = (P == 1) && g_dc_pipe;
   const int ldq = (P > 1) ? pad_ld(rp + 2) : pad_ld(n);
   double* Qa_base = ctx.pool.get_t<double>("dc.Qa", (size_t)ldq * n);
   double* Qb_base = ctx.pool.get_t<double>("dc.Qb", (size_t)ldq * n);
@@ -716,48 +841,66 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   // a chunk buffer of n x SCW doubles (all merges of a low height side by side, or one chunk of roots of a big merge)
   const int SCW = g_dc_chunk;
   const int lds_mg = SCW;
-  double* S = ctx.pool.get_t<double>("dc.S", (P > 1) ? (size_t)n * SCW + 64 : (size_t)ldq * n);
+  double* Sbuf[2];
+  Sbuf[0] = ctx.pool.get_t<double>("dc.S", (P > 1) ? (size_t)n * SCW + 64 : (size_t)ldq * n);
+  Sbuf[1] = pipe ? ctx.pool.get_t<double>("dc.S2", (size_t)ldq * n) : Sbuf[0];
   double* sec = (P > 1) ? ctx.pool.get_t<double>("dc.sec", (size_t)3 * n) : nullptr;
   double* dd = ctx.pool.get_t<double>("dc.d", (size_t)n);
   double* de = ctx.pool.get_t<double>("dc.e", (size_t)lde * band);
   double* zh = ctx.pool.get_t<double>("dc.zh", (size_t)n);
   double* vnp = ctx.pool.get_t<double>("dc.vnp", (size_t)n * ((n + VEC_IC - 1) / VEC_IC + 1));  // partial column norms
+  double* zp = pipe ? ctx.pool.get_t<double>("dc.zp", (size_t)n * ((n + ZN_IC - 1) / ZN_IC + 1)) : nullptr;
   const int maxmerge = n / (LEAF / 2) + 8;
   int* leafinfo = ctx.pool.get_t<int>("dc.leaf", (size_t)2 * maxmerge);
   int* perm_dev = ctx.pool.get_t<int>("dc.perm", (size_t)n);
   int* iota_dev = ctx.pool.get_t<int>("dc.iota", (size_t)n);  // 0,1,2,...: identity map for the pole index of dense updates
   // One arena holds everything the host exchanges with the device per merge step, mirrored in pinned host
   // memory: a step is one D2H copy (Dcur | z), the host deflation, and one H2D copy (everything up to Dcur).
-  //   doubles: dlam | wz | rc | rs | Dcur | zbuf        ints: nd rpj rjj cps cpd cpr cpn topA topB botA botB
+  //   merge table | product table | ints: nd rpj rjj cps cpd cpr cpn topA topB botA botB dsrc | doubles: dlam wz rc rs Dcur zbuf
+  // Arena p&1 belongs to pass p: its Dcur receives the pass's eigenvalues and its zbuf the z of pass p + 1.
+  struct Arena {
+    char *dev, *host;
+    MergeDev *md_dev, *md_h;
+    GemmBatch *gb_dev, *gb_h;
+    int *nd_dev, *nd_h, *rpj_dev, *rpj_h, *rjj_dev, *rjj_h, *cps_dev, *cps_h, *cpd_dev, *cpd_h, *cpr_dev, *cpr_h, *cpn_dev, *cpn_h;
+    int *topA_dev, *topA_h, *topB_dev, *topB_h, *botA_dev, *botA_h, *botB_dev, *botB_h, *dsrc_dev, *dsrc_h;
+    double *dlam, *dl_h, *wz, *wz_h, *rc_dev, *rc_h, *rs_dev, *rs_h, *Dcur, *Dh, *zbuf, *zhost;
+  } ar[2];
   const size_t npad = ((size_t)n + 7) / 8 * 8;
   const size_t md_bytes = ((size_t)maxmerge * sizeof(MergeDev) + 63) / 64 * 64;
-  const size_t up_bytes = md_bytes + 11 * npad * sizeof(int) + 5 * npad * sizeof(double);   // H2D part
-  const size_t arena_bytes = up_bytes + npad * sizeof(double);                              // + zbuf
-  char* arena = (char*)ctx.pool.get("dc.arena", arena_bytes);
-  char* harena = (char*)ctx.pool.get_host("dc.arena", arena_bytes);
-  auto carve = [&](char* base, size_t& pos, size_t bytes) { char* p_ = base + pos; pos += bytes; return p_; };
-  size_t pos = 0, hpos = 0;
-  MergeDev* md_dev = (MergeDev*)carve(arena, pos, md_bytes);
-  MergeDev* md_h = (MergeDev*)carve(harena, hpos, md_bytes);
-#define EIGX_ARENA_INT(name) int* name##_dev = (int*)carve(arena, pos, npad * sizeof(int)); \
-                             int* name##_h = (int*)carve(harena, hpos, npad * sizeof(int));
-  EIGX_ARENA_INT(nd)     // [n] non-deflated column (global) per merge range, dlam order
-  EIGX_ARENA_INT(rpj) EIGX_ARENA_INT(rjj)
-  EIGX_ARENA_INT(cps) EIGX_ARENA_INT(cpd) EIGX_ARENA_INT(cpr) EIGX_ARENA_INT(cpn)   // copy src / dst / row0 / nrows
-  EIGX_ARENA_INT(topA) EIGX_ARENA_INT(topB)   // first update: columns with a non-zero top part (global index), their pole indices
-  EIGX_ARENA_INT(botA) EIGX_ARENA_INT(botB)   // same for the bottom part
-#undef EIGX_ARENA_INT
-  double* dlam = (double*)carve(arena, pos, npad * 8);  double* dl_h = (double*)carve(harena, hpos, npad * 8);
-  double* wz = (double*)carve(arena, pos, npad * 8);    double* wz_h = (double*)carve(harena, hpos, npad * 8);
-  double* rc_dev = (double*)carve(arena, pos, npad * 8); double* rc_h = (double*)carve(harena, hpos, npad * 8);
-  double* rs_dev = (double*)carve(arena, pos, npad * 8); double* rs_h = (double*)carve(harena, hpos, npad * 8);
-  double* Dcur = (double*)carve(arena, pos, npad * 8);   double* Dh = (double*)carve(harena, hpos, npad * 8);
-  double* zbuf = (double*)carve(arena, pos, npad * 8);   double* zhost = (double*)carve(harena, hpos, npad * 8);
+  const size_t gb_bytes = ((size_t)2 * maxmerge * sizeof(GemmBatch) + 63) / 64 * 64;
+  const size_t up_bytes = md_bytes + gb_bytes + 12 * npad * sizeof(int) + 5 * npad * sizeof(double);   // H2D part
+  const size_t arena_bytes = up_bytes + npad * sizeof(double);                                         // + zbuf
   const size_t down_off = up_bytes - npad * 8;   // byte offset of Dcur: the D2H copy takes [Dcur | zbuf]
-  // the merge descriptors also go up once BEFORE the deflation (zgather needs offsets): own staging buffer, because
-  // the previous step's arena upload may still be in flight when the host prepares them
+  {
+    char* dev_all = (char*)ctx.pool.get("dc.arena", 2 * arena_bytes);
+    char* host_all = (char*)ctx.pool.get_host("dc.arena", 2 * arena_bytes);
+    memset(host_all, 0, 2 * arena_bytes);
+    for (int q = 0; q < 2; ++q) {
+      Arena& A = ar[q];
+      A.dev = dev_all + q * arena_bytes;
+      A.host = host_all + q * arena_bytes;
+      size_t pos = 0;
+      auto carve = [&](size_t bytes, void* pd, void* ph) {
+        *(char**)pd = A.dev + pos; *(char**)ph = A.host + pos; pos += bytes;
+      };
+      carve(md_bytes, &A.md_dev, &A.md_h);
+      carve(gb_bytes, &A.gb_dev, &A.gb_h);
+      carve(npad * 4, &A.nd_dev, &A.nd_h);      // [n] non-deflated column (global) per merge range, dlam order
+      carve(npad * 4, &A.rpj_dev, &A.rpj_h);  carve(npad * 4, &A.rjj_dev, &A.rjj_h);
+      carve(npad * 4, &A.cps_dev, &A.cps_h);  carve(npad * 4, &A.cpd_dev, &A.cpd_h);   // copy src / dst / row0 / nrows
+      carve(npad * 4, &A.cpr_dev, &A.cpr_h);  carve(npad * 4, &A.cpn_dev, &A.cpn_h);
+      carve(npad * 4, &A.topA_dev, &A.topA_h); carve(npad * 4, &A.topB_dev, &A.topB_h);   // first update: columns with a non-zero top part (global index), their pole indices
+      carve(npad * 4, &A.botA_dev, &A.botA_h); carve(npad * 4, &A.botB_dev, &A.botB_h);   // same for the bottom part
+      carve(npad * 4, &A.dsrc_dev, &A.dsrc_h);   // source column of every deflated output slot
+      carve(npad * 8, &A.dlam, &A.dl_h);  carve(npad * 8, &A.wz, &A.wz_h);
+      carve(npad * 8, &A.rc_dev, &A.rc_h); carve(npad * 8, &A.rs_dev, &A.rs_h);
+      carve(npad * 8, &A.Dcur, &A.Dh);    carve(npad * 8, &A.zbuf, &A.zhost);
+    }
+  }
+  // the merge descriptors also go up once BEFORE the deflation when z is gathered from Q (zgather needs offsets): own
+  // staging buffer
   MergeDev* md_h2 = (MergeDev*)ctx.pool.get_host("dc.md2", md_bytes);
-  memset(harena, 0, arena_bytes);
 
   EIGX_HIP_CHECK(hipMemcpyAsync(dd, H.d.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
   EIGX_HIP_CHECK(hipMemcpyAsync(de, H.e.data(), (size_t)lde * band * 8, hipMemcpyHostToDevice, st));
@@ -777,6 +920,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   }
 
   // ---- leaves ---------------------------------------------------------------------------------------
+  double* Dfinal = ar[1].Dcur;   // pass 0 reads the leaves' eigenvalues from the arena "before" its own
   {
     std::vector<int> lo, ln;
     for (const Node& nd : H.nodes)
@@ -786,46 +930,98 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
     both.insert(both.end(), ln.begin(), ln.end());
     EIGX_HIP_CHECK(hipMemcpyAsync(leafinfo, both.data(), (size_t)2 * nl * 4, hipMemcpyHostToDevice, st));
     EIGX_HIP_CHECK(hipStreamSynchronize(st));  // `both` is a stack vector
-    hipLaunchKernelGGL(jacobi_leaf_kernel, dim3(nl), dim3(256), 0, st, dd, de, lde, band, leafinfo, leafinfo + nl,
-                       Dcur, Qa, ldq, r0, r1);
+    hipLaunchKernelGGL(jacobi_leaf_kernel, dim3(nl), dim3(LEAF_T), 0, st, dd, de, lde, band, leafinfo, leafinfo + nl,
+                       Dfinal, Qa, ldq, r0, r1);
+    if (ctx.dc_after_leaves) {
+      EIGX_HIP_CHECK(hipEventRecord(ctx.dc_b_ev, st));
+      EIGX_HIP_CHECK(hipStreamWaitEvent(ctx.side_stream, ctx.dc_b_ev, 0));
+      std::function<void()> f = std::move(ctx.dc_after_leaves);
+      ctx.dc_after_leaves = nullptr;
+      f();
+    }
   }
 
-  // ---- merges, height by height ---------------------------------------------------------------------
-  std::vector<double> Dold(n);
-  std::vector<int> ctype(n), ktop(n / 2 + 8), kbot(n / 2 + 8);
-  std::vector<MergeDev> mds;
-  std::vector<std::pair<double, int>> ord;
-  double gemm_flops = 0.0;
-  const bool trace = getenv("EIGX_TRACE_DC") != nullptr;
-  auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  // ---- merges: the passes (height, k) in order --------------------------------------------------------
+  struct Pass { int h, k; std::vector<int> ids; };
+  std::vector<Pass> passes;
   for (int h = 1; h <= maxh; ++h) {
     std::vector<int> ids;
     for (int id = 0; id < (int)H.nodes.size(); ++id)
       if (H.nodes[id].left >= 0 && H.nodes[id].height == h) ids.push_back(id);
     if (ids.empty()) continue;
-    for (int k = 0; k < band; ++k) {
-      // -- z = Q^T w ------------------------------------------------------------------------------------
+    for (int k = 0; k < band; ++k) passes.push_back(Pass{h, k, ids});
+  }
+  std::vector<double> Dold(n);
+  std::vector<int> ctype(n), ktop(n / 2 + 8), kbot(n / 2 + 8), defl;
+  std::vector<MergeDev> mds;
+  std::vector<std::pair<double, int>> ord;
+  std::vector<int> ordi, ordt, ordb;
+  double gemm_flops = 0.0;
+  const bool trace = getenv("EIGX_TRACE_DC") != nullptr;
+  auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  // stream of a pass's secular / eigenvector-row kernels: the high-priority side stream where there is a product to run
+  // under (big merges); the low heights are one dependent chain either way, and a second stream only adds event hand-offs
+  bool z_ready = false;                         // [Dcur | z] of this pass are already on their way to the host
+  for (size_t pi = 0; pi < passes.size(); ++pi) {
+    const std::vector<int>& ids = passes[pi].ids;
+    const int h = passes[pi].h, k = passes[pi].k;
+    Arena& C = ar[pi & 1];          // this pass
+    Arena& V = ar[(pi & 1) ^ 1];    // the previous one: its Dcur / zbuf are this pass's input
+    double* const S = Sbuf[pi & 1];
+    {
       mds.assign(ids.size(), MergeDev());
       int maxnm = 0;
+      size_t covered = 0;
       for (size_t q = 0; q < ids.size(); ++q) {
         const Node& nd = H.nodes[ids[q]];
         MergeDev& M = mds[q];
         M.off = nd.off; M.nm = nd.n; M.n1 = nd.n1; M.K = 0; M.rot_beg = 0; M.rot_end = 0; M.rho = nd.sig[k];
         for (int t = 0; t < 4; ++t) M.wv[t] = nd.wv[k][t];
+        M.zr_n = 0; M.zr_pad = 0;
+        for (int t = 0; t < 4; ++t) { M.zr_row[t] = 0; M.zr_w[t] = 0.0; }
         maxnm = std::max(maxnm, nd.n);
+        covered += (size_t)nd.n;
       }
-      memcpy(md_h2, mds.data(), mds.size() * sizeof(MergeDev));
-      EIGX_HIP_CHECK(hipMemcpyAsync(md_dev, md_h2, mds.size() * sizeof(MergeDev), hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(zgather_kernel, dim3((maxnm + 255) / 256, (unsigned)ids.size()), dim3(256), 0, st, md_dev,
-                         band, Qa, ldq, zbuf, r0, r1);
-      if (P > 1) comm_allreduce_sum(ctx, COMM_WORLD, zbuf, (size_t)n, st);
+      // rows of the next pass's z inside each merge (only when this pass rewrites every column: balanced heights)
+      const bool z_ahead = pipe && covered == (size_t)n && pi + 1 < passes.size();
+      if (z_ahead) {
+        for (size_t q = 0; q < ids.size(); ++q) {
+          const Node& nd = H.nodes[ids[q]];
+          MergeDev& M = mds[q];
+          if (k + 1 < band) {           // same merges, next singular triplet
+            M.zr_n = 2 * band;
+            for (int t = 0; t < 2 * band; ++t) { M.zr_row[t] = nd.off + nd.n1 - band + t; M.zr_w[t] = nd.wv[k + 1][t]; }
+          } else {                      // the parents' first triplet: `band` rows on this child's side of the tear
+            const Node& pn = H.nodes[nd.parent];
+            const bool is_left = (pn.left == ids[q]);
+            M.zr_n = band;
+            for (int t = 0; t < band; ++t) {
+              M.zr_row[t] = is_left ? pn.off + pn.n1 - band + t : pn.off + pn.n1 + t;
+              M.zr_w[t] = pn.wv[0][is_left ? t : band + t];
+            }
+          }
+        }
+      }
+      // -- z = Q^T w ------------------------------------------------------------------------------------
       const double tt0 = trace ? now_s() : 0.0;
-      EIGX_HIP_CHECK(hipMemcpyAsync(harena + down_off, arena + down_off, 2 * npad * 8, hipMemcpyDeviceToHost, st));  // Dcur | z
-      EIGX_HIP_CHECK(hipStreamSynchronize(st));
+      if (!z_ready) {
+        memcpy(md_h2, mds.data(), mds.size() * sizeof(MergeDev));
+        EIGX_HIP_CHECK(hipMemcpyAsync(C.md_dev, md_h2, mds.size() * sizeof(MergeDev), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(zgather_kernel, dim3((maxnm + 255) / 256, (unsigned)ids.size()), dim3(256), 0, st, C.md_dev,
+                           band, Qa, ldq, V.zbuf, r0, r1);
+        if (P > 1) comm_allreduce_sum(ctx, COMM_WORLD, V.zbuf, (size_t)n, st);
+        EIGX_HIP_CHECK(hipMemcpyAsync(V.host + down_off, V.dev + down_off, 2 * npad * 8, hipMemcpyDeviceToHost, st));  // Dcur | z
+        EIGX_HIP_CHECK(hipStreamSynchronize(st));
+      } else {
+        EIGX_HIP_CHECK(hipEventSynchronize(ctx.dc_z_ev));
+      }
+      z_ready = false;
       const double tt1 = trace ? now_s() : 0.0;
       // -- host deflation -------------------------------------------------------------------------------
       int nrot = 0, ncopy = 0;
-      std::copy(Dh, Dh + n, Dold.begin());   // Dh (pinned) becomes the new D in place
+      std::copy(V.Dh, V.Dh + n, Dold.begin());
+      std::copy(V.Dh, V.Dh + n, C.Dh);       // columns outside this pass's merges keep their eigenvalue
+      double* const zhost = V.zhost;
       for (size_t q = 0; q < ids.size(); ++q) {
         MergeDev& M = mds[q];
         const int off = M.off, nm = M.nm;
@@ -840,23 +1036,21 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
         // column types for the first update: 1 = non-zero only in block 1's rows, 2 = only block 2's, 3 = both
         for (int i2 = 0; i2 < nm; ++i2) ctype[off + i2] = (k == 0) ? (i2 < M.n1 ? 1 : 2) : 3;
         // output slots: roots first, then deflated columns
-        std::vector<int> defl;
+        defl.clear();
         if (zn > 0.0 && rho > 0.0) {
           for (int i = 0; i < nm; ++i) zloc[i] /= zn;
           rho *= zn * zn;
-          ord.resize(nm);
           double dmax = 0.0, zmax = 0.0;
           for (int i = 0; i < nm; ++i) {
-            ord[i] = std::make_pair(dloc[i], i);
             dmax = std::max(dmax, fabs(dloc[i]));
             zmax = std::max(zmax, fabs(zloc[i]));
           }
-          std::sort(ord.begin(), ord.end());
+          sort_index_runs(dloc, nm, ordi, ordt, ordb);
           const double tol = 8.0 * eps * std::max(dmax, zmax);
           if (rho * zmax > tol) {
             int pj = -1;
             for (int t = 0; t < nm; ++t) {
-              const int jj = ord[t].second;
+              const int jj = ordi[t];
               if (rho * fabs(zloc[jj]) <= tol) { defl.push_back(jj); continue; }
               if (pj < 0) { pj = jj; continue; }
               double s = zloc[pj], c = zloc[jj];
@@ -865,7 +1059,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
               c /= tau; s = -s / tau;
               if (fabs(tt * c * s) <= tol) {
                 zloc[jj] = tau; zloc[pj] = 0.0;
-                rpj_h[nrot] = off + pj; rjj_h[nrot] = off + jj; rc_h[nrot] = c; rs_h[nrot] = s;
+                C.rpj_h[nrot] = off + pj; C.rjj_h[nrot] = off + jj; C.rc_h[nrot] = c; C.rs_h[nrot] = s;
                 ++nrot;
                 if (ctype[off + pj] != ctype[off + jj]) { ctype[off + pj] = 3; ctype[off + jj] = 3; }
                 const double dp = dloc[pj] * c * c + dloc[jj] * s * s;
@@ -874,12 +1068,12 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
                 defl.push_back(pj);
                 pj = jj;
               } else {
-                nd_h[off + K] = off + pj;
+                C.nd_h[off + K] = off + pj;
                 ++K;
                 pj = jj;
               }
             }
-            if (pj >= 0) { nd_h[off + K] = off + pj; ++K; }
+            if (pj >= 0) { C.nd_h[off + K] = off + pj; ++K; }
           } else {
             for (int i = 0; i < nm; ++i) defl.push_back(i);
           }
@@ -888,13 +1082,13 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
         }
         M.rot_end = nrot;
         // poles in strictly ascending order
-        for (int t = 0; t < K; ++t) { dl_h[off + t] = dloc[nd_h[off + t] - off]; wz_h[off + t] = zloc[nd_h[off + t] - off]; }
+        for (int t = 0; t < K; ++t) { C.dl_h[off + t] = dloc[C.nd_h[off + t] - off]; C.wz_h[off + t] = zloc[C.nd_h[off + t] - off]; }
         for (int t = 1; t < K; ++t) {
           int u = t;
-          while (u > 0 && dl_h[off + u] < dl_h[off + u - 1]) {
-            std::swap(dl_h[off + u], dl_h[off + u - 1]);
-            std::swap(wz_h[off + u], wz_h[off + u - 1]);
-            std::swap(nd_h[off + u], nd_h[off + u - 1]);
+          while (u > 0 && C.dl_h[off + u] < C.dl_h[off + u - 1]) {
+            std::swap(C.dl_h[off + u], C.dl_h[off + u - 1]);
+            std::swap(C.wz_h[off + u], C.wz_h[off + u - 1]);
+            std::swap(C.nd_h[off + u], C.nd_h[off + u - 1]);
             --u;
           }
         }
@@ -903,9 +1097,9 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
         {
           int nt_ = 0, nb_ = 0;
           for (int t = 0; t < K; ++t) {
-            const int col = nd_h[off + t], ty = ctype[col];
-            if (ty != 2) { topA_h[off + nt_] = col; topB_h[off + nt_] = t; ++nt_; }
-            if (ty != 1) { botA_h[off + nb_] = col; botB_h[off + nb_] = t; ++nb_; }
+            const int col = C.nd_h[off + t], ty = ctype[col];
+            if (ty != 2) { C.topA_h[off + nt_] = col; C.topB_h[off + nt_] = t; ++nt_; }
+            if (ty != 1) { C.botA_h[off + nb_] = col; C.botB_h[off + nb_] = t; ++nb_; }
           }
           ktop[q] = nt_; kbot[q] = nb_;
         }
@@ -914,69 +1108,120 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
           const int src = off + defl[t], dst = off + K + (int)t;
           int ca, cb;
           if (clip(off, off + nm, ca, cb)) {
-            cps_h[ncopy] = src; cpd_h[ncopy] = dst; cpr_h[ncopy] = ca; cpn_h[ncopy] = cb - ca;
+            C.cps_h[ncopy] = src; C.cpd_h[ncopy] = dst; C.cpr_h[ncopy] = ca; C.cpn_h[ncopy] = cb - ca;
             ++ncopy;
           }
-          Dh[dst] = dloc[defl[t]];
+          C.dsrc_h[dst] = src;
+          C.Dh[dst] = dloc[defl[t]];
         }
-        for (int t = 0; t < K; ++t) Dh[off + t] = 0.0;  // overwritten by the secular kernel
+        for (int t = 0; t < K; ++t) C.Dh[off + t] = 0.0;  // overwritten by the secular kernel
+      }
+      int maxK = 0;
+      for (const MergeDev& M : mds) maxK = std::max(maxK, M.K);
+      const unsigned nmg = (unsigned)ids.size();
+      hipStream_t sb = (pipe && maxnm > g_dc_side_min) ? ctx.dc_stream : st;
+      // one launch for all products of the pass where each of them is a few 64 x 64 tiles (one GPU, low heights)
+      const bool batched = (P == 1) && g_dc_batch && maxK > 0 && mds.size() > 1 &&
+                           (long)ceil_div(maxnm, 128) * ceil_div(maxK, 128) < 192;
+      int nbatch = 0, bmaxM = 0;
+      if (batched) {
+        // product table (part of the arena upload).  Gather maps: first update = topA/topB for the top rows, botA/botB
+        // (2 npad ints further in the arena) for the bottom rows; second update = nd and the identity
+        const int bot_shift = (int)(C.botA_dev - C.topA_dev);
+        for (size_t q = 0; q < mds.size(); ++q) {
+          const MergeDev& M = mds[q];
+          if (M.K <= 0) continue;
+          auto add = [&](int row0, int rows, int kk, int offKA, int offKB) {
+            if (rows <= 0) return;
+            GemmBatch& B = C.gb_h[nbatch++];
+            B.M = rows; B.N = M.K; B.K = kk; B.pad = 0;
+            B.offA = row0; B.offB = (long)M.off * ldq + M.off; B.offC = (long)M.off * ldq + row0;
+            B.offKA = offKA; B.offKB = offKB;
+            bmaxM = std::max(bmaxM, rows);
+          };
+          if (k == 0) {
+            add(M.off, M.n1, ktop[q], M.off, M.off);
+            add(M.off + M.n1, M.nm - M.n1, kbot[q], M.off + bot_shift, M.off + bot_shift);
+            gemm_flops += 2.0 * (double)M.K * ((double)M.n1 * ktop[q] + (double)(M.nm - M.n1) * kbot[q]);
+          } else {
+            add(M.off, M.nm, M.K, M.off, 0);
+            gemm_flops += 2.0 * M.nm * (double)M.K * M.K;
+          }
+        }
       }
       // -- upload and run the GPU part ---------------------------------------------------------------------
       const double tt2 = trace ? now_s() : 0.0;
       double t_gemm_enq = 0.0;
-      memcpy(md_h, mds.data(), mds.size() * sizeof(MergeDev));
-      EIGX_HIP_CHECK(hipMemcpyAsync(arena, harena, up_bytes, hipMemcpyHostToDevice, st));   // everything at once
-      if (nrot > 0)
-        hipLaunchKernelGGL(rotate_kernel, dim3((maxnm + 255) / 256, (unsigned)ids.size()), dim3(256), 0, st, md_dev,
-                           rpj_dev, rjj_dev, rc_dev, rs_dev, Qa, ldq, r0, r1);
-      int maxK = 0;
-      for (const MergeDev& M : mds) maxK = std::max(maxK, M.K);
+      memcpy(C.md_h, mds.data(), mds.size() * sizeof(MergeDev));
+      EIGX_HIP_CHECK(hipMemcpyAsync(C.dev, C.host, up_bytes, hipMemcpyHostToDevice, sb));   // everything at once
       // several GPUs: chunked eigenvector rows.  compact = all merges of this height fit side by side into S
       // (lds = SCW >= merge size); otherwise the (one or two) big merges go chunk by chunk below.
       const bool mg = P > 1;
       const bool compact = mg && maxnm <= lds_mg;
       if (maxK > 0) {
-        const unsigned nmg = (unsigned)ids.size();
         if (mg) {
           const int kmx = maxK / P + 2;   // roots per rank and merge
           EIGX_HIP_CHECK(hipMemsetAsync(sec, 0, (size_t)3 * n * 8, st));
           if (maxK >= 512)
-            hipLaunchKernelGGL(secular_kernel<32>, dim3((kmx + 7) / 8, nmg), dim3(256), 0, st, md_dev, dlam, wz, Dcur, S, ldq, P,
+            hipLaunchKernelGGL(secular_kernel<32>, dim3((kmx + 7) / 8, nmg), dim3(256), 0, st, C.md_dev, C.dlam, C.wz, C.Dcur, S, ldq, P,
                                ctx.grid.rank, sec, n);
           else
-            hipLaunchKernelGGL(secular_kernel<8>, dim3((kmx + 31) / 32, nmg), dim3(256), 0, st, md_dev, dlam, wz, Dcur, S, ldq, P,
+            hipLaunchKernelGGL(secular_kernel<8>, dim3((kmx + 31) / 32, nmg), dim3(256), 0, st, C.md_dev, C.dlam, C.wz, C.Dcur, S, ldq, P,
                                ctx.grid.rank, sec, n);
           comm_allreduce_sum(ctx, COMM_WORLD, sec, (size_t)3 * n, st);
-          hipLaunchKernelGGL(scatter_lambda_kernel, dim3((maxK + 255) / 256, nmg), dim3(256), 0, st, md_dev, sec, Dcur);
-          hipLaunchKernelGGL(loewner_mg_kernel, dim3((maxK + 3) / 4, nmg), dim3(256), 0, st, md_dev, dlam, wz, sec, n, zh);
+          hipLaunchKernelGGL(scatter_lambda_kernel, dim3((maxK + 255) / 256, nmg), dim3(256), 0, st, C.md_dev, sec, C.Dcur);
+          hipLaunchKernelGGL(loewner_mg_kernel, dim3((maxK + 3) / 4, nmg), dim3(256), 0, st, C.md_dev, C.dlam, C.wz, sec, n, zh);
           if (compact)
-            hipLaunchKernelGGL(vectors_mg_kernel, dim3((maxK + 63) / 64, 1, nmg), dim3(256), 0, st, md_dev, 0, dlam, zh, sec, n, 0,
+            hipLaunchKernelGGL(vectors_mg_kernel, dim3((maxK + 63) / 64, 1, nmg), dim3(256), 0, st, C.md_dev, 0, C.dlam, zh, sec, n, 0,
                                maxK, 1, S, lds_mg);
         } else {
-        if (maxK >= 512)
-          hipLaunchKernelGGL(secular_kernel<32>, dim3((maxK + 7) / 8, nmg), dim3(256), 0, st, md_dev, dlam, wz, Dcur, S, ldq, 1, 0,
-                             (double*)nullptr, 0);
-        else
-          hipLaunchKernelGGL(secular_kernel<8>, dim3((maxK + 31) / 32, nmg), dim3(256), 0, st, md_dev, dlam, wz, Dcur, S, ldq, 1, 0,
-                             (double*)nullptr, 0);
-        hipLaunchKernelGGL(loewner_kernel, dim3((maxK + 3) / 4, nmg), dim3(256), 0, st, md_dev, dlam, wz, S, ldq, zh);
-        {
+          if (maxK >= 512)
+            hipLaunchKernelGGL(secular_kernel<32>, dim3((maxK + 7) / 8, nmg), dim3(256), 0, sb, C.md_dev, C.dlam, C.wz, C.Dcur, S, ldq, 1, 0,
+                               (double*)nullptr, 0);
+          else
+            hipLaunchKernelGGL(secular_kernel<8>, dim3((maxK + 31) / 32, nmg), dim3(256), 0, sb, C.md_dev, C.dlam, C.wz, C.Dcur, S, ldq, 1, 0,
+                               (double*)nullptr, 0);
+          hipLaunchKernelGGL(loewner_kernel, dim3((maxK + 3) / 4, nmg), dim3(256), 0, sb, C.md_dev, C.dlam, C.wz, S, ldq, zh);
           const dim3 vg((maxK + 63) / 64, (maxK + VEC_IC - 1) / VEC_IC, nmg);
-          hipLaunchKernelGGL(vectors1_kernel, vg, dim3(256), 0, st, md_dev, zh, S, ldq, vnp, n);
-          hipLaunchKernelGGL(vectors2_kernel, vg, dim3(256), 0, st, md_dev, S, ldq, vnp, n);
+          hipLaunchKernelGGL(vectors1_kernel, vg, dim3(256), 0, sb, C.md_dev, zh, S, ldq, vnp, n);
+          hipLaunchKernelGGL(vectors2_kernel, vg, dim3(256), 0, sb, C.md_dev, S, ldq, vnp, n);
         }
-        }
+      }
+      if (sb != st) {   // the compute stream takes over: rotations and products need the previous product AND this pass's rows
+        EIGX_HIP_CHECK(hipEventRecord(ctx.dc_b_ev, sb));
+        EIGX_HIP_CHECK(hipStreamWaitEvent(st, ctx.dc_b_ev, 0));
+      }
+      if (nrot > 0)
+        hipLaunchKernelGGL(rotate_kernel, dim3((maxnm + 255) / 256, nmg), dim3(256), 0, st, C.md_dev,
+                           C.rpj_dev, C.rjj_dev, C.rc_dev, C.rs_dev, Qa, ldq, r0, r1);
+      if (z_ahead) {
+        if (maxK > 0)
+          hipLaunchKernelGGL(znext1_kernel, dim3((maxK + 63) / 64, (maxK + ZN_IC - 1) / ZN_IC, nmg), dim3(256), 0, st, C.md_dev,
+                             C.nd_dev, Qa, ldq, S, ldq, zp, n);
+        hipLaunchKernelGGL(znext2_kernel, dim3((maxnm + 255) / 256, nmg), dim3(256), 0, st, C.md_dev, C.dsrc_dev, Qa, ldq, zp, n,
+                           C.zbuf);
+        EIGX_HIP_CHECK(hipMemcpyAsync(C.host + down_off, C.dev + down_off, 2 * npad * 8, hipMemcpyDeviceToHost, st));  // Dcur | z'
+        EIGX_HIP_CHECK(hipEventRecord(ctx.dc_z_ev, st));
+        z_ready = true;
+      }
+      if (maxK > 0) {
         // the merges of one height are independent: when there are several, spread their GEMMs over the aux
         // streams so that small products run side by side instead of one after another
         // (not in chunked mode: there the chunk buffer S is reused from chunk to chunk and from merge to merge, and only
         // the order of ONE stream keeps a chunk's generation behind the GEMMs that still read the previous one)
-        const bool fan = mds.size() > 1 && !(mg && !compact);
+        const bool fan = mds.size() > 1 && !(mg && !compact) && !batched;
         if (fan) {
           EIGX_HIP_CHECK(hipEventRecord(ctx.aux_ev[Context::kAux], st));
           for (int q = 0; q < Context::kAux; ++q) EIGX_HIP_CHECK(hipStreamWaitEvent(ctx.aux[q], ctx.aux_ev[Context::kAux], 0));
         }
         int rr = 0;
         const double tg0 = trace ? now_s() : 0.0;
+        if (batched) {
+          if (k == 0)
+            dgemm_gather_batch_dev(st, C.gb_dev, nbatch, bmaxM, maxK, Qa, ldq, S, ldq, Qb, ldq, C.topA_dev, C.topB_dev);
+          else
+            dgemm_gather_batch_dev(st, C.gb_dev, nbatch, bmaxM, maxK, Qa, ldq, S, ldq, Qb, ldq, C.nd_dev, iota_dev);
+        } else
         for (size_t q = 0; q < mds.size(); ++q) {
           const MergeDev& M = mds[q];
           if (M.K <= 0) continue;
@@ -991,7 +1236,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
           const double* Sb = mg ? (chunked ? S : S + (size_t)M.off * lds_mg) : S + (size_t)M.off * ldq + M.off;
           if (chunked) {
             // the chunk buffer is reused: order this chunk's generation after the previous chunk's GEMMs
-            hipLaunchKernelGGL(vectors_mg_kernel, dim3((cw + 63) / 64, 1, 1), dim3(256), 0, st, md_dev, (int)q, dlam, zh, sec, n, j0,
+            hipLaunchKernelGGL(vectors_mg_kernel, dim3((cw + 63) / 64, 1, 1), dim3(256), 0, st, C.md_dev, (int)q, C.dlam, zh, sec, n, j0,
                                j0 + cw, 0, S, ldsb);
           }
           double* Cb = Qb + (size_t)(M.off + j0) * ldq + M.off;
@@ -1008,10 +1253,10 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
             int ga, gb;
             if (clip(M.off, M.off + M.n1, ga, gb))
               dgemm_dev(g1, 'N', 'T', gb - ga, cw, ktop[q], 1.0, Qa + ga, ldq, Sb, ldsb, 0.0, Cb + (ga - M.off), ldq, 0,
-                        nullptr, topA_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, topB_dev + M.off);
+                        nullptr, C.topA_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, C.topB_dev + M.off);
             if (clip(M.off + M.n1, M.off + M.nm, ga, gb))
               dgemm_dev(g2, 'N', 'T', gb - ga, cw, kbot[q], 1.0, Qa + ga, ldq, Sb, ldsb, 0.0, Cb + (ga - M.off), ldq, 0,
-                        nullptr, botA_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, botB_dev + M.off);
+                        nullptr, C.botA_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, C.botB_dev + M.off);
             if (!fan && g2 != st) {
               EIGX_HIP_CHECK(hipEventRecord(ctx.aux_ev[0], g2));
               EIGX_HIP_CHECK(hipStreamWaitEvent(st, ctx.aux_ev[0], 0));
@@ -1022,7 +1267,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
             int ga, gb;
             if (clip(M.off, M.off + M.nm, ga, gb))
               dgemm_dev(gs, 'N', 'T', gb - ga, cw, M.K, 1.0, Qa + ga, ldq, Sb, ldsb, 0.0, Cb + (ga - M.off), ldq, 0,
-                        nullptr, nd_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, iota_dev);
+                        nullptr, C.nd_dev + M.off, nullptr, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, iota_dev);
             gemm_flops += 2.0 * M.nm * (double)M.K * cw;
           }
           }
@@ -1035,15 +1280,12 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
         if (trace) t_gemm_enq = now_s() - tg0;
       }
       if (ncopy > 0)
-        hipLaunchKernelGGL(copycols_kernel, dim3(ncopy), dim3(256), 0, st, cps_dev, cpd_dev, cpr_dev, cpn_dev, Qa, Qb,
+        hipLaunchKernelGGL(copycols_kernel, dim3(ncopy), dim3(256), 0, st, C.cps_dev, C.cpd_dev, C.cpr_dev, C.cpn_dev, Qa, Qb,
                            ldq);
-      // the host vectors are reused next round: wait for the uploads (tiny) before touching them
       // merged blocks go back into Qa (blocks that do not merge at this height stay where they are)
       // When the merges of this height cover every column (balanced tree: always), Qb now IS the new Q: swap the
       // buffers instead of copying n^2 doubles back.  Both buffers are zero outside the diagonal blocks (memset at
       // the start; GEMMs and column copies only ever write rows inside their own block).
-      size_t covered = 0;
-      for (const MergeDev& M : mds) covered += (size_t)M.nm;
       if (covered == (size_t)n) {
         std::swap(Qa, Qb);
       } else {
@@ -1055,22 +1297,28 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
                                           (size_t)M.nm, hipMemcpyDeviceToDevice, st));
         }
       }
-      EIGX_HIP_CHECK(hipStreamSynchronize(st));
+      Dfinal = C.Dcur;
+      // classic flow: the host arrays of this pass are free again once the stream is idle; pipelined: the two arenas
+      // alternate, and the wait for the next z orders everything that matters
+      if (!pipe || trace) EIGX_HIP_CHECK(hipStreamSynchronize(st));
       if (trace) {
         long sumK = 0, sumN = 0;
         for (const MergeDev& M : mds) { sumK += M.K; sumN += M.nm; }
         long mine = 0;   // secular roots this rank solved (several GPUs: K (r+1)/P - K r/P of every merge)
         for (const MergeDev& M : mds) mine += (P > 1) ? (long)((long)M.K * (ctx.grid.rank + 1) / P - (long)M.K * ctx.grid.rank / P) : M.K;
         fprintf(stderr, "[eigx dc] rank %d/%d height %d pass %d: %zu merges (non-deflated %ld of %ld; secular roots solved here %ld), "
-                "z gather + D2H %.3f ms, host deflation %.3f ms, device part %.3f ms (GEMM enqueue %.3f ms)\n", ctx.grid.rank, P, h, k,
-                ids.size(), sumK, sumN, mine, (tt1 - tt0) * 1e3, (tt2 - tt1) * 1e3, (now_s() - tt2) * 1e3, t_gemm_enq * 1e3);
+                "z gather + D2H %.3f ms, host deflation %.3f ms, device part %.3f ms (GEMM enqueue %.3f ms)%s\n", ctx.grid.rank, P, h, k,
+                ids.size(), sumK, sumN, mine, (tt1 - tt0) * 1e3, (tt2 - tt1) * 1e3, (now_s() - tt2) * 1e3, t_gemm_enq * 1e3,
+                batched ? " [one product launch]" : "");
       }
     }
   }
+  if (pipe) EIGX_HIP_CHECK(hipStreamSynchronize(ctx.dc_stream));
 
   // ---- final sort + copy-out ----------------------------------------------------------------------------
   stage_trace(ctx.grid.rank, "D&C merges done");
-  EIGX_HIP_CHECK(hipMemcpyAsync(Dh, Dcur, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  double* Dh = ar[0].Dh;
+  EIGX_HIP_CHECK(hipMemcpyAsync(Dh, Dfinal, (size_t)n * 8, hipMemcpyDeviceToHost, st));
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
   ord.resize(n);
   for (int i = 0; i < n; ++i) ord[i] = std::make_pair(Dh[i], i);

@@ -90,6 +90,17 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
                int batch2 = 1, long strideA2 = 0, long strideB2 = 0, long strideC2 = 0, int ownP = 1,
                int ownp = 0, const int* kmapB = nullptr, int tn_lo = 0, int tn_hi = 0x7fffffff);
 
+// Batch of independent gather products C_b = A(:, kmapA_b) * B(:, kmapB_b)^T with their own sizes (the merges of one D&C
+// height): ONE launch, the table lives in device memory (blockIdx.y = entry); offsets are in elements from the bases.
+struct GemmBatch {
+  int M, N, K, pad;
+  long offA, offB, offC;
+  int offKA, offKB;
+};
+void dgemm_gather_batch_dev(hipStream_t stream, const GemmBatch* tab_dev, int nbatch, int maxM, int maxN,
+                            const double* A, int lda, const double* B, int ldb, double* C, int ldc,
+                            const int* kmapA, const int* kmapB);
+
 // EIGX_TRACE_STAGES=1: one stderr line per stage boundary of a solve (rank, wall clock), for locating a stall on a
 // process grid; costs one getenv per process
 inline void stage_trace(int rank, const char* what, long detail = -1) {
@@ -114,5 +125,8 @@ int set_bt_q(int v);
 int set_symv_threshold(int which, int v);
 // tuning hook (eigx_tune key 8): chunk width (roots) of the multi-rank D&C's eigenvector-row buffer, 64 .. 2048
 int set_dc_chunk(int v);
+// lab switches (eigx_tune keys 15, 16): pipelined D&C passes / one product launch per low height (one GPU)
+int set_dc_pipe(int v);
+int set_dc_batch(int v);
 
 }  // namespace eigx

@@ -2,6 +2,7 @@
 // TRD_COMM_WORLD, x_nnod, ... in src/eigen_devel.F:53-61; one live grid at a time, not re-entrant).
 #pragma once
 #include "eigx_common.h"
+#include <functional>
 #include <map>
 #include <vector>
 #include <string>
@@ -76,6 +77,13 @@ struct Context {
   // back-transformation plan prepared ahead (trbak_prepare_dev on the side stream during the D&C): event + key
   hipEvent_t bt_ev = nullptr;
   hipEvent_t dc_ev = nullptr;          // D&C buffers zero-filled ahead (band_dc_prepare)
+  // D&C pipeline (one GPU): the secular / Loewner / eigenvector-row kernels of the NEXT pass run on dc_stream under the
+  // big product of the current one; dc_b_ev = their completion, dc_z_ev = [new eigenvalues | next z] are on the host
+  hipStream_t dc_stream = nullptr;
+  // work the solver wants enqueued on the side stream once the D&C's leaves are through (the T factors of the
+  // back-transformation: beside the leaf kernel they take the chip from 256 single waves that everything else waits for)
+  std::function<void()> dc_after_leaves;
+  hipEvent_t dc_b_ev = nullptr, dc_z_ev = nullptr;
   int dc_zero_n = 0; const double* dc_zero_qa = nullptr; const double* dc_zero_qb = nullptr;
   bool bt_ready = false;
   const double* bt_a = nullptr; double* bt_V = nullptr;

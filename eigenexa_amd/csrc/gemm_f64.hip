@@ -60,6 +60,7 @@ struct GemmArgs {
   // rg_start[q] of the tile list (rg_start[nrg] = total); 0 groups: the full rectangle is launched (older form).
   int nrg, rg_h, rg_c1;
   unsigned rg_magic;   // floor(2^32 / Py) + 1: x / Py == umulhi(x, rg_magic) for the x < 2^22 that occur (Py > 1)
+  const GemmBatch* btab;  // gemm_f64_kernel only: per-batch sizes / offsets (blockIdx.y), nullptr = one shape for all
 };
 // tri mode 2: first tile column of row group q = the tile column that holds the first local column whose global index
 // reaches the first global row of the group, clipped to the launch's column window [tn_lo, rg_c1]
@@ -157,6 +158,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   g.A += (long)blockIdx.y * g.sA + (long)blockIdx.z * g.sA2;
   g.B += (long)blockIdx.y * g.sB + (long)blockIdx.z * g.sB2;
   g.C += (long)blockIdx.y * g.sC + (long)blockIdx.z * g.sC2;
+  if (g.btab) {   // table batch: the entry's own shape (uniform per workgroup: scalar loads)
+    const GemmBatch b = g.btab[blockIdx.y];
+    g.M = b.M; g.N = b.N; g.K = b.K;
+    g.A += b.offA; g.B += b.offB; g.C += b.offC;
+    if (GATHER) { g.kmapA += b.offKA; g.kmapB += b.offKB; }
+    if ((int)blockIdx.x >= ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN)) return;
+  }
   // stage buffer b: A slab at smem + 2*b*OPER_DOUBLES, B slab right behind it
 
   const int tid = threadIdx.x;
@@ -649,7 +657,7 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
   g.sA2 = strideA2; g.sB2 = strideB2; g.sC2 = strideC2;
   g.ownP = ownP; g.ownp = ownp; g.tri_gb = 1;
   g.tn_lo = tn_lo; g.tn_hi = tn_hi;
-  g.nrg = 0; g.rg_h = 8; g.rg_c1 = 0; g.rg_magic = 0;
+  g.nrg = 0; g.rg_h = 8; g.rg_c1 = 0; g.rg_magic = 0; g.btab = nullptr;
   g.c_stream = (tri_mode != 0 && g_gemm_cstream) ? 1 : 0;
   g.Px = grid ? grid->Px : 1; g.px = grid ? grid->px : 0;
   g.Py = grid ? grid->Py : 1; g.py = grid ? grid->py : 0;
@@ -737,6 +745,35 @@ void dgemm_dev(hipStream_t stream, char opA, char opB, int M, int N, int K, doub
   else EIGX_LAUNCH_T(false, false);
 #undef EIGX_LAUNCH_T
 #undef EIGX_LAUNCH
+  EIGX_HIP_CHECK(hipGetLastError());
+}
+
+// One launch for a table of gather products of different shapes (64 x 64 tiles; the D&C's low heights, where a height is
+// dozens of products of a few tiles each and the per-product launches were the cost).  Role of the PDGEMM calls of
+// src/my_pdlaed1.F:310-341 for all merges of one tree level at once.
+void dgemm_gather_batch_dev(hipStream_t stream, const GemmBatch* tab_dev, int nbatch, int maxM, int maxN,
+                            const double* A, int lda, const double* B, int ldb, double* C, int ldc,
+                            const int* kmapA, const int* kmapB) {
+  if (nbatch <= 0 || maxM <= 0 || maxN <= 0) return;
+  GemmArgs g;
+  g.M = maxM; g.N = maxN; g.K = 0; g.alpha = 1.0; g.beta = 0.0;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.tri_mode = 0; g.kmapA = kmapA; g.cmapC = nullptr; g.kmapB = kmapB;
+  g.sA = g.sB = g.sC = 0; g.sA2 = g.sB2 = g.sC2 = 0;
+  g.ownP = 1; g.ownp = 0; g.tri_gb = 1; g.tn_lo = 0; g.tn_hi = 0x7fffffff;
+  g.nrg = 0; g.rg_h = 8; g.rg_c1 = 0; g.rg_magic = 0; g.c_stream = 0;
+  g.Px = 1; g.px = 0; g.Py = 1; g.py = 0;
+  g.btab = tab_dev;
+  constexpr int WT = 32;
+  const int tiles = ceil_div(maxM, Geo<WT>::BM) * ceil_div(maxN, Geo<WT>::BN);
+  const size_t shmem = (size_t)4 * Geo<WT>::OPER * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f64_kernel<false, false, WT, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_f64_kernel<false, false, WT, true>), dim3(tiles, nbatch, 1), dim3(256), shmem, stream, g);
   EIGX_HIP_CHECK(hipGetLastError());
 }
 

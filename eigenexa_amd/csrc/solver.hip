@@ -360,7 +360,12 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   // The T factors of the back-transformation depend on the reflectors only: build them on the side stream while the
   // divide and conquer (launch-bound at its low levels) has the compute stream.  The reduction is complete here
   // (the host synchronised the compute stream above).
-  if (do_bt && nvec > 0 && P == 1) trbak_prepare_dev(ctx, n, a, lda, e, lde, mb, band, ctx.side_stream);
+  const bool runs_dc = !(mode == 'N' || mode == 'S' || mode == 'C');
+  ctx.dc_after_leaves = nullptr;   // (a solve that failed before its D&C ran may have left one behind)
+  if (do_bt && nvec > 0 && P == 1) {
+    if (runs_dc) ctx.dc_after_leaves = [&ctx, n, a, lda, e, lde, mb, band] { trbak_prepare_dev(ctx, n, a, lda, e, lde, mb, band, ctx.side_stream); };
+    else trbak_prepare_dev(ctx, n, a, lda, e, lde, mb, band, ctx.side_stream);
+  }
   // several GPUs: this rank's eigenvector columns [zc0, zc0 + zcnt) (the D&C delivers them, all n rows each)
   const int zc0 = (P > 1) ? ((G.rank * zcols_per_rank < nvec) ? G.rank * zcols_per_rank : nvec) : 0;
   const int zcnt = (P > 1) ? ((nvec - zc0 < zcols_per_rank) ? nvec - zc0 : zcols_per_rank) : nvec;
@@ -369,6 +374,7 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
     band_bisect_dev(ctx, n, d, e, lde, band, w);
   } else {
     band_dc_dev(ctx, n, nvec, d, e, lde, band, w, z, ldz);
+    if (ctx.dc_after_leaves) { std::function<void()> f = std::move(ctx.dc_after_leaves); ctx.dc_after_leaves = nullptr; f(); }   // not consumed (cannot happen today)
     if (mode == 'X') band_bisect_dev(ctx, n, d, e, lde, band, w);
   }
   const double t3 = now_s();
@@ -637,8 +643,8 @@ int64_t solver_workspace_bytes(const Context& ctx, int n, int lda, int ldz, int 
   const int64_t ldp = pad_ld((n + 127) / 128 * 128 + 128);
   if (P == 1) {
     const int64_t nn = ldn * n;
-    // D&C: Qa, Qb, S ; reduction: panels + partials ; back-transform: V, W, X
-    return 8 * (3 * nn + (int64_t)(n + 256) * (3 * mf + 2 * (n / 128 + 2) * 2 + 8) + (int64_t)(n + 512) * mb +
+    // D&C: Qa, Qb, S, S2 ; reduction: panels + partials ; back-transform: V, W, X
+    return 8 * (4 * nn + (int64_t)(n + 256) * (3 * mf + 2 * (n / 128 + 2) * 2 + 8) + (int64_t)(n + 512) * mb +
                 2 * (int64_t)mb * n);
   }
   // Several GPUs: everything of size n^2 is divided by P (the caller's a and z blocks are n^2/P each as well):
