@@ -267,6 +267,15 @@ int64_t eigx_held_bytes(void) {
   return t + comm_held_bytes(g_ctx);
 }
 
+int64_t eigx_held_bytes_named(const char* prefix) {
+  if (!g_ctx.initialized || !prefix) return -1;
+  const std::string pre(prefix);
+  int64_t t = 0;
+  for (const auto& kv : g_ctx.pool.bufs)
+    if (kv.first.compare(0, pre.size(), pre) == 0) t += (int64_t)kv.second.bytes;
+  return t;
+}
+
 int eigx_get_timers(double* out16) {
   if (!out16) return EIGX_ERR_BAD_ARG;
   for (int i = 0; i < 16; ++i) out16[i] = g_ctx.timers[i];

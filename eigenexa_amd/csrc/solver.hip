@@ -487,32 +487,156 @@ __global__ void scale_cols_rsqrt_kernel(const double* __restrict__ z, int ldz, c
 }
 
 
-// ---- multi-rank KMATH_EIGEN_GEV: cyclic blocks <-> the full matrix -------------------------------------------------
-__global__ void rg_pack_kernel(const double* __restrict__ a, int lda, int nr, int nc, double* __restrict__ out, int bx) {
-  const int lj = blockIdx.y;
-  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < bx; li += gridDim.x * blockDim.x)
-    out[(size_t)lj * bx + li] = (li < nr && lj < nc) ? a[(size_t)lj * lda + li] : 0.0;
-}
-__global__ void rg_cyclic_to_full_kernel(const double* __restrict__ recv, int bx, int by, int Px, int Py, int order_r, int n,
-                                         double* __restrict__ F, int ldf) {
-  const int q = blockIdx.z;
-  const int qx = order_r ? q / Py : q % Px, qy = order_r ? q % Py : q / Px;
-  const int lj = blockIdx.y;
-  const int gj = lj * Py + qy;
-  if (gj >= n) return;
-  const double* src = recv + (size_t)q * bx * by + (size_t)lj * bx;
-  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < bx; li += gridDim.x * blockDim.x) {
-    const int gi = li * Px + qx;
-    if (gi < n) F[(size_t)gj * ldf + gi] = __hip_atomic_load(src + li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// ---- multi-rank KMATH_EIGEN_GEV on the 2-D cyclic blocks -------------------------------------------------------------
+// Two building blocks, both O(n^2 / P) memory per rank:
+//   dist_transpose : Z = A^T.  Element A(j, i) lives on rank (j % Px, i % Py) and goes to rank (i % Px, j % Py): on a
+//                    non-square grid that is a genuine all-to-all.  The rows i that rank (px, .) receives from a source in
+//                    process column sy are the i = i0 + t L (L = lcm(Px, Py), i0 by the Chinese remainder theorem, none
+//                    if px != sy mod gcd); likewise the columns j = j0 + u L: a piece is the (t, u) rectangle, piece
+//                    [u][t].  (role of PDTRAN + trpos_utol, src/KMATH_EIGEN_GEV_1.F:57-58)
+//   dist_gemm_nn   : C = A B (SUMMA): for every panel of kb global indices k the ranks of a process ROW allgather their
+//                    columns of A(:, k-panel), the ranks of a process COLUMN their rows of B(k-panel, :), and the local
+//                    fp64 MFMA GEMM accumulates the panel product.  (role of the three PDGEMMs, :100-139)
+struct TrPeers { int i0[EIGX_MAXP], j0[EIGX_MAXP]; };   // per peer (world rank order): first row / column of the piece, -1 = empty
+// pack: piece for destination d, element [u][t] = A(j0 + u L, i0 + t L) of my block (row j, column i)
+__global__ void tr_pack_kernel(const double* __restrict__ a, int lda, int n, int Px, int Py, int L, TrPeers tp, int nimax,
+                               int u0, int ucw, double* __restrict__ send) {
+  const int d = blockIdx.z;
+  const int i0 = tp.i0[d], j0 = tp.j0[d];
+  for (int uu = blockIdx.y; uu < ucw; uu += gridDim.y) {
+    const int u = u0 + uu;
+    double* dst = send + ((size_t)d * ucw + uu) * nimax;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nimax; t += gridDim.x * blockDim.x) {
+      double v = 0.0;
+      if (i0 >= 0 && j0 >= 0) {
+        const int i = i0 + t * L, j = j0 + u * L;   // I hold row j (local j / Px), column i (local i / Py)
+        if (i < n && j < n) v = a[(size_t)(i / Py) * lda + j / Px];
+      }
+      dst[t] = v;
+    }
   }
 }
-__global__ void rg_full_to_cyclic_kernel(const double* __restrict__ F, int ldf, int nloc_r, int n, int Px, int px, int Py, int py,
-                                         double* __restrict__ dst, int ldd) {
-  const int lj = blockIdx.y;
-  const int gj = lj * Py + py;
-  if (gj >= n) return;
-  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < nloc_r; li += gridDim.x * blockDim.x)
-    dst[(size_t)lj * ldd + li] = F[(size_t)gj * ldf + (size_t)li * Px + px];
+// unpack: Z(i, j) = piece from source s at [u][t]; I hold row i (local i / Px), column j (local j / Py)
+__global__ void tr_unpack_kernel(const double* __restrict__ recv, int n, int Px, int Py, int L, TrPeers tp, int nimax,
+                                 int u0, int ucw, double* __restrict__ z, int ldz) {
+  const int sidx = blockIdx.z;
+  const int i0 = tp.i0[sidx], j0 = tp.j0[sidx];
+  if (i0 < 0 || j0 < 0) return;
+  for (int uu = blockIdx.y; uu < ucw; uu += gridDim.y) {
+    const int u = u0 + uu;
+    const double* src = recv + ((size_t)sidx * ucw + uu) * nimax;
+    const int j = j0 + u * L;
+    if (j >= n) return;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nimax; t += gridDim.x * blockDim.x) {
+      const int i = i0 + t * L;
+      if (i < n) z[(size_t)(j / Py) * ldz + i / Px] = __hip_atomic_load(src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+static int crt_small(int a, int A_, int b, int B_, int L) {   // smallest x < L with x % A_ == a and x % B_ == b, -1 if none
+  for (int x = 0; x < L; ++x)
+    if (x % A_ == a && x % B_ == b) return x;
+  return -1;
+}
+static int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+
+// z(ldz, nc) = (a(lda, nc))^T on the cyclic blocks (both n x n); enqueued on st.  The all-to-all's pieces are uniform, and
+// only gcd(Px, Py)^-2 of the rank pairs exchange anything, so the exchange runs in rounds over the pieces' columns u that
+// keep the send + receive buffers at about one local block each.
+static void dist_transpose(Context& ctx, int n, const double* a, int lda, double* z, int ldz, hipStream_t st) {
+  const Grid& G = ctx.grid;
+  const int g = gcd_int(G.Px, G.Py);
+  const int P = G.nranks, L = G.Px / g * G.Py;
+  const int nimax = ceil_div(n, L);
+  const int ucw = ceil_div(nimax, g * g);                      // piece columns per round
+  const size_t count = (size_t)nimax * ucw;
+  double* sendb = ctx.pool.get_t<double>("gev.tsend", count * P);
+  double* recvb = ctx.pool.get_t<double>("gev.trecv", count * P);
+  TrPeers to, from;
+  for (int q = 0; q < P; ++q) {
+    const int qx = G.row_major ? q / G.Py : q % G.Px, qy = G.row_major ? q % G.Py : q / G.Px;
+    // to q = (qx, qy): its rows i (i % Px == qx) among my columns (i % Py == py); its columns j (j % Py == qy) among my rows
+    to.i0[q] = crt_small(qx, G.Px, G.py, G.Py, L);
+    to.j0[q] = crt_small(G.px, G.Px, qy, G.Py, L);
+    // from q: my rows i (i % Px == px) among its columns (i % Py == qy); my columns j (j % Py == py) among its rows (j % Px == qx)
+    from.i0[q] = crt_small(G.px, G.Px, qy, G.Py, L);
+    from.j0[q] = crt_small(qx, G.Px, G.py, G.Py, L);
+  }
+  const int gy = ucw < 32768 ? ucw : 32768;
+  for (int u0 = 0; u0 < nimax; u0 += ucw) {
+    hipLaunchKernelGGL(tr_pack_kernel, dim3(ceil_div(nimax, 256), gy, P), dim3(256), 0, st, a, lda, n, G.Px, G.Py, L, to, nimax, u0,
+                       ucw, sendb);
+    comm_exchange_big(ctx, COMM_WORLD, sendb, count, recvb, count, st);
+    hipLaunchKernelGGL(tr_unpack_kernel, dim3(ceil_div(nimax, 256), gy, P), dim3(256), 0, st, (const double*)recvb, n, G.Px, G.Py, L,
+                       from, nimax, u0, ucw, z, ldz);
+  }
+}
+
+// a(i, j) for i > j (global indices) from t = a^T: the full symmetric matrix out of its upper triangle
+__global__ void sym_merge_kernel(double* __restrict__ a, int lda, const double* __restrict__ t, int ldt, int nr, int Px, int px,
+                                 int Py, int py) {
+  const int lc = blockIdx.y, gj = lc * Py + py;
+  for (int lr = blockIdx.x * blockDim.x + threadIdx.x; lr < nr; lr += gridDim.x * blockDim.x)
+    if (lr * Px + px > gj) a[(size_t)lc * lda + lr] = t[(size_t)lc * ldt + lr];
+}
+// b(:, lc) = z(:, lc) * w(global column)^(-1/2) on the local block   (diag_mult, src/KMATH_EIGEN_GEV_misc.F:49-104)
+__global__ void scale_cols_rsqrt_cyclic_kernel(const double* __restrict__ z, int ldz, const double* __restrict__ w,
+                                               double* __restrict__ b, int ldb, int nr, int Py, int py) {
+  const int lc = blockIdx.y;
+  const double sc = 1.0 / sqrt(w[lc * Py + py]);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += gridDim.x * blockDim.x)
+    b[(size_t)lc * ldb + i] = z[(size_t)lc * ldz + i] * sc;
+}
+// SUMMA panels.  A side: my columns lc0 .. lc0 + kbl - 1 of the panel, rows padded to nrp: out[c * nrp + r]
+__global__ void mm_pack_a_kernel(const double* __restrict__ a, int lda, int nr, int nc, int lc0, int nrp, double* __restrict__ out) {
+  const int c = blockIdx.y, lc = lc0 + c;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrp; r += gridDim.x * blockDim.x)
+    out[(size_t)c * nrp + r] = (r < nr && lc < nc) ? a[(size_t)lc * lda + r] : 0.0;
+}
+// B side: my rows lr0 .. lr0 + kbl - 1 of the panel for every local column j: out[j * kbl + rr]
+__global__ void mm_pack_b_kernel(const double* __restrict__ b, int ldb, int nr, int nc, int lr0, int kbl, double* __restrict__ out) {
+  const int j = blockIdx.y;
+  for (int rr = blockIdx.x * blockDim.x + threadIdx.x; rr < kbl; rr += gridDim.x * blockDim.x)
+    out[(size_t)j * kbl + rr] = (j < nc && lr0 + rr < nr) ? b[(size_t)j * ldb + lr0 + rr] : 0.0;
+}
+// gathered B rows [q'][j][rr] (k = k0 + rr Px + q') -> panel matrix Bp(pos, j) in the k order of the gathered A columns:
+// k - k0 = c Py + q  ->  pos = q kbl_y + c
+__global__ void mm_unpack_b_kernel(const double* __restrict__ recv, int Px, int Py, int kbl_x, int kbl_y, int ncp, int kb,
+                                   double* __restrict__ Bp) {
+  const int j = blockIdx.y, q = blockIdx.z;
+  for (int rr = blockIdx.x * blockDim.x + threadIdx.x; rr < kbl_x; rr += gridDim.x * blockDim.x) {
+    const int dk = rr * Px + q;
+    Bp[(size_t)j * kb + (size_t)(dk % Py) * kbl_y + dk / Py] = recv[((size_t)q * ncp + j) * kbl_x + rr];
+  }
+}
+// C(ldc, nc) = A B on the cyclic blocks (all n x n, A and B complete -- not triangles); synchronous
+static int dist_gemm_nn(Context& ctx, int n, const double* A, int lda, const double* B, int ldb, double* C, int ldc) {
+  const Grid& G = ctx.grid;
+  hipStream_t st = ctx.stream;
+  const int nr = local_count(n, G.Px, G.px), nc = local_count(n, G.Py, G.py);
+  const int L = G.Px / gcd_int(G.Px, G.Py) * G.Py;
+  const int unit = 2 * L;                                    // panels start at multiples of Px and Py; even widths
+  // panel width: about n / 8 between 128 and 1024 (the panels are O(n kb / sqrt(P)) of workspace)
+  const int kb_want = (n / 8 < 128) ? (n < 128 ? n : 128) : (n / 8 > 1024 ? 1024 : n / 8);
+  const int kb = unit * ceil_div(kb_want, unit);
+  const int kbl_x = kb / G.Px, kbl_y = kb / G.Py;
+  const int nrp = ((nr > 2 ? nr : 2) + 1) & ~1, ncp = nc > 1 ? nc : 1;
+  double* sendA = ctx.pool.get_t<double>("gev.sa", (size_t)nrp * kbl_y);
+  double* Ap = ctx.pool.get_t<double>("gev.pa", (size_t)nrp * kb);
+  double* sendB = ctx.pool.get_t<double>("gev.sb", (size_t)kbl_x * ncp);
+  double* recvB = ctx.pool.get_t<double>("gev.rb", (size_t)kb * ncp);
+  double* Bp = ctx.pool.get_t<double>("gev.pb", (size_t)kb * ncp);
+  for (int k0 = 0; k0 < n; k0 += kb) {
+    hipLaunchKernelGGL(mm_pack_a_kernel, dim3(ceil_div(nrp, 256), kbl_y), dim3(256), 0, st, A, lda, nr, nc, k0 / G.Py, nrp, sendA);
+    comm_allgather(ctx, COMM_Y, sendA, Ap, (size_t)nrp * kbl_y, st);          // Ap(:, q kbl_y + c) = A(my rows, k0 + c Py + q)
+    hipLaunchKernelGGL(mm_pack_b_kernel, dim3(ceil_div(kbl_x, 256), ncp), dim3(256), 0, st, B, ldb, nr, nc, k0 / G.Px, kbl_x, sendB);
+    comm_allgather(ctx, COMM_X, sendB, recvB, (size_t)kbl_x * ncp, st);
+    hipLaunchKernelGGL(mm_unpack_b_kernel, dim3(ceil_div(kbl_x, 256), ncp, G.Px), dim3(256), 0, st, (const double*)recvB, G.Px, G.Py,
+                       kbl_x, kbl_y, ncp, kb, Bp);
+    if (nr > 0 && nc > 0) dgemm_dev(st, 'N', 'N', nr, nc, kb, 1.0, Ap, nrp, Bp, kb, k0 == 0 ? 0.0 : 1.0, C, ldc);
+  }
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  return comm_failed(ctx) ? EIGX_ERR_INTERNAL : EIGX_OK;
 }
 
 // Same sequence as KMATH_EIGEN_GEV_1 (src/KMATH_EIGEN_GEV_1.F:57-139): eigen_s(B, 'X') -> B^(-1/2) := Z_B W_B^(-1/2);
@@ -521,51 +645,53 @@ __global__ void rg_full_to_cyclic_kernel(const double* __restrict__ F, int ldf, 
 // the reference).  One GPU; all three products run on the fp64 MFMA GEMM.
 int gev_dev(Context& ctx, int n, double* a, int lda, double* b, int ldb, double* w, double* z, int ldz);
 
-// Several ranks (the reference's KMATH_EIGEN_GEV is distributed: two eigen_s calls + three PDGEMMs on the cyclic blocks,
-// src/KMATH_EIGEN_GEV_1.F:57-139): first version as for eigen_h -- the cyclic blocks of A and B are gathered (two
-// allgathers of n^2 / P doubles per rank), every rank solves the replicated problem with the one-GPU sequence, and z, a
-// (= Y) and b (= B^(-1/2)) go back to the callers' cyclic blocks.  Correct on every grid; the O(n^3) work is not divided.
+// Several ranks: the same sequence on the 2-D cyclic blocks, nothing gathered -- two distributed eigen_s solves, the
+// symmetrisation of A and the transposed factor by dist_transpose, three SUMMA products with local MFMA GEMMs
+// (round 4; the first version gathered A and B on every rank).
 static int gev_dev_mg(Context& ctx, int n, double* a, int lda, double* b, int ldb, double* w, double* z, int ldz) {
   const Grid G = ctx.grid;
-  const int nloc_r = local_count(n, G.Px, G.px), nloc_c = local_count(n, G.Py, G.py);
-  if (n <= 0 || !a || !b || !w || !z || lda < (nloc_r > 1 ? nloc_r : 1) || ldb < (nloc_r > 1 ? nloc_r : 1) ||
-      ldz < (nloc_r > 1 ? nloc_r : 1)) return EIGX_ERR_BAD_ARG;
+  const int nr = local_count(n, G.Px, G.px), nc = local_count(n, G.Py, G.py);
+  if (n <= 0 || !a || !b || !w || !z || lda < (nr > 1 ? nr : 1) || ldb < (nr > 1 ? nr : 1) || ldz < (nr > 1 ? nr : 1))
+    return EIGX_ERR_BAD_ARG;
   EIGX_HIP_CHECK(hipSetDevice(ctx.device));
   EIGX_HIP_CHECK(hipStreamSynchronize(nullptr));
   hipStream_t st = ctx.stream;
-  const int bx = ceil_div(n, G.Px), by = ceil_div(n, G.Py);
-  const int ldf = pad_ld(n + 2);
-  double* sendb = ctx.pool.get_t<double>("gev.send", (size_t)bx * by);
-  double* recvb = ctx.pool.get_t<double>("gev.recv", (size_t)bx * by * G.nranks);
-  double* Af = ctx.pool.get_t<double>("gev.A", (size_t)ldf * n);
-  double* Bf = ctx.pool.get_t<double>("gev.B", (size_t)ldf * n);
-  double* Zf = ctx.pool.get_t<double>("gev.Z", (size_t)ldf * n);
-  double* const src[2] = {a, b};
-  const int lds[2] = {lda, ldb};
-  double* const full[2] = {Af, Bf};
-  for (int t = 0; t < 2; ++t) {
-    hipLaunchKernelGGL(rg_pack_kernel, dim3(8, by), dim3(256), 0, st, (const double*)src[t], lds[t], nloc_r, nloc_c, sendb, bx);
-    comm_allgather(ctx, COMM_WORLD, sendb, recvb, (size_t)bx * by, st);
-    hipLaunchKernelGGL(rg_cyclic_to_full_kernel, dim3(8, by, G.nranks), dim3(256), 0, st, (const double*)recvb, bx, by, G.Px, G.Py,
-                       G.row_major, n, full[t], ldf);
-  }
+  const double t0 = now_s();
+  const int ldt = pad_ld((nr > 2 ? nr : 2));
+  const int ncd = nc > 0 ? nc : 1;
+  double* tb = ctx.pool.get_t<double>("gev.t", (size_t)ldt * ncd);    // A^T, later (B^(-1/2))^T
+  double* cb = ctx.pool.get_t<double>("gev.c", (size_t)ldt * ncd);    // C = A B^(-1/2)
+  dist_transpose(ctx, n, a, lda, tb, ldt, st);
+  if (nr > 0 && nc > 0)
+    hipLaunchKernelGGL(sym_merge_kernel, dim3(ceil_div(nr, 256), nc), dim3(256), 0, st, a, lda, (const double*)tb, ldt, nr, G.Px, G.px,
+                       G.Py, G.py);
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
   if (comm_failed(ctx)) return EIGX_ERR_INTERNAL;
-  int rc;
-  {
-    GridSwap one_rank(ctx);                // the replicated problem runs the one-GPU sequence on every rank
-    rc = gev_dev(ctx, n, Af, ldf, Bf, ldf, w, Zf, ldf);
-  }
+  int rc = solve_dev(ctx, n, n, b, ldb, w, z, ldz, 128, 128, 'X', 1, 1);      // B = Z_B W_B Z_B^T
   if (rc != EIGX_OK) return rc;
-  if (nloc_r > 0 && nloc_c > 0) {
-    double* const dst[3] = {z, a, b};
-    const int ldd[3] = {ldz, lda, ldb};
-    const double* const from[3] = {Zf, Af, Bf};
-    for (int t = 0; t < 3; ++t)
-      hipLaunchKernelGGL(rg_full_to_cyclic_kernel, dim3(8, nloc_c), dim3(256), 0, st, from[t], ldf, nloc_r, n, G.Px, G.px, G.Py,
-                         G.py, dst[t], ldd[t]);
+  const double t1 = now_s();
+  double wmin = 0.0;
+  EIGX_HIP_CHECK(hipMemcpy(&wmin, w, 8, hipMemcpyDeviceToHost));
+  if (!(wmin > 0.0)) {   // w is replicated bit for bit: every rank takes the same way out
+    if (G.rank == 0) fprintf(stderr, "[eigx] Matrix B is not positive definite!\n");            // src/KMATH_EIGEN_GEV_1.F:75-80
+    return EIGX_ERR_NOT_SPD;
   }
-  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  if (nr > 0 && nc > 0)
+    hipLaunchKernelGGL(scale_cols_rsqrt_cyclic_kernel, dim3(ceil_div(nr, 256), nc), dim3(256), 0, st, (const double*)z, ldz,
+                       (const double*)w, b, ldb, nr, G.Py, G.py);
+  rc = dist_gemm_nn(ctx, n, a, lda, b, ldb, cb, ldt);                          // C  = A B^(-1/2)
+  if (rc != EIGX_OK) return rc;
+  dist_transpose(ctx, n, b, ldb, tb, ldt, st);                                 // (B^(-1/2))^T
+  rc = dist_gemm_nn(ctx, n, tb, ldt, cb, ldt, z, ldz);                         // A' = B^(-1/2)^T C
+  if (rc != EIGX_OK) return rc;
+  const double t2 = now_s();
+  rc = solve_dev(ctx, n, n, z, ldz, w, a, lda, 128, 128, 'X', 1, 1);            // A' = Y W Y^T, Y in a
+  if (rc != EIGX_OK) return rc;
+  const double t3 = now_s();
+  rc = dist_gemm_nn(ctx, n, b, ldb, a, lda, z, ldz);                           // Z = B^(-1/2) Y
+  if (rc != EIGX_OK) return rc;
+  const double t4 = now_s();
+  ctx.timers[0] = t4 - t0; ctx.timers[1] = t1 - t0; ctx.timers[2] = t2 - t1; ctx.timers[3] = t3 - t2; ctx.timers[4] = t4 - t3;
   return EIGX_OK;
 }
 

@@ -126,6 +126,9 @@ int64_t eigx_memory_internal(int n, int lda, int ldz, int m_forward, int m_backw
 /* bytes of device memory the library holds right now (pooled workspace + communication windows); the tests check it
  * against eigx_memory_internal and that it scales like 1/P on several ranks.  -1 before eigx_init. */
 int64_t eigx_held_bytes(void);
+/* the same for the pooled workspace buffers whose name starts with `prefix` (e.g. "gev." = what KMATH_EIGEN_GEV holds
+ * beside the two eigen_s solves: the tests check that it is a few n^2 / P, nothing gathered).  -1 before eigx_init. */
+int64_t eigx_held_bytes_named(const char* prefix);
 
 /* ---- index helpers (pure functions; 1-based like the reference, src/eigen_libs0.F:1744-2356) - */
 int eigx_loop_start(int istart, int nnod, int inod);

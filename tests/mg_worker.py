@@ -86,12 +86,21 @@ if route == "gev":
     rows = np.arange(xi - 1, n, xp)
     cols = np.arange(yi - 1, n, yp)
     nx, ny = ee.eigen_get_matdims(n)
-    a = np.zeros((nx, ny), order="F"); a[: len(rows), : len(cols)] = A[np.ix_(rows, cols)]
-    b = np.zeros((nx, ny), order="F"); b[: len(rows), : len(cols)] = B[np.ix_(rows, cols)]
+    # only the upper triangles are significant on entry: the strict lower ones carry NaN
+    low = rows[:, None] > cols[None, :]
+    a = np.zeros((nx, ny), order="F"); a[: len(rows), : len(cols)] = np.where(low, np.nan, A[np.ix_(rows, cols)])
+    b = np.zeros((nx, ny), order="F"); b[: len(rows), : len(cols)] = np.where(low, np.nan, B[np.ix_(rows, cols)])
     z = np.zeros((nx, ny), order="F")
     w = np.zeros(n)
     ee.KMATH_EIGEN_GEV(n, a, nx, b, nx, w, z, nx)
     assert api.last_status() == 0, api.last_status()
+    # nothing is gathered: what the routine holds beside the two eigen_s solves (transposed blocks, SUMMA panels, the
+    # transposes' exchange buffers) is a few n^2 / P; the gathered first version held 4 n^2 doubles on every rank
+    from eigenexa_amd import _lib as _l
+    gev_bytes = _l.load().eigx_held_bytes_named(b"gev.")
+    assert 0 < gev_bytes <= 8 * 8 * n * n // world + (1 << 20), (gev_bytes, n, world)
+    if n >= 500:
+        assert gev_bytes < 0.7 * 4 * 8 * n * n, gev_bytes
     zl = np.zeros(((n + xp - 1) // xp, (n + yp - 1) // yp))
     zl[: len(rows), : len(cols)] = z[: len(rows), : len(cols)]
     blocks = [torch.zeros(zl.shape, dtype=torch.float64) for _ in range(world)]

@@ -635,11 +635,13 @@ def test_multi_rank_no_transport_fails_on_every_rank():
     _run_multi_rank(3, 64, "initfail", 0, "", {"EIGX_SELFTEST_FAIL": "ipc"})
 
 
-@pytest.mark.parametrize("world,n,dims", [(2, 150, ""), (4, 301, ""), (3, 97, "3x1")])
+@pytest.mark.parametrize("world,n,dims", [(2, 150, ""), (4, 600, ""), (3, 97, "3x1"), (4, 203, "1x4")])
 def test_multi_rank_kmath_eigen_gev(world, n, dims):
-    """KMATH_EIGEN_GEV on the process grid (the reference's is distributed, src/KMATH_EIGEN_GEV_1.F:57-139): cyclic blocks
-    in and out, first version by gathering the blocks and solving the replicated problem on every rank; against scipy's
-    generalised eigenvalues and the checks of benchmark/KMATH_EIGEN_GEV_check.f"""
+    """KMATH_EIGEN_GEV on the process grid, distributed like the reference's (src/KMATH_EIGEN_GEV_1.F:57-139): cyclic blocks
+    in (upper triangles only, NaN below) and out, two distributed eigen_s solves, the symmetrisation and the transposed
+    factor by an all-to-all transpose, three SUMMA products with local MFMA GEMMs; the routine's own workspace is asserted
+    to be a few n^2 / P (nothing gathered); against scipy's generalised eigenvalues and the checks of
+    benchmark/KMATH_EIGEN_GEV_check.f"""
     _run_multi_rank(world, n, "gev", 0, dims)
 
 
