@@ -108,6 +108,7 @@ int eigx_init_multi(int device, int rank, int nranks, const void* uid, char orde
   }
   EIGX_HIP_CHECK(hipEventCreateWithFlags(&g_ctx.dc_b_ev, hipEventDisableTiming));
   EIGX_HIP_CHECK(hipEventCreateWithFlags(&g_ctx.dc_z_ev, hipEventDisableTiming));
+  g_ctx.bt_stream = g_ctx.side_stream;
   g_ctx.initialized = true;
   g_ctx.errinfo = 0;
   return EIGX_OK;
@@ -127,6 +128,7 @@ int eigx_free(void) {
   EIGX_HIP_CHECK(hipEventDestroy(g_ctx.bt_ev));
   EIGX_HIP_CHECK(hipEventDestroy(g_ctx.dc_ev));
   EIGX_HIP_CHECK(hipStreamDestroy(g_ctx.dc_stream));
+  g_ctx.bt_stream = nullptr;
   EIGX_HIP_CHECK(hipEventDestroy(g_ctx.dc_b_ev));
   EIGX_HIP_CHECK(hipEventDestroy(g_ctx.dc_z_ev));
   g_ctx = Context();

@@ -932,14 +932,17 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
     EIGX_HIP_CHECK(hipStreamSynchronize(st));  // `both` is a stack vector
     hipLaunchKernelGGL(jacobi_leaf_kernel, dim3(nl), dim3(LEAF_T), 0, st, dd, de, lde, band, leafinfo, leafinfo + nl,
                        Dfinal, Qa, ldq, r0, r1);
-    if (ctx.dc_after_leaves) {
-      EIGX_HIP_CHECK(hipEventRecord(ctx.dc_b_ev, st));
-      EIGX_HIP_CHECK(hipStreamWaitEvent(ctx.side_stream, ctx.dc_b_ev, 0));
-      std::function<void()> f = std::move(ctx.dc_after_leaves);
-      ctx.dc_after_leaves = nullptr;
-      f();
-    }
   }
+  // The solver's side work (T factors of the back-transformation: ~2.4 ms of latency-bound kernels on a few dozen CUs) is
+  // enqueued when the LAST pass's product starts: beside the leaves or the low heights it made their small dependent
+  // kernels wait behind its long workgroups (leaf kernel 0.45 -> 1.4 ms, or a secular launch 0.03 -> 0.7 ms); beside a
+  // chip-filling product it costs its own CU time and nothing else.
+  auto run_side_work = [&] {
+    if (!ctx.dc_after_leaves) return;
+    std::function<void()> f = std::move(ctx.dc_after_leaves);
+    ctx.dc_after_leaves = nullptr;
+    f();
+  };
 
   // ---- merges: the passes (height, k) in order --------------------------------------------------------
   struct Pass { int h, k; std::vector<int> ids; };
@@ -1204,6 +1207,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
         EIGX_HIP_CHECK(hipEventRecord(ctx.dc_z_ev, st));
         z_ready = true;
       }
+      if (pi + 1 == passes.size()) run_side_work();
       if (maxK > 0) {
         // the merges of one height are independent: when there are several, spread their GEMMs over the aux
         // streams so that small products run side by side instead of one after another
@@ -1313,6 +1317,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
       }
     }
   }
+  run_side_work();   // (no pass at all: a matrix of one leaf)
   if (pipe) EIGX_HIP_CHECK(hipStreamSynchronize(ctx.dc_stream));
 
   // ---- final sort + copy-out ----------------------------------------------------------------------------

@@ -80,9 +80,11 @@ struct Context {
   // D&C pipeline (one GPU): the secular / Loewner / eigenvector-row kernels of the NEXT pass run on dc_stream under the
   // big product of the current one; dc_b_ev = their completion, dc_z_ev = [new eigenvalues | next z] are on the host
   hipStream_t dc_stream = nullptr;
-  // work the solver wants enqueued on the side stream once the D&C's leaves are through (the T factors of the
-  // back-transformation: beside the leaf kernel they take the chip from 256 single waves that everything else waits for)
+  // work the solver wants enqueued on the side stream when the D&C's last product starts (the T factors of the
+  // back-transformation; see band_dc_dev for why not earlier)
   std::function<void()> dc_after_leaves;
+  // stream of that work (== side_stream; a CU-masked stream of its own changed nothing: profiles/r04_bt_mask_ab.log)
+  hipStream_t bt_stream = nullptr;
   hipEvent_t dc_b_ev = nullptr, dc_z_ev = nullptr;
   int dc_zero_n = 0; const double* dc_zero_qa = nullptr; const double* dc_zero_qb = nullptr;
   bool bt_ready = false;

@@ -363,7 +363,7 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   const bool runs_dc = !(mode == 'N' || mode == 'S' || mode == 'C');
   ctx.dc_after_leaves = nullptr;   // (a solve that failed before its D&C ran may have left one behind)
   if (do_bt && nvec > 0 && P == 1) {
-    if (runs_dc) ctx.dc_after_leaves = [&ctx, n, a, lda, e, lde, mb, band] { trbak_prepare_dev(ctx, n, a, lda, e, lde, mb, band, ctx.side_stream); };
+    if (runs_dc) ctx.dc_after_leaves = [&ctx, n, a, lda, e, lde, mb, band] { trbak_prepare_dev(ctx, n, a, lda, e, lde, mb, band, ctx.bt_stream); };
     else trbak_prepare_dev(ctx, n, a, lda, e, lde, mb, band, ctx.side_stream);
   }
   // several GPUs: this rank's eigenvector columns [zc0, zc0 + zcnt) (the D&C delivers them, all n rows each)
