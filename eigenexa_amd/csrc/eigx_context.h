@@ -163,6 +163,9 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d, const double* e
 void band_bisect_dev(Context& ctx, int n, const double* d, const double* e, int lde, int band, double* w);
 
 // solver.hip
+// eigenvector column blocks -> the callers' 2-D (block-)cyclic blocks (one all-to-all); see solver.hip
+void cols_to_cyclic_dev(Context& ctx, int n, int nvec, int nb, int zc, int zc0, int zcnt, const double* zcols, int ldz,
+                        double* z_user, int ldz_user, hipStream_t st);
 int64_t solver_workspace_bytes(const Context& ctx, int n, int lda, int ldz, int mf, int mb);
 
 }  // namespace eigx

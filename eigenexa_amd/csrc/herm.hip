@@ -49,7 +49,15 @@ struct HArgs {
   double *pd;      // panel-dot partials [chunk][HM][4]
   double *yrr, *yri, *ycr, *yci;  // mat-vec partials: row sums [tile column][ldp], column sums [tile row][ldp]
   double *ps;      // partials of u^H q [mat-vec tile][2]
+  // several ranks, sharded reduction: this rank holds the tile columns tx (HTL columns each) with tx % P == p, stored
+  // compactly (local tile column tx / P); P = 1: the whole matrix
+  int P, p;
 };
+// element offset of global column c in the planes Ar / Ai
+__device__ __host__ __forceinline__ size_t hcol(const HArgs& H, int c) {
+  return (H.P == 1) ? (size_t)c * H.ld : (size_t)(((c >> 7) / H.P) * 128 + (c & 127)) * H.ld;
+}
+static_assert(HTL == 128, "hcol assumes 128-column tiles");
 
 __device__ __forceinline__ double hwave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -256,7 +264,8 @@ typedef double hd2_t __attribute__((ext_vector_type(2)));
 // half as long -- for small active sizes, where a launch has fewer tiles than the chip has CUs and its time is that chain
 // (11.7 us per launch below L = 2000 with 4 waves); one workgroup per CU then.
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void h_hemv_kernel(HArgs H, int L, int k, int nt, int npdc, int npairs, int nparts) {
+__global__ __launch_bounds__(NW * 64) void h_hemv_kernel(HArgs H, int L, int k, int nt, int npdc, int npairs, int nparts,
+                                                         int ntl) {
   __shared__ double ucr[HTL], uci[HTL], urr[HTL], uri[HTL];
   __shared__ double part[NW][HTL][2];
   __shared__ double sred[NW];
@@ -266,14 +275,25 @@ __global__ __launch_bounds__(NW * 64) void h_hemv_kernel(HArgs H, int L, int k, 
   const bool pdot = (int)blockIdx.x < k * npdc;
   // tile index -> (ty, tx), row-major over the upper block triangle
   const int bid = pdot ? 0 : (int)blockIdx.x - k * npdc;
-  const float fn = 2.0f * (float)nt + 1.0f;
-  int ty = (int)((fn - sqrtf(fn * fn - 8.0f * (float)bid)) * 0.5f);
-  if (ty < 0) ty = 0;
-  if (ty > nt - 1) ty = nt - 1;
-  while (ty > 0 && ty * nt - ty * (ty - 1) / 2 > bid) --ty;
-  while ((ty + 1) * nt - (ty + 1) * ty / 2 <= bid) ++ty;
-  const int tx = ty + (bid - (ty * nt - ty * (ty - 1) / 2));
+  // (ntl = tiles of this launch; a rank that owns no active tile still sends ONE workgroup for the scalars below)
+  const bool idle = !pdot && bid >= ntl;
+  int ty = 0, tx = 0;
+  if (H.P == 1) {
+    const float fn = 2.0f * (float)nt + 1.0f;
+    ty = (int)((fn - sqrtf(fn * fn - 8.0f * (float)bid)) * 0.5f);
+    if (ty < 0) ty = 0;
+    if (ty > nt - 1) ty = nt - 1;
+    while (ty > 0 && ty * nt - ty * (ty - 1) / 2 > bid) --ty;
+    while ((ty + 1) * nt - (ty + 1) * ty / 2 <= bid) ++ty;
+    tx = ty + (bid - (ty * nt - ty * (ty - 1) / 2));
+  } else if (!idle && !pdot) {
+    // sharded: my tile columns tx = g P + p < nt, column by column; column tx holds the tiles ty = 0 .. tx
+    int g = 0, rest = bid;
+    for (;;) { const int cnt = g * H.P + H.p + 1; if (rest < cnt) break; rest -= cnt; ++g; }
+    tx = g * H.P + H.p; ty = rest;
+  }
   const int row0 = ty * HTL, col0 = tx * HTL;
+  const size_t cbase = hcol(H, col0);
   const bool diag = (ty == tx);
   const int l0 = 2 * lane, l1 = 2 * lane + 1;           // my rows inside the tile
   const int r0 = row0 + l0, r1 = row0 + l1;
@@ -283,10 +303,10 @@ __global__ __launch_bounds__(NW * 64) void h_hemv_kernel(HArgs H, int L, int k, 
   auto load4 = [&](hd2_t (&vr)[4], hd2_t (&vi)[4], int g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int c = col0 + wc0 + g * 4 + j;
-      const int ccl = (c < L) ? c : 0;
-      vr[j] = *reinterpret_cast<const hd2_t*>(H.Ar + (size_t)rc + (size_t)ccl * H.ld);
-      vi[j] = *reinterpret_cast<const hd2_t*>(H.Ai + (size_t)rc + (size_t)ccl * H.ld);
+      const int cc_ = wc0 + g * 4 + j;
+      const size_t co = cbase + (size_t)((col0 + cc_ < L) ? cc_ : 0) * H.ld;   // (beyond L: the tile's first column, masked below)
+      vr[j] = *reinterpret_cast<const hd2_t*>(H.Ar + (size_t)rc + co);
+      vi[j] = *reinterpret_cast<const hd2_t*>(H.Ai + (size_t)rc + co);
     }
   };
   // Requests first, in the order they are needed: the norm partials and the pivot (reflector scalars), x at this
@@ -297,7 +317,7 @@ __global__ __launch_bounds__(NW * 64) void h_hemv_kernel(HArgs H, int L, int k, 
   const int myi = (tid < HTL) ? col0 + tid : row0 + ((tid - HTL) & (HTL - 1));
   const int myc = (myi < L) ? myi : L - 1;
   const double mxr = H.xr[myc], mxi = H.xi[myc];
-  if (!pdot) load4(av0r, av0i, 0);
+  if (!pdot && !idle) load4(av0r, av0i, 0);
   // reflector scalars of column i (L = i rows) from the norm partials of K1: every workgroup of the mat-vec and of K1
   // recomputes them in the same order (bit-identical everywhere), so no separate reflector kernel runs
   hblock_sum_w<1, NW>(nr, sred);
@@ -307,6 +327,7 @@ __global__ __launch_bounds__(NW * 64) void h_hemv_kernel(HArgs H, int L, int k, 
     h_paneldot_body<NW>(H, f, L, k, (int)blockIdx.x % k, (int)blockIdx.x / k);
     return;
   }
+  if (idle) return;
   {
     double a_, b_;
     h_u_of(f, L, myi, mxr, mxi, a_, b_);
@@ -413,8 +434,12 @@ __global__ __launch_bounds__(NW * 64) void h_hemv_kernel(HArgs H, int L, int k, 
 // costs: everything is requested in one round trip before the first barrier), the
 // waves are combined through LDS.  x overwrites the previous x in place: a row is read and written by the one thread
 // that owns it, and the previous pivot row (= row i) is not part of the new x.
+// Sharded reduction (several ranks): the mat-vec result arrives already summed over tiles and ranks (H.ycr / H.yci point at
+// it, ntp = 0: one "partial" per row), likewise s (H.ps, nps = 1) and the raw column i of A (acr / aci: only its owner
+// holds it); the reflector goes into column Lp of A on the rank that owns that column.
 __global__ __launch_bounds__(HS) void h_step_kernel(HArgs H, int i, int do_x, int Lp, int kp, int ntp, int npdcp,
-                                                    int npartsp, double* __restrict__ pn_out) {
+                                                    int npartsp, double* __restrict__ pn_out, int nps,
+                                                    const double* __restrict__ acr, const double* __restrict__ aci) {
   __shared__ double dwr[HM], dwi[HM], dur[HM], dui[HM];
   __shared__ double cwr[HM], cwi[HM], cur[HM], cui[HM];
   __shared__ double comb[HSW][64][4];
@@ -425,7 +450,7 @@ __global__ __launch_bounds__(HS) void h_step_kernel(HArgs H, int i, int do_x, in
     if (q != 0) return;
     double nrm = 0.0;
     if (r <= i) {
-      const double xr = H.Ar[(size_t)r + (size_t)i * H.ld], xi = H.Ai[(size_t)r + (size_t)i * H.ld];
+      const double xr = acr ? acr[r] : H.Ar[(size_t)r + (size_t)i * H.ld], xi = aci ? aci[r] : H.Ai[(size_t)r + (size_t)i * H.ld];
       if (r < i) { H.xr[r] = xr; H.xi[r] = xi; nrm = xr * xr + xi * xi; }
       else H.d[i] = xr;
     }
@@ -440,7 +465,10 @@ __global__ __launch_bounds__(HS) void h_step_kernel(HArgs H, int i, int do_x, in
   const int rc = (r < Lp) ? r : Lp - 1;        // my row, clamped
   double axr = 0.0, axi = 0.0, anr = 0.0, ani = 0.0, xpr = 0.0, xpi = 0.0;
   if (q == 0) {
-    if (do_x && r <= i) { axr = H.Ar[(size_t)r + (size_t)i * H.ld]; axi = H.Ai[(size_t)r + (size_t)i * H.ld]; }
+    if (do_x && r <= i) {
+      axr = acr ? acr[r] : H.Ar[(size_t)r + (size_t)i * H.ld];
+      axi = aci ? aci[r] : H.Ai[(size_t)r + (size_t)i * H.ld];
+    }
     anr = H.xr[Lp - 1]; ani = H.xi[Lp - 1];
     xpr = H.xr[rc]; xpi = H.xi[rc];
   }
@@ -464,8 +492,7 @@ __global__ __launch_bounds__(HS) void h_step_kernel(HArgs H, int i, int do_x, in
     rwr = H.Wr[(size_t)i + (size_t)tid * H.ldp]; rwi = H.Wi[(size_t)i + (size_t)tid * H.ldp];
     cwr[tid] = rwr; cwi[tid] = -rwi; cur[tid] = rur; cui[tid] = -rui;   // conj of row i of the panel
   }
-  const int ntiles = ntp * (ntp + 1) / 2;
-  for (int t = tid; t < ntiles; t += HS) { v5[1] += H.ps[2 * t]; v5[2] += H.ps[2 * t + 1]; }
+  for (int t = tid; t < nps; t += HS) { v5[1] += H.ps[2 * t]; v5[2] += H.ps[2 * t + 1]; }
   // partial u of row x: u <= R(x) -> column sums of tile (u, R); u > R -> row sums of tile (R, u-1)   (R = x / HTL)
   auto part_r = [&](int u, int x) { return (u <= x / HTL) ? H.ycr[(size_t)u * H.ldp + x] : H.yrr[(size_t)(u - 1) * H.ldp + x]; };
   auto part_i = [&](int u, int x) { return (u <= x / HTL) ? H.yci[(size_t)u * H.ldp + x] : H.yri[(size_t)(u - 1) * H.ldp + x]; };
@@ -539,7 +566,7 @@ __global__ __launch_bounds__(HS) void h_step_kernel(HArgs H, int i, int do_x, in
     H.Wr[(size_t)r + (size_t)kp * H.ldp] = wr; H.Wi[(size_t)r + (size_t)kp * H.ldp] = wi;
     // the reflector goes into the panel and stays in column Lp of A (rows 0..Lp-1), as the reference leaves it
     H.Ur[(size_t)r + (size_t)kp * H.ldp] = ur; H.Ui[(size_t)r + (size_t)kp * H.ldp] = ui;
-    H.Ar[(size_t)r + (size_t)Lp * H.ld] = ur; H.Ai[(size_t)r + (size_t)Lp * H.ld] = ui;
+    if (H.P == 1 || ((Lp >> 7) % H.P) == H.p) { H.Ar[(size_t)r + hcol(H, Lp)] = ur; H.Ai[(size_t)r + hcol(H, Lp)] = ui; }
     if (do_x) {
       // row i of the column that is being finished: conj v(i), conj u(i)  (i = Lp - 1, the pivot row)
       double uir, uii;
@@ -741,7 +768,7 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
   const int ld = pad_ld(n + 2);
   const int ldp = ld;
   HArgs H;
-  H.n = n; H.ld = ld; H.ldp = ldp;
+  H.n = n; H.ld = ld; H.ldp = ldp; H.P = 1; H.p = 0;
   H.Ar = ctx.pool.get_t<double>("h.Ar", (size_t)ld * (n + HMB));   // HMB columns of slack: the batched Gram products of phase A
   // The two planes are streamed together at equal offsets; with plane sizes that are multiples of 16 KiB every pair of
   // requests met on the same memory channel.  Half a period (+128 B) between them: reduction 488 -> 459 ms at N = 8192
@@ -789,7 +816,7 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
     const int rows = std::max(do_x ? i + 1 : 0, Lp);
     H.pn = pnb[par ^ 1];
     hipLaunchKernelGGL(h_step_kernel, dim3(ceil_div(rows, 64)), dim3(HS), 0, st, H, i, do_x, Lp, Lp ? k - 1 : 0, ntp, npdcp,
-                       npartsp, pnb[par]);
+                       npartsp, pnb[par], ntp * (ntp + 1) / 2, (const double*)nullptr, (const double*)nullptr);
     return ceil_div(rows, 64);
   };
   for (int i = n - 1; i >= 1; --i) {
@@ -799,9 +826,11 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
     const int nt = ceil_div(L, HTL);
     H.pn = pnb[par];
     if (nt <= hemv8_nt)   // few tiles (253 for nt = 22): 8 waves per tile, one workgroup per CU
-      hipLaunchKernelGGL(h_hemv_kernel<8>, dim3(k * npdc + nt * (nt + 1) / 2), dim3(512), 0, st, H, L, k, nt, npdc, 2, nparts);
+      hipLaunchKernelGGL(h_hemv_kernel<8>, dim3(k * npdc + nt * (nt + 1) / 2), dim3(512), 0, st, H, L, k, nt, npdc, 2, nparts,
+                         nt * (nt + 1) / 2);
     else
-      hipLaunchKernelGGL(h_hemv_kernel<4>, dim3(k * npdc + nt * (nt + 1) / 2), dim3(HTH), 0, st, H, L, k, nt, npdc, 4, nparts);
+      hipLaunchKernelGGL(h_hemv_kernel<4>, dim3(k * npdc + nt * (nt + 1) / 2), dim3(HTH), 0, st, H, L, k, nt, npdc, 4, nparts,
+                         nt * (nt + 1) / 2);
     Lp = L; ntp = nt; npdcp = npdc; npartsp = nparts;
     par ^= 1;
     ++k;
@@ -954,6 +983,452 @@ static int herm_solve_full(Context& ctx, int n, int nvec, double* a, int lda, do
   return EIGX_OK;
 }
 
+// =====================================================================================================================
+// Several ranks: SHARDED reduction (round 4).  The reference distributes eigen_hrd over the process grid (src/eigen_hrd.F:1-448,
+// src/eigen_hrd_t2.F: a rank forms its part of A u and the parts are summed by allreduces over the grid's rows and
+// columns); here
+//   * a rank holds the tile columns tx (128 columns) of the split planes with tx mod P == rank, stored compactly: n^2 / P
+//     per plane (the upper triangle's tile column tx holds tx + 1 tiles, so dealing tile columns round-robin balances);
+//   * per column: the tiled Hermitian mat-vec over the rank's own tiles, a local sum of its partial results per row
+//     (hs_yreduce_kernel), ONE deterministic allreduce of [y (2 L) | u^H q (2) | the raw next column of A (2 L, from its
+//     owner)] over all ranks, then the panel work (h_step_kernel) replicated on every rank from bit-identical inputs --
+//     d, e, beta, x and the panels U, W are therefore replicated bit for bit (what the distributed D&C needs);
+//   * the trailing update on the rank's tile columns only (one batched GEMM per plane);
+//   * T factors of the blocks a rank owns; the real tridiagonal D&C distributed (dc.hip) delivering eigenvector column
+//     blocks; the back-transformation on the rank's column block with the reflector blocks streaming past in groups of P
+//     (each rank contributes the one it owns to an allgather); exit through the real solvers' all-to-all, plane by plane.
+// Nothing of size n^2 is gathered anywhere.
+namespace {
+__global__ __launch_bounds__(HT) void hs_absmax_kernel(const double* __restrict__ a, int lda, int nr, int nc, int Px, int px, int Py,
+                                                       int py, double* __restrict__ out) {
+  __shared__ double red[2 * (HT / 64)];
+  double mx = 0.0, bad = 0.0;
+  for (int lj = blockIdx.x; lj < nc; lj += gridDim.x) {
+    const int gj = lj * Py + py;
+    for (int li = threadIdx.x; li < nr; li += HT) {
+      if (li * Px + px > gj) break;                       // upper triangle only (rows ascend with li)
+      const double re = a[2 * ((size_t)lj * lda + li)], im = a[2 * ((size_t)lj * lda + li) + 1];
+      if (!(fabs(re) <= DBL_MAX) || !(fabs(im) <= DBL_MAX)) bad = 1.0;
+      else mx = fmax(mx, fmax(fabs(re), fabs(im)));
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { mx = fmax(mx, __shfl_xor(mx, o, 64)); bad = fmax(bad, __shfl_xor(bad, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = mx; red[2 * (threadIdx.x >> 6) + 1] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < HT / 64; ++w) { mx = fmax(mx, red[2 * w]); bad = fmax(bad, red[2 * w + 1]); }
+    out[2 * blockIdx.x] = mx; out[2 * blockIdx.x + 1] = bad;
+  }
+}
+// entry all-to-all, sender: piece for rank d = [plane][k][lr], k-th of my local columns whose tile column d owns
+__global__ void hs_pack_kernel(const double* __restrict__ a, int lda, int nr, const int* __restrict__ cols, int ncmax, int nrmax,
+                               double sigma, double* __restrict__ send) {
+  const int k = blockIdx.y, d = blockIdx.z;
+  const int lc = cols[d * ncmax + k];
+  if (lc < 0) return;
+  double* dst = send + ((size_t)d * 2 * ncmax + k) * nrmax;
+  for (int lr = blockIdx.x * blockDim.x + threadIdx.x; lr < nr; lr += gridDim.x * blockDim.x) {
+    dst[lr] = sigma * a[2 * ((size_t)lc * lda + lr)];
+    dst[(size_t)ncmax * nrmax + lr] = sigma * a[2 * ((size_t)lc * lda + lr) + 1];
+  }
+}
+// receiver: source s = (sx, .) sent its k-th such column = global column gcols[s * ncmax + k]; its rows are sx, sx + Px, ...
+__global__ void hs_unpack_kernel(const double* __restrict__ recv, const int* __restrict__ gcols, int ncmax, int nrmax, int n,
+                                 int Px, int Py, int row_major, HArgs H) {
+  const int k = blockIdx.y, sidx = blockIdx.z;
+  const int gj = gcols[sidx * ncmax + k];
+  if (gj < 0) return;
+  const int sx = row_major ? sidx / Py : sidx % Px;
+  const double* src = recv + ((size_t)sidx * 2 * ncmax + k) * nrmax;
+  const size_t co = hcol(H, gj);
+  for (int lr = blockIdx.x * blockDim.x + threadIdx.x; lr * Px + sx < n; lr += gridDim.x * blockDim.x) {
+    const int gi = lr * Px + sx;
+    H.Ar[co + gi] = __hip_atomic_load(src + lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    H.Ai[co + gi] = __hip_atomic_load(src + (size_t)ncmax * nrmax + lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// ybuf = [y re (ldp) | y im (ldp) | raw column ci re (ldp) | im (ldp) | s re, s im]: this rank's share of each
+__global__ __launch_bounds__(HT) void hs_yreduce_kernel(HArgs H, int L, int nt, int ntl, int ci, double* __restrict__ ybuf) {
+  __shared__ double red[2 * (HT / 64)];
+  const int ldp = H.ldp;
+  const int r = blockIdx.x * HT + threadIdx.x;
+  if (r < ldp) {
+    double yr = 0.0, yi = 0.0;
+    if (r < L) {
+      const int R = r >> 7;
+      if (R % H.P == H.p)
+        for (int u = 0; u <= R; ++u) { yr += H.ycr[(size_t)u * ldp + r]; yi += H.yci[(size_t)u * ldp + r]; }      // tiles (u, R): column sums
+      for (int tx = R + ((H.p - R % H.P) + H.P) % H.P; tx < nt; tx += H.P) {                                       // tiles (R, tx): row sums
+        yr += H.yrr[(size_t)tx * ldp + r]; yi += H.yri[(size_t)tx * ldp + r];
+      }
+    }
+    ybuf[r] = yr; ybuf[(size_t)ldp + r] = yi;
+    double cr = 0.0, cim = 0.0;
+    if (ci >= 0 && r <= ci && (ci >> 7) % H.P == H.p) { cr = H.Ar[hcol(H, ci) + r]; cim = H.Ai[hcol(H, ci) + r]; }
+    ybuf[(size_t)2 * ldp + r] = cr; ybuf[(size_t)3 * ldp + r] = cim;
+  }
+  if (blockIdx.x == 0) {
+    double sr = 0.0, si = 0.0;
+    for (int t = threadIdx.x; t < ntl; t += HT) { sr += H.ps[2 * t]; si += H.ps[2 * t + 1]; }
+    for (int o = 32; o > 0; o >>= 1) { sr += __shfl_xor(sr, o, 64); si += __shfl_xor(si, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = sr; red[2 * (threadIdx.x >> 6) + 1] = si; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < HT / 64; ++w) { sr += red[2 * w]; si += red[2 * w + 1]; }
+      ybuf[(size_t)4 * ldp] = sr; ybuf[(size_t)4 * ldp + 1] = si;
+    }
+  }
+}
+// rows >= j of my reflector columns j (what is left there is the old lower triangle)
+__global__ void hs_zero_below_kernel(HArgs H, int n, int nlc) {
+  const int lc = blockIdx.y;
+  if (lc >= nlc) return;
+  const int j = ((lc >> 7) * H.P + H.p) * 128 + (lc & 127);
+  if (j >= n) return;
+  for (int r = j + blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    H.Ar[(size_t)lc * H.ld + r] = 0.0; H.Ai[(size_t)lc * H.ld + r] = 0.0;
+  }
+}
+__global__ void hs_identity_block_kernel(double* __restrict__ z, int ldz, int c0, int cn) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < cn) z[(size_t)j * ldz + c0 + j] = 1.0;
+}
+__global__ void hs_join_cyclic_kernel(const double* __restrict__ zr, const double* __restrict__ zi, int ldt, int nr, int nzc,
+                                      double* __restrict__ z, int ldz) {
+  const int lj = blockIdx.y;
+  if (lj >= nzc) return;
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < nr; li += gridDim.x * blockDim.x) {
+    z[2 * ((size_t)lj * ldz + li)] = zr[(size_t)lj * ldt + li];
+    z[2 * ((size_t)lj * ldz + li) + 1] = zi[(size_t)lj * ldt + li];
+  }
+}
+}  // namespace
+
+// a, z: this rank's 2-D cyclic blocks (device, interleaved complex)
+static int herm_solve_sharded(Context& ctx, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb,
+                              char mode) {
+  const Grid G = ctx.grid;
+  const int P = G.nranks, me = G.rank;
+  const int nloc_r = local_count(n, G.Px, G.px), nloc_c = local_count(n, G.Py, G.py);
+  if (mode >= 'a' && mode <= 'z') mode = (char)(mode - 'a' + 'A');
+  if (nvec == 0) mode = 'N';                      // src/eigen_h.F:104-106
+  if (nvec < 0) nvec = -nvec;
+  if (nvec > n) nvec = n;
+  if (mode != 'N' && mode != 'A' && mode != 'X' && mode != 'S') mode = 'A';
+  const bool want_vec = mode != 'N';
+  int m = mf <= 0 ? 48 : mf;
+  if (m > HM) m = HM;
+  if (m > n) m = n;
+  hipStream_t st = ctx.stream;
+  EIGX_HIP_CHECK(hipStreamSynchronize(nullptr));
+  ctx.errinfo = 0;
+  for (int q = 0; q < 16; ++q) ctx.timers[q] = 0.0;
+  (void)comm_seconds(ctx, true);
+  const double t0 = hnow();
+
+  // ---- eigen_scaling_h on the local blocks, maxima combined over the ranks ------------------------------------------
+  double sigma = 1.0;
+  {
+    const int nbk = 64;
+    double* part = ctx.pool.get_t<double>("hs.absmax", (size_t)2 * nbk + 2);
+    hipLaunchKernelGGL(hs_absmax_kernel, dim3(nbk), dim3(HT), 0, st, a, lda, nloc_r, nloc_c, G.Px, G.px, G.Py, G.py, part);
+    std::vector<double> hp(2 * nbk);
+    EIGX_HIP_CHECK(hipMemcpyAsync(hp.data(), part, hp.size() * 8, hipMemcpyDeviceToHost, st));
+    EIGX_HIP_CHECK(hipStreamSynchronize(st));
+    double two[2] = {0.0, 0.0};
+    for (int q = 0; q < nbk; ++q) { two[0] = std::max(two[0], hp[2 * q]); two[1] = std::max(two[1], hp[2 * q + 1]); }
+    EIGX_HIP_CHECK(hipMemcpyAsync(part, two, 16, hipMemcpyHostToDevice, st));
+    comm_allreduce_max(ctx, COMM_WORLD, part, 2, st);
+    EIGX_HIP_CHECK(hipMemcpyAsync(two, part, 16, hipMemcpyDeviceToHost, st));
+    EIGX_HIP_CHECK(hipStreamSynchronize(st));
+    if (comm_failed(ctx)) return EIGX_ERR_INTERNAL;
+    if (two[1] != 0.0) {   // NaN / Inf in the input (on any rank): w(:) = NaN on every rank (src/eigen_h.F:147-150)
+      hipLaunchKernelGGL(h_fill_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, n,
+                         std::numeric_limits<double>::quiet_NaN());
+      EIGX_HIP_CHECK(hipStreamSynchronize(st));
+      ctx.errinfo = -1;
+      return EIGX_ERR_NONFINITE;
+    }
+    const double anrm = two[0];
+    if (anrm > 0.0 && (anrm < 1e-90 || anrm > 1e90)) { int ex = 0; (void)frexp(anrm, &ex); sigma = ldexp(1.0, -ex); }
+  }
+
+  // ---- workspace: the rank's tile columns of the two planes ------------------------------------------------------------
+  const int ld = pad_ld(n + 2);
+  const int ldp = ld;
+  const int nt_all = ceil_div(n, HTL);
+  const int ntc = ceil_div(nt_all, P);                 // tile columns per rank (upper bound)
+  const int nlc = ntc * HTL;                           // local columns
+  HArgs H;
+  H.n = n; H.ld = ld; H.ldp = ldp; H.P = P; H.p = me;
+  static const int plane_skew = [] { const char* e = getenv("EIGX_H_SKEW"); return e ? atoi(e) : 1040; }();   // doubles
+  H.Ar = ctx.pool.get_t<double>("hs.Ar", (size_t)ld * (nlc + HMB));
+  H.Ai = ctx.pool.get_t<double>("hs.Ai", (size_t)ld * (nlc + HMB) + plane_skew) + plane_skew;
+  H.Ur = ctx.pool.get_t<double>("h.UW", (size_t)4 * ldp * m);
+  H.Ui = H.Ur + (size_t)ldp * m;
+  H.Wr = H.Ui + (size_t)ldp * m;
+  H.Wi = H.Wr + (size_t)ldp * m;
+  double* P1 = ctx.pool.get_t<double>("h.P1", (size_t)ldp * 4 * m);
+  double* P2 = ctx.pool.get_t<double>("h.P2", (size_t)ldp * 4 * m);
+  double* P3 = ctx.pool.get_t<double>("h.P3", (size_t)ldp * 4 * m);
+  H.xr = ctx.pool.get_t<double>("h.xr", (size_t)ldp); H.xi = ctx.pool.get_t<double>("h.xi", (size_t)ldp);
+  H.beta = ctx.pool.get_t<double>("h.beta", (size_t)2 * n + 2);
+  const int lde = (n + 3) / 4 * 4;
+  H.d = ctx.pool.get_t<double>("h.d", (size_t)n);
+  H.e = ctx.pool.get_t<double>("h.e", (size_t)lde);
+  const int nwg = ceil_div(n, 64) + 1;
+  const int nt_max = nt_all + 1;
+  const int npdc_max = ceil_div(n, PDR) + 1;
+  H.pn = ctx.pool.get_t<double>("h.pn", (size_t)2 * nwg);
+  H.ps = ctx.pool.get_t<double>("h.ps", (size_t)nt_max * (nt_max + 1));
+  H.pd = ctx.pool.get_t<double>("h.pd", (size_t)npdc_max * HM * 4);
+  H.yrr = ctx.pool.get_t<double>("h.yrr", (size_t)nt_max * ldp);
+  H.yri = ctx.pool.get_t<double>("h.yri", (size_t)nt_max * ldp);
+  H.ycr = ctx.pool.get_t<double>("h.ycr", (size_t)nt_max * ldp);
+  H.yci = ctx.pool.get_t<double>("h.yci", (size_t)nt_max * ldp);
+  double* ybuf = ctx.pool.get_t<double>("hs.ybuf", (size_t)4 * ldp + 8);
+  const size_t ycount = (size_t)4 * ldp + 2;
+  hipLaunchKernelGGL(h_fill_kernel, dim3(1024), dim3(256), 0, st, H.Ar, (size_t)ld * (nlc + HMB), 0.0);
+  hipLaunchKernelGGL(h_fill_kernel, dim3(1024), dim3(256), 0, st, H.Ai, (size_t)ld * (nlc + HMB), 0.0);
+
+  // ---- entry: 2-D cyclic blocks -> tile columns, one all-to-all --------------------------------------------------------
+  {
+    auto world_of = [&](int qx, int qy) { return G.row_major ? qx * G.Py + qy : qx + qy * G.Px; };
+    // the widest list any (source process column, destination) pair has: the same number on every rank
+    int ncmax = 1;
+    for (int sy = 0; sy < G.Py; ++sy) {
+      std::vector<int> cnt(P, 0);
+      for (int j = sy; j < n; j += G.Py) ++cnt[(j / HTL) % P];
+      for (int d = 0; d < P; ++d) ncmax = std::max(ncmax, cnt[d]);
+    }
+    const int nrmax = ceil_div(n, G.Px);
+    const size_t piece = (size_t)2 * ncmax * nrmax;
+    std::vector<int> cols((size_t)2 * P * ncmax, -1);   // [0, P ncmax): my local columns per destination; then global columns per source
+    {
+      std::vector<int> fill(P, 0);
+      for (int lc = 0; lc < nloc_c; ++lc) { const int d = ((lc * G.Py + G.py) / HTL) % P; cols[(size_t)d * ncmax + fill[d]++] = lc; }
+      for (int sx = 0; sx < G.Px; ++sx)
+        for (int sy = 0; sy < G.Py; ++sy) {
+          const int s_ = world_of(sx, sy);
+          int f = 0;
+          for (int j = sy; j < n; j += G.Py)
+            if ((j / HTL) % P == me) cols[(size_t)(P + s_) * ncmax + f++] = j;
+        }
+    }
+    int* tab = ctx.pool.get_t<int>("hs.tab", cols.size());
+    EIGX_HIP_CHECK(hipMemcpyAsync(tab, cols.data(), cols.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    EIGX_HIP_CHECK(hipStreamSynchronize(st));   // (cols is a stack vector)
+    double* sendb = ctx.pool.get_t<double>("mg.xsend", piece * P);
+    double* recvb = ctx.pool.get_t<double>("mg.xrecv", piece * P);
+    if (nloc_r > 0)
+      hipLaunchKernelGGL(hs_pack_kernel, dim3(ceil_div(nloc_r, 256), ncmax, P), dim3(256), 0, st, (const double*)a, lda, nloc_r,
+                         (const int*)tab, ncmax, nrmax, sigma, sendb);
+    comm_exchange_big(ctx, COMM_WORLD, sendb, piece, recvb, piece, st);
+    hipLaunchKernelGGL(hs_unpack_kernel, dim3(ceil_div(nrmax, 256), ncmax, P), dim3(256), 0, st, (const double*)recvb,
+                       (const int*)(tab + (size_t)P * ncmax), ncmax, nrmax, n, G.Px, G.Py, G.row_major, H);
+  }
+  hipLaunchKernelGGL(h_fill_kernel, dim3(64), dim3(256), 0, st, H.e, (size_t)lde, 0.0);
+  hipLaunchKernelGGL(h_fill_kernel, dim3(64), dim3(256), 0, st, H.beta, (size_t)2 * n + 2, 0.0);
+  auto zero_panel = [&]() { hipLaunchKernelGGL(h_fill_kernel, dim3(512), dim3(256), 0, st, H.Ur, (size_t)4 * ldp * m, 0.0); };
+  zero_panel();
+
+  // ---- eigen_hrd, sharded -------------------------------------------------------------------------------------------------
+  const double t1 = hnow();
+  auto ntl_of = [&](int nt) { long c = 0; for (int tx = me; tx < nt; tx += P) c += tx + 1; return (int)c; };   // my tiles of an nt x nt triangle
+  int k = 0, par = 0;
+  int Lp = 0, ntp = 0, npdcp = 0, npartsp = 0;
+  double* pnb[2] = {H.pn, H.pn + nwg};
+  HArgs Hk = H;                               // the panel kernel's view: the summed mat-vec result instead of the tile partials
+  Hk.ycr = ybuf; Hk.yci = ybuf + ldp; Hk.ps = ybuf + (size_t)4 * ldp;
+  // my share of [y | s | raw column ci] of the pending column, summed over the ranks: every rank gets the same bits
+  auto exchange = [&](int ci) {
+    hipLaunchKernelGGL(hs_yreduce_kernel, dim3(ceil_div(ldp, HT)), dim3(HT), 0, st, H, Lp, ntp, ntl_of(ntp), ci, ybuf);
+    comm_allreduce_sum(ctx, COMM_WORLD, ybuf, ycount, st);
+  };
+  auto step = [&](int i, int do_x) {
+    const int rows = std::max(do_x ? i + 1 : 0, Lp);
+    Hk.pn = pnb[par ^ 1];
+    hipLaunchKernelGGL(h_step_kernel, dim3(ceil_div(rows, 64)), dim3(HS), 0, st, Hk, i, do_x, Lp, Lp ? k - 1 : 0, 0, npdcp, npartsp,
+                       pnb[par], Lp ? 1 : 0, (const double*)(ybuf + (size_t)2 * ldp), (const double*)(ybuf + (size_t)3 * ldp));
+    return ceil_div(rows, 64);
+  };
+  for (int i = n - 1; i >= 1; --i) {
+    const int L = i;
+    exchange(i);
+    const int nparts = step(i, 1);
+    const int npdc = ceil_div(L, PDR);
+    const int nt = ceil_div(L, HTL);
+    const int ntl = ntl_of(nt);
+    H.pn = pnb[par];
+    const int grid = std::max(1, k * npdc + ntl);
+    if (nt <= 22)
+      hipLaunchKernelGGL(h_hemv_kernel<8>, dim3(grid), dim3(512), 0, st, H, L, k, nt, npdc, 2, nparts, ntl);
+    else
+      hipLaunchKernelGGL(h_hemv_kernel<4>, dim3(grid), dim3(HTH), 0, st, H, L, k, nt, npdc, 4, nparts, ntl);
+    Lp = L; ntp = nt; npdcp = npdc; npartsp = nparts;
+    par ^= 1;
+    ++k;
+    if (k == m || i == 1) {
+      exchange(-1);
+      (void)step(i - 1, 0);
+      Lp = 0;
+      const int nr = i;
+      hipLaunchKernelGGL(h_pack_kernel, dim3(ceil_div(nr, 256), k), dim3(256), 0, st, H, nr, k, P1, P2, P3);
+      // my tile columns of the active block: the full ones in one batched product per plane, then the ragged last one
+      const int tfull = nr / HTL;                                   // tile columns 0 .. tfull-1 lie inside nr completely
+      const int gfull = (tfull > me) ? (tfull - 1 - me) / P + 1 : 0;
+      if (gfull > 0) {
+        dgemm_dev(st, 'N', 'T', nr, HTL, 4 * k, -1.0, P1, ldp, P3 + (size_t)me * HTL, ldp, 1.0, H.Ar, ld, 0, nullptr, nullptr,
+                  nullptr, gfull, 0, (long)P * HTL, (long)HTL * ld);
+        dgemm_dev(st, 'N', 'T', nr, HTL, 4 * k, -1.0, P2, ldp, P3 + (size_t)me * HTL, ldp, 1.0, H.Ai, ld, 0, nullptr, nullptr,
+                  nullptr, gfull, 0, (long)P * HTL, (long)HTL * ld);
+      }
+      if (nr % HTL != 0 && tfull % P == me) {
+        const int c0_ = tfull * HTL;
+        dgemm_dev(st, 'N', 'T', nr, nr - c0_, 4 * k, -1.0, P1, ldp, P3 + c0_, ldp, 1.0, H.Ar + hcol(H, c0_), ld);
+        dgemm_dev(st, 'N', 'T', nr, nr - c0_, 4 * k, -1.0, P2, ldp, P3 + c0_, ldp, 1.0, H.Ai + hcol(H, c0_), ld);
+      }
+      zero_panel();
+      k = 0;
+    }
+  }
+  exchange(0);
+  (void)step(0, 1);   // d_0 = Re A(0,0)
+
+  // ---- T factors of my reflector blocks.  Block b = the reflector columns of tile column b: [max(1, 128 b), 128 (b+1)) ----
+  const int nblk = nt_all;
+  auto blk_j0 = [&](int b) { return b == 0 ? 1 : b * HTL; };
+  auto blk_j1 = [&](int b) { return std::min(n, (b + 1) * HTL); };
+  double* Tloc = nullptr;
+  if (want_vec && n > 1) {
+    double* G1 = ctx.pool.get_t<double>("h.Gall", (size_t)4 * HMB * HMB);
+    Tloc = ctx.pool.get_t<double>("h.Tall", (size_t)ntc * 2 * HMB * HMB);
+    const size_t shm = (size_t)2 * (HMB * (HMB + 1) / 2) * sizeof(double);
+    static bool attr = false;
+    if (!attr) {
+      EIGX_HIP_CHECK(hipFuncSetAttribute((const void*)h_tinv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      attr = true;
+    }
+    hipLaunchKernelGGL(hs_zero_below_kernel, dim3(8, nlc), dim3(256), 0, st, H, n, nlc);
+    for (int b = me; b < nblk; b += P) {
+      const int j0 = blk_j0(b), nb = blk_j1(b) - j0;
+      if (nb <= 0) continue;
+      const size_t co = hcol(H, j0);
+      for (int half = 0; half < 2; ++half)
+        dgemm_dev(st, 'T', 'N', nb, nb, n, 1.0, (half ? H.Ai : H.Ar) + co, ld, H.Ar + co, ld, 0.0, G1 + (half ? nb : 0), 2 * HMB, 0,
+                  nullptr, nullptr, nullptr, 1, 0, 0, 0, 2, 0, (long)(H.Ai - H.Ar), (long)nb * 2 * HMB);
+      hipLaunchKernelGGL(h_tinv_kernel, dim3(1), dim3(HMB), shm, st, (const double*)G1, (const double*)H.beta, j0, nb, j0 + nb,
+                         Tloc + (size_t)(b / P) * 2 * HMB * HMB);
+    }
+  }
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  if (comm_failed(ctx)) return EIGX_ERR_INTERNAL;
+  const double t2 = hnow();
+
+  // ---- real tridiagonal eigenproblem: distributed D&C (my eigenvector columns, all rows) / bisection --------------------
+  const int zc = ceil_div(nvec > 0 ? nvec : 1, P);
+  const int c0 = (me * zc < nvec) ? me * zc : nvec;
+  const int cn = want_vec ? ((c0 + zc <= nvec) ? zc : nvec - c0) : 0;
+  const int ldzp = pad_ld(n + 2);
+  double* Zr = nullptr;
+  double* Zi = nullptr;
+  if (!want_vec) {
+    band_bisect_dev(ctx, n, H.d, H.e, lde, 1, w);
+  } else {
+    const size_t zplane = (size_t)ldzp * (zc + 1) + 1040;
+    Zr = ctx.pool.get_t<double>("hs.Zri", 2 * zplane);
+    Zi = Zr + zplane;
+    if (mode == 'S') {
+      hipLaunchKernelGGL(h_fill_kernel, dim3(1024), dim3(256), 0, st, Zr, (size_t)ldzp * zc, 0.0);
+      if (cn > 0) hipLaunchKernelGGL(hs_identity_block_kernel, dim3(ceil_div(cn, 256)), dim3(256), 0, st, Zr, ldzp, c0, cn);
+      band_bisect_dev(ctx, n, H.d, H.e, lde, 1, w);
+    } else {
+      band_dc_dev(ctx, n, nvec, H.d, H.e, lde, 1, w, Zr, ldzp);
+    }
+    if (mode == 'X') band_bisect_dev(ctx, n, H.d, H.e, lde, 1, w);
+    hipLaunchKernelGGL(h_fill_kernel, dim3(1024), dim3(256), 0, st, Zi, (size_t)ldzp * zc, 0.0);
+  }
+  if (comm_failed(ctx)) return EIGX_ERR_INTERNAL;
+  const double t3 = hnow();
+
+  // ---- eigen_hrbakwyx on my column block; the reflector blocks stream past in groups of P ---------------------------------
+  if (want_vec && n > 1) {
+    const int nv = cn > 0 ? cn : 1;
+    double* YA = ctx.pool.get_t<double>("h.YAB", (size_t)2 * 2 * HMB * nv);
+    double* YB = YA + (size_t)2 * HMB * nv;
+    double* Yr = ctx.pool.get_t<double>("h.Yr", (size_t)HMB * nv);
+    double* Yi = ctx.pool.get_t<double>("h.Yi", (size_t)HMB * nv);
+    double* Xr = ctx.pool.get_t<double>("h.Xr", (size_t)HMB * nv);
+    double* Xi = ctx.pool.get_t<double>("h.Xi", (size_t)HMB * nv);
+    const int lds = ld;
+    const size_t SB = (size_t)lds * 2 * HMB + (size_t)2 * HMB * HMB;      // [Vs | Tr | Ti] of one block
+    double* bsend = ctx.pool.get_t<double>("hs.bsend", SB);
+    double* brecv = ctx.pool.get_t<double>("hs.brecv", SB * P);
+    for (int g0 = 0; g0 < nblk; g0 += P) {
+      {
+        const int b = g0 + me;
+        const int j0 = blk_j0(b), nb = (b < nblk) ? blk_j1(b) - j0 : 0;
+        if (nb > 0) {
+          hipLaunchKernelGGL(h_stack_v_kernel, dim3(8, 2 * nb), dim3(256), 0, st, H.Ar + hcol(H, j0), H.Ai + hcol(H, j0), ld,
+                             j0 + nb - 1, nb, bsend, lds);
+          EIGX_HIP_CHECK(hipMemcpyAsync(bsend + (size_t)lds * 2 * HMB, Tloc + (size_t)(b / P) * 2 * HMB * HMB,
+                                        (size_t)2 * HMB * HMB * 8, hipMemcpyDeviceToDevice, st));
+        }
+      }
+      comm_allgather(ctx, COMM_WORLD, bsend, brecv, SB, st);
+      for (int q = 0; q < P && cn > 0; ++q) {
+        const int b = g0 + q;
+        if (b >= nblk) break;
+        const int j0 = blk_j0(b), nb = blk_j1(b) - j0;
+        if (nb <= 0) continue;
+        const int rows = j0 + nb - 1;
+        const double* Vs = brecv + (size_t)q * SB;
+        const double* Tr = Vs + (size_t)lds * 2 * HMB;
+        const double* Ti = Tr + (size_t)HMB * HMB;
+        dgemm_dev(st, 'T', 'N', 2 * nb, cn, rows, 1.0, Vs, lds, Zr, ldzp, 0.0, YA, 2 * HMB, 0, nullptr, nullptr, nullptr, 2, 0,
+                  (long)(Zi - Zr), (long)(YB - YA));
+        hipLaunchKernelGGL(h_ycombine_kernel, dim3(1, cn), dim3(128), 0, st, YA, YB, nb, cn, Yr, Yi);
+        dgemm_dev(st, 'N', 'N', nb, cn, nb, 1.0, Tr, HMB, Yr, HMB, 0.0, Xr, HMB);
+        dgemm_dev(st, 'N', 'N', nb, cn, nb, -1.0, Ti, HMB, Yi, HMB, 1.0, Xr, HMB);
+        dgemm_dev(st, 'N', 'N', nb, cn, nb, 1.0, Tr, HMB, Yi, HMB, 0.0, Xi, HMB);
+        dgemm_dev(st, 'N', 'N', nb, cn, nb, 1.0, Ti, HMB, Yr, HMB, 1.0, Xi, HMB);
+        hipLaunchKernelGGL(h_xstack_kernel, dim3(1, cn), dim3(128), 0, st, Xr, Xi, nb, cn, YA, YB);
+        dgemm_dev(st, 'N', 'N', rows, cn, 2 * nb, -1.0, Vs, lds, YA, 2 * HMB, 1.0, Zr, ldzp);
+        dgemm_dev(st, 'N', 'N', rows, cn, 2 * nb, -1.0, Vs, lds, YB, 2 * HMB, 1.0, Zi, ldzp);
+      }
+    }
+  }
+  // ---- exit: my column block -> the callers' cyclic blocks, plane by plane, then interleave --------------------------------
+  if (want_vec) {
+    const int ldt = pad_ld((nloc_r > 2 ? nloc_r : 2));
+    const int nzc = local_count(nvec, G.Py, G.py);
+    double* tr_ = ctx.pool.get_t<double>("hs.zr", (size_t)ldt * (nloc_c > 0 ? nloc_c : 1));
+    double* ti_ = ctx.pool.get_t<double>("hs.zi", (size_t)ldt * (nloc_c > 0 ? nloc_c : 1));
+    cols_to_cyclic_dev(ctx, n, nvec, 1, zc, c0, cn, Zr, ldzp, tr_, ldt, st);
+    cols_to_cyclic_dev(ctx, n, nvec, 1, zc, c0, cn, Zi, ldzp, ti_, ldt, st);
+    if (nzc > 0 && nloc_r > 0)
+      hipLaunchKernelGGL(hs_join_cyclic_kernel, dim3(ceil_div(nloc_r, 256), nzc), dim3(256), 0, st, (const double*)tr_,
+                         (const double*)ti_, ldt, nloc_r, nzc, z, ldz);
+  }
+  if (sigma != 1.0 && sigma != 0.0)
+    hipLaunchKernelGGL(h_scale_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, n, 1.0 / sigma);
+  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  EIGX_HIP_CHECK(hipGetLastError());
+  if (comm_failed(ctx)) return EIGX_ERR_INTERNAL;
+  const double t4 = hnow();
+  const double f_red = 4.0 / 3.0 * (double)n * n * n;
+  const double f_dc = ctx.timers[11];
+  const double f_bt = want_vec ? 2.0 * (double)nvec * n * n : 0.0;
+  const double ret = f_red + f_dc + f_bt;
+  ctx.timers[0] = t4 - t0; ctx.timers[1] = t2 - t1; ctx.timers[2] = t3 - t2; ctx.timers[3] = t4 - t3; ctx.timers[12] = ret;
+  if (G.px == 0 && G.py == 0 && nloc_r > 0 && nloc_c > 0) {   // statistics a(1,1), a(2,1) on the owner of the first column
+    const double stats[4] = {ret, 0.0, t4 - t0, 0.0};
+    EIGX_HIP_CHECK(hipMemcpyAsync(a, stats, (size_t)(nloc_r >= 2 ? 4 : 2) * 8, hipMemcpyHostToDevice, st));
+    EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  }
+  return EIGX_OK;
+}
+
 namespace {
 // complex (interleaved) versions of the 2-D cyclic layout kernels of solver.hip
 __global__ void hz_pack_kernel(const double* __restrict__ a, int lda, int nr, int nc, double* __restrict__ out, int bx) {
@@ -1005,6 +1480,10 @@ int herm_solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w,
   const bool want_vec = !(md == 'N' || nv == 0);
   if (want_vec && (!z || ldz < nloc_r)) return EIGX_ERR_BAD_ARG;
   EIGX_HIP_CHECK(hipSetDevice(ctx.device));
+  // the sharded form (nothing gathered) is the default; EIGX_H_GATHER=1 keeps the first version -- gather the matrix,
+  // reduce it on every rank -- for comparisons
+  static const bool gather = [] { const char* e = getenv("EIGX_H_GATHER"); return e && atoi(e) != 0; }();
+  if (!gather) return herm_solve_sharded(ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode);
   hipStream_t st = ctx.stream;
   const int bx = ceil_div(n, G.Px), by = ceil_div(n, G.Py);
   const int ldf = n + 2;

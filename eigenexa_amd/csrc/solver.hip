@@ -239,6 +239,32 @@ static int bc_to_cyclic(Context& ctx, const double* a, int lda, int n, int nb, d
   return EIGX_OK;
 }
 
+}  // namespace
+
+// Eigenvector column blocks (rank r holds columns [r zc, r zc + zc) of the first nvec, all n rows: zcols(ldz, zcnt) are
+// mine, starting at global column zc0) -> the callers' 2-D (block-)cyclic blocks: one all-to-all of
+// (rows of qx) x (my columns of qy) pieces.  Enqueued on st.  (eigen_h's split planes go through it one plane at a time.)
+void cols_to_cyclic_dev(Context& ctx, int n, int nvec, int nb, int zc, int zc0, int zcnt, const double* zcols, int ldz,
+                        double* z_user, int ldz_user, hipStream_t st) {
+  const Grid& G = ctx.grid;
+  const int P = G.nranks;
+  const int nloc_r = numroc(n, nb, G.px, G.Px);
+  const int nrmax = numroc(n, nb, 0, G.Px);
+  const int ncmax = (zc / (nb * G.Py) + 2) * nb;
+  const size_t piece = (size_t)nrmax * ncmax;
+  double* sendb = ctx.pool.get_t<double>("mg.xsend", piece * P);
+  double* recvb = ctx.pool.get_t<double>("mg.xrecv", piece * P);
+  if (zcnt > 0)
+    hipLaunchKernelGGL(pack_z_pieces_kernel, dim3(8, zcnt, G.Px), dim3(256), 0, st, zcols, ldz, n, zc0, zcnt, nb, G.Px,
+                       G.Py, G.row_major, nrmax, piece, sendb);
+  comm_exchange_big(ctx, COMM_WORLD, sendb, piece, recvb, piece, st);
+  if (nloc_r > 0)
+    hipLaunchKernelGGL(unpack_z_pieces_kernel, dim3(8, ncmax, P), dim3(256), 0, st, (const double*)recvb, piece, nrmax,
+                       nvec, zc, nb, G.py, G.Py, nloc_r, z_user, ldz_user);
+}
+
+namespace {
+
 // nb = block size of the 2-D block-cyclic layout of a and z over the process grid (1 = the cyclic layout of the
 // EigenExa API; a ScaLAPACK caller passes its descriptor's MB = NB and needs no pdgemr2d redistribution, manual 3.4)
 int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb,
@@ -392,19 +418,7 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   }
   stage_trace(G.rank, "back-transformation enqueued");
   if (P > 1 && want_vec) {
-    // column blocks -> the caller's 2-D (block-)cyclic blocks: one all-to-all of (rows of qx) x (my columns of qy) pieces
-    const int nrmax = numroc(n, nb, 0, G.Px);
-    const int ncmax = (zcols_per_rank / (nb * G.Py) + 2) * nb;
-    const size_t piece = (size_t)nrmax * ncmax;
-    double* sendb = ctx.pool.get_t<double>("mg.xsend", piece * P);
-    double* recvb = ctx.pool.get_t<double>("mg.xrecv", piece * P);
-    if (zcnt > 0)
-      hipLaunchKernelGGL(pack_z_pieces_kernel, dim3(8, zcnt, G.Px), dim3(256), 0, st, (const double*)z, ldz, n, zc0, zcnt, nb, G.Px,
-                         G.Py, G.row_major, nrmax, piece, sendb);
-    comm_exchange_big(ctx, COMM_WORLD, sendb, piece, recvb, piece, st);
-    if (nloc_r > 0)
-      hipLaunchKernelGGL(unpack_z_pieces_kernel, dim3(8, ncmax, P), dim3(256), 0, st, (const double*)recvb, piece, nrmax,
-                         nvec, zcols_per_rank, nb, G.py, G.Py, nloc_r, z_user, ldz_user);
+    cols_to_cyclic_dev(ctx, n, nvec, nb, zcols_per_rank, zc0, zcnt, z, ldz, z_user, ldz_user, st);
   } else if (want_vec && z != z_user) {
     EIGX_HIP_CHECK(hipMemcpy2DAsync(z_user, (size_t)ldz_user * 8, z, (size_t)ldz * 8, (size_t)n * 8, (size_t)nvec,
                                     hipMemcpyDeviceToDevice, st));

@@ -258,6 +258,13 @@ if route == "h":
     dist.broadcast(wt, src=0)
     assert np.array_equal(wt.numpy(), w), "w must be bit-identical on every rank (replicated)"
     assert werr < 1e-12 and res < 768 and orth < 8, (werr, res, orth)
+    # sharded reduction: nothing of size n^2 is gathered -- the buffers of the first (gathering) version do not exist, and
+    # what the sharded path holds (its tile columns of the two planes, its eigenvector columns, the streaming reflector
+    # blocks) is a few n^2 / P plus O(P n) terms
+    _lh = api._lib.load()
+    assert _lh.eigx_held_bytes_named(b"hm.") == 0
+    hs_bytes = _lh.eigx_held_bytes_named(b"hs.")
+    assert 0 < hs_bytes <= 8 * (6 * n * n // world + 400 * (world + 3) * n) + (1 << 20), (hs_bytes, n, world)
     # partial eigenvector sets (src/eigen_h.F:104-106): the back-transformation is shared by eigenvector columns, so
     # take fewer columns than ranks (some ranks get none) and a count that does not divide
     for nv in sorted({min(n, world - 1), n // 3 + 1}):
