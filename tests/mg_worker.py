@@ -265,6 +265,18 @@ if route == "h":
     assert _lh.eigx_held_bytes_named(b"hm.") == 0
     hs_bytes = _lh.eigx_held_bytes_named(b"hs.")
     assert 0 < hs_bytes <= 8 * (6 * n * n // world + 400 * (world + 3) * n) + (1 << 20), (hs_bytes, n, world)
+    # the reference driver's "Repro test" (benchmark_h/bench_eigen_h.f:100-127) on the process grid: a second solve of the
+    # same matrix returns w and z bit for bit; then the eigenvalue-only modes ('N'; 'X' = D&C then bisection)
+    w1, z1 = w.copy(), z.copy()
+    a[: len(rows), : len(cols)] = A[np.ix_(rows, cols)]
+    z[:] = 0.0
+    ee.eigen_h(n, n, a, nx, w, z, nx, m_forward=32, mode="A")
+    assert api.last_status() == 0 and np.array_equal(w, w1) and np.array_equal(z, z1), "eigen_h is not reproducible run to run"
+    for md in ("N", "X"):
+        a[: len(rows), : len(cols)] = A[np.ix_(rows, cols)]
+        w[:] = 0.0
+        ee.eigen_h(n, n if md == "X" else 0, a, nx, w, z, nx, m_forward=32, mode=md)
+        assert api.last_status() == 0 and np.abs(w - wr).max() / np.abs(wr).max() < 1e-12, md
     # partial eigenvector sets (src/eigen_h.F:104-106): the back-transformation is shared by eigenvector columns, so
     # take fewer columns than ranks (some ranks get none) and a count that does not divide
     for nv in sorted({min(n, world - 1), n // 3 + 1}):
