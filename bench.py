@@ -256,7 +256,9 @@ def main():
 
     def pmc_traffic(nn, alg_per_launch):
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_symv_traffic.json")) as fh:
+            pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            src = next(f for f in ("r04_symv_traffic.json", "r03_symv_traffic.json") if os.path.exists(os.path.join(pdir, f)))
+            with open(os.path.join(pdir, src)) as fh:
                 pm = json.load(fh)
             if int(pm["n"]) != int(nn):
                 return {"traffic": None}
@@ -264,10 +266,9 @@ def main():
             # nothing of this is measured in THIS run: `traffic` stays null, the committed PMC passes are quoted beside it
             return {"traffic": None,
                     "traffic_from_profile": round(ratio * alg_per_launch, 1),
-                    "traffic_source": f"profiles/r03_symv_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
-                                      f"one N={nn} reduction of round 3's kernel (gfx950 correction of the guide applied), {ratio:.3f} x "
-                                      f"the algorithmic bytes; the mat-vec's tiling and loads are unchanged since, but it was not "
-                                      f"collected in this run"}
+                    "traffic_source": f"profiles/{src}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                                      f"one N={nn} reduction of that round's kernel (gfx950 correction of the guide applied), {ratio:.3f} x "
+                                      f"the algorithmic bytes; not collected in this run"}
         except Exception:
             return {"traffic": None}
 

@@ -31,6 +31,7 @@ SIGNATURES = {
     "eigx_matdims_for_grid": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char, _c_int_p, _c_int_p]),
     "eigx_held_bytes": (C.c_int64, []),
     "eigx_held_bytes_named": (C.c_int64, [C.c_char_p]),
+    "eigx_transpose_plan": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_int)] * 5),
     "eigx_memory_internal": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "eigx_loop_start": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "eigx_loop_end": (C.c_int, [C.c_int, C.c_int, C.c_int]),

@@ -553,6 +553,19 @@ static int crt_small(int a, int A_, int b, int B_, int L) {   // smallest x < L 
   return -1;
 }
 static int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+// the pieces rank (px, py) exchanges with rank (qx, qy) in Z = A^T (pure arithmetic; eigx_transpose_plan exposes it to the
+// CPU tests, which assemble A^T from the pieces for every grid)
+static void transpose_plan(int Px, int Py, int px, int py, int qx, int qy, int* send_i0, int* send_j0, int* recv_i0,
+                           int* recv_j0, int* step) {
+  const int L = Px / gcd_int(Px, Py) * Py;
+  // to (qx, qy): its rows i (i % Px == qx) among my columns (i % Py == py); its columns j (j % Py == qy) among my rows
+  *send_i0 = crt_small(qx, Px, py, Py, L);
+  *send_j0 = crt_small(px, Px, qy, Py, L);
+  // from (qx, qy): my rows i (i % Px == px) among its columns (i % Py == qy); my columns j (j % Py == py) among its rows
+  *recv_i0 = crt_small(px, Px, qy, Py, L);
+  *recv_j0 = crt_small(qx, Px, py, Py, L);
+  *step = L;
+}
 
 // z(ldz, nc) = (a(lda, nc))^T on the cyclic blocks (both n x n); enqueued on st.  The all-to-all's pieces are uniform, and
 // only gcd(Px, Py)^-2 of the rank pairs exchange anything, so the exchange runs in rounds over the pieces' columns u that
@@ -569,12 +582,8 @@ static void dist_transpose(Context& ctx, int n, const double* a, int lda, double
   TrPeers to, from;
   for (int q = 0; q < P; ++q) {
     const int qx = G.row_major ? q / G.Py : q % G.Px, qy = G.row_major ? q % G.Py : q / G.Px;
-    // to q = (qx, qy): its rows i (i % Px == qx) among my columns (i % Py == py); its columns j (j % Py == qy) among my rows
-    to.i0[q] = crt_small(qx, G.Px, G.py, G.Py, L);
-    to.j0[q] = crt_small(G.px, G.Px, qy, G.Py, L);
-    // from q: my rows i (i % Px == px) among its columns (i % Py == qy); my columns j (j % Py == py) among its rows (j % Px == qx)
-    from.i0[q] = crt_small(G.px, G.Px, qy, G.Py, L);
-    from.j0[q] = crt_small(qx, G.Px, G.py, G.Py, L);
+    int step_;
+    transpose_plan(G.Px, G.Py, G.px, G.py, qx, qy, &to.i0[q], &to.j0[q], &from.i0[q], &from.j0[q], &step_);
   }
   const int gy = ucw < 32768 ? ucw : 32768;
   for (int u0 = 0; u0 < nimax; u0 += ucw) {
@@ -815,6 +824,14 @@ int64_t solver_workspace_bytes(const Context& ctx, int n, int lda, int ldz, int 
 using namespace eigx;
 
 extern "C" {
+
+int eigx_transpose_plan(int Px, int Py, int px, int py, int qx, int qy, int* send_i0, int* send_j0, int* recv_i0,
+                        int* recv_j0, int* step) {
+  if (Px < 1 || Py < 1 || px < 0 || px >= Px || py < 0 || py >= Py || qx < 0 || qx >= Px || qy < 0 || qy >= Py || !send_i0 ||
+      !send_j0 || !recv_i0 || !recv_j0 || !step) return EIGX_ERR_BAD_ARG;
+  transpose_plan(Px, Py, px, py, qx, qy, send_i0, send_j0, recv_i0, recv_j0, step);
+  return EIGX_OK;
+}
 
 int eigx_sx(int n, int nvec, double* a, int lda, double* w, double* z, int ldz, int mf, int mb, char mode) {
   return eigx_guard(g_ctx, [&] { return solve_host(g_ctx, n, nvec, a, lda, w, z, ldz, mf, mb, mode, 2, 1); });

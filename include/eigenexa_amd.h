@@ -129,6 +129,13 @@ int64_t eigx_held_bytes(void);
 /* the same for the pooled workspace buffers whose name starts with `prefix` (e.g. "gev." = what KMATH_EIGEN_GEV holds
  * beside the two eigen_s solves: the tests check that it is a few n^2 / P, nothing gathered).  -1 before eigx_init. */
 int64_t eigx_held_bytes_named(const char* prefix);
+/* pure arithmetic, no GPU needed: the pieces of the distributed transpose Z = A^T on the 2-D cyclic layout (the PDTRAN of
+ * src/KMATH_EIGEN_GEV_1.F:57) that rank (px, py) of a Px x Py grid exchanges with rank (qx, qy).  A piece is the set of
+ * elements Z(i, j) = A(j, i) with i = i0 + t step, j = j0 + u step (step = lcm(Px, Py)); send_*: the piece I pack for
+ * (qx, qy), recv_*: the one I get from it; i0 or j0 = -1: that pair exchanges nothing.  The CPU tests assemble A^T from
+ * the pieces for every grid up to 8 ranks. */
+int eigx_transpose_plan(int x_procs, int y_procs, int px, int py, int qx, int qy, int* send_i0, int* send_j0, int* recv_i0,
+                        int* recv_j0, int* step);
 
 /* ---- index helpers (pure functions; 1-based like the reference, src/eigen_libs0.F:1744-2356) - */
 int eigx_loop_start(int istart, int nnod, int inod);

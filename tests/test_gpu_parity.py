@@ -186,6 +186,46 @@ def test_band_dc_matches_oracle(gpu_lib, orc, band, n):
     assert res < GATE_RES and orth < GATE_ORTH
 
 
+@pytest.mark.parametrize("band", [1, 2])
+@pytest.mark.parametrize("n", [65, 1000, 2600])
+def test_band_dc_pass_pipeline_switches(gpu_lib, band, n):
+    """the one-GPU D&C's pass pipeline (next z ahead of the product, secular solves on the side stream, one product launch
+    per low height; eigx_tune keys 15 / 16) against the sequential form it replaced: the same eigenvalues to rounding and
+    the reference's gates either way; n = 65 has a height that does not rewrite every column (gathered-z fallback inside
+    the pipeline), n = 2600 has merges on both sides of every size threshold"""
+    import torch
+    from eigenexa_amd import layout
+
+    rng = np.random.default_rng(7 * n + band)
+    d = rng.standard_normal(n)
+    e = np.zeros((band, n))
+    for b in range(1, band + 1):
+        e[b - 1, b:] = rng.standard_normal(n - b)
+    T = _band_matrix(d, e, band)
+    tn = np.abs(T).max()
+    dd = torch.from_numpy(d).to(_dev())
+    ee = torch.from_numpy(e.reshape(-1).copy()).to(_dev())
+    ldz = n + (n & 1)
+    ws = []
+    try:
+        for pipe, batch in ((1, 1), (0, 1), (1, 0), (0, 0)):
+            gpu_lib.eigx_tune(15, pipe)
+            gpu_lib.eigx_tune(16, batch)
+            z = torch.zeros(n, ldz, dtype=torch.float64, device=_dev())
+            w = torch.zeros(n, dtype=torch.float64, device=_dev())
+            assert gpu_lib.eigx_band_dc_dev(n, n, dd.data_ptr(), ee.data_ptr(), n, band, w.data_ptr(), z.data_ptr(), ldz) == 0
+            wg = w.cpu().numpy()
+            res, orth = layout.accuracy_metrics(T, wg, z[:, :n].T.cpu().numpy())
+            assert res < GATE_RES and orth < GATE_ORTH, (pipe, batch, res, orth)
+            ws.append(wg)
+    finally:
+        gpu_lib.eigx_tune(15, 1)
+        gpu_lib.eigx_tune(16, 1)
+    for wg in ws[1:]:
+        assert np.abs(wg - ws[0]).max() < 1e-13 * tn * max(1, n / 100)
+    assert np.abs(ws[0] - np.linalg.eigvalsh(T)).max() < 1e-12 * tn * max(1, n / 100)
+
+
 # ------------------------------------------------------------------------------------ back-transform
 @pytest.mark.parametrize("band", [1, 2])
 @pytest.mark.parametrize("n,nvec,mb,q", [(5, 5, 8, 0), (130, 130, 16, 0), (300, 77, 128, 0), (517, 517, 48, 0),

@@ -507,6 +507,49 @@ def test_owner_directed_step_exchange(Px, Py, row_major):
         assert (msg[own[:L], oidx[:L]] == x).all()
 
 
+@pytest.mark.parametrize("Px,Py", [(1, 2), (2, 1), (2, 2), (1, 3), (3, 1), (2, 3), (3, 2), (2, 4), (4, 2), (1, 8), (8, 1)])
+def test_distributed_transpose_plan_assembles_the_transpose(Px, Py):
+    """KMATH_EIGEN_GEV on several ranks symmetrises A and transposes B^(-1/2) by an all-to-all whose pieces come from
+    eigx_transpose_plan (pure arithmetic in the library: Chinese remainder theorem on lcm(Px, Py)).  Restated with numpy
+    for every grid up to 8 ranks (2 x 4 included): every rank packs the pieces the plan names from its cyclic block, the
+    receivers place them by the plan's receive side -- the assembled blocks must be exactly the cyclic blocks of A^T,
+    every element sent once, and send / receive sides of a pair must agree."""
+    import ctypes as C
+
+    from eigenexa_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+
+    def plan(px, py, qx, qy):
+        v = [C.c_int() for _ in range(5)]
+        assert lib.eigx_transpose_plan(Px, Py, px, py, qx, qy, *[C.byref(x) for x in v]) == 0
+        return [x.value for x in v]
+
+    for n in (1, 2, 7, 24, 37):
+        A = rng.standard_normal((n, n))
+        Z = {(px, py): np.full((len(range(px, n, Px)), len(range(py, n, Py))), np.nan) for px in range(Px) for py in range(Py)}
+        sent = np.zeros((n, n), dtype=int)
+        for px in range(Px):
+            for py in range(Py):
+                Aloc = A[px::Px, py::Py]                      # my cyclic block: rows j = px mod Px, columns i = py mod Py
+                for qx in range(Px):
+                    for qy in range(Py):
+                        si0, sj0, _, _, L = plan(px, py, qx, qy)
+                        ri0, rj0 = plan(qx, qy, px, py)[2:4]
+                        assert (si0, sj0) == (ri0, rj0), "the two sides of a pair disagree"
+                        if si0 < 0 or sj0 < 0:
+                            continue
+                        for i in range(si0, n, L):            # Z(i, j) = A(j, i): I hold row j, column i
+                            for j in range(sj0, n, L):
+                                assert j % Px == px and i % Py == py and i % Px == qx and j % Py == qy
+                                Z[(qx, qy)][i // Px, j // Py] = Aloc[j // Px, i // Py]
+                                sent[j, i] += 1
+        assert (sent == 1).all()
+        for (px, py), blk in Z.items():
+            assert np.array_equal(blk, A.T[px::Px, py::Py])
+
+
 def test_matrix_type_10_reads_w_dat(tmp_path, monkeypatch):
     """matrix type 10 of the reference driver (benchmark/mat_set.f:205-216, :714-729): the spectrum comes from the file
     'W.dat' in the working directory (free format, first n numbers); without the file its content is regenerated
