@@ -1057,8 +1057,16 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
               if (rho * fabs(zloc[jj]) <= tol) { defl.push_back(jj); continue; }
               if (pj < 0) { pj = jj; continue; }
               double s = zloc[pj], c = zloc[jj];
-              const double tau = hypot(c, s);
               const double tt = dloc[jj] - dloc[pj];
+              // |tt c s| = |tt| |z_p z_j| / (z_p^2 + z_j^2): far from the threshold (the usual case) no hypot / divisions are
+              // needed to see that this pair does not deflate (they were most of the host time of a low height)
+              if (fabs(tt * c * s) > 2.0 * tol * (c * c + s * s)) {
+                C.nd_h[off + K] = off + pj;
+                ++K;
+                pj = jj;
+                continue;
+              }
+              const double tau = hypot(c, s);
               c /= tau; s = -s / tau;
               if (fabs(tt * c * s) <= tol) {
                 zloc[jj] = tau; zloc[pj] = 0.0;
