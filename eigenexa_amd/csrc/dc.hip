@@ -938,9 +938,9 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   // kernels wait behind its long workgroups (leaf kernel 0.45 -> 1.4 ms, or a secular launch 0.03 -> 0.7 ms); beside a
   // chip-filling product it costs its own CU time and nothing else.
   auto run_side_work = [&] {
-    if (!ctx.dc_after_leaves) return;
-    std::function<void()> f = std::move(ctx.dc_after_leaves);
-    ctx.dc_after_leaves = nullptr;
+    if (!ctx.dc_side_work) return;
+    std::function<void()> f = std::move(ctx.dc_side_work);
+    ctx.dc_side_work = nullptr;
     f();
   };
 

@@ -82,7 +82,7 @@ struct Context {
   hipStream_t dc_stream = nullptr;
   // work the solver wants enqueued on the side stream when the D&C's last product starts (the T factors of the
   // back-transformation; see band_dc_dev for why not earlier)
-  std::function<void()> dc_after_leaves;
+  std::function<void()> dc_side_work;
   // stream of that work (== side_stream; a CU-masked stream of its own changed nothing: profiles/r04_bt_mask_ab.log)
   hipStream_t bt_stream = nullptr;
   hipEvent_t dc_b_ev = nullptr, dc_z_ev = nullptr;

@@ -387,9 +387,9 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
   // divide and conquer (launch-bound at its low levels) has the compute stream.  The reduction is complete here
   // (the host synchronised the compute stream above).
   const bool runs_dc = !(mode == 'N' || mode == 'S' || mode == 'C');
-  ctx.dc_after_leaves = nullptr;   // (a solve that failed before its D&C ran may have left one behind)
+  ctx.dc_side_work = nullptr;   // (a solve that failed before its D&C ran may have left one behind)
   if (do_bt && nvec > 0 && P == 1) {
-    if (runs_dc) ctx.dc_after_leaves = [&ctx, n, a, lda, e, lde, mb, band] { trbak_prepare_dev(ctx, n, a, lda, e, lde, mb, band, ctx.bt_stream); };
+    if (runs_dc) ctx.dc_side_work = [&ctx, n, a, lda, e, lde, mb, band] { trbak_prepare_dev(ctx, n, a, lda, e, lde, mb, band, ctx.bt_stream); };
     else trbak_prepare_dev(ctx, n, a, lda, e, lde, mb, band, ctx.side_stream);
   }
   // several GPUs: this rank's eigenvector columns [zc0, zc0 + zcnt) (the D&C delivers them, all n rows each)
@@ -400,7 +400,7 @@ int solve_dev(Context& ctx, int n, int nvec, double* a, int lda, double* w, doub
     band_bisect_dev(ctx, n, d, e, lde, band, w);
   } else {
     band_dc_dev(ctx, n, nvec, d, e, lde, band, w, z, ldz);
-    if (ctx.dc_after_leaves) { std::function<void()> f = std::move(ctx.dc_after_leaves); ctx.dc_after_leaves = nullptr; f(); }   // not consumed (cannot happen today)
+    if (ctx.dc_side_work) { std::function<void()> f = std::move(ctx.dc_side_work); ctx.dc_side_work = nullptr; f(); }   // not consumed (cannot happen today)
     if (mode == 'X') band_bisect_dev(ctx, n, d, e, lde, band, w);
   }
   const double t3 = now_s();

@@ -20,3 +20,12 @@ for s, e, name, q in rows[i0:i1 + 1]:
     mark = f"   <-- idle {gap:.0f} us" if gap > 20 else ""
     print(f"{(s-t0)/1e3:10.1f} {(e-s)/1e3:9.1f} q{q:>3} {short}{mark}")
     busy_end = max(busy_end, e)
+if len(sys.argv) > 2 and sys.argv[2] == "bt":   # what follows the D&C in the same solve (the back-transformation)
+    print("---- after the D&C ----")
+    t1 = rows[i1][1]
+    for s, e, name, q in rows[i1 + 1:]:
+        if "at::native" in name or "Cijk" in name:
+            break
+        m = re.search(r"(\w+)(<[^>]*>)?\(", name)
+        short = (m.group(1) + (m.group(2) or "")) if m else name[:40]
+        print(f"{(s-t1)/1e3:10.1f} {(e-s)/1e3:9.1f} q{q:>3} {short}")
