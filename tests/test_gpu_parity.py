@@ -444,7 +444,8 @@ def _run_multi_rank(world, n, route, nb, dims, env_extra=None):
     (5, 230, "sx", 0, "1x5"), (3, 333, "s", 0, "3x1"), (4, 600, "sx", 0, "1x4"), (4, 515, "s", 0, "4x1"),
     (4, 517, "sx", 32, ""), (4, 301, "s", 7, ""), (2, 260, "sx", 64, ""), (3, 200, "sx", 5, "3x1"), (4, 131, "s", 3, "1x4"),
     (4, 129, "sx", 0, ""), (4, 3, "sx", 0, ""), (4, 1, "s", 0, ""), (4, 5, "s", 0, ""), (5, 7, "sx", 0, "1x5"),
-    (4, 200, "h", 0, ""), (3, 131, "h", 0, ""), (3, 700, "h", 0, ""), (2, 390, "h", 0, "2x1"), (4, 1400, "sx", 0, "")])
+    (4, 200, "h", 0, ""), (3, 131, "h", 0, ""), (3, 700, "h", 0, ""), (2, 390, "h", 0, "2x1"), (4, 3, "h", 0, ""), (4, 1, "h", 0, ""),
+    (4, 1400, "sx", 0, "")])
     # (round 4: the list was trimmed of near-duplicates -- the suite has to stay well inside the driver's 900-s step; every
     # grid shape, route, block-cyclic form and degenerate size is still there once)
     # (n > 4096 -- two merges above the D&C's 2048-column chunk width at one height -- took 84 s of the suite with four ranks
@@ -675,7 +676,7 @@ def test_multi_rank_no_transport_fails_on_every_rank():
     _run_multi_rank(3, 64, "initfail", 0, "", {"EIGX_SELFTEST_FAIL": "ipc"})
 
 
-@pytest.mark.parametrize("world,n,dims", [(2, 150, ""), (4, 600, ""), (3, 97, "3x1"), (4, 203, "1x4")])
+@pytest.mark.parametrize("world,n,dims", [(2, 150, ""), (4, 600, ""), (3, 97, "3x1"), (4, 203, "1x4"), (4, 3, ""), (3, 1, "")])
 def test_multi_rank_kmath_eigen_gev(world, n, dims):
     """KMATH_EIGEN_GEV on the process grid, distributed like the reference's (src/KMATH_EIGEN_GEV_1.F:57-139): cyclic blocks
     in (upper triangles only, NaN below) and out, two distributed eigen_s solves, the symmetrisation and the transposed
