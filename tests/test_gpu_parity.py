@@ -440,12 +440,12 @@ def _run_multi_rank(world, n, route, nb, dims, env_extra=None):
 
 
 @pytest.mark.parametrize("world,n,route,nb,dims", [
-    (2, 300, "sx", 0, ""), (2, 301, "s", 0, "2x1"), (3, 260, "sx", 0, ""),
+    (2, 300, "sx", 0, ""), (2, 301, "s", 0, "2x1"),
     (5, 230, "sx", 0, "1x5"), (3, 333, "s", 0, "3x1"), (4, 600, "sx", 0, "1x4"), (4, 515, "s", 0, "4x1"),
     (4, 517, "sx", 32, ""), (4, 301, "s", 7, ""), (2, 260, "sx", 64, ""), (3, 200, "sx", 5, "3x1"), (4, 131, "s", 3, "1x4"),
-    (4, 129, "sx", 0, ""), (4, 3, "sx", 0, ""), (4, 1, "s", 0, ""), (4, 5, "s", 0, ""), (5, 7, "sx", 0, "1x5"),
+    (4, 3, "sx", 0, ""), (4, 1, "s", 0, ""), (5, 7, "sx", 0, "1x5"),
     (4, 200, "h", 0, ""), (3, 131, "h", 0, ""), (3, 700, "h", 0, ""), (2, 390, "h", 0, "2x1"), (4, 3, "h", 0, ""), (4, 1, "h", 0, ""),
-    (4, 1400, "sx", 0, "")])
+    (4, 1100, "sx", 0, "")])
     # (round 4: the list was trimmed of near-duplicates -- the suite has to stay well inside the driver's 900-s step; every
     # grid shape, route, block-cyclic form and degenerate size is still there once)
     # (n > 4096 -- two merges above the D&C's 2048-column chunk width at one height -- took 84 s of the suite with four ranks
@@ -470,7 +470,7 @@ def test_multi_rank_modes_and_partial_spectrum(world, n, route, dims):
     _run_multi_rank(world, n, route, 0, dims)
 
 
-@pytest.mark.parametrize("world,n,route,dims", [(2, 700, "sx", ""), (4, 400, "s", ""), (3, 260, "sx", ""), (4, 5, "s", ""), (5, 7, "sx", "1x5")])
+@pytest.mark.parametrize("world,n,route,dims", [(2, 700, "sx", ""), (4, 400, "s", ""), (3, 260, "sx", ""), (5, 7, "sx", "1x5")])
 def test_multi_rank_one_launch_per_step(world, n, route, dims):
     """the form that runs when every rank has its own GPU (EIGX_FUSE_WAIT=1 forces it on the shared card): ONE launch per
     reduction step, roles [kl of the previous step | ka_kernel over the rank's own rows | mat-vec] dispatched in that order,
@@ -647,7 +647,7 @@ def test_multi_rank_error_behaviour_and_scaling(world, n, route, dims):
     _run_multi_rank(world, n, route, 0, dims)
 
 
-@pytest.mark.parametrize("world,n,route,dims", [(2, 300, "s", ""), (4, 700, "sx", "1x4"), (3, 260, "sx", "")])
+@pytest.mark.parametrize("world,n,route,dims", [(2, 300, "s", ""), (4, 400, "sx", "1x4"), (3, 260, "sx", "")])
 def test_multi_rank_collective_step_exchange(world, n, route, dims):
     """second rung of the transport ladder: the per-step exchange as ONE allgather of the step messages through the
     comm_* interface (ncclAllGather over the world communicator on a node -- the reference's reduce_dbl over X and Y,
