@@ -965,6 +965,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   // stream of a pass's secular / eigenvector-row kernels: the high-priority side stream where there is a product to run
   // under (big merges); the low heights are one dependent chain either way, and a second stream only adds event hand-offs
   bool z_ready = false;                         // [Dcur | z] of this pass are already on their way to the host
+  double* early_final = nullptr;                // host copy of the final eigenvalues, requested inside the last pass
   for (size_t pi = 0; pi < passes.size(); ++pi) {
     const std::vector<int>& ids = passes[pi].ids;
     const int h = passes[pi].h, k = passes[pi].k;
@@ -1202,6 +1203,13 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
         EIGX_HIP_CHECK(hipEventRecord(ctx.dc_b_ev, sb));
         EIGX_HIP_CHECK(hipStreamWaitEvent(st, ctx.dc_b_ev, 0));
       }
+      if (pipe && pi + 1 == passes.size()) {
+        // the eigenvalues are final once the last pass's secular equations are solved: fetch them now and sort on the
+        // host under the last product (the serial tail -- copy, sort, two uploads -- was 0.26 ms at N = 8192)
+        EIGX_HIP_CHECK(hipMemcpyAsync(V.Dh, C.Dcur, (size_t)n * 8, hipMemcpyDeviceToHost, sb));
+        EIGX_HIP_CHECK(hipEventRecord(ctx.dc_z_ev, sb));
+        early_final = V.Dh;
+      }
       if (nrot > 0)
         hipLaunchKernelGGL(rotate_kernel, dim3((maxnm + 255) / 256, nmg), dim3(256), 0, st, C.md_dev,
                            C.rpj_dev, C.rjj_dev, C.rc_dev, C.rs_dev, Qa, ldq, r0, r1);
@@ -1326,13 +1334,19 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
     }
   }
   run_side_work();   // (no pass at all: a matrix of one leaf)
-  if (pipe) EIGX_HIP_CHECK(hipStreamSynchronize(ctx.dc_stream));
 
   // ---- final sort + copy-out ----------------------------------------------------------------------------
   stage_trace(ctx.grid.rank, "D&C merges done");
   double* Dh = ar[0].Dh;
-  EIGX_HIP_CHECK(hipMemcpyAsync(Dh, Dfinal, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-  EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  hipStream_t up = st;                          // stream of the two uploads (permutation, eigenvalues)
+  if (early_final) {
+    EIGX_HIP_CHECK(hipEventSynchronize(ctx.dc_z_ev));
+    Dh = early_final;
+    up = ctx.dc_stream;                         // not behind the product that is still running on the compute stream
+  } else {
+    EIGX_HIP_CHECK(hipMemcpyAsync(Dh, Dfinal, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  }
   ord.resize(n);
   for (int i = 0; i < n; ++i) ord[i] = std::make_pair(Dh[i], i);
   std::sort(ord.begin(), ord.end());
@@ -1340,8 +1354,12 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
   std::vector<double> wh(n);
   for (int i = 0; i < n; ++i) { perm[i] = ord[i].second; wh[i] = ord[i].first * nrm; }
   if (nrm == 0.0) for (int i = 0; i < n; ++i) wh[i] = 0.0;
-  EIGX_HIP_CHECK(hipMemcpyAsync(perm_dev, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-  EIGX_HIP_CHECK(hipMemcpyAsync(w_dev, wh.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+  EIGX_HIP_CHECK(hipMemcpyAsync(perm_dev, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, up));
+  EIGX_HIP_CHECK(hipMemcpyAsync(w_dev, wh.data(), (size_t)n * 8, hipMemcpyHostToDevice, up));
+  if (up != st) {
+    EIGX_HIP_CHECK(hipEventRecord(ctx.dc_b_ev, up));
+    EIGX_HIP_CHECK(hipStreamWaitEvent(st, ctx.dc_b_ev, 0));
+  }
   if (nvec > 0 && z_dev && P == 1)
     hipLaunchKernelGGL(final_permute_kernel, dim3(8, nvec), dim3(256), 0, st, perm_dev, Qa, ldq, n, z_dev, ldz, nvec);
   if (nvec > 0 && z_dev && P > 1) {
@@ -1357,6 +1375,7 @@ void band_dc_dev(Context& ctx, int n, int nvec, const double* d_dev, const doubl
     hipLaunchKernelGGL(unpack_cols_kernel, dim3(8, zc, P), dim3(256), 0, st, (const double*)recvb, rp, zc, n, z_dev, ldz);
   }
   EIGX_HIP_CHECK(hipStreamSynchronize(st));
+  if (pipe) EIGX_HIP_CHECK(hipStreamSynchronize(ctx.dc_stream));
   stage_trace(ctx.grid.rank, "D&C done");
   EIGX_HIP_CHECK(hipGetLastError());
   ctx.timers[11] = gemm_flops;
