@@ -277,6 +277,23 @@ if route == "h":
         w[:] = 0.0
         ee.eigen_h(n, n if md == "X" else 0, a, nx, w, z, nx, m_forward=32, mode=md)
         assert api.last_status() == 0 and np.abs(w - wr).max() / np.abs(wr).max() < 1e-12, md
+    # mode 'S' (identity + bisection + back-transformation, src/eigen_h.F:207-210): z = the unitary matrix of the reduction
+    # itself, Z^H A Z real symmetric tridiagonal with the spectrum w
+    a[: len(rows), : len(cols)] = A[np.ix_(rows, cols)]
+    z[:] = 0.0
+    ee.eigen_h(n, n, a, nx, w, z, nx, m_forward=32, mode="S")
+    assert api.last_status() == 0
+    zl[:] = 0.0
+    zl[: len(rows), : len(cols)] = z[: len(rows), : len(cols)]
+    dist.all_gather(br, torch.from_numpy(np.ascontiguousarray(zl.real)))
+    dist.all_gather(bi, torch.from_numpy(np.ascontiguousarray(zl.imag)))
+    Zs = layout.gather_cyclic([r_.numpy() + 1j * i_.numpy() for r_, i_ in zip(br, bi)], n, n, dims=dims)
+    Ts = Zs.conj().T @ A @ Zs
+    anorm = np.linalg.norm(A)
+    off = Ts - np.diag(np.diag(Ts)) - np.diag(np.diag(Ts, 1), 1) - np.diag(np.diag(Ts, -1), -1)
+    assert np.linalg.norm(off) < 1e-13 * n * anorm and np.abs(Ts.imag).max() < 1e-13 * n * anorm, (np.linalg.norm(off), np.abs(Ts.imag).max())
+    assert np.linalg.norm(Zs.conj().T @ Zs - np.eye(n)) / (n * eps) < 8
+    assert np.abs(w - wr).max() / np.abs(wr).max() < 1e-12
     # partial eigenvector sets (src/eigen_h.F:104-106): the back-transformation is shared by eigenvector columns, so
     # take fewer columns than ranks (some ranks get none) and a count that does not divide
     for nv in sorted({min(n, world - 1), n // 3 + 1}):
